@@ -1,0 +1,918 @@
+// chipvideo.cpp — host runtime behind include/chipvideo.h.
+//
+// Owns devices, contexts (one HIP stream each), device buffers, pitched
+// transfers with a pinned staging ring, descriptor building/validation and
+// kernel dispatch.  There is no CPU pixel path in this library: every entry
+// that would touch pixels either launches a gfx950 kernel or returns an error.
+#include "../../include/chipvideo.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+
+namespace chv {
+hipError_t launch_tick_general(int target_format, const DTick *ticks, const DLayer *layers,
+                               int n_ticks, int maxW, int maxH, hipStream_t stream);
+hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
+                           const float *den, float *out_q, int n, hipStream_t stream);
+// kernels_fast.hip.cpp
+const char *fast_path_name(int path);
+int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
+hipError_t launch_tick_fast(int path, const DTick *ticks, const DLayer *layers, int n_ticks,
+                            int maxW, int maxH, hipStream_t stream);
+// kernels_lanczos.hip.cpp
+hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *fx, const float *wx,
+                          int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream);
+}  // namespace chv
+
+using namespace chv;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_detail;
+
+static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_detail = buf;
+    return code;
+}
+
+// HIP error -> ComputeError-shaped status (the role of check(), compute.cuda.swift:102-112)
+static int hip_fail(hipError_t e, const char *what) {
+    int code = CHV_ERR_UNKNOWN;
+    switch (e) {
+    case hipErrorOutOfMemory: code = CHV_ERR_OUT_OF_MEMORY; break;
+    case hipErrorInvalidValue: code = CHV_ERR_INVALID_VALUE; break;
+    case hipErrorInvalidDevice: code = CHV_ERR_INVALID_DEVICE; break;
+    case hipErrorNoDevice: code = CHV_ERR_DEVICE_NOT_AVAILABLE; break;
+    case hipErrorInvalidContext: code = CHV_ERR_INVALID_CONTEXT; break;
+    case hipErrorNotSupported: code = CHV_ERR_NOT_IMPLEMENTED; break;
+    default: break;
+    }
+    return fail(code, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+}
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);     \
+    } while (0)
+
+extern "C" const char *chv_error_string(int s) {
+    switch (s) {
+    case CHV_OK: return "success";
+    case CHV_ERR_INVALID_VALUE: return "invalidValue";
+    case CHV_ERR_OUT_OF_MEMORY: return "outOfMemory";
+    case CHV_ERR_INVALID_CONTEXT: return "invalidContext";
+    case CHV_ERR_BAD_TARGET: return "badTarget";
+    case CHV_ERR_BAD_INPUT: return "badInputData";
+    case CHV_ERR_NOT_IMPLEMENTED: return "notImplemented";
+    case CHV_ERR_KERNEL_NOT_FOUND: return "computeKernelNotFound";
+    case CHV_ERR_DEVICE_NOT_AVAILABLE: return "deviceNotAvailable";
+    case CHV_ERR_INVALID_DEVICE: return "invalidDevice";
+    case CHV_ERR_INVALID_OPERATION: return "invalidOperation";
+    case CHV_ERR_BAD_CONTEXT_STATE: return "badContextState";
+    case CHV_ERR_INVALID_PLATFORM: return "invalidPlatform";
+    default: return "unknownError";
+    }
+}
+extern "C" const char *chv_last_error_detail(void) { return g_detail.c_str(); }
+extern "C" int chv_version(void) { return CHV_VERSION; }
+
+// ---------------------------------------------------------------------------
+// kernel name table (defaultComputeKernelFromString, compute.swift:90-110)
+// ---------------------------------------------------------------------------
+struct KernelName { const char *name; int id; };
+static const KernelName kNames[] = {
+    { "img_nv12_nv12", CHV_K_IMG_NV12_NV12 },   { "img_bgra_nv12", CHV_K_IMG_BGRA_NV12 },
+    { "img_rgba_nv12", CHV_K_IMG_RGBA_NV12 },   { "img_bgra_bgra", CHV_K_IMG_BGRA_BGRA },
+    { "img_y420p_y420p", CHV_K_IMG_Y420P_Y420P }, { "img_y420p_nv12", CHV_K_IMG_Y420P_NV12 },
+    { "img_clear_nv12", CHV_K_IMG_CLEAR_NV12 }, { "img_clear_yuvs", CHV_K_IMG_CLEAR_YUVS },
+    { "img_clear_bgra", CHV_K_IMG_CLEAR_BGRA }, { "img_clear_rgba", CHV_K_IMG_CLEAR_BGRA },
+    { "img_rgba_y420p", CHV_K_IMG_RGBA_Y420P }, { "img_bgra_y420p", CHV_K_IMG_BGRA_Y420P },
+    { "img_clear_y420p", CHV_K_IMG_CLEAR_Y420P },
+    // names findKernel can synthesise for BGRA canvases (mix.video.swift:142-146)
+    { "img_nv12_bgra", CHV_K_IMG_NV12_BGRA },   { "img_y420p_bgra", CHV_K_IMG_Y420P_BGRA },
+    { "img_bgra_bgra_tx", CHV_K_IMG_BGRA_BGRA_TX }, { "img_rgba_bgra_tx", CHV_K_IMG_RGBA_BGRA_TX },
+};
+
+extern "C" int chv_kernel_from_string(const char *name, int *kernel) {
+    if (!name || !kernel) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    for (const auto &k : kNames)
+        if (!strcmp(k.name, name)) { *kernel = k.id; return CHV_OK; }
+    return fail(CHV_ERR_INVALID_VALUE, "no default kernel named '%s'", name);
+}
+
+extern "C" const char *chv_kernel_name(int kernel) {
+    switch (kernel) {
+    case CHV_K_IMG_NV12_NV12: return "img_nv12_nv12";
+    case CHV_K_IMG_BGRA_NV12: return "img_bgra_nv12";
+    case CHV_K_IMG_RGBA_NV12: return "img_rgba_nv12";
+    case CHV_K_IMG_BGRA_BGRA: return "img_bgra_bgra";
+    case CHV_K_IMG_Y420P_Y420P: return "img_y420p_y420p";
+    case CHV_K_IMG_Y420P_NV12: return "img_y420p_nv12";
+    case CHV_K_IMG_CLEAR_NV12: return "img_clear_nv12";
+    case CHV_K_IMG_CLEAR_YUVS: return "img_clear_yuvs";
+    case CHV_K_IMG_CLEAR_BGRA: return "img_clear_bgra";
+    case CHV_K_IMG_CLEAR_Y420P: return "img_clear_y420p";
+    case CHV_K_IMG_CLEAR_RGBA: return "img_clear_rgba";
+    case CHV_K_IMG_RGBA_Y420P: return "img_rgba_y420p";
+    case CHV_K_IMG_BGRA_Y420P: return "img_bgra_y420p";
+    case CHV_K_SND_S16I_S16I: return "snd_s16i_s16i";
+    case CHV_K_ME_FULLSEARCH: return "me_fullsearch";
+    case CHV_K_IMG_NV12_BGRA: return "img_nv12_bgra";
+    case CHV_K_IMG_Y420P_BGRA: return "img_y420p_bgra";
+    case CHV_K_IMG_BGRA_BGRA_TX: return "img_bgra_bgra_tx";
+    case CHV_K_IMG_RGBA_BGRA_TX: return "img_rgba_bgra_tx";
+    default: return NULL;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------
+struct LanczosTable {
+    int taps = 0;
+    int32_t *first = nullptr;  // device
+    float *weights = nullptr;  // device
+};
+
+// State shared by a context and everything created with chv_context_share
+// (the role of InternalContext, compute.cl.swift:60-74).
+struct DeviceShared {
+    int device = 0;
+    std::mutex mu;
+    std::map<std::pair<int, int>, LanczosTable> lanczos;  // (in, out) -> tables
+    ~DeviceShared() {
+        (void)hipSetDevice(device);
+        for (auto &kv : lanczos) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.weights); }
+    }
+};
+
+struct StagingSlot {
+    void *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+
+struct DescSlot {
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+
+static constexpr int kStagingSlots = 4;
+static constexpr int kDescSlots = 64;
+static constexpr size_t kDescSlotBytes = sizeof(DTick) + CHV_MAX_LAYERS * sizeof(DLayer);
+
+struct chv_context {
+    uint32_t magic = 0x43485643;  // 'CHVC'
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::shared_ptr<DeviceShared> shared;
+    bool in_pass = false;
+    StagingSlot staging[kStagingSlots];
+    int next_staging = 0;
+    // descriptor ring in pinned, device-mapped host memory
+    uint8_t *desc_host = nullptr;
+    DescSlot desc[kDescSlots];
+    int next_desc = 0;
+};
+
+struct chv_buffer {
+    uint32_t magic = 0x43485642;  // 'CHVB'
+    void *ptr = nullptr;
+    size_t size = 0;
+    int device = 0;
+    bool owned = true;
+};
+
+struct chv_event {
+    hipEvent_t ev = nullptr;
+    int device = 0;
+};
+
+struct chv_batch {
+    int device = 0;
+    int n_ticks = 0, n_layers = 0;
+    int target_format = 0;
+    int maxW = 0, maxH = 0;
+    int fast_path = -1;
+    DTick *d_ticks = nullptr;
+    DLayer *d_layers = nullptr;
+    std::string kernel_name;
+};
+
+static bool ctx_ok(chv_context *c) { return c && c->magic == 0x43485643 && c->stream; }
+static bool buf_ok(const chv_buffer *b) { return b && b->magic == 0x43485642 && b->ptr; }
+
+// ---------------------------------------------------------------------------
+// devices
+// ---------------------------------------------------------------------------
+extern "C" int chv_device_count(int *count) {
+    if (!count) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return hip_fail(e, "hipGetDeviceCount"); }
+    *count = n;
+    return CHV_OK;
+}
+
+extern "C" int chv_device_info_get(int device, chv_device_info *info) {
+    if (!info) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    int n = 0;
+    int rc = chv_device_count(&n);
+    if (rc) return rc;
+    if (device < 0 || device >= n) return fail(CHV_ERR_INVALID_DEVICE, "device %d of %d", device, n);
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    memset(info, 0, sizeof *info);
+    info->index = device;
+    info->device_type = 0;
+    info->vendor_id = 0x1002;
+    info->compute_units = p.multiProcessorCount;
+    info->supports_images = 0;
+    info->total_memory = p.totalGlobalMem;
+    snprintf(info->name, sizeof info->name, "%s", p.name);
+    snprintf(info->arch, sizeof info->arch, "%s", p.gcnArchName);
+    // kernels in this library are built for gfx950 only
+    info->available = strncmp(p.gcnArchName, "gfx950", 6) == 0;
+    return CHV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// contexts
+// ---------------------------------------------------------------------------
+static int context_new(int device, std::shared_ptr<DeviceShared> shared, chv_context **out) {
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<chv_context> c(new chv_context);
+    c->device = device;
+    c->shared = std::move(shared);
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    hipError_t e = hipHostMalloc((void **)&c->desc_host, kDescSlots * kDescSlotBytes, hipHostMallocMapped);
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); return hip_fail(e, "hipHostMalloc(descriptors)"); }
+    *out = c.release();
+    return CHV_OK;
+}
+
+extern "C" int chv_context_create(int device, chv_context **out) {
+    if (!out) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    *out = nullptr;
+    chv_device_info info;
+    int rc = chv_device_info_get(device, &info);
+    if (rc) return rc;
+    if (!info.available)
+        return fail(CHV_ERR_DEVICE_NOT_AVAILABLE, "device %d is %s; this library carries gfx950 code only", device, info.arch);
+    auto shared = std::make_shared<DeviceShared>();
+    shared->device = device;
+    return context_new(device, shared, out);
+}
+
+extern "C" int chv_context_share(chv_context *parent, chv_context **out) {
+    if (!out) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    *out = nullptr;
+    if (!ctx_ok(parent)) return fail(CHV_ERR_INVALID_CONTEXT, "bad parent context");
+    return context_new(parent->device, parent->shared, out);
+}
+
+extern "C" int chv_context_destroy(chv_context *c) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->staging) {
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.host) (void)hipHostFree(s.host);
+    }
+    for (auto &d : c->desc) if (d.done) (void)hipEventDestroy(d.done);
+    if (c->desc_host) (void)hipHostFree(c->desc_host);
+    (void)hipStreamDestroy(c->stream);
+    c->magic = 0;
+    c->stream = nullptr;
+    delete c;
+    return CHV_OK;
+}
+
+extern "C" int chv_context_device(chv_context *c, int *device) {
+    if (!ctx_ok(c) || !device) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    *device = c->device;
+    return CHV_OK;
+}
+extern "C" int chv_context_stream(chv_context *c, void **s) {
+    if (!ctx_ok(c) || !s) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    *s = (void *)c->stream;
+    return CHV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// buffers and transfers
+// ---------------------------------------------------------------------------
+extern "C" int chv_buffer_alloc(chv_context *c, size_t bytes, chv_buffer **out) {
+    if (!out) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    *out = nullptr;
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (bytes == 0) return fail(CHV_ERR_INVALID_VALUE, "zero-sized buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    chv_buffer *b = new chv_buffer;
+    b->ptr = p; b->size = bytes; b->device = c->device; b->owned = true;
+    *out = b;
+    return CHV_OK;
+}
+
+extern "C" int chv_buffer_wrap(chv_context *c, void *device_ptr, size_t bytes, chv_buffer **out) {
+    if (!out) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    *out = nullptr;
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!device_ptr || bytes == 0) return fail(CHV_ERR_INVALID_VALUE, "null/empty device memory");
+    chv_buffer *b = new chv_buffer;
+    b->ptr = device_ptr; b->size = bytes; b->device = c->device; b->owned = false;
+    *out = b;
+    return CHV_OK;
+}
+
+extern "C" int chv_buffer_free(chv_buffer *b) {
+    if (!b || b->magic != 0x43485642) return fail(CHV_ERR_INVALID_VALUE, "bad buffer");
+    if (b->owned && b->ptr) {
+        // any thread, any time: make the owning device current first
+        // (compute.cuda.swift:82-88 pushes the context in deinit for the same reason)
+        (void)hipSetDevice(b->device);
+        (void)hipFree(b->ptr);  // hipFree waits for in-flight work on the allocation
+    }
+    b->magic = 0;
+    b->ptr = nullptr;
+    delete b;
+    return CHV_OK;
+}
+
+extern "C" int chv_buffer_info(chv_buffer *b, void **device_ptr, size_t *bytes) {
+    if (!buf_ok(b)) return fail(CHV_ERR_INVALID_VALUE, "bad buffer");
+    if (device_ptr) *device_ptr = b->ptr;
+    if (bytes) *bytes = b->size;
+    return CHV_OK;
+}
+
+extern "C" int chv_plane_alloc(chv_context *c, int width, int height, int components,
+                               chv_buffer **out, size_t *pitch) {
+    if (!out || !pitch) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    if (width <= 0 || height <= 0) return fail(CHV_ERR_INVALID_OPERATION, "plane size %dx%d", width, height);
+    if (components != 1 && components != 2 && components != 4)
+        return fail(CHV_ERR_BAD_INPUT, "components must be 1, 2 or 4, got %d", components);
+    size_t row = (size_t)width * components;
+    size_t p = (row + 255) & ~(size_t)255;
+    *pitch = p;
+    return chv_buffer_alloc(c, p * (size_t)height, out);
+}
+
+static int check_span(const chv_buffer *b, size_t offset, size_t pitch, size_t width_bytes, size_t rows,
+                      const char *what) {
+    if (!buf_ok(b)) return fail(CHV_ERR_BAD_INPUT, "%s: bad buffer", what);
+    if (rows == 0 || width_bytes == 0) return fail(CHV_ERR_INVALID_VALUE, "%s: empty region", what);
+    if (pitch < width_bytes) return fail(CHV_ERR_BAD_INPUT, "%s: pitch %zu < row bytes %zu", what, pitch, width_bytes);
+    size_t end = offset + (rows - 1) * pitch + width_bytes;
+    if (end > b->size) return fail(CHV_ERR_BAD_INPUT, "%s: region ends at %zu, buffer has %zu bytes", what, end, b->size);
+    return CHV_OK;
+}
+
+extern "C" int chv_upload(chv_context *c, chv_buffer *dst, size_t dst_offset, size_t dst_pitch,
+                          const void *src, size_t src_pitch, size_t width_bytes, size_t rows, int async) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!src) return fail(CHV_ERR_BAD_INPUT, "null source");
+    int rc = check_span(dst, dst_offset, dst_pitch, width_bytes, rows, "upload");
+    if (rc) return rc;
+    if (src_pitch < width_bytes) return fail(CHV_ERR_BAD_INPUT, "source pitch %zu < row bytes %zu", src_pitch, width_bytes);
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t *d = (uint8_t *)dst->ptr + dst_offset;
+    if (!async) {
+        HIP_TRY(hipMemcpy2DAsync(d, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return CHV_OK;
+    }
+    // stage into pinned memory so the caller's bytes are only borrowed for this call
+    StagingSlot &s = c->staging[c->next_staging];
+    c->next_staging = (c->next_staging + 1) % kStagingSlots;
+    if (s.pending) { HIP_TRY(hipEventSynchronize(s.done)); s.pending = false; }
+    size_t need = width_bytes * rows;
+    if (s.cap < need) {
+        if (s.host) { HIP_TRY(hipHostFree(s.host)); s.host = nullptr; s.cap = 0; }
+        size_t cap = (need + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+        HIP_TRY(hipHostMalloc(&s.host, cap, hipHostMallocDefault));
+        s.cap = cap;
+    }
+    if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    const uint8_t *sp = (const uint8_t *)src;
+    uint8_t *hp = (uint8_t *)s.host;
+    if (src_pitch == width_bytes) memcpy(hp, sp, need);
+    else for (size_t r = 0; r < rows; r++) memcpy(hp + r * width_bytes, sp + r * src_pitch, width_bytes);
+    HIP_TRY(hipMemcpy2DAsync(d, dst_pitch, hp, width_bytes, width_bytes, rows, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(s.done, c->stream));
+    s.pending = true;
+    return CHV_OK;
+}
+
+extern "C" int chv_download(chv_context *c, void *dst, size_t dst_pitch, chv_buffer *src,
+                            size_t src_offset, size_t src_pitch, size_t width_bytes, size_t rows) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!dst) return fail(CHV_ERR_BAD_INPUT, "null destination");
+    int rc = check_span(src, src_offset, src_pitch, width_bytes, rows, "download");
+    if (rc) return rc;
+    if (dst_pitch < width_bytes) return fail(CHV_ERR_BAD_INPUT, "destination pitch %zu < row bytes %zu", dst_pitch, width_bytes);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, (const uint8_t *)src->ptr + src_offset, src_pitch, width_bytes, rows,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CHV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// descriptor building
+// ---------------------------------------------------------------------------
+struct KernelShape {
+    int src_planes;      // 0 for clear
+    int src_comps[3];
+    int target_format;   // TargetFormat
+    int kind;            // LayerKind
+    int swizzle;
+    bool is_clear;
+};
+
+static int kernel_shape(int kernel, KernelShape *s) {
+    memset(s, 0, sizeof *s);
+    auto yuv_nv12 = [&](int tf, int kind) { s->src_planes = 2; s->src_comps[0] = 1; s->src_comps[1] = 2; s->target_format = tf; s->kind = kind; };
+    auto yuv_420p = [&](int tf, int kind) { s->src_planes = 3; s->src_comps[0] = s->src_comps[1] = s->src_comps[2] = 1; s->target_format = tf; s->kind = kind; };
+    auto rgb = [&](int tf, int kind, int swz) { s->src_planes = 1; s->src_comps[0] = 4; s->target_format = tf; s->kind = kind; s->swizzle = swz; };
+    switch (kernel) {
+    case CHV_K_IMG_NV12_NV12: yuv_nv12(TF_NV12, LK_YUV_FROM_NV12); break;
+    case CHV_K_IMG_Y420P_NV12: yuv_420p(TF_NV12, LK_YUV_FROM_Y420P); break;
+    case CHV_K_IMG_Y420P_Y420P: yuv_420p(TF_Y420P, LK_YUV_FROM_Y420P); break;
+    case CHV_K_IMG_BGRA_NV12: rgb(TF_NV12, LK_YUV_FROM_RGB, 1); break;   // .zyxw, kernels.cl.swift:518
+    case CHV_K_IMG_RGBA_NV12: rgb(TF_NV12, LK_YUV_FROM_RGB, 0); break;
+    case CHV_K_IMG_BGRA_Y420P: rgb(TF_Y420P, LK_YUV_FROM_RGB, 1); break;
+    case CHV_K_IMG_RGBA_Y420P: rgb(TF_Y420P, LK_YUV_FROM_RGB, 0); break;
+    case CHV_K_IMG_BGRA_BGRA: rgb(TF_BGRA, LK_BGRA_METAL, 0); break;
+    case CHV_K_IMG_NV12_BGRA: yuv_nv12(TF_BGRA, LK_BGRA_FROM_NV12); break;
+    case CHV_K_IMG_Y420P_BGRA: yuv_420p(TF_BGRA, LK_BGRA_FROM_Y420P); break;
+    case CHV_K_IMG_BGRA_BGRA_TX: rgb(TF_BGRA, LK_BGRA_FROM_RGB, 0); break;
+    case CHV_K_IMG_RGBA_BGRA_TX: rgb(TF_BGRA, LK_BGRA_FROM_RGB, 1); break;
+    case CHV_K_IMG_CLEAR_NV12: s->is_clear = true; s->target_format = TF_NV12; break;
+    case CHV_K_IMG_CLEAR_Y420P: s->is_clear = true; s->target_format = TF_Y420P; break;
+    case CHV_K_IMG_CLEAR_BGRA: case CHV_K_IMG_CLEAR_RGBA: s->is_clear = true; s->target_format = TF_BGRA; break;
+    case CHV_K_IMG_CLEAR_YUVS: case CHV_K_SND_S16I_S16I: case CHV_K_ME_FULLSEARCH:
+        // enum cases for which no backend of the reference has a kernel either
+        return fail(CHV_ERR_KERNEL_NOT_FOUND, "kernel %s has no implementation", chv_kernel_name(kernel));
+    default:
+        return fail(CHV_ERR_KERNEL_NOT_FOUND, "unknown kernel id %d", kernel);
+    }
+    return CHV_OK;
+}
+
+static int plane_to_device(const chv_plane &p, int comps, int device, DPlane *out, int err, const char *what, int idx) {
+    if (!buf_ok(p.buffer)) return fail(err, "%s plane %d: no device buffer", what, idx);
+    if (p.buffer->device != device) return fail(err, "%s plane %d lives on device %d, context on %d", what, idx, p.buffer->device, device);
+    if (p.width <= 0 || p.height <= 0) return fail(err, "%s plane %d: size %dx%d", what, idx, p.width, p.height);
+    if (p.components != comps) return fail(err, "%s plane %d: %d components, kernel expects %d", what, idx, p.components, comps);
+    if (p.pitch < p.width * comps) return fail(err, "%s plane %d: pitch %d < %d", what, idx, p.pitch, p.width * comps);
+    size_t end = p.offset + (size_t)(p.height - 1) * p.pitch + (size_t)p.width * comps;
+    if (end > p.buffer->size) return fail(err, "%s plane %d: extent %zu exceeds buffer size %zu", what, idx, end, p.buffer->size);
+    if (comps == 4 && (((uintptr_t)p.buffer->ptr + p.offset) & 3 || (p.pitch & 3)))
+        return fail(err, "%s plane %d: 4-component planes must be 4-byte aligned", what, idx);
+    out->ptr = (uint8_t *)p.buffer->ptr + p.offset;
+    out->w = p.width; out->h = p.height; out->pitch = p.pitch; out->comps = comps;
+    return CHV_OK;
+}
+
+static int target_to_device(const chv_image *t, int target_format, int device, DImage *out) {
+    if (!t) return fail(CHV_ERR_BAD_TARGET, "null target");
+    static const int np[3] = { 2, 3, 1 };
+    static const int comps[3][3] = { { 1, 2, 0 }, { 1, 1, 1 }, { 4, 0, 0 } };
+    if (t->n_planes != np[target_format])
+        return fail(CHV_ERR_BAD_TARGET, "target has %d planes, kernel writes %d", t->n_planes, np[target_format]);
+    memset(out, 0, sizeof *out);
+    for (int i = 0; i < t->n_planes; i++) {
+        int rc = plane_to_device(t->planes[i], comps[target_format][i], device, &out->pl[i], CHV_ERR_BAD_TARGET, "target", i);
+        if (rc) return rc;
+    }
+    return CHV_OK;
+}
+
+// host-side analysis of a layer's uniforms for fast-path selection
+static int32_t layer_flags(const float *u) {
+    int32_t f = 0;
+    auto axis = [&](const float *m) {
+        // row 0 must not depend on y/z, row 1 not on x/z, rows 2,3 = (0,0,*,*), so that
+        // component 0 is a function of x only and component 1 of y only
+        return m[1] == 0.f && m[2] == 0.f && m[4] == 0.f && m[6] == 0.f;
+    };
+    const float *T = u + U_TRANSFORM, *X = u + U_TEXTURE, *B = u + U_BORDER;
+    // uv = textureTx . tx uses all four tx components: tx.z/tx.w must not depend on x or y
+    bool tzw_const = T[8] == 0.f && T[9] == 0.f && T[12] == 0.f && T[13] == 0.f;
+    if (axis(T) && axis(B) && axis(X) && tzw_const) f |= LF_AXIS_ALIGNED;
+    if (u[U_OPACITY] * u[U_FILL + 3] == 0.f) f |= LF_NO_FILL;
+    if (u[U_OPACITY] == 1.f) f |= LF_OPAQUE;
+    return f;
+}
+
+static int layer_to_device(const chv_layer &l, int device, int *target_format, DLayer *out) {
+    KernelShape s;
+    int rc = kernel_shape(l.kernel, &s);
+    if (rc) return rc;
+    if (s.is_clear) return fail(CHV_ERR_INVALID_OPERATION, "%s is not a layer kernel", chv_kernel_name(l.kernel));
+    if (*target_format < 0) *target_format = s.target_format;
+    else if (*target_format != s.target_format)
+        return fail(CHV_ERR_BAD_TARGET, "%s does not write this target format", chv_kernel_name(l.kernel));
+    if (l.image.n_planes < s.src_planes)
+        return fail(CHV_ERR_BAD_INPUT, "%s needs %d input planes, image has %d", chv_kernel_name(l.kernel), s.src_planes, l.image.n_planes);
+    memset(out, 0, sizeof *out);
+    for (int i = 0; i < s.src_planes; i++) {
+        rc = plane_to_device(l.image.planes[i], s.src_comps[i], device, &out->src.pl[i], CHV_ERR_BAD_INPUT, "input", i);
+        if (rc) return rc;
+    }
+    static_assert(sizeof(chv_uniforms) == 236, "ImageUniforms must be 236 bytes (compute.swift:76-86)");
+    memcpy(out->u, &l.uniforms, sizeof(chv_uniforms));
+    if (s.kind == LK_BGRA_METAL) {
+        if (!(out->u[U_OUTSIZE] > 0.f) || !(out->u[U_OUTSIZE + 1] > 0.f))
+            return fail(CHV_ERR_INVALID_VALUE, "img_bgra_bgra needs a positive outputSize in the uniforms");
+    }
+    out->kind = s.kind;
+    out->swizzle = s.swizzle;
+    out->csc = l.opts.colorspace & 3;
+    out->flags = layer_flags(out->u);
+    return CHV_OK;
+}
+
+static int tick_to_device(const chv_tick &t, int device, int forced_target_format, DTick *dt,
+                          std::vector<DLayer> *layers, int *target_format_out) {
+    if (t.n_layers < 0 || t.n_layers > CHV_MAX_LAYERS)
+        return fail(CHV_ERR_INVALID_VALUE, "%d layers (max %d)", t.n_layers, CHV_MAX_LAYERS);
+    if (t.n_layers > 0 && !t.layers) return fail(CHV_ERR_BAD_INPUT, "null layers");
+    int tf = forced_target_format;
+    int first = (int)layers->size();
+    for (int i = 0; i < t.n_layers; i++) {
+        DLayer dl;
+        int rc = layer_to_device(t.layers[i], device, &tf, &dl);
+        if (rc) return rc;
+        layers->push_back(dl);
+    }
+    if (tf < 0) {
+        // no layers: infer the clear flavour from the target's plane structure
+        if (t.target.n_planes == 1) tf = TF_BGRA;
+        else if (t.target.n_planes == 2) tf = TF_NV12;
+        else if (t.target.n_planes == 3) tf = TF_Y420P;
+        else return fail(CHV_ERR_BAD_TARGET, "target has %d planes", t.target.n_planes);
+    }
+    memset(dt, 0, sizeof *dt);
+    int rc = target_to_device(&t.target, tf, device, &dt->dst);
+    if (rc) return rc;
+    dt->W = dt->dst.pl[0].w;
+    dt->H = dt->dst.pl[0].h;
+    dt->clear_first = t.clear_first ? 1 : 0;
+    dt->n_layers = t.n_layers;
+    dt->first_layer = first;
+    *target_format_out = tf;
+    return CHV_OK;
+}
+
+// launch one transient tick through the pinned descriptor ring
+static int launch_transient(chv_context *c, const DTick &tick_in, const std::vector<DLayer> &layers, int tf) {
+    HIP_TRY(hipSetDevice(c->device));
+    int slot = c->next_desc;
+    c->next_desc = (c->next_desc + 1) % kDescSlots;
+    DescSlot &ds = c->desc[slot];
+    if (ds.pending) { HIP_TRY(hipEventSynchronize(ds.done)); ds.pending = false; }
+    if (!ds.done) HIP_TRY(hipEventCreateWithFlags(&ds.done, hipEventDisableTiming));
+    uint8_t *base = c->desc_host + (size_t)slot * kDescSlotBytes;
+    DTick *ht = (DTick *)base;
+    DLayer *hl = (DLayer *)(base + sizeof(DTick));
+    *ht = tick_in;
+    ht->first_layer = 0;
+    if (!layers.empty()) memcpy(hl, layers.data(), layers.size() * sizeof(DLayer));
+    DTick *dt = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&dt, ht, 0));
+    DLayer *dl = (DLayer *)((uint8_t *)dt + sizeof(DTick));
+    int path = select_fast_path(tf, ht, hl, 1);
+    hipError_t e = path >= 0 ? launch_tick_fast(path, dt, dl, 1, ht->W, ht->H, c->stream)
+                             : launch_tick_general(tf, dt, dl, 1, ht->W, ht->H, c->stream);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    HIP_TRY(hipEventRecord(ds.done, c->stream));
+    ds.pending = true;
+    return CHV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// passes and kernels
+// ---------------------------------------------------------------------------
+extern "C" int chv_pass_begin(chv_context *c) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    c->in_pass = true;  // no device work: like OpenCL, a pass is just a bracket (compute.cl.swift:234-237)
+    return CHV_OK;
+}
+
+extern "C" int chv_pass_end(chv_context *c, int wait) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    c->in_pass = false;
+    HIP_TRY(hipSetDevice(c->device));
+    if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
+    else (void)hipStreamQuery(c->stream);  // nudge submission, the clFlush analogue
+    return CHV_OK;
+}
+
+extern "C" int chv_run_kernel(chv_context *c, int kernel, const chv_image *target,
+                              const chv_image *inputs, int n_inputs,
+                              const void *uniforms, size_t uniforms_size, int blends,
+                              const chv_kernel_opts *opts) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!target) return fail(CHV_ERR_BAD_TARGET, "null target");
+    KernelShape s;
+    int rc = kernel_shape(kernel, &s);
+    if (rc) return rc;
+    chv_tick t;
+    memset(&t, 0, sizeof t);
+    t.target = *target;
+    chv_layer layer;
+    if (s.is_clear) {
+        t.clear_first = 1;
+        t.n_layers = 0;
+    } else {
+        if (n_inputs != 1 || !inputs)
+            return fail(CHV_ERR_BAD_INPUT, "%s takes exactly one input image, got %d", chv_kernel_name(kernel), n_inputs);
+        if (!uniforms || uniforms_size != sizeof(chv_uniforms))
+            return fail(CHV_ERR_INVALID_VALUE, "%s needs the 236-byte ImageUniforms, got %zu bytes", chv_kernel_name(kernel), uniforms_size);
+        if (!blends)
+            return fail(CHV_ERR_INVALID_OPERATION, "%s reads the current target; call it with blends = true", chv_kernel_name(kernel));
+        memset(&layer, 0, sizeof layer);
+        layer.kernel = kernel;
+        layer.image = inputs[0];
+        memcpy(&layer.uniforms, uniforms, sizeof(chv_uniforms));
+        if (opts) layer.opts = *opts;
+        t.clear_first = 0;
+        t.n_layers = 1;
+        t.layers = &layer;
+    }
+    DTick dt;
+    std::vector<DLayer> dl;
+    int tf = -1;
+    rc = tick_to_device(t, c->device, s.is_clear ? s.target_format : -1, &dt, &dl, &tf);
+    if (rc) return rc;
+    return launch_transient(c, dt, dl, tf);
+}
+
+extern "C" int chv_composite(chv_context *c, const chv_image *target, int clear_first,
+                             const chv_layer *layers, int n_layers) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!target) return fail(CHV_ERR_BAD_TARGET, "null target");
+    chv_tick t;
+    memset(&t, 0, sizeof t);
+    t.target = *target;
+    t.clear_first = clear_first;
+    t.n_layers = n_layers;
+    t.layers = layers;
+    DTick dt;
+    std::vector<DLayer> dl;
+    int tf = -1;
+    int rc = tick_to_device(t, c->device, -1, &dt, &dl, &tf);
+    if (rc) return rc;
+    return launch_transient(c, dt, dl, tf);
+}
+
+// ---------------------------------------------------------------------------
+// batches
+// ---------------------------------------------------------------------------
+extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_ticks, chv_batch **out) {
+    if (!out) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    *out = nullptr;
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!ticks || n_ticks <= 0) return fail(CHV_ERR_INVALID_VALUE, "empty batch");
+    if (n_ticks > 65535) return fail(CHV_ERR_INVALID_VALUE, "at most 65535 ticks per batch");
+    std::vector<DTick> dts((size_t)n_ticks);
+    std::vector<DLayer> dls;
+    int tf0 = -1, maxW = 0, maxH = 0;
+    for (int i = 0; i < n_ticks; i++) {
+        int tf = -1;
+        int rc = tick_to_device(ticks[i], c->device, -1, &dts[i], &dls, &tf);
+        if (rc) return rc;
+        if (tf0 < 0) tf0 = tf;
+        else if (tf != tf0) return fail(CHV_ERR_BAD_TARGET, "all ticks of a batch must share the target format");
+        if (dts[i].W > maxW) maxW = dts[i].W;
+        if (dts[i].H > maxH) maxH = dts[i].H;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    std::unique_ptr<chv_batch> b(new chv_batch);
+    b->device = c->device; b->n_ticks = n_ticks; b->n_layers = (int)dls.size();
+    b->target_format = tf0; b->maxW = maxW; b->maxH = maxH;
+    HIP_TRY(hipMalloc((void **)&b->d_ticks, sizeof(DTick) * dts.size()));
+    hipError_t e = hipMalloc((void **)&b->d_layers, sizeof(DLayer) * (dls.size() ? dls.size() : 1));
+    if (e != hipSuccess) { (void)hipFree(b->d_ticks); return hip_fail(e, "hipMalloc(layers)"); }
+    e = hipMemcpy(b->d_ticks, dts.data(), sizeof(DTick) * dts.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !dls.empty())
+        e = hipMemcpy(b->d_layers, dls.data(), sizeof(DLayer) * dls.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(b->d_ticks); (void)hipFree(b->d_layers); return hip_fail(e, "hipMemcpy(descriptors)"); }
+    b->fast_path = select_fast_path(tf0, dts.data(), dls.data(), n_ticks);
+    if (b->fast_path >= 0) b->kernel_name = fast_path_name(b->fast_path);
+    else b->kernel_name = tf0 == TF_BGRA ? "tick_general_bgra" : (tf0 == TF_NV12 ? "tick_general_yuv<nv12>" : "tick_general_yuv<y420p>");
+    *out = b.release();
+    return CHV_OK;
+}
+
+extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!b || !b->d_ticks) return fail(CHV_ERR_INVALID_VALUE, "bad batch");
+    if (b->device != c->device) return fail(CHV_ERR_INVALID_CONTEXT, "batch belongs to device %d", b->device);
+    HIP_TRY(hipSetDevice(c->device));
+    hipError_t e = b->fast_path >= 0
+        ? launch_tick_fast(b->fast_path, b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
+        : launch_tick_general(b->target_format, b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return CHV_OK;
+}
+
+extern "C" int chv_batch_destroy(chv_batch *b) {
+    if (!b) return fail(CHV_ERR_INVALID_VALUE, "null batch");
+    (void)hipSetDevice(b->device);
+    (void)hipFree(b->d_ticks);
+    (void)hipFree(b->d_layers);
+    b->d_ticks = nullptr;
+    delete b;
+    return CHV_OK;
+}
+
+extern "C" int chv_batch_describe(chv_batch *b, char *kernel_name, size_t cap, int *n_launches) {
+    if (!b) return fail(CHV_ERR_INVALID_VALUE, "null batch");
+    if (kernel_name && cap) snprintf(kernel_name, cap, "%s", b->kernel_name.c_str());
+    if (n_launches) *n_launches = 1;
+    return CHV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Lanczos-3: tables in double on the host, resampling on the GPU
+// ---------------------------------------------------------------------------
+static double sinc_pi(double t) {
+    if (t == 0.0) return 1.0;
+    double pt = 3.14159265358979323846 * t;
+    return std::sin(pt) / pt;
+}
+
+static int lanczos_host_table(int in_size, int out_size, int *taps_out, std::vector<int32_t> *first,
+                              std::vector<float> *weights) {
+    double scale = (double)in_size / (double)out_size;
+    double fs = scale > 1.0 ? scale : 1.0;
+    double support = 3.0 * fs;
+    int taps = 2 * (int)std::ceil(support);
+    if (taps > 256) return fail(CHV_ERR_INVALID_VALUE, "Lanczos ratio %d:%d needs %d taps (max 256)", in_size, out_size, taps);
+    first->resize(out_size);
+    weights->resize((size_t)out_size * taps);
+    std::vector<double> w(taps);
+    for (int o = 0; o < out_size; o++) {
+        double center = ((double)o + 0.5) * scale - 0.5;
+        int f = (int)std::floor(center - support) + 1;
+        double sum = 0.0;
+        for (int k = 0; k < taps; k++) {
+            double t = ((double)(f + k) - center) / fs;
+            double v = (t > -3.0 && t < 3.0) ? sinc_pi(t) * sinc_pi(t / 3.0) : 0.0;
+            w[k] = v;
+            sum += v;
+        }
+        (*first)[o] = f;
+        for (int k = 0; k < taps; k++) (*weights)[(size_t)o * taps + k] = (float)(w[k] / sum);
+    }
+    *taps_out = taps;
+    return CHV_OK;
+}
+
+static int lanczos_table(chv_context *c, int in_size, int out_size, LanczosTable *out) {
+    std::lock_guard<std::mutex> lock(c->shared->mu);
+    auto key = std::make_pair(in_size, out_size);
+    auto it = c->shared->lanczos.find(key);
+    if (it != c->shared->lanczos.end()) { *out = it->second; return CHV_OK; }
+    std::vector<int32_t> first;
+    std::vector<float> weights;
+    LanczosTable t;
+    int rc = lanczos_host_table(in_size, out_size, &t.taps, &first, &weights);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc((void **)&t.first, first.size() * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void **)&t.weights, weights.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(t.first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.weights, weights.data(), weights.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->shared->lanczos[key] = t;
+    *out = t;
+    return CHV_OK;
+}
+
+extern "C" int chv_scale_lanczos(chv_context *c, const chv_image *dst, const chv_image *src) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!dst || dst->n_planes != 1) return fail(CHV_ERR_BAD_TARGET, "Lanczos target must be one 4-component plane");
+    if (!src || src->n_planes != 1) return fail(CHV_ERR_BAD_INPUT, "Lanczos source must be one 4-component plane");
+    DPlane d, s;
+    int rc = plane_to_device(dst->planes[0], 4, c->device, &d, CHV_ERR_BAD_TARGET, "target", 0);
+    if (rc) return rc;
+    rc = plane_to_device(src->planes[0], 4, c->device, &s, CHV_ERR_BAD_INPUT, "input", 0);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    LanczosTable tx, ty;
+    rc = lanczos_table(c, s.w, d.w, &tx);
+    if (rc) return rc;
+    rc = lanczos_table(c, s.h, d.h, &ty);
+    if (rc) return rc;
+    hipError_t e = launch_lanczos(d, s, tx.first, tx.weights, tx.taps, ty.first, ty.weights, ty.taps, c->stream);
+    if (e != hipSuccess) return hip_fail(e, "lanczos launch");
+    return CHV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// events
+// ---------------------------------------------------------------------------
+extern "C" int chv_event_create(chv_context *c, chv_event **out) {
+    if (!out) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    *out = nullptr;
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    chv_event *e = new chv_event;
+    e->ev = ev; e->device = c->device;
+    *out = e;
+    return CHV_OK;
+}
+extern "C" int chv_event_record(chv_context *c, chv_event *ev) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!ev || !ev->ev) return fail(CHV_ERR_INVALID_VALUE, "bad event");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(ev->ev, c->stream));
+    return CHV_OK;
+}
+extern "C" int chv_event_synchronize(chv_event *ev) {
+    if (!ev || !ev->ev) return fail(CHV_ERR_INVALID_VALUE, "bad event");
+    HIP_TRY(hipSetDevice(ev->device));
+    HIP_TRY(hipEventSynchronize(ev->ev));
+    return CHV_OK;
+}
+extern "C" int chv_event_elapsed_ms(chv_event *a, chv_event *b, float *ms) {
+    if (!a || !b || !ms) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    HIP_TRY(hipSetDevice(a->device));
+    HIP_TRY(hipEventElapsedTime(ms, a->ev, b->ev));
+    return CHV_OK;
+}
+extern "C" int chv_event_destroy(chv_event *ev) {
+    if (!ev) return fail(CHV_ERR_INVALID_VALUE, "null event");
+    (void)hipSetDevice(ev->device);
+    if (ev->ev) (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return CHV_OK;
+}
+extern "C" int chv_device_synchronize(chv_context *c) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return CHV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// device self-test of the primitive conversions; not part of chipvideo.h
+// (bound by tests/test_gpu_primitives.py only)
+// ---------------------------------------------------------------------------
+extern "C" int chv_selftest_primitives(chv_context *c, float *unorm_out /*256*/, const float *in_f,
+                                       uint8_t *codes_out, const float *num, const float *den,
+                                       float *quot_out, int n) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (n < 0 || !unorm_out) return fail(CHV_ERR_INVALID_VALUE, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    float *d_f = nullptr, *d_in = nullptr, *d_num = nullptr, *d_den = nullptr, *d_q = nullptr;
+    uint8_t *d_c = nullptr;
+    size_t m = n > 0 ? (size_t)n : 1;
+    HIP_TRY(hipMalloc((void **)&d_f, 256 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&d_in, m * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&d_num, m * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&d_den, m * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&d_q, m * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&d_c, m));
+    if (n > 0) {
+        HIP_TRY(hipMemcpy(d_in, in_f, n * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_num, num, n * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_den, den, n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    hipError_t e = launch_selftest(d_f, d_in, d_c, d_num, d_den, d_q, n, c->stream);
+    if (e != hipSuccess) return hip_fail(e, "selftest launch");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(unorm_out, d_f, 256 * sizeof(float), hipMemcpyDeviceToHost));
+    if (n > 0) {
+        HIP_TRY(hipMemcpy(codes_out, d_c, n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(quot_out, d_q, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_f); (void)hipFree(d_in); (void)hipFree(d_num); (void)hipFree(d_den); (void)hipFree(d_q); (void)hipFree(d_c);
+    return CHV_OK;
+}

@@ -1,0 +1,65 @@
+// device_types.h — descriptors shared by the host runtime and the gfx950 kernels.
+//
+// A "tick" is one VideoMixer.mix pass (mix.video.swift:116-124): an optional
+// clear of the canvas followed by n_layers applyComputeImage calls in z order.
+// Descriptors live in device memory; a kernel block reads the one it owns with
+// wave-uniform (scalar) loads.
+#pragma once
+#include <stdint.h>
+
+namespace chv {
+
+struct DPlane {
+    uint8_t *ptr;
+    int32_t w, h;      // texels
+    int32_t pitch;     // bytes
+    int32_t comps;     // bytes per texel
+};
+
+struct DImage {
+    DPlane pl[3];
+};
+
+// How a layer is applied; derived on the host from (kernel id, target format).
+enum LayerKind : int32_t {
+    LK_YUV_FROM_NV12 = 0,   // img_nv12_nv12
+    LK_YUV_FROM_Y420P = 1,  // img_y420p_nv12 / img_y420p_y420p
+    LK_YUV_FROM_RGB = 2,    // img_{bgra,rgba}_{nv12,y420p}; swizzle flag for bgra
+    LK_BGRA_FROM_NV12 = 3,  // img_nv12_bgra
+    LK_BGRA_FROM_Y420P = 4, // img_y420p_bgra
+    LK_BGRA_FROM_RGB = 5,   // img_{bgra,rgba}_bgra_tx; swizzle flag for rgba
+    LK_BGRA_METAL = 6       // img_bgra_bgra, kernels.metal:52-62
+};
+
+struct DLayer {
+    DImage src;
+    float u[59];        // ImageUniforms, compute.swift:76-86
+    int32_t kind;       // LayerKind
+    int32_t swizzle;    // 1: exchange byte 0 and byte 2 of the sampled texel
+    int32_t csc;        // chv_colorspace
+    int32_t flags;      // LF_* below (host-side analysis; fast paths only)
+    int32_t pad;
+};
+
+enum LayerFlags : int32_t {
+    LF_AXIS_ALIGNED = 1,  // no rotation/shear: tx.x/uv.x depend on x only, tx.y/uv.y on y only
+    LF_NO_FILL = 2,       // opacity * fillColor.w == 0 exactly
+    LF_OPAQUE = 4         // opacity == 1 exactly
+};
+
+enum TargetFormat : int32_t { TF_NV12 = 0, TF_Y420P = 1, TF_BGRA = 2 };
+
+struct DTick {
+    DImage dst;
+    int32_t W, H;          // launch domain = plane 0 size (compute.cl.swift:329)
+    int32_t clear_first;
+    int32_t n_layers;
+    int32_t first_layer;   // index into the batch's DLayer array
+    int32_t pad;
+};
+
+// uniforms blob offsets (floats)
+enum { U_TRANSFORM = 0, U_TEXTURE = 16, U_BORDER = 32, U_FILL = 48, U_INSIZE = 52,
+       U_OUTSIZE = 54, U_OPACITY = 56, U_IMAGETIME = 57, U_TARGETTIME = 58 };
+
+}  // namespace chv

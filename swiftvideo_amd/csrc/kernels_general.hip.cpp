@@ -1,0 +1,287 @@
+// kernels_general.hip.cpp — the general (any affine transform) tick kernels.
+//
+// One launch = a batch of mixer ticks (grid.z = tick).  Each thread owns one
+// canvas pixel (BGRA target) or one 2x2 luma quad + its chroma sample (4:2:0
+// targets: the quad's even/even pixel is the reference's `handleChroma` owner,
+// kernels.cl.swift:76), keeps the canvas value in registers as 8-bit codes,
+// applies every layer of the tick in z order and stores once.  Between layers
+// the value is re-quantised exactly as the reference's per-layer kernels do
+// through their UNORM8 canvas (write_imagef then read_imagef), so the result is
+// byte-identical to clear + N x runComputeKernel(blends: true)
+// (mix.video.swift:116-124, compute.cl.swift:288-335).
+//
+// Sources are gathered straight from global memory; the axis-aligned LDS-tiled
+// fast paths live in kernels_fast.hip.cpp.
+#include "pixel_math.hip.h"
+
+#pragma clang fp contract(off)
+
+namespace chv {
+
+// ---------------------------------------------------------------------------
+// BGRA target
+// ---------------------------------------------------------------------------
+CHV_DEV uint32_t apply_layer_bgra(const DLayer &L, int x, int y, float sx, float sy, uint32_t cur) {
+    const float *U = L.u;
+    if (L.kind == LK_BGRA_METAL) {
+        // kernels.metal:52-62
+        float rx = U[U_INSIZE + 0] / U[U_OUTSIZE + 0];
+        float ry = U[U_INSIZE + 1] / U[U_OUTSIZE + 1];
+        int ix = min(max((int)((float)x * rx), 0), L.src.pl[0].w - 1);
+        int iy = min(max((int)((float)y * ry), 0), L.src.pl[0].h - 1);
+        uint32_t s = *(const uint32_t *)(L.src.pl[0].ptr + (size_t)iy * L.src.pl[0].pitch + (size_t)ix * 4);
+        float a = unorm8(s >> 24);
+        float ia = 1.0f - a;
+        uint32_t o0 = to_code(unorm8(s & 255) * a + unorm8(cur & 255) * ia);
+        uint32_t o1 = to_code(unorm8((s >> 8) & 255) * a + unorm8((cur >> 8) & 255) * ia);
+        uint32_t o2 = to_code(unorm8((s >> 16) & 255) * a + unorm8((cur >> 16) & 255) * ia);
+        return o0 | (o1 << 8) | (o2 << 16) | 0xFF000000u;
+    }
+    Geo g = geometry(U, x, y, sx, sy);
+    if (!g.in_border) return cur;
+    // fill colour under the picture / on the border, straight alpha
+    float af = U[U_OPACITY] * U[U_FILL + 3];
+    float iaf = 1.f - af;
+    float r0 = clampf(unorm8(cur & 255) * iaf + U[U_FILL + 2] * af, 0.f, 1.f);          // B
+    float r1 = clampf(unorm8((cur >> 8) & 255) * iaf + U[U_FILL + 1] * af, 0.f, 1.f);   // G
+    float r2 = clampf(unorm8((cur >> 16) & 255) * iaf + U[U_FILL + 0] * af, 0.f, 1.f);  // R
+    if (g.in_tx && g.in_uv) {
+        float p0, p1, p2, a;
+        if (L.kind == LK_BGRA_FROM_RGB) {
+            const DPlane &P = L.src.pl[0];
+            Lin2 l = lin_setup(P, g.u, g.v);
+            uint32_t t00 = *(const uint32_t *)(P.ptr + l.o00), t10 = *(const uint32_t *)(P.ptr + l.o10);
+            uint32_t t01 = *(const uint32_t *)(P.ptr + l.o01), t11 = *(const uint32_t *)(P.ptr + l.o11);
+            float q0 = lin_mix(l, unorm8(t00 & 255), unorm8(t10 & 255), unorm8(t01 & 255), unorm8(t11 & 255));
+            float q1 = lin_mix(l, unorm8((t00 >> 8) & 255), unorm8((t10 >> 8) & 255),
+                               unorm8((t01 >> 8) & 255), unorm8((t11 >> 8) & 255));
+            float q2 = lin_mix(l, unorm8((t00 >> 16) & 255), unorm8((t10 >> 16) & 255),
+                               unorm8((t01 >> 16) & 255), unorm8((t11 >> 16) & 255));
+            float q3 = lin_mix(l, unorm8(t00 >> 24), unorm8(t10 >> 24), unorm8(t01 >> 24), unorm8(t11 >> 24));
+            p0 = L.swizzle ? q2 : q0; p1 = q1; p2 = L.swizzle ? q0 : q2;
+            a = q3 * U[U_OPACITY];
+        } else {
+            Lin2 ly = lin_setup(L.src.pl[0], g.u, g.v);
+            Lin2 lc = lin_setup(L.src.pl[1], g.u, g.v);
+            float fy = lin_fetch(L.src.pl[0], ly, 0), fu, fv;
+            if (L.kind == LK_BGRA_FROM_NV12) {
+                fu = lin_fetch(L.src.pl[1], lc, 0);
+                fv = lin_fetch(L.src.pl[1], lc, 1);
+            } else {
+                fu = lin_fetch(L.src.pl[1], lc, 0);
+                Lin2 lv = lin_setup(L.src.pl[2], g.u, g.v);
+                fv = lin_fetch(L.src.pl[2], lv, 0);
+            }
+            uint32_t w = yuv_to_bgra_word(kCsc[L.csc & 3], (int)to_code(fy), (int)to_code(fu), (int)to_code(fv));
+            p0 = unorm8(w & 255); p1 = unorm8((w >> 8) & 255); p2 = unorm8((w >> 16) & 255);
+            a = 1.0f * U[U_OPACITY];
+        }
+        float ia = 1.f - a;
+        r0 = r0 * ia + p0 * a;
+        r1 = r1 * ia + p1 * a;
+        r2 = r2 * ia + p2 * a;
+    }
+    return to_code(r0) | (to_code(r1) << 8) | (to_code(r2) << 16) | 0xFF000000u;
+}
+
+__global__ __launch_bounds__(256) void tick_general_bgra(const DTick *__restrict__ ticks,
+                                                         const DLayer *__restrict__ layers) {
+    const DTick &T = ticks[blockIdx.z];
+    int x = blockIdx.x * 64 + threadIdx.x;
+    int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= T.W || y >= T.H) return;
+    const DPlane &D = T.dst.pl[0];
+    if (x >= D.w || y >= D.h) return;
+    uint32_t *dp = (uint32_t *)(D.ptr + (size_t)y * D.pitch + (size_t)x * 4);
+    // img_clear_bgra: (0,0,0,1), kernels.cl.swift:257-265
+    uint32_t cur = T.clear_first ? 0xFF000000u : *dp;
+    float sx = (float)T.W, sy = (float)T.H;
+    const DLayer *L = layers + T.first_layer;
+    for (int l = 0; l < T.n_layers; l++) cur = apply_layer_bgra(L[l], x, y, sx, sy, cur);
+    *dp = cur;
+}
+
+// ---------------------------------------------------------------------------
+// 4:2:0 targets (NV12 / Y420P)
+// ---------------------------------------------------------------------------
+struct QuadState {
+    uint32_t y[4];   // luma codes of (2qx+i, 2qy+j), index j*2+i
+    uint32_t u, v;   // chroma codes at (qx, qy)
+};
+
+// YUV source: kernels.cl.swift:78-105 (img_nv12_nv12), :141-170, :219-252
+CHV_DEV void apply_yuv_from_yuv(const DLayer &L, int x, int y, float sx, float sy, bool owner,
+                                uint32_t &cy, uint32_t &cu, uint32_t &cv) {
+    const float *U = L.u;
+    Geo g = geometry(U, x, y, sx, sy);
+    if (!g.in_border) return;
+    float curY = unorm8(cy);
+    if (g.in_tx && g.in_uv) {
+        Lin2 ly = lin_setup(L.src.pl[0], g.u, g.v);
+        float luma = lin_fetch(L.src.pl[0], ly, 0);
+        float alpha = U[U_OPACITY];
+        cy = to_code(curY * (1.f - alpha) + luma * alpha);
+        if (owner) {
+            float cb, cr;
+            Lin2 lc = lin_setup(L.src.pl[1], g.u, g.v);  // same normalized uv on the half-size plane
+            if (L.kind == LK_YUV_FROM_NV12) {
+                cb = lin_fetch(L.src.pl[1], lc, 0);
+                cr = lin_fetch(L.src.pl[1], lc, 1);
+            } else {
+                cb = lin_fetch(L.src.pl[1], lc, 0);
+                Lin2 lv = lin_setup(L.src.pl[2], g.u, g.v);
+                cr = lin_fetch(L.src.pl[2], lv, 0);
+            }
+            cu = to_code(unorm8(cu) * (1.f - alpha) + cb * alpha);
+            cv = to_code(unorm8(cv) * (1.f - alpha) + cr * alpha);
+        }
+        return;
+    }
+    float fy, fu, fv;
+    rgb2yuv(U[U_FILL + 0], U[U_FILL + 1], U[U_FILL + 2], fy, fu, fv);
+    float alpha = U[U_OPACITY] * U[U_FILL + 3];
+    cy = to_code(clampf(curY * (1.f - alpha) + fy * alpha, 0.f, 1.f));
+    if (owner) {
+        cu = to_code(clampf(unorm8(cu) * (1.f - alpha) + fu * alpha, -1.f, 1.f));
+        cv = to_code(clampf(unorm8(cv) * (1.f - alpha) + fv * alpha, -1.f, 1.f));
+    }
+}
+
+// RGB source: kernels.cl.swift:495-530 (img_bgra_nv12) and its three siblings
+CHV_DEV void apply_yuv_from_rgb(const DLayer &L, int x, int y, float sx, float sy, bool owner,
+                                uint32_t &cy, uint32_t &cu, uint32_t &cv) {
+    const float *U = L.u;
+    Geo g = geometry(U, x, y, sx, sy);
+    if (!g.in_border || !g.in_tx) return;
+    float alpha = U[U_OPACITY] * U[U_FILL + 3];
+    float fy, fu, fv;
+    rgb2yuv(U[U_FILL + 0] * alpha, U[U_FILL + 1] * alpha, U[U_FILL + 2] * alpha, fy, fu, fv);
+    float rx = unorm8(cy) * (1.f - alpha) + fy * alpha;
+    float ry = clampf(unorm8(cu) * (1.f - alpha) + fu * alpha, -1.f, 1.f);
+    float rz = clampf(unorm8(cv) * (1.f - alpha) + fv * alpha, -1.f, 1.f);
+    if (g.in_uv) {
+        const DPlane &P = L.src.pl[0];
+        Lin2 l = lin_setup(P, g.u, g.v);
+        uint32_t t00 = *(const uint32_t *)(P.ptr + l.o00), t10 = *(const uint32_t *)(P.ptr + l.o10);
+        uint32_t t01 = *(const uint32_t *)(P.ptr + l.o01), t11 = *(const uint32_t *)(P.ptr + l.o11);
+        float q0 = lin_mix(l, unorm8(t00 & 255), unorm8(t10 & 255), unorm8(t01 & 255), unorm8(t11 & 255));
+        float q1 = lin_mix(l, unorm8((t00 >> 8) & 255), unorm8((t10 >> 8) & 255),
+                           unorm8((t01 >> 8) & 255), unorm8((t11 >> 8) & 255));
+        float q2 = lin_mix(l, unorm8((t00 >> 16) & 255), unorm8((t10 >> 16) & 255),
+                           unorm8((t01 >> 16) & 255), unorm8((t11 >> 16) & 255));
+        float q3 = lin_mix(l, unorm8(t00 >> 24), unorm8(t10 >> 24), unorm8(t01 >> 24), unorm8(t11 >> 24));
+        float r = L.swizzle ? q2 : q0, gg = q1, b = L.swizzle ? q0 : q2;  // .zyxw for bgra, :518
+        float a2 = q3 * U[U_OPACITY];
+        float yy, uu, vv;
+        rgb2yuv(r * a2, gg * a2, b * a2, yy, uu, vv);
+        rx = rx * (1.f - a2) + yy * a2;
+        ry = ry * (1.f - a2) + uu * a2;
+        rz = rz * (1.f - a2) + vv * a2;
+    }
+    cy = to_code(rx);
+    if (owner) { cu = to_code(ry); cv = to_code(rz); }
+}
+
+template <int TF>
+__global__ __launch_bounds__(256) void tick_general_yuv(const DTick *__restrict__ ticks,
+                                                        const DLayer *__restrict__ layers) {
+    const DTick &T = ticks[blockIdx.z];
+    int qx = blockIdx.x * 32 + threadIdx.x;
+    int qy = blockIdx.y * 8 + threadIdx.y;
+    int x0 = qx * 2, y0 = qy * 2;
+    if (x0 >= T.W || y0 >= T.H) return;
+    const DPlane &PY = T.dst.pl[0];
+    const DPlane &PC = T.dst.pl[1];
+    bool hx = x0 + 1 < T.W, hy = y0 + 1 < T.H;
+    // gid/2 can fall outside the chroma plane on odd-sized canvases: such reads
+    // are zero and such writes are dropped (oracle/ref_kernels.c, rd_near1/wr1)
+    bool cvalid = qx < PC.w && qy < PC.h;
+    uint8_t *py0 = PY.ptr + (size_t)y0 * PY.pitch + x0;
+    uint8_t *py1 = py0 + PY.pitch;
+    uint8_t *pu, *pv;
+    if (TF == TF_NV12) { pu = PC.ptr + (size_t)qy * PC.pitch + (size_t)qx * 2; pv = pu + 1; }
+    else {
+        pu = PC.ptr + (size_t)qy * PC.pitch + qx;
+        pv = T.dst.pl[2].ptr + (size_t)qy * T.dst.pl[2].pitch + qx;
+    }
+    QuadState s;
+    if (T.clear_first) {
+        // img_clear_nv12 / img_clear_y420p: Y = 0.0, chroma = 0.5 -> code 128 (RTE)
+        s.y[0] = s.y[1] = s.y[2] = s.y[3] = 0;
+        s.u = s.v = cvalid ? 128u : 0u;
+    } else {
+        s.y[0] = py0[0];
+        s.y[1] = hx ? py0[1] : 0;
+        s.y[2] = hy ? py1[0] : 0;
+        s.y[3] = (hx && hy) ? py1[1] : 0;
+        s.u = cvalid ? *pu : 0;
+        s.v = cvalid ? *pv : 0;
+    }
+    float sx = (float)T.W, sy = (float)T.H;
+    const DLayer *L = layers + T.first_layer;
+    for (int l = 0; l < T.n_layers; l++) {
+        const DLayer &Ly = L[l];
+        if (!cvalid) { s.u = 0; s.v = 0; }
+        uint32_t du = 0, dv = 0;  // chroma of non-owner pixels: computed by the reference, never stored
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int i = k & 1, j = k >> 1;
+            if ((i && !hx) || (j && !hy)) continue;
+            bool owner = (k == 0);
+            if (Ly.kind == LK_YUV_FROM_RGB)
+                apply_yuv_from_rgb(Ly, x0 + i, y0 + j, sx, sy, owner, s.y[k], owner ? s.u : du, owner ? s.v : dv);
+            else
+                apply_yuv_from_yuv(Ly, x0 + i, y0 + j, sx, sy, owner, s.y[k], owner ? s.u : du, owner ? s.v : dv);
+        }
+    }
+    py0[0] = (uint8_t)s.y[0];
+    if (hx) py0[1] = (uint8_t)s.y[1];
+    if (hy) py1[0] = (uint8_t)s.y[2];
+    if (hx && hy) py1[1] = (uint8_t)s.y[3];
+    if (cvalid) { *pu = (uint8_t)s.u; *pv = (uint8_t)s.v; }
+}
+
+// ---------------------------------------------------------------------------
+// launchers (called from chipvideo.cpp)
+// ---------------------------------------------------------------------------
+hipError_t launch_tick_general(int target_format, const DTick *ticks, const DLayer *layers,
+                               int n_ticks, int maxW, int maxH, hipStream_t stream) {
+    if (n_ticks <= 0) return hipSuccess;
+    if (target_format == TF_BGRA) {
+        dim3 block(64, 4), grid((maxW + 63) / 64, (maxH + 3) / 4, n_ticks);
+        hipLaunchKernelGGL(tick_general_bgra, grid, block, 0, stream, ticks, layers);
+    } else {
+        int qw = (maxW + 1) / 2, qh = (maxH + 1) / 2;
+        dim3 block(32, 8), grid((qw + 31) / 32, (qh + 7) / 8, n_ticks);
+        if (target_format == TF_NV12)
+            hipLaunchKernelGGL(tick_general_yuv<TF_NV12>, grid, block, 0, stream, ticks, layers);
+        else
+            hipLaunchKernelGGL(tick_general_yuv<TF_Y420P>, grid, block, 0, stream, ticks, layers);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// device self-test of the primitive conversions (tests/test_gpu_primitives.py)
+// out_f[0..255]   = unorm8(c)
+// out_c[i]        = to_code(in_f[i])            i < n
+// out_q[i]        = (float)num[i] / den[i]      i < n   (division used by `geometry`)
+// ---------------------------------------------------------------------------
+__global__ void selftest_kernel(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
+                                const float *den, float *out_q, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 256) out_f[i] = unorm8((uint32_t)i);
+    if (i < n) {
+        out_c[i] = (uint8_t)to_code(in_f[i]);
+        out_q[i] = num[i] / den[i];
+    }
+}
+hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
+                           const float *den, float *out_q, int n, hipStream_t stream) {
+    int m = n > 256 ? n : 256;
+    hipLaunchKernelGGL(selftest_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, out_f, in_f, out_c,
+                       num, den, out_q, n);
+    return hipGetLastError();
+}
+
+}  // namespace chv

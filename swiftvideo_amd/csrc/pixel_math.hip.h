@@ -1,0 +1,152 @@
+// pixel_math.hip.h — device-side arithmetic of the SwiftVideo picture kernels
+// for gfx950.  All float math is IEEE binary32, evaluated in the reference's
+// source order with contraction disabled (this file is compiled with
+// -ffp-contract=off and the pragma below); the few fused operations are
+// written explicitly with __builtin_fmaf where a single rounding is intended.
+//
+// Semantics (bit-exact contract, checked by tests/ against oracle/):
+//   sampler      — Khronos OpenCL 1.2 section 8.2, LINEAR / CLAMP_TO_EDGE /
+//                  normalized coords, as bound by kernels.cl.swift:61
+//   unorm8 load  — c / 255.0f correctly rounded      (OpenCL 1.2 section 8.3.1.1)
+//   unorm8 store — convert_uchar_sat_rte(f * 255.0f), NaN -> 0
+//   dot()        — ((x+y)+z)+w, kernels.cuda.swift:45-47
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+#pragma clang fp contract(off)
+
+namespace chv {
+
+#define CHV_DEV __device__ __forceinline__
+
+// c / 255.0f, correctly rounded, without a divide: one Newton step on
+// q = c * RN(1/255) with the residual taken in a fused op is exact for all 256
+// codes (exhaustively checked on device by tests/test_gpu_primitives.py).
+CHV_DEV float unorm8(uint32_t c) {
+    const float r = 0x1.010102p-8f;  // RN(1/255)
+    float f = (float)c;
+    float q = f * r;
+    float e = __builtin_fmaf(-q, 255.0f, f);
+    return __builtin_fmaf(e, r, q);
+}
+
+// convert_uchar_sat_rte(f * 255.0f); fmaxf drops a NaN operand, so NaN -> 0.
+CHV_DEV uint32_t to_code(float f) {
+    float v = __builtin_rintf(f * 255.0f);
+    v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);
+    return (uint32_t)v;
+}
+// same for a value already on the 0..255 code scale (Lanczos output)
+CHV_DEV uint32_t to_code_raw(float v) {
+    v = __builtin_rintf(v);
+    v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);
+    return (uint32_t)v;
+}
+
+CHV_DEV float clampf(float v, float lo, float hi) {
+    return __builtin_fminf(__builtin_fmaxf(v, lo), hi);
+}
+
+CHV_DEV float dot4(float x, float y, float z, float w, const float *__restrict__ r) {
+    return ((x * r[0] + y * r[1]) + z * r[2]) + w * r[3];
+}
+
+// Geometry prologue shared by the composite family (kernels.cl.swift:70-77).
+struct Geo {
+    float tx, ty;    // tx.xy
+    float u, v;      // uv.xy
+    bool in_border, in_tx, in_uv;
+};
+
+CHV_DEV Geo geometry(const float *__restrict__ U, int x, int y, float sx, float sy) {
+    Geo g;
+    float ou = (float)x / sx;          // true division: out_uv = gid / size
+    float ov = (float)y / sy;
+    float nx = ou * 2.f - 1.f, ny = ov * 2.f - 1.f;
+    float t0 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 0);
+    float t1 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 4);
+    float t2 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 8);
+    float t3 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 12);
+    float b0 = dot4(nx, ny, 0.f, 1.f, U + U_BORDER + 0);
+    float b1 = dot4(nx, ny, 0.f, 1.f, U + U_BORDER + 4);
+    g.tx = t0; g.ty = t1;
+    g.u = dot4(t0, t1, t2, t3, U + U_TEXTURE + 0);
+    g.v = dot4(t0, t1, t2, t3, U + U_TEXTURE + 4);
+    g.in_border = b0 >= 0.f && b1 >= 0.f && b0 <= 1.f && b1 <= 1.f;
+    g.in_tx = t0 >= 0.f && t1 >= 0.f && t0 <= 1.f && t1 <= 1.f;
+    g.in_uv = g.u >= 0.f && g.v >= 0.f && g.u <= 1.f && g.v <= 1.f;
+    return g;
+}
+
+// One axis of the linear filter: u = s*w; i0 = floor(u-0.5); a = frac(u-0.5).
+struct Lin1 {
+    int i0, i1;
+    float a;
+};
+CHV_DEV Lin1 lin_axis(float s, int w) {
+    Lin1 r;
+    float um = s * (float)w - 0.5f;
+    float fl = __builtin_floorf(um);
+    r.a = um - fl;
+    int i = (int)fl;
+    r.i0 = min(max(i, 0), w - 1);
+    r.i1 = min(max(i + 1, 0), w - 1);
+    return r;
+}
+
+struct Lin2 {
+    int o00, o10, o01, o11;  // byte offsets of the four taps' texels
+    float w00, w10, w01, w11;
+};
+CHV_DEV Lin2 lin_setup(const DPlane &p, float s, float t) {
+    Lin1 lx = lin_axis(s, p.w), ly = lin_axis(t, p.h);
+    Lin2 l;
+    int r0 = ly.i0 * p.pitch, r1 = ly.i1 * p.pitch;
+    int c0 = lx.i0 * p.comps, c1 = lx.i1 * p.comps;
+    l.o00 = r0 + c0; l.o10 = r0 + c1; l.o01 = r1 + c0; l.o11 = r1 + c1;
+    float ia = 1.0f - lx.a, ib = 1.0f - ly.a;
+    l.w00 = ia * ib;
+    l.w10 = lx.a * ib;
+    l.w01 = ia * ly.a;
+    l.w11 = lx.a * ly.a;
+    return l;
+}
+CHV_DEV float lin_mix(const Lin2 &l, float t00, float t10, float t01, float t11) {
+    return ((l.w00 * t00 + l.w10 * t10) + l.w01 * t01) + l.w11 * t11;
+}
+CHV_DEV float lin_fetch(const DPlane &p, const Lin2 &l, int c) {
+    const uint8_t *b = p.ptr + c;
+    return lin_mix(l, unorm8(b[l.o00]), unorm8(b[l.o10]), unorm8(b[l.o01]), unorm8(b[l.o11]));
+}
+
+// rgb2yuv rows, kernels.cl.swift:96-99 (0.113 is the reference's value).
+CHV_DEV void rgb2yuv(float r, float g, float b, float &y, float &u, float &v) {
+    // dot((r,g,b,1), row): the .w lane multiplies 1.0 by the row's offset
+    y = ((r * 0.299f + g * 0.587f) + b * 0.113f) + 1.0f * 0.f;
+    u = ((r * -0.169f + g * -0.331f) + b * 0.5f) + 1.0f * 0.5f;
+    v = ((r * 0.5f + g * -0.419f) + b * -0.081f) + 1.0f * 0.5f;
+}
+
+// Integer YUV -> RGB, 16.16 fixed point.
+struct Csc { int32_t yoff, cy, crv, cgu, cgv, cbu; };
+__device__ __constant__ const Csc kCsc[4] = {
+    { 16, 76309, 104597, 25675, 53279, 132201 },  // BT.601 limited
+    { 16, 76309, 117489, 13975, 34925, 138438 },  // BT.709 limited
+    { 0, 65536, 91881, 22553, 46802, 116130 },    // BT.601 full
+    { 0, 65536, 103206, 12276, 30679, 121609 },   // BT.709 full
+};
+CHV_DEV uint32_t clip8(int32_t v) { return (uint32_t)min(max(v, 0), 255); }
+// returns memory-order BGRA word: B | G<<8 | R<<16 | 255<<24
+CHV_DEV uint32_t yuv_to_bgra_word(const Csc &k, int y, int u, int v) {
+    int32_t c = k.cy * (y - k.yoff) + 32768;
+    int32_t d = u - 128, e = v - 128;
+    uint32_t r = clip8((c + k.crv * e) >> 16);
+    uint32_t g = clip8((c - k.cgu * d - k.cgv * e) >> 16);
+    uint32_t b = clip8((c + k.cbu * d) >> 16);
+    return b | (g << 8) | (r << 16) | 0xFF000000u;
+}
+
+}  // namespace chv

@@ -1,0 +1,173 @@
+"""HIP path (through the C ABI) == oracle, bit for bit, on identical seeded inputs."""
+import zlib
+
+import numpy as np
+import pytest
+
+import gpuutil as G
+import scenarios as S
+import util
+from oracle import oracle as O
+from swiftvideo_amd import compute as sv
+
+pytestmark = pytest.mark.gpu
+
+ALL_LAYER = S.LAYER_KERNELS_REF + S.LAYER_KERNELS_OWN
+
+
+@pytest.mark.parametrize("scenario", list(S.SCENARIOS))
+@pytest.mark.parametrize("kernel", ALL_LAYER)
+def test_layer_kernel_matches_oracle(ctx, kernel, scenario):
+    cw, ch, iw, ih, _ = S.SCENARIOS[scenario]
+    u = S.uniforms_for(scenario)
+    seed = (zlib.crc32(f"{kernel}/{scenario}".encode()) & 0xFFFF) + 1
+    got, exp = G.run_both(ctx, kernel, cw, ch, iw, ih, u, seed)
+    G.assert_same(got, exp, f"{kernel}/{scenario}")
+
+
+@pytest.mark.parametrize("csc", [0, 1, 2, 3])
+@pytest.mark.parametrize("kernel", ["img_nv12_bgra", "img_y420p_bgra"])
+def test_yuv_to_bgra_colorspaces(ctx, kernel, csc):
+    u = S.uniforms_for("downscale")
+    got, exp = G.run_both(ctx, kernel, 64, 36, 96, 54, u, seed=77 + csc, csc=csc, clear_first=True)
+    G.assert_same(got, exp, f"{kernel}/csc{csc}")
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "y420p", "bgra"])
+@pytest.mark.parametrize("size", [(64, 36), (7, 5), (1, 1), (130, 3)])
+def test_clear_kernels(ctx, fmt, size):
+    w, h = size
+    canvas0 = util.alloc_image(fmt, w, h, seed=5)
+    exp = util.copy_image(canvas0)
+    assert O.run_kernel(f"img_clear_{fmt}", exp) == 0
+    g = G.to_gpu(ctx, fmt, w, h, canvas0)
+    k = sv.defaultComputeKernelFromString(f"img_clear_{fmt}")
+    sv.usingContext(ctx, lambda c: sv.runComputeKernel(c, images=[], target=g, kernel=k))
+    G.assert_same(G.from_gpu(ctx, g, fmt, w, h), exp, f"clear {fmt} {size}")
+
+
+@pytest.mark.parametrize("insize", [(64, 36), (96, 54), (20, 11)])
+def test_metal_bgra_bgra(ctx, insize):
+    iw, ih = insize
+    u = util.full_canvas_uniforms((64, 36), (iw, ih))
+    got, exp = G.run_both(ctx, "img_bgra_bgra", 64, 36, iw, ih, u, seed=31)
+    G.assert_same(got, exp, "img_bgra_bgra (Metal semantics)")
+
+
+def _tick_layers(dst_fmt, cw, ch):
+    """Four layers of mixed formats/geometry for a fused-vs-sequential check."""
+    if dst_fmt == "bgra":
+        kernels = ["img_nv12_bgra", "img_bgra_bgra_tx", "img_y420p_bgra", "img_rgba_bgra_tx"]
+    else:
+        kernels = [f"img_nv12_{dst_fmt}" if dst_fmt == "nv12" else "img_y420p_y420p",
+                   f"img_bgra_{dst_fmt}", f"img_y420p_{dst_fmt}", f"img_rgba_{dst_fmt}"]
+    geos = [dict(), dict(rect=(5, 3, 40, 25), opacity=0.7, border=(2, 2, 2, 2), fill=(0.3, 0.1, 0.8, 0.9)),
+            dict(rect=(30, 10, 30, 20), rotation=0.3, opacity=0.5),
+            dict(rect=(-4, 20, 50, 14), opacity=0.9, fill=(0.5, 0.5, 0.5, 0.4))]
+    sizes = [(96, 54), (40, 30), (32, 18), (50, 14)]
+    out = []
+    for i, (k, g, (iw, ih)) in enumerate(zip(kernels, geos, sizes)):
+        s, _ = G.kernel_formats(k)
+        out.append((k, s, iw, ih, util.make_uniforms((cw, ch), in_size=(iw, ih), **g), 400 + i))
+    return out
+
+
+@pytest.mark.parametrize("dst_fmt", ["nv12", "y420p", "bgra"])
+def test_fused_tick_equals_sequential_and_oracle(ctx, dst_fmt):
+    cw, ch = 64, 36
+    layers = _tick_layers(dst_fmt, cw, ch)
+    # oracle: clear + one kernel per layer (mix.video.swift:116-124)
+    exp = util.alloc_image(dst_fmt, cw, ch, seed=9)
+    assert O.run_kernel(f"img_clear_{dst_fmt}", exp) == 0
+    srcs = []
+    for k, s, iw, ih, u, seed in layers:
+        src = util.alloc_image(s, iw, ih, seed=seed)
+        srcs.append(src)
+        assert O.run_kernel(k, exp, src, u) == 0
+    gl = [(sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, iw, ih, src), u, 0)
+          for (k, s, iw, ih, u, _), src in zip(layers, srcs)]
+    # fused: one launch
+    fused = G.to_gpu(ctx, dst_fmt, cw, ch, util.alloc_image(dst_fmt, cw, ch, seed=9))
+    sv.usingContext(ctx, lambda c: sv.compositeTick(c, fused, gl, True))
+    G.assert_same(G.from_gpu(ctx, fused, dst_fmt, cw, ch), exp, f"fused {dst_fmt}")
+    # sequential: the reference's call sequence
+    seq = G.to_gpu(ctx, dst_fmt, cw, ch, util.alloc_image(dst_fmt, cw, ch, seed=9))
+
+    def body(c):
+        c = sv.runComputeKernel(c, images=[], target=seq, kernel=sv.defaultComputeKernelFromString(f"img_clear_{dst_fmt}"))
+        for k, im, u, csc in gl:
+            c = sv.runComputeKernel(c, images=[im], target=seq, kernel=k, uniforms=u, blends=True)
+        return c
+    sv.usingContext(ctx, body)
+    G.assert_same(G.from_gpu(ctx, seq, dst_fmt, cw, ch), exp, f"sequential {dst_fmt}")
+
+
+def test_pitched_planes_and_padding_untouched(ctx):
+    """Device planes are 256-byte pitched; host planes may carry their own stride."""
+    cw, ch, iw, ih = 50, 22, 36, 20
+    src = util.alloc_image("nv12", iw, ih, seed=3, pad=12)
+    canvas0 = util.alloc_image("nv12", cw, ch, seed=4, pad=6)
+    u = util.make_uniforms((cw, ch), rect=(3, 2, 40, 18), opacity=0.8, in_size=(iw, ih))
+    exp = util.copy_image(canvas0)
+    assert O.run_kernel("img_nv12_nv12", exp, src, u) == 0
+    gs, gd = G.to_gpu(ctx, "nv12", iw, ih, src), G.to_gpu(ctx, "nv12", cw, ch, canvas0)
+    sv.usingContext(ctx, lambda c: sv.runComputeKernel(c, images=[gs], target=gd,
+                                                       kernel=sv.ComputeKernel.img_nv12_nv12, uniforms=u, blends=True))
+    G.assert_same(G.from_gpu(ctx, gd, "nv12", cw, ch), exp, "pitched nv12")
+
+
+def test_error_behaviour(ctx):
+    """Error codes follow ComputeError (compute.swift:22-39); nothing aborts."""
+    bgra = G.to_gpu(ctx, "bgra", 16, 8, util.alloc_image("bgra", 16, 8, seed=1))
+    nv12 = G.to_gpu(ctx, "nv12", 16, 8, util.alloc_image("nv12", 16, 8, seed=2))
+    u = util.full_canvas_uniforms((16, 8), (16, 8))
+    # unknown name -> invalidValue (compute.swift:106-108)
+    with pytest.raises(sv.ComputeError) as e:
+        sv.defaultComputeKernelFromString("img_nv21_nv12")
+    assert e.value.case == "invalidValue"
+    # enum case without a kernel -> computeKernelNotFound
+    with pytest.raises(sv.ComputeError) as e:
+        sv.runComputeKernel(ctx, images=[], target=nv12, kernel=sv.ComputeKernel.img_clear_yuvs)
+    assert e.value.case == "computeKernelNotFound"
+    # wrong target plane structure -> badTarget
+    with pytest.raises(sv.ComputeError) as e:
+        sv.runComputeKernel(ctx, images=[bgra], target=bgra, kernel=sv.ComputeKernel.img_bgra_nv12, uniforms=u, blends=True)
+    assert e.value.case == "badTarget"
+    # wrong input plane structure -> badInputData
+    with pytest.raises(sv.ComputeError) as e:
+        sv.runComputeKernel(ctx, images=[nv12], target=nv12, kernel=sv.ComputeKernel.img_bgra_nv12, uniforms=u, blends=True)
+    assert e.value.case == "badInputData"
+    # CPU-resident target -> badTarget (compute.cl.swift:277-279)
+    cpu = sv.createPictureSample((16, 8), sv.PixelFormat.nv12)
+    with pytest.raises(sv.ComputeError) as e:
+        sv.runComputeKernel(ctx, images=[], target=cpu, kernel=sv.ComputeKernel.img_clear_nv12)
+    assert e.value.case == "badTarget"
+    # composite kernel without uniforms -> invalidValue
+    with pytest.raises(sv.ComputeError) as e:
+        sv.runComputeKernel(ctx, images=[bgra], target=nv12, kernel=sv.ComputeKernel.img_bgra_nv12, blends=True)
+    assert e.value.case == "invalidValue"
+    # the context is still usable afterwards
+    sv.usingContext(ctx, lambda c: sv.runComputeKernel(c, images=[], target=nv12, kernel=sv.ComputeKernel.img_clear_nv12))
+
+
+def test_upload_download_roundtrip_and_barriers(ctx):
+    """GPUBarrierUpload/Download (compute.swift:175-255): idempotent pass-through, own shared context."""
+    src = util.alloc_image("y420p", 38, 22, seed=11)
+    pict = sv.pictureFromArrays(sv.PixelFormat.y420p, (38, 22), src)
+    up, down = sv.GPUBarrierUpload(ctx), sv.GPUBarrierDownload(ctx, retainGpuBuffer=False)
+    tag, gpu = up(pict)
+    assert tag == "just" and gpu.bufferType() == "gpu"
+    assert up(gpu)[1] is gpu                      # already on the GPU: passes through
+    tag, cpu = down(gpu.derive(img=gpu.imageBuffer().withChanges(buffers=[])))
+    assert tag == "just" and cpu.bufferType() == "cpu" and cpu.imageBuffer().computeTextures == []
+    for a, b in zip(cpu.imageBuffer().buffers, src):
+        assert np.array_equal(a[:, : b.shape[1]], b)
+    assert down(cpu)[1] is cpu
+    # async upload stages the bytes before returning: the source may be overwritten immediately
+    big = util.alloc_image("bgra", 320, 200, seed=12)
+    keep = big[0].copy()
+    p2 = sv.pictureFromArrays(sv.PixelFormat.BGRA, (320, 200), big)
+    g2 = sv.uploadComputePicture(ctx, p2, asynchronous=True, retainCpuBuffer=False)
+    p2.imageBuffer().buffers[0][:] = 0
+    back = sv.downloadComputePicture(ctx, g2).imageBuffer().buffers[0]
+    assert np.array_equal(back.reshape(200, 320, 4), keep)
