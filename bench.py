@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the picture hot path on MI355X.
+
+Workload at every N (weak scaling, one process per GPU, no collective on the data
+path): BASELINE.json configs[1] — 1920x1080 NV12 -> BGRA (integer BT.601) with
+bilinear downscale to 1280x720 — over a batch of `--frames` distinct device-resident
+frames per GPU (the per-device PictureSample buses of configs[3]); one step = one
+pass of the path over the batch = one chv_batch_run launch.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description):
+  value     = target pixels written per second, whole job, inputs resident in HBM
+  roofline  = algorithmic bytes per launch / mean launch duration (HIP events on the
+              context's stream) against the 8 TB/s HBM peak
+  cpu_baseline = the oracle (CPU restatement of the same kernels, "port") timed on the
+              host cores of this box on a bounded sample of the same workload (N=1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+WORKLOADS = {
+    # name: (src fmt, src w, h, dst w, h, n_layers, algorithmic bytes per tick)
+    "cfg2": dict(desc="1920x1080 NV12 -> BGRA (BT.601 int) + bilinear downscale to 1280x720",
+                 sw=1920, sh=1080, dw=1280, dh=720, layers=1, bytes=3110400 + 3686400),
+    "cfg3": dict(desc="4 x 1080p BGRA layers (opacity 1/.75/.5/.25) alpha-composited onto a 1080p BGRA canvas",
+                 sw=1920, sh=1080, dw=1920, dh=1080, layers=4, bytes=4 * 8294400 + 8294400),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=256, help="distinct frames (ticks) per launch per GPU")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        # control plane only (barrier, max over ranks): gloo on the host; the pixel path has no collective
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist = dist_mod
+    return rank, local, world, dist
+
+
+def build_workload(sv, ctx, wl, frames, seed_base):
+    """Device-resident source frames, canvases and the batch descriptor."""
+    import util
+    from swiftvideo_amd import chipvideo as cv
+    lib = cv.load()
+    sw, sh, dw, dh = wl["sw"], wl["sh"], wl["dw"], wl["dh"]
+    distinct = 4
+    host_src = []
+    keep = []  # keep PictureSamples alive (they own the device memory)
+    ticks = (cv.Tick * frames)()
+    layer_arrays = []
+    if wl["layers"] == 1:
+        for i in range(distinct):
+            host_src.append(util.alloc_image("nv12", sw, sh, seed=seed_base + i))
+        u = util.full_canvas_uniforms((dw, dh), (sw, sh))
+        for f in range(frames):
+            src = sv.uploadComputePicture(ctx, sv.pictureFromArrays(sv.PixelFormat.nv12, (sw, sh), host_src[f % distinct]),
+                                          retainCpuBuffer=False)
+            dst = sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False)
+            keep += [src, dst]
+            arr = sv._layer_array([(sv.ComputeKernel.img_nv12_bgra, src, u, cv.CSC_BT601_LIMITED)])
+            layer_arrays.append(arr)
+            ticks[f].target = sv._image_desc(dst)
+            ticks[f].clear_first = 1
+            ticks[f].n_layers = 1
+            ticks[f].layers = arr
+        verify = ("img_nv12_bgra", host_src, [u])
+    else:
+        nl = wl["layers"]
+        for i in range(distinct):
+            host_src.append(util.alloc_image("bgra", sw, sh, seed=seed_base + i))
+        us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in (1.0, 0.75, 0.5, 0.25)[:nl]]
+        for f in range(frames):
+            layers = []
+            for l in range(nl):
+                src = sv.uploadComputePicture(ctx, sv.pictureFromArrays(sv.PixelFormat.BGRA, (sw, sh), host_src[(f + l) % distinct]),
+                                              retainCpuBuffer=False)
+                keep.append(src)
+                layers.append((sv.ComputeKernel.img_bgra_bgra_tx, src, us[l], 0))
+            dst = sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False)
+            keep.append(dst)
+            arr = sv._layer_array(layers)
+            layer_arrays.append(arr)
+            ticks[f].target = sv._image_desc(dst)
+            ticks[f].clear_first = 1
+            ticks[f].n_layers = nl
+            ticks[f].layers = arr
+        verify = ("img_bgra_bgra_tx", host_src, us)
+    batch = C.c_void_p()
+    cv.check(lib.chv_batch_create(ctx.handle, ticks, frames, C.byref(batch)))
+    name = C.create_string_buffer(128)
+    cv.check(lib.chv_batch_describe(batch, name, 128, None))
+    return dict(batch=batch, keep=keep, layer_arrays=layer_arrays, ticks=ticks, kernel=name.value.decode(), verify=verify)
+
+
+def verify_frame(sv, ctx, wl, w, frame=0):
+    """Frame `frame` of the batch output == oracle (outside any timed region)."""
+    import util
+    from oracle import oracle as O
+    kernel, host_src, us = w["verify"]
+    dw, dh = wl["dw"], wl["dh"]
+    exp = util.alloc_image("bgra", dw, dh)
+    assert O.run_kernel("img_clear_bgra", exp, threads=os.cpu_count()) == 0
+    distinct = len(host_src)
+    for l, u in enumerate(us):
+        src = host_src[(frame + l) % distinct] if len(us) > 1 else host_src[frame % distinct]
+        assert O.run_kernel(kernel, exp, src, u, threads=os.cpu_count()) == 0
+    per_frame = 1 + len(us) if len(us) > 1 else 2
+    dst = w["keep"][frame * per_frame + per_frame - 1]
+    got = sv.downloadComputePicture(ctx, dst, retainGpuBuffer=True).imageBuffer().buffers[0]
+    return bool(np.array_equal(got[:, : dw * 4].reshape(dh, dw, 4), exp[0]))
+
+
+def cpu_baseline(wl, w, budget_s):
+    """The oracle on this box's host cores, same kernels/uniforms, bounded sample.
+    Stream-parallel like the GPU path: every worker thread composites whole ticks on its
+    own canvas (ctypes releases the GIL), so no per-call thread start-up is measured."""
+    import threading
+    import util
+    from oracle import oracle as O
+    kernel, host_src, us = w["verify"]
+    dw, dh = wl["dw"], wl["dh"]
+    cores = os.cpu_count() or 1
+    O.lib()
+    counts = [0] * cores
+    t_end = [0.0]
+
+    def worker(i):
+        canvas = util.alloc_image("bgra", dw, dh)
+        n = 0
+        while time.perf_counter() < t_end[0]:
+            O.run_kernel("img_clear_bgra", canvas, threads=1)
+            for l, u in enumerate(us):
+                O.run_kernel(kernel, canvas, host_src[(n + l) % len(host_src)], u, threads=1)
+            n += 1
+        counts[i] = n
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    t_end[0] = t0 + budget_s
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    el = time.perf_counter() - t0
+    n = sum(counts)
+    gpix = n * dw * dh / el / 1e9
+    return {"value": gpix, "unit": "Gpix/s", "cores": cores, "kind": "port",
+            "sample": f"{n} ticks of the same workload in {el:.1f} s: oracle/ref_kernels.c, {cores} threads each "
+                      f"compositing whole ticks (clear + {len(us)} layer kernel(s) per tick, as the reference issues them)"}
+
+
+def main():
+    args = parse_args()
+    rank, local, world, dist = dist_setup(args.gpus)
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    n_gpus = max(world, 1)
+
+    from swiftvideo_amd import chipvideo as cv
+    from swiftvideo_amd import compute as sv
+    lib = cv.load()
+    ctx = sv.makeComputeContext(forType="GPU", index=local)
+    wl = WORKLOADS[args.workload]
+    w = build_workload(sv, ctx, wl, args.frames, seed_base=0x5EED0000 + 16 * 2 + rank)
+
+    def step():
+        cv.check(lib.chv_batch_run(ctx.handle, w["batch"]))
+
+    def sync():
+        cv.check(lib.chv_device_synchronize(ctx.handle))
+        try:
+            import torch
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    verified = None
+    if not args.no_verify and rank == 0:
+        verified = verify_frame(sv, ctx, wl, w, frame=0) and verify_frame(sv, ctx, wl, w, frame=args.frames - 1)
+
+    # per-launch HIP events on the stream the kernels run on
+    evs = []
+    for _ in range(args.steps + 1):
+        e = C.c_void_p()
+        cv.check(lib.chv_event_create(ctx.handle, C.byref(e)))
+        evs.append(e)
+
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    cv.check(lib.chv_event_record(ctx.handle, evs[0]))
+    for k in range(args.steps):
+        step()
+        cv.check(lib.chv_event_record(ctx.handle, evs[k + 1]))
+    sync()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    durs = []
+    for k in range(args.steps):
+        ms = C.c_float()
+        cv.check(lib.chv_event_elapsed_ms(evs[k], evs[k + 1], C.byref(ms)))
+        durs.append(ms.value)
+    launch_ms = float(np.mean(durs))
+
+    if rank == 0:
+        px_per_step = args.frames * wl["dw"] * wl["dh"]
+        value = n_gpus * px_per_step * args.steps / elapsed / 1e9
+        bytes_per_launch = args.frames * wl["bytes"]
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_latest.json"
+        if pmc.exists():
+            try:
+                j = json.loads(pmc.read_text())
+                if j.get("workload") == args.workload and j.get("frames") == args.frames:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Gpix/s + achieved HBM GB/s, 1080p NV12→BGRA+scale+4-layer composite, 1/2/4/8 GPU",
+            "value": value, "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "frames_per_step_per_gpu": args.frames,
+                       "gpix_counts": "target pixels written", "source_mpix_per_step_per_gpu": args.frames * wl["sw"] * wl["sh"] * wl["layers"] / 1e6,
+                       "parallelism": f"{n_gpus} independent per-device picture buses, no collective",
+                       "kernel": w["kernel"], "verified_vs_oracle": verified},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": w["kernel"], "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, w, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,12 @@ def test_yuv_to_bgra_colorspaces(ctx, kernel, csc):
 @pytest.mark.parametrize("size", [(64, 36), (7, 5), (1, 1), (130, 3)])
 def test_clear_kernels(ctx, fmt, size):
     w, h = size
+    if fmt != "bgra" and min(w, h) < 2:
+        # a 4:2:0 canvas needs at least one chroma sample: size/2 == 0 cannot be allocated
+        # (the reference's clCreateImage fails the same way, compute.cl.swift:570-579)
+        with pytest.raises(sv.ComputeError):
+            G.to_gpu(ctx, fmt, w, h, util.alloc_image(fmt, w, h, seed=5))
+        return
     canvas0 = util.alloc_image(fmt, w, h, seed=5)
     exp = util.copy_image(canvas0)
     assert O.run_kernel(f"img_clear_{fmt}", exp) == 0
