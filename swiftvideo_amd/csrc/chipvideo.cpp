@@ -29,7 +29,8 @@ hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, cons
 // kernels_fast.hip.cpp
 const char *fast_path_name(int path);
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
-hipError_t launch_tick_fast(int path, const DTick *ticks, const DLayer *layers, int n_ticks,
+hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
+                            const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream);
 // kernels_lanczos.hip.cpp
 hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *fx, const float *wx,
@@ -216,6 +217,8 @@ struct chv_batch {
     int fast_path = -1;
     DTick *d_ticks = nullptr;
     DLayer *d_layers = nullptr;
+    std::vector<DTick> h_ticks;    // host copies: launch geometry of the fast paths
+    std::vector<DLayer> h_layers;
     std::string kernel_name;
 };
 
@@ -606,7 +609,7 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     HIP_TRY(hipHostGetDevicePointer((void **)&dt, ht, 0));
     DLayer *dl = (DLayer *)((uint8_t *)dt + sizeof(DTick));
     int path = select_fast_path(tf, ht, hl, 1);
-    hipError_t e = path >= 0 ? launch_tick_fast(path, dt, dl, 1, ht->W, ht->H, c->stream)
+    hipError_t e = path >= 0 ? launch_tick_fast(path, ht, hl, dt, dl, 1, ht->W, ht->H, c->stream)
                              : launch_tick_general(tf, dt, dl, 1, ht->W, ht->H, c->stream);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     HIP_TRY(hipEventRecord(ds.done, c->stream));
@@ -723,6 +726,8 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
         e = hipMemcpy(b->d_layers, dls.data(), sizeof(DLayer) * dls.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(b->d_ticks); (void)hipFree(b->d_layers); return hip_fail(e, "hipMemcpy(descriptors)"); }
     b->fast_path = select_fast_path(tf0, dts.data(), dls.data(), n_ticks);
+    b->h_ticks = dts;
+    b->h_layers = dls;
     if (b->fast_path >= 0) b->kernel_name = fast_path_name(b->fast_path);
     else b->kernel_name = tf0 == TF_BGRA ? "tick_general_bgra" : (tf0 == TF_NV12 ? "tick_general_yuv<nv12>" : "tick_general_yuv<y420p>");
     *out = b.release();
@@ -735,7 +740,7 @@ extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
     if (b->device != c->device) return fail(CHV_ERR_INVALID_CONTEXT, "batch belongs to device %d", b->device);
     HIP_TRY(hipSetDevice(c->device));
     hipError_t e = b->fast_path >= 0
-        ? launch_tick_fast(b->fast_path, b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
+        ? launch_tick_fast(b->fast_path, b->h_ticks.data(), b->h_layers.data(), b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
         : launch_tick_general(b->target_format, b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CHV_OK;

@@ -1,26 +1,498 @@
-// kernels_fast.hip.cpp — axis-aligned fast paths (LDS-tiled, vectorised).
-// Selected on the host from the layer flags; every path produces exactly the
-// bytes of the general kernels in kernels_general.hip.cpp.
+// kernels_fast.hip.cpp — axis-aligned, LDS-tiled tick kernels for gfx950.
+//
+// When a layer's matrices have no rotation/shear (every BASELINE configuration),
+// tx.x / border.x / uv.x depend on the pixel column only and tx.y / border.y /
+// uv.y on the row only.  A block then
+//   0. evaluates the reference's coordinate arithmetic once per tile column and
+//      once per tile row (same instruction sequence as the general kernel, so the
+//      bits are identical) and parks tap offsets + weights in LDS tables,
+//   1. stages the source rectangle the tile's taps touch into LDS with 16-byte
+//      coalesced global loads (each source byte leaves HBM once) and normalises it
+//      to float there — c/255 is paid once per source texel, not once per tap,
+//   2. lets every thread produce 4 horizontally adjacent pixels x 2 rows from LDS
+//      and store them as one 16-byte BGRA write per row.
+// Blocks are numbered so that all tiles of one frame run on one XCD (block b runs
+// on XCD b % 8): tile halos are shared through that XCD's L2.
+//
+// The kernels are VALU-bound, not HBM-bound, on gfx950 (profiles/): the inner loop
+// is kept to single-rate f32 ops (no v_pk_*, see tools/ubench_valu.cpp).
+//
+// Every path here produces exactly the bytes of kernels_general.hip.cpp; the host
+// picks a path per batch (select_fast_path) and falls back to the general kernel.
 #include "pixel_math.hip.h"
+
+#include <algorithm>
+#include <cmath>
 
 #pragma clang fp contract(off)
 
 namespace chv {
 
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_COUNT };
+
+constexpr int TW = 128;          // tile width  (output pixels)
+constexpr int TH = 16;           // tile height (output rows)
+constexpr int NTHREADS = 256;    // 32 x 8 threads, each 4 px x 2 rows
+constexpr int LDS_BUDGET = 64 * 1024;
+
+enum { AX_BORDER = 1, AX_TX = 2, AX_UV = 4, AX_ALL = 7 };
+
+// Per-tile tables, structure-of-arrays so that lane-adjacent reads are conflict free.
+// Tap positions are the UNCLAMPED i0 = floor(u - 0.5) of the linear filter (tap 1 is
+// i0 + 1): the staged tile replicates the edge texels, so CLAMP_TO_EDGE costs nothing
+// in the inner loop and tap 1 always sits right next to tap 0.
+struct TileTables {
+    int cy[TW]; float cya[TW];     // luma column:   tap-0 position, weight of tap 1
+    int cc[TW]; float cca[TW];     // chroma column
+    int cfl[TW];
+    int ry[TH]; float rya[TH];     // luma row
+    int rc[TH]; float rca[TH];     // chroma row
+    int rfl[TH];
+    int bounds[8];     // min/max unclamped tap positions: [0,1] luma cols, [2,3] chroma cols, [4,5] luma rows, [6,7] chroma rows
+    int flags_and;     // AND of all column and row flags
+    int pad[3];
+};
+
+// unclamped tap-0 position and weight of one axis of the linear filter (cf. lin_axis)
+CHV_DEV void lin_axis_raw(float s, int w, int &i0, float &a) {
+    float um = s * (float)w - 0.5f;
+    float fl = __builtin_floorf(um);
+    a = um - fl;
+    i0 = (int)fl;
+}
+
+// x-dependent half of `geometry` + the sampler's x axis, evaluated at row 0 (under axis
+// alignment the x components do not depend on y; signs of zero apart, which no later
+// operation observes)
+CHV_DEV void axis_entry_x(const float *__restrict__ U, int x, float sx, float sy, int wy, int wc,
+                          int &iy, float &ay, int &ic, float &ac, int &flags) {
+    float ou = (float)x / sx, ov = 0.0f / sy;
+    float nx = ou * 2.f - 1.f, ny = ov * 2.f - 1.f;
+    float t0 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 0);
+    float t1 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 4);
+    float t2 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 8);
+    float t3 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 12);
+    float b0 = dot4(nx, ny, 0.f, 1.f, U + U_BORDER + 0);
+    float u = dot4(t0, t1, t2, t3, U + U_TEXTURE + 0);
+    flags = ((b0 >= 0.f && b0 <= 1.f) ? AX_BORDER : 0) | ((t0 >= 0.f && t0 <= 1.f) ? AX_TX : 0) |
+            ((u >= 0.f && u <= 1.f) ? AX_UV : 0);
+    lin_axis_raw(u, wy, iy, ay);
+    lin_axis_raw(u, wc, ic, ac);
+}
+CHV_DEV void axis_entry_y(const float *__restrict__ U, int y, float sx, float sy, int hy, int hc,
+                          int &iy, float &ay, int &ic, float &ac, int &flags) {
+    float ou = 0.0f / sx, ov = (float)y / sy;
+    float nx = ou * 2.f - 1.f, ny = ov * 2.f - 1.f;
+    float t0 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 0);
+    float t1 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 4);
+    float t2 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 8);
+    float t3 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 12);
+    float b1 = dot4(nx, ny, 0.f, 1.f, U + U_BORDER + 4);
+    float v = dot4(t0, t1, t2, t3, U + U_TEXTURE + 4);
+    flags = ((b1 >= 0.f && b1 <= 1.f) ? AX_BORDER : 0) | ((t1 >= 0.f && t1 <= 1.f) ? AX_TX : 0) |
+            ((v >= 0.f && v <= 1.f) ? AX_UV : 0);
+    lin_axis_raw(v, hy, iy, ay);
+    lin_axis_raw(v, hc, ic, ac);
+}
+
+// 16 source bytes -> 16 normalised floats
+CHV_DEV void unorm16(const uint4 &v, float4 &f0, float4 &f1, float4 &f2, float4 &f3) {
+    f0 = make_float4(unorm8(v.x & 255), unorm8((v.x >> 8) & 255), unorm8((v.x >> 16) & 255), unorm8(v.x >> 24));
+    f1 = make_float4(unorm8(v.y & 255), unorm8((v.y >> 8) & 255), unorm8((v.y >> 16) & 255), unorm8(v.y >> 24));
+    f2 = make_float4(unorm8(v.z & 255), unorm8((v.z >> 8) & 255), unorm8((v.z >> 16) & 255), unorm8(v.z >> 24));
+    f3 = make_float4(unorm8(v.w & 255), unorm8((v.w >> 8) & 255), unorm8((v.w >> 16) & 255), unorm8(v.w >> 24));
+}
+
+// 16 bytes at byte offset `off` of row `row` of a plane whose base and pitch are 16-byte
+// aligned (host-checked).  A vector that would run past the end of the LAST row is read
+// bytewise; bytes past the row's payload are don't-care.
+CHV_DEV uint4 load_row_vec(const DPlane &P, int row, int off) {
+    const int row_bytes = P.w * P.comps;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (off < 0 || off >= row_bytes) return val;
+    const uint8_t *s = P.ptr + (size_t)row * P.pitch + off;
+    if (row < P.h - 1 || off + 16 <= row_bytes) return *(const uint4 *)s;
+    uint32_t w[4] = { 0, 0, 0, 0 };
+    for (int k = 0; k < 16 && off + k < row_bytes; k++) w[k >> 2] |= (uint32_t)s[k] << ((k & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Replace the texels of a 16-byte vector that lie outside the row (left of texel 0 when
+// the vector is the padding vector, at or beyond the row end otherwise) by the nearest
+// edge texel: CLAMP_TO_EDGE resolved once at staging time.  BPT = bytes per texel (1, 2).
+template <int BPT>
+CHV_DEV uint4 patch_edges(uint4 val, const DPlane &P, int row, int off) {
+    const int row_bytes = P.w * BPT;
+    if (off >= 0 && off + 16 <= row_bytes) return val;
+    const uint8_t *s = P.ptr + (size_t)row * P.pitch;
+    uint32_t w[4] = { val.x, val.y, val.z, val.w };
+    if (off < 0) {
+        // padding vector in front of texel 0: only its last texel slot is ever addressed
+        uint32_t e = BPT == 1 ? (uint32_t)s[0] << 24 : (uint32_t)(*(const uint16_t *)s) << 16;
+        w[3] = (w[3] & (BPT == 1 ? 0x00FFFFFFu : 0x0000FFFFu)) | e;
+    } else {
+        uint32_t e = BPT == 1 ? (uint32_t)s[row_bytes - 1] * 0x01010101u
+                              : (uint32_t)(*(const uint16_t *)(s + row_bytes - 2)) * 0x00010001u;
+        int nvalid = max(row_bytes - off, 0);     // bytes of this vector inside the row
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            int nb = min(max(nvalid - 4 * d, 0), 4);
+            uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+            w[d] = (w[d] & mask) | (e & ~mask);
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Thread -> (row, vector) mapping of the staging loops without an integer division:
+// the low `shift` bits of the thread id walk the vectors of a row.
+CHV_DEV int stage_shift(int nv) { return nv <= 16 ? 4 : (nv <= 32 ? 5 : 6); }
+
+// Stage a byte plane as bytes.  LDS row r holds source row clamp(r_lo + r); LDS byte
+// 16 + k of a row holds source byte b0 + k (b0 a multiple of 16; one padding vector in
+// front so that position b0 - 1 exists).  `edge` (block-uniform): the tile touches a
+// picture edge, so vectors -1 .. nvec are written with the outside texels replicated.
+CHV_DEV void stage_plane_u8(uint8_t *lds, int lds_pitch, const DPlane &P, int r_lo, int rows, int b0, int nvec,
+                            bool edge, int tid) {
+    if (!edge) {
+        const int sh = stage_shift(nvec);
+        for (int r = tid >> sh; r < rows; r += NTHREADS >> sh)
+            for (int v = tid & ((1 << sh) - 1); v < nvec; v += 1 << sh)
+                *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) =
+                    *(const uint4 *)(P.ptr + (size_t)(r_lo + r) * P.pitch + b0 + v * 16);
+        return;
+    }
+    const int nv = nvec + 2, sh = stage_shift(nv);
+    for (int r = tid >> sh; r < rows; r += NTHREADS >> sh) {
+        int row = min(max(r_lo + r, 0), P.h - 1);
+        for (int vv = tid & ((1 << sh) - 1); vv < nv; vv += 1 << sh) {
+            int v = vv - 1, off = b0 + v * 16;
+            *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = patch_edges<1>(load_row_vec(P, row, off), P, row, off);
+        }
+    }
+}
+
+// Stage a 2-byte-per-texel plane (NV12 chroma) as normalised float pairs: LDS texel
+// slot 8 + k of a row holds source texel t0 + k (t0 a multiple of 8); edges as above.
+CHV_DEV void stage_plane_rg_f32(uint8_t *lds, int lds_pitch, const DPlane &P, int r_lo, int rows, int t0, int nvec,
+                                bool edge, int tid) {
+    float4 f0, f1, f2, f3;
+    if (!edge) {
+        const int sh = stage_shift(nvec);
+        for (int r = tid >> sh; r < rows; r += NTHREADS >> sh)
+            for (int v = tid & ((1 << sh) - 1); v < nvec; v += 1 << sh) {
+                unorm16(*(const uint4 *)(P.ptr + (size_t)(r_lo + r) * P.pitch + (t0 + v * 8) * 2), f0, f1, f2, f3);
+                float4 *d = (float4 *)(lds + r * lds_pitch + 64 + v * 64);
+                d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
+            }
+        return;
+    }
+    const int nv = nvec + 2, sh = stage_shift(nv);
+    for (int r = tid >> sh; r < rows; r += NTHREADS >> sh) {
+        int row = min(max(r_lo + r, 0), P.h - 1);
+        for (int vv = tid & ((1 << sh) - 1); vv < nv; vv += 1 << sh) {
+            int v = vv - 1, off = (t0 + v * 8) * 2;
+            unorm16(patch_edges<2>(load_row_vec(P, row, off), P, row, off), f0, f1, f2, f3);
+            float4 *d = (float4 *)(lds + r * lds_pitch + 64 + v * 64);
+            d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
+        }
+    }
+}
+
+// One pixel of the BGRA-target family from already-sampled, quantised YUV.
+CHV_DEV uint32_t blend_bgra_general(uint32_t c, const float *__restrict__ U, bool in_pic, uint32_t w) {
+    const float opacity = U[U_OPACITY];
+    const float af = opacity * U[U_FILL + 3];
+    const float iaf = 1.f - af;
+    float r0 = clampf(unorm8(c & 255) * iaf + U[U_FILL + 2] * af, 0.f, 1.f);
+    float r1 = clampf(unorm8((c >> 8) & 255) * iaf + U[U_FILL + 1] * af, 0.f, 1.f);
+    float r2 = clampf(unorm8((c >> 16) & 255) * iaf + U[U_FILL + 0] * af, 0.f, 1.f);
+    if (in_pic) {
+        const float a = 1.0f * opacity, ia = 1.f - a;
+        r0 = r0 * ia + unorm8(w & 255) * a;
+        r1 = r1 * ia + unorm8((w >> 8) & 255) * a;
+        r2 = r2 * ia + unorm8((w >> 16) & 255) * a;
+    }
+    return to_code(r0) | (to_code(r1) << 8) | (to_code(r2) << 16) | 0xFF000000u;
+}
+
+// NV12 sample at one pixel from the staged tile: luma bytes (normalised per tap),
+// chroma float pairs; tap 1 is the next texel, the next row is one LDS pitch further.
+CHV_DEV void sample_nv12_lds(const uint8_t *smem, int ya, int ypitch, int ca, int cpitch,
+                             float w00, float w10, float w01, float w11,
+                             float c00, float c10, float c01, float c11,
+                             float &fy, float &fu, float &fv) {
+    const uint8_t *py = smem + ya;
+    float t00 = unorm8(py[0]), t10 = unorm8(py[1]);
+    float t01 = unorm8(py[ypitch]), t11 = unorm8(py[ypitch + 1]);
+    fy = ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;
+    const float2 *pc0 = (const float2 *)(smem + ca);
+    const float2 *pc1 = (const float2 *)(smem + ca + cpitch);
+    float2 q00 = pc0[0], q10 = pc0[1], q01 = pc1[0], q11 = pc1[1];
+    fu = ((c00 * q00.x + c10 * q10.x) + c01 * q01.x) + c11 * q11.x;
+    fv = ((c00 * q00.y + c10 * q10.y) + c01 * q01.y) + c11 * q11.y;
+}
+
+// the same sample straight from the source planes (tile did not fit the LDS budget)
+CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, int ix, int iy, int cx, int cy,
+                                float w00, float w10, float w01, float w11,
+                                float c00, float c10, float c01, float c11,
+                                float &fy, float &fu, float &fv) {
+    int x0 = min(max(ix, 0), SY.w - 1), x1 = min(max(ix + 1, 0), SY.w - 1);
+    int y0 = min(max(iy, 0), SY.h - 1), y1 = min(max(iy + 1, 0), SY.h - 1);
+    const uint8_t *p0 = SY.ptr + (size_t)y0 * SY.pitch, *p1 = SY.ptr + (size_t)y1 * SY.pitch;
+    fy = ((w00 * unorm8(p0[x0]) + w10 * unorm8(p0[x1])) + w01 * unorm8(p1[x0])) + w11 * unorm8(p1[x1]);
+    int u0 = min(max(cx, 0), SC.w - 1), u1 = min(max(cx + 1, 0), SC.w - 1);
+    int v0 = min(max(cy, 0), SC.h - 1), v1 = min(max(cy + 1, 0), SC.h - 1);
+    const uint8_t *q0 = SC.ptr + (size_t)v0 * SC.pitch, *q1 = SC.ptr + (size_t)v1 * SC.pitch;
+    uint32_t a00 = *(const uint16_t *)(q0 + u0 * 2), a10 = *(const uint16_t *)(q0 + u1 * 2);
+    uint32_t a01 = *(const uint16_t *)(q1 + u0 * 2), a11 = *(const uint16_t *)(q1 + u1 * 2);
+    fu = ((c00 * unorm8(a00 & 255) + c10 * unorm8(a10 & 255)) + c01 * unorm8(a01 & 255)) + c11 * unorm8(a11 & 255);
+    fv = ((c00 * unorm8(a00 >> 8) + c10 * unorm8(a10 >> 8)) + c01 * unorm8(a01 >> 8)) + c11 * unorm8(a11 >> 8);
+}
+
+// ---------------------------------------------------------------------------
+// FP_NV12_BGRA_TILED: one LK_BGRA_FROM_NV12 layer per tick, axis aligned.
+// CLEAR: canvas starts as img_clear_bgra's value instead of being read.
+// ---------------------------------------------------------------------------
+template <bool CLEAR>
+__global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__restrict__ ticks,
+                                                                  const DLayer *__restrict__ layers,
+                                                                  int n_ticks, int tiles_x, int tiles_y,
+                                                                  int ypitch, int yrows, int cpitch, int crows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    TileTables &tb = *(TileTables *)smem;
+    const int ybase = (int)sizeof(TileTables);          // [yrows][ypitch] luma bytes
+    const int cbase = ybase + yrows * ypitch;           // [crows][cpitch] chroma float pairs
+
+    // XCD-aware numbering: consecutive blocks go to consecutive XCDs, so give each
+    // XCD whole frames: block -> (xcd, slot) -> (tick = group*8 + xcd, tile)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int tiles = tiles_x * tiles_y;
+    const int tick = (slot / tiles) * 8 + xcd;
+    if (tick >= n_ticks) return;
+    const int tile = slot % tiles;
+    const DTick &T = ticks[tick];
+    const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+    if (x0 >= T.W || y0 >= T.H) return;
+    const DLayer &L = layers[T.first_layer];
+    const float *U = L.u;
+    const DPlane &SY = L.src.pl[0];
+    const DPlane &SC = L.src.pl[1];
+    const int tid = threadIdx.x;
+    const float sx = (float)T.W, sy = (float)T.H;
+
+    // ---- phase 0: per-column / per-row entries ----------------------------------------
+    if (tid < 8) tb.bounds[tid] = (tid & 1) ? -0x7fffffff : 0x7fffffff;   // even: min, odd: max
+    if (tid == 8) tb.flags_and = AX_ALL;
+    __syncthreads();
+    if (tid < TW) {
+        int x = x0 + tid;
+        int iy, ic, fl; float ay, ac;
+        axis_entry_x(U, min(x, T.W - 1), sx, sy, SY.w, SC.w, iy, ay, ic, ac, fl);
+        if (x >= T.W) fl = AX_ALL;   // past the canvas edge: never stored; copy of the last column
+        else if (fl == AX_ALL) {
+            atomicMin(&tb.bounds[0], iy); atomicMax(&tb.bounds[1], iy + 1);
+            atomicMin(&tb.bounds[2], ic); atomicMax(&tb.bounds[3], ic + 1);
+        } else atomicAnd(&tb.flags_and, fl);
+        tb.cy[tid] = iy; tb.cya[tid] = ay; tb.cc[tid] = ic; tb.cca[tid] = ac; tb.cfl[tid] = fl;
+    } else if (tid < TW + TH) {
+        int j = tid - TW, y = y0 + j;
+        int iy, ic, fl; float ay, ac;
+        axis_entry_y(U, min(y, T.H - 1), sx, sy, SY.h, SC.h, iy, ay, ic, ac, fl);
+        if (y >= T.H) fl = AX_ALL;
+        else if (fl == AX_ALL) {
+            atomicMin(&tb.bounds[4], iy); atomicMax(&tb.bounds[5], iy + 1);
+            atomicMin(&tb.bounds[6], ic); atomicMax(&tb.bounds[7], ic + 1);
+        } else atomicAnd(&tb.flags_and, fl);
+        tb.ry[j] = iy; tb.rya[j] = ay; tb.rc[j] = ic; tb.rca[j] = ac; tb.rfl[j] = fl;
+    }
+    __syncthreads();
+
+    // ---- phase 1: stage the touched source rectangle -------------------------------------
+    const bool any = tb.bounds[1] > tb.bounds[0] && tb.bounds[5] > tb.bounds[4];
+    bool staged = false;
+    int ycol0 = 0, ccol0 = 0, yr0 = 0, cr0 = 0;
+    if (any) {
+        const int ylo = tb.bounds[0], yhi = tb.bounds[1], clo = tb.bounds[2], chi = tb.bounds[3];
+        ycol0 = max(ylo, 0) & ~15;                       // luma: byte == texel, 16 per vector
+        ccol0 = max(clo, 0) & ~7;                        // chroma: 8 texels per 16-byte vector
+        const int ynv = (min(yhi, SY.w - 1) - ycol0) / 16 + 1;
+        const int cnv = (min(chi, SC.w - 1) - ccol0) / 8 + 1;
+        yr0 = tb.bounds[4]; cr0 = tb.bounds[6];
+        const int yr = tb.bounds[5] - yr0 + 1, cr = tb.bounds[7] - cr0 + 1;
+        staged = (ynv + 2) * 16 <= ypitch && yr <= yrows && (cnv + 2) * 64 <= cpitch && cr <= crows;
+        if (staged) {
+            // interior tiles: every tap and every staged 16-byte vector lies inside the planes
+            // (taps outside the picture need the replicated edge texels; a vector that runs past
+            // the payload of the plane's last row must not be read as 16 bytes)
+            const bool yedge = ylo < 0 || yhi >= SY.w || yr0 < 0 || tb.bounds[5] >= SY.h - 1 + (int)(ycol0 + ynv * 16 <= SY.w);
+            const bool cedge = clo < 0 || chi >= SC.w || cr0 < 0 || tb.bounds[7] >= SC.h - 1 + (int)(ccol0 + cnv * 8 <= SC.w);
+            stage_plane_u8(smem + ybase, ypitch, SY, yr0, yr, ycol0, ynv, yedge, tid);
+            stage_plane_rg_f32(smem + cbase, cpitch, SC, cr0, cr, ccol0, cnv, cedge, tid);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: 4 px x 2 rows per thread ------------------------------------------------
+    const int txi = tid & 31, tyi = tid >> 5;
+    const DPlane &D = T.dst.pl[0];
+    const int xq = x0 + txi * 4;
+    if (xq >= T.W) return;
+    const bool full4 = xq + 3 < T.W;
+    const CscFolded csc = csc_fold(kCsc[L.csc & 3]);
+    const bool opaque = (L.flags & LF_OPAQUE) != 0;
+    const bool uniform_inside = tb.flags_and == AX_ALL && staged;
+
+    // column entries of this thread's four pixels (shared by its rows); when staged,
+    // turned into LDS byte offsets inside a tile row
+    int cy[4], cc[4], cfl[4];
+    float cya[4], icya[4], cca[4], icca[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int c = txi * 4 + k;
+        cy[k] = tb.cy[c]; cya[k] = tb.cya[c]; icya[k] = 1.0f - cya[k];
+        cc[k] = tb.cc[c]; cca[k] = tb.cca[c]; icca[k] = 1.0f - cca[k];
+        cfl[k] = tb.cfl[c];
+        if (staged) { cy[k] = cy[k] - ycol0 + 16; cc[k] = (cc[k] - ccol0 + 8) * 8; }
+    }
+
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int ly = tyi + rr * 8;
+        const int y = y0 + ly;
+        if (y >= T.H) continue;
+        uint8_t *drow = D.ptr + (size_t)y * D.pitch;
+        const int ry = tb.ry[ly], rc = tb.rc[ly], rfl = tb.rfl[ly];
+        const float yb = tb.rya[ly], iyb = 1.0f - yb, cb = tb.rca[ly], icb = 1.0f - cb;
+        const int yrow = ybase + (ry - yr0) * ypitch, crow = cbase + (rc - cr0) * cpitch;   // staged only
+        uint32_t outw[4];
+
+        if (uniform_inside && opaque) {
+            // every pixel of the tile is inside the picture and the layer is opaque:
+            // result = cur*0 + px*1 = px exactly and to_code(unorm8(c)) == c, so the
+            // colour-matrix word is the output (no canvas read, no float round trip)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float fy, fu, fv;
+                sample_nv12_lds(smem, yrow + cy[k], ypitch, crow + cc[k], cpitch,
+                                icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                outw[k] = yuv_to_bgra_word(csc, (int)to_code_unit(fy), (int)to_code_unit(fu), (int)to_code_unit(fv));
+            }
+        } else {
+            uint32_t cur[4];
+            if (CLEAR) { cur[0] = cur[1] = cur[2] = cur[3] = 0xFF000000u; }
+            else if (full4) { uint4 c = *(const uint4 *)(drow + (size_t)xq * 4); cur[0] = c.x; cur[1] = c.y; cur[2] = c.z; cur[3] = c.w; }
+            else { for (int k = 0; k < 4; k++) cur[k] = (xq + k < T.W) ? *(const uint32_t *)(drow + (size_t)(xq + k) * 4) : 0; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int fl = cfl[k] & rfl;
+                uint32_t c = cur[k];
+                if (fl & AX_BORDER) {
+                    const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
+                    uint32_t w = 0;
+                    if (in_pic) {
+                        float fy, fu, fv;
+                        if (staged)
+                            sample_nv12_lds(smem, yrow + cy[k], ypitch, crow + cc[k], cpitch,
+                                            icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                            icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                        else
+                            sample_nv12_global(SY, SC, cy[k], ry, cc[k], rc,
+                                               icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                               icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                        w = yuv_to_bgra_word(csc, (int)to_code(fy), (int)to_code(fu), (int)to_code(fv));
+                    }
+                    c = blend_bgra_general(c, U, in_pic, w);
+                }
+                outw[k] = c;
+            }
+        }
+        if (full4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+        else for (int k = 0; k < 4; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side: path selection and launch geometry
+// ---------------------------------------------------------------------------
+struct TileDims { int ypitch, yrows, cpitch, crows; size_t lds; };
+
+static bool finite16(const float *m) {
+    for (int i = 0; i < 16; i++) if (!(m[i] - m[i] == 0.f)) return false;
+    return true;
+}
+
+// LDS rectangle one tile of this layer can touch, from the layer's scale factors.
+static TileDims tile_dims(const DTick &T, const DLayer &L) {
+    const float *U = L.u;
+    // |d(uv)/d(pixel)| as a fraction of the source per output pixel
+    double sxr = std::fabs((double)U[U_TEXTURE + 0] * (double)U[U_TRANSFORM + 0] * 2.0 / (double)T.W);
+    double syr = std::fabs((double)U[U_TEXTURE + 5] * (double)U[U_TRANSFORM + 5] * 2.0 / (double)T.H);
+    TileDims d;
+    int yspan = (int)std::ceil(TW * sxr * L.src.pl[0].w) + 4;   // texels incl. tap 1 and rounding slack
+    int cspan = (int)std::ceil(TW * sxr * L.src.pl[1].w) + 4;
+    d.ypitch = ((yspan + 15) / 16 + 3) * 16;                    // luma bytes: vectors + alignment + 2 pad vectors
+    d.cpitch = ((cspan + 7) / 8 + 3) * 64;                      // chroma float pairs
+    d.yrows = (int)std::ceil(TH * syr * L.src.pl[0].h) + 5;
+    d.crows = (int)std::ceil(TH * syr * L.src.pl[1].h) + 5;
+    d.lds = sizeof(TileTables) + (size_t)d.ypitch * d.yrows + (size_t)d.cpitch * d.crows;
+    return d;
+}
+
+static bool aligned16(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0; }
+
 const char *fast_path_name(int path) {
-    (void)path;
-    return "none";
+    switch (path) {
+    case FP_NV12_BGRA_TILED: return "tick_nv12_bgra_tiled";
+    default: return "none";
+    }
 }
 
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
-    (void)target_format; (void)ticks; (void)layers; (void)n_ticks;
-    return -1;
+    if (target_format != TF_BGRA || n_ticks <= 0) return FP_NONE;
+    for (int i = 0; i < n_ticks; i++) {
+        const DTick &T = ticks[i];
+        if (T.n_layers != 1 || T.clear_first != ticks[0].clear_first) return FP_NONE;
+        const DLayer &L = layers[T.first_layer];
+        if (L.kind != LK_BGRA_FROM_NV12 || !(L.flags & LF_AXIS_ALIGNED)) return FP_NONE;
+        if (!finite16(L.u + U_TRANSFORM) || !finite16(L.u + U_TEXTURE) || !finite16(L.u + U_BORDER)) return FP_NONE;
+        if (!aligned16(T.dst.pl[0]) || !aligned16(L.src.pl[0]) || !aligned16(L.src.pl[1])) return FP_NONE;
+        if (tile_dims(T, L).lds > (size_t)LDS_BUDGET) return FP_NONE;
+    }
+    return FP_NV12_BGRA_TILED;
 }
 
-hipError_t launch_tick_fast(int path, const DTick *ticks, const DLayer *layers, int n_ticks,
+hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
+                            const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
-    (void)path; (void)ticks; (void)layers; (void)n_ticks; (void)maxW; (void)maxH; (void)stream;
-    return hipErrorNotSupported;
+    if (path != FP_NV12_BGRA_TILED) return hipErrorNotSupported;
+    TileDims m = { 0, 0, 0, 0, 0 };
+    for (int i = 0; i < n_ticks; i++) {
+        TileDims d = tile_dims(ticks_host[i], layers_host[ticks_host[i].first_layer]);
+        m.ypitch = std::max(m.ypitch, d.ypitch); m.yrows = std::max(m.yrows, d.yrows);
+        m.cpitch = std::max(m.cpitch, d.cpitch); m.crows = std::max(m.crows, d.crows);
+    }
+    size_t lds = sizeof(TileTables) + (size_t)m.ypitch * m.yrows + (size_t)m.cpitch * m.crows;
+    if (lds > (size_t)LDS_BUDGET) {
+        // per-tick maxima combined exceed the budget: shrink to it; tiles that do not fit
+        // fall back to unstaged taps inside the kernel
+        m.yrows = std::max(1, (int)((LDS_BUDGET - sizeof(TileTables)) / 2 / m.ypitch));
+        m.crows = std::max(1, (int)((LDS_BUDGET - sizeof(TileTables)) / 2 / m.cpitch));
+        lds = sizeof(TileTables) + (size_t)m.ypitch * m.yrows + (size_t)m.cpitch * m.crows;
+    }
+    int tiles_x = (maxW + TW - 1) / TW, tiles_y = (maxH + TH - 1) / TH;
+    int groups = (n_ticks + 7) / 8;
+    dim3 grid((unsigned)(groups * 8 * tiles_x * tiles_y));
+    if (ticks_host[0].clear_first)
+        hipLaunchKernelGGL(tick_nv12_bgra_tiled<true>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks,
+                           tiles_x, tiles_y, m.ypitch, m.yrows, m.cpitch, m.crows);
+    else
+        hipLaunchKernelGGL(tick_nv12_bgra_tiled<false>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks,
+                           tiles_x, tiles_y, m.ypitch, m.yrows, m.cpitch, m.crows);
+    return hipGetLastError();
 }
 
 }  // namespace chv

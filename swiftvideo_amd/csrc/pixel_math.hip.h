@@ -22,16 +22,16 @@ namespace chv {
 
 #define CHV_DEV __device__ __forceinline__
 
-// c / 255.0f, correctly rounded, without a divide: one Newton step on
-// q = c * RN(1/255) with the residual taken in a fused op is exact for all 256
-// codes (exhaustively checked on device by tests/test_gpu_primitives.py).
-CHV_DEV float unorm8(uint32_t c) {
-    const float r = 0x1.010102p-8f;  // RN(1/255)
-    float f = (float)c;
-    float q = f * r;
-    float e = __builtin_fmaf(-q, 255.0f, f);
-    return __builtin_fmaf(e, r, q);
+// c / 255.0f, correctly rounded, without a divide: with r_hi = RN(1/255) and
+// r_lo = RN(1/255 - r_hi), RN(c*r_hi + RN(c*r_lo)) equals RN(c/255) for all 256 codes
+// (checked in exact rational arithmetic by tests/test_host_logic.py and on device by
+// tests/test_gpu_primitives.py).
+CHV_DEV float unorm8f(float f) {
+    const float r_hi = 0x1.010102p-8f;
+    const float r_lo = -0x1.fdfdfep-33f;
+    return __builtin_fmaf(f, r_hi, f * r_lo);
 }
+CHV_DEV float unorm8(uint32_t c) { return unorm8f((float)c); }
 
 // convert_uchar_sat_rte(f * 255.0f); fmaxf drops a NaN operand, so NaN -> 0.
 CHV_DEV uint32_t to_code(float f) {
@@ -44,6 +44,12 @@ CHV_DEV uint32_t to_code_raw(float v) {
     v = __builtin_rintf(v);
     v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);
     return (uint32_t)v;
+}
+
+// to_code for a value known to lie in [0, 1 + a few ulp] and not NaN (a convex
+// combination of unorm8 samples): the saturation cannot trigger, so it is dropped.
+CHV_DEV uint32_t to_code_unit(float f) {
+    return (uint32_t)__builtin_rintf(f * 255.0f);
 }
 
 CHV_DEV float clampf(float v, float lo, float hi) {
@@ -139,14 +145,45 @@ __device__ __constant__ const Csc kCsc[4] = {
     { 0, 65536, 103206, 12276, 30679, 121609 },   // BT.709 full
 };
 CHV_DEV uint32_t clip8(int32_t v) { return (uint32_t)min(max(v, 0), 255); }
+
+// Pack three 16.16 fixed-point channels into a memory-order BGRA word:
+// clip8(x >> 16) == clamp(x, 0, 0xFFFFFF) >> 16, so saturate first and then move the
+// integer byte of each channel into place.  (Written this way on purpose: for the
+// ashr-then-clamp form hipcc 7.2 selects gfx950's v_ashr_pk_u8_i32 and then ORs the third
+// channel into a register whose upper half that instruction does not leave zero.)
+CHV_DEV uint32_t pack_bgra_fixed(int32_t b16, int32_t g16, int32_t r16) {
+    uint32_t b = (uint32_t)min(max(b16, 0), 0xFFFFFF);
+    uint32_t g = (uint32_t)min(max(g16, 0), 0xFFFFFF);
+    uint32_t r = (uint32_t)min(max(r16, 0), 0xFFFFFF);
+    return (b >> 16) | ((g >> 8) & 0xFF00u) | (r & 0xFF0000u) | 0xFF000000u;
+}
+
 // returns memory-order BGRA word: B | G<<8 | R<<16 | 255<<24
 CHV_DEV uint32_t yuv_to_bgra_word(const Csc &k, int y, int u, int v) {
     int32_t c = k.cy * (y - k.yoff) + 32768;
     int32_t d = u - 128, e = v - 128;
-    uint32_t r = clip8((c + k.crv * e) >> 16);
-    uint32_t g = clip8((c - k.cgu * d - k.cgv * e) >> 16);
-    uint32_t b = clip8((c + k.cbu * d) >> 16);
-    return b | (g << 8) | (r << 16) | 0xFF000000u;
+    return pack_bgra_fixed(c + k.cbu * d, c - k.cgu * d - k.cgv * e, c + k.crv * e);
+}
+
+// The same matrix with the offsets folded into one constant per channel and 24-bit
+// multiplies (v_mad_i32_i24, full rate): all intermediate sums stay below 2^27, so the
+// regrouping is exact integer arithmetic.
+CHV_DEV int32_t mad24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }
+struct CscFolded { int32_t cy, crv, ncgu, ncgv, cbu, kr, kg, kb; };
+CHV_DEV CscFolded csc_fold(const Csc &k) {
+    CscFolded f;
+    int32_t base = 32768 - k.cy * k.yoff;
+    f.cy = k.cy; f.crv = k.crv; f.ncgu = -k.cgu; f.ncgv = -k.cgv; f.cbu = k.cbu;
+    f.kr = base - 128 * k.crv;
+    f.kg = base + 128 * (k.cgu + k.cgv);
+    f.kb = base - 128 * k.cbu;
+    return f;
+}
+CHV_DEV uint32_t yuv_to_bgra_word(const CscFolded &k, int y, int u, int v) {
+    int32_t r = mad24(v, k.crv, mad24(y, k.cy, k.kr));
+    int32_t g = mad24(v, k.ncgv, mad24(u, k.ncgu, mad24(y, k.cy, k.kg)));
+    int32_t b = mad24(u, k.cbu, mad24(y, k.cy, k.kb));
+    return pack_bgra_fixed(b, g, r);
 }
 
 }  // namespace chv

@@ -60,3 +60,37 @@ def run_both(ctx, kernel, cw, ch, iw, ih, uniforms, seed, csc=0, clear_first=Fal
         sv.usingContext(ctx, lambda c: sv.runComputeKernel(c, images=[gsrc], target=gdst, kernel=k,
                                                            uniforms=uniforms, blends=True, colorspace=csc))
     return from_gpu(ctx, gdst, d, cw, ch), exp
+
+
+def make_batch(ctx, ticks):
+    """ticks: [(target PictureSample, clear_first, [(kernel, sample, uniforms, csc)])] -> (handle, kernel name, keepalive)"""
+    import ctypes as C
+    from swiftvideo_amd import chipvideo as cv
+    lib = cv.load()
+    arr = (cv.Tick * len(ticks))()
+    keep = []
+    for i, (target, clear, layers) in enumerate(ticks):
+        la = sv._layer_array(layers)
+        keep.append(la)
+        arr[i].target = sv._image_desc(target)
+        arr[i].clear_first = 1 if clear else 0
+        arr[i].n_layers = len(layers)
+        arr[i].layers = la
+    h = C.c_void_p()
+    cv.check(lib.chv_batch_create(ctx.handle, arr, len(ticks), C.byref(h)))
+    name = C.create_string_buffer(128)
+    cv.check(lib.chv_batch_describe(h, name, 128, None))
+    return h, name.value.decode(), (arr, keep)
+
+
+def run_batch(ctx, h):
+    from swiftvideo_amd import chipvideo as cv
+    lib = cv.load()
+    cv.check(lib.chv_pass_begin(ctx.handle))
+    cv.check(lib.chv_batch_run(ctx.handle, h))
+    cv.check(lib.chv_pass_end(ctx.handle, 1))
+
+
+def destroy_batch(h):
+    from swiftvideo_amd import chipvideo as cv
+    cv.check(cv.load().chv_batch_destroy(h))

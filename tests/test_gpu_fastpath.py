@@ -1,0 +1,84 @@
+"""The axis-aligned LDS-tiled kernels give exactly the bytes of the oracle (and therefore of
+the general kernels), across tile edges, scale factors, partial cover, borders, fill, opacity,
+flips, odd sizes and the LDS-overflow fallback; and the host really selects them."""
+import numpy as np
+import pytest
+
+import gpuutil as G
+import util
+from oracle import oracle as O
+from swiftvideo_amd import compute as sv
+
+pytestmark = pytest.mark.gpu
+
+# (canvas w, h, src w, h, make_uniforms kwargs, clear_first)
+NV12_BGRA_CASES = {
+    "cfg2_small":     (320, 180, 480, 270, dict(), True),
+    "same_size":      (200, 60, 200, 60, dict(), True),
+    "upscale_3x":     (300, 90, 100, 30, dict(opacity=0.5), True),
+    "down_2.5x":      (130, 50, 326, 124, dict(), True),
+    "rect_border":    (260, 70, 96, 54, dict(rect=(33, 9, 180, 40), border=(5, 3, 7, 2), fill=(0.9, 0.2, 0.1, 0.6), opacity=0.8), True),
+    "noclear_opaque": (260, 70, 96, 54, dict(rect=(33, 9, 180, 40)), False),
+    "noclear_blend":  (260, 70, 96, 54, dict(rect=(-20, -10, 200, 100), opacity=0.35, fill=(0.1, 0.5, 0.9, 1.0), border=(40, 40, 40, 40)), False),
+    "tex_window":     (257, 33, 120, 80, dict(tex=(0.2, 0.1, 0.5, 0.7)), True),
+    "letterbox":      (256, 48, 64, 64, dict(rect=(40, 4, 180, 40), tex=(0.25, 0.0, 0.5, 1.0), fill=(1, 1, 0, 1)), True),
+    "flip_x":         (192, 40, 96, 54, dict(tex=(1.0, 0.0, -1.0, 1.0)), True),
+    "odd_width":      (131, 19, 97, 41, dict(), True),
+    "tiny":           (3, 2, 8, 6, dict(), True),
+    "huge_downscale": (64, 20, 2048, 640, dict(), True),   # tile does not fit LDS -> unstaged taps or general path
+}
+
+
+@pytest.mark.parametrize("case", list(NV12_BGRA_CASES))
+@pytest.mark.parametrize("csc", [0, 3])
+def test_nv12_bgra_tiled_matches_oracle(ctx, case, csc):
+    cw, ch, sw, sh, kw, clear = NV12_BGRA_CASES[case]
+    u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+    src = util.alloc_image("nv12", sw, sh, seed=21)
+    canvas0 = util.alloc_image("bgra", cw, ch, seed=22)
+    exp = util.copy_image(canvas0)
+    if clear:
+        assert O.run_kernel("img_clear_bgra", exp) == 0
+    assert O.run_kernel("img_nv12_bgra", exp, src, u, csc=csc, threads=4) == 0
+    gs = G.to_gpu(ctx, "nv12", sw, sh, src)
+    gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+    h, name, keep = G.make_batch(ctx, [(gd, clear, [(sv.ComputeKernel.img_nv12_bgra, gs, u, csc)])])
+    if case not in ("huge_downscale", "down_2.5x", "tiny"):   # those exceed the LDS tile budget -> general kernel
+        assert name == "tick_nv12_bgra_tiled", f"axis-aligned NV12->BGRA batch dispatched to {name}"
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"{case}/csc{csc} via {name}")
+
+
+def test_rotated_layer_falls_back_to_general(ctx):
+    u = util.make_uniforms((64, 36), rect=(10, 5, 40, 20), rotation=0.2, in_size=(32, 18))
+    gs = G.to_gpu(ctx, "nv12", 32, 18, util.alloc_image("nv12", 32, 18, seed=1))
+    gd = G.to_gpu(ctx, "bgra", 64, 36, util.alloc_image("bgra", 64, 36, seed=2))
+    h, name, keep = G.make_batch(ctx, [(gd, True, [(sv.ComputeKernel.img_nv12_bgra, gs, u, 0)])])
+    G.destroy_batch(h)
+    assert name == "tick_general_bgra"
+
+
+def test_batch_of_mixed_sizes(ctx):
+    """One launch, ticks with different canvas/source sizes and geometry (grid.z-less XCD numbering)."""
+    specs = [(320, 180, 480, 270, dict()), (130, 50, 326, 124, dict(opacity=0.7)), (64, 36, 64, 36, dict()),
+             (257, 33, 120, 80, dict(tex=(0.2, 0.1, 0.5, 0.7))), (200, 60, 100, 30, dict(rect=(10, 10, 150, 40), border=(3, 3, 3, 3), fill=(0, 1, 0, 1))),
+             (320, 180, 480, 270, dict()), (16, 16, 16, 16, dict()), (300, 90, 100, 30, dict()), (131, 19, 97, 41, dict()),
+             (320, 180, 160, 90, dict()), (48, 200, 96, 400, dict())]
+    ticks, exps, gds = [], [], []
+    for i, (cw, ch, sw, sh, kw) in enumerate(specs):
+        u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+        src = util.alloc_image("nv12", sw, sh, seed=50 + i)
+        exp = util.alloc_image("bgra", cw, ch)
+        assert O.run_kernel("img_clear_bgra", exp) == 0
+        assert O.run_kernel("img_nv12_bgra", exp, src, u, threads=4) == 0
+        gd = G.to_gpu(ctx, "bgra", cw, ch, util.alloc_image("bgra", cw, ch, seed=99))
+        ticks.append((gd, True, [(sv.ComputeKernel.img_nv12_bgra, G.to_gpu(ctx, "nv12", sw, sh, src), u, 0)]))
+        exps.append(exp)
+        gds.append((gd, cw, ch))
+    h, name, keep = G.make_batch(ctx, ticks)
+    G.run_batch(ctx, h)
+    G.run_batch(ctx, h)   # a batch can be replayed; clear_first makes it idempotent
+    G.destroy_batch(h)
+    for i, ((gd, cw, ch), exp) in enumerate(zip(gds, exps)):
+        G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"tick {i}")
