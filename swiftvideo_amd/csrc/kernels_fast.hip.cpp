@@ -48,10 +48,30 @@ struct TileTables {
     int ry[TH]; float rya[TH];     // luma row
     int rc[TH]; float rca[TH];     // chroma row
     int rfl[TH];
-    int bounds[8];     // min/max unclamped tap positions: [0,1] luma cols, [2,3] chroma cols, [4,5] luma rows, [6,7] chroma rows
-    int flags_and;     // AND of all column and row flags
-    int pad[3];
+    // per computing wave (0,1: columns; 2: rows): {min luma, max luma + 1, min chroma, max chroma + 1,
+    // any entry fully inside, every in-canvas entry fully inside, -, -}
+    int summary[3][8];
 };
+
+// Summarise one wave's entries.  Positions are monotone in the pixel index (every step of
+// the coordinate arithmetic is a monotone rounding of a monotone function) and the "fully
+// inside" entries form an interval, so the extremes sit at its first and last lane.
+CHV_DEV void wave_summary(int *out, bool in_canvas, int fl, int iy, int ic) {
+    const unsigned long long valid = __ballot(in_canvas && fl == AX_ALL);
+    const unsigned long long partial = __ballot(in_canvas && fl != AX_ALL);
+    int first = valid ? __ffsll((long long)valid) - 1 : 0;
+    int last = valid ? 63 - __clzll((long long)valid) : 0;
+    int y_a = __shfl(iy, first), y_b = __shfl(iy, last);
+    int c_a = __shfl(ic, first), c_b = __shfl(ic, last);
+    if ((threadIdx.x & 63) == 0) {
+        out[0] = valid ? min(y_a, y_b) : 0x7fffffff;
+        out[1] = valid ? max(y_a, y_b) + 1 : -0x7fffffff;
+        out[2] = valid ? min(c_a, c_b) : 0x7fffffff;
+        out[3] = valid ? max(c_a, c_b) + 1 : -0x7fffffff;
+        out[4] = valid != 0;
+        out[5] = partial == 0;
+    }
+}
 
 // unclamped tap-0 position and weight of one axis of the linear filter (cf. lin_axis)
 CHV_DEV void lin_axis_raw(float s, int w, int &i0, float &a) {
@@ -284,51 +304,47 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
     const float sx = (float)T.W, sy = (float)T.H;
 
     // ---- phase 0: per-column / per-row entries ----------------------------------------
-    if (tid < 8) tb.bounds[tid] = (tid & 1) ? -0x7fffffff : 0x7fffffff;   // even: min, odd: max
-    if (tid == 8) tb.flags_and = AX_ALL;
-    __syncthreads();
     if (tid < TW) {
         int x = x0 + tid;
         int iy, ic, fl; float ay, ac;
         axis_entry_x(U, min(x, T.W - 1), sx, sy, SY.w, SC.w, iy, ay, ic, ac, fl);
+        wave_summary(tb.summary[tid >> 6], x < T.W, fl, iy, ic);
         if (x >= T.W) fl = AX_ALL;   // past the canvas edge: never stored; copy of the last column
-        else if (fl == AX_ALL) {
-            atomicMin(&tb.bounds[0], iy); atomicMax(&tb.bounds[1], iy + 1);
-            atomicMin(&tb.bounds[2], ic); atomicMax(&tb.bounds[3], ic + 1);
-        } else atomicAnd(&tb.flags_and, fl);
         tb.cy[tid] = iy; tb.cya[tid] = ay; tb.cc[tid] = ic; tb.cca[tid] = ac; tb.cfl[tid] = fl;
-    } else if (tid < TW + TH) {
+    } else if (tid < TW + 64) {
         int j = tid - TW, y = y0 + j;
         int iy, ic, fl; float ay, ac;
         axis_entry_y(U, min(y, T.H - 1), sx, sy, SY.h, SC.h, iy, ay, ic, ac, fl);
+        wave_summary(tb.summary[2], j < TH && y < T.H, fl, iy, ic);
         if (y >= T.H) fl = AX_ALL;
-        else if (fl == AX_ALL) {
-            atomicMin(&tb.bounds[4], iy); atomicMax(&tb.bounds[5], iy + 1);
-            atomicMin(&tb.bounds[6], ic); atomicMax(&tb.bounds[7], ic + 1);
-        } else atomicAnd(&tb.flags_and, fl);
-        tb.ry[j] = iy; tb.rya[j] = ay; tb.rc[j] = ic; tb.rca[j] = ac; tb.rfl[j] = fl;
+        if (j < TH) { tb.ry[j] = iy; tb.rya[j] = ay; tb.rc[j] = ic; tb.rca[j] = ac; tb.rfl[j] = fl; }
     }
     __syncthreads();
+    int bounds[8];
+    bounds[0] = min(tb.summary[0][0], tb.summary[1][0]); bounds[1] = max(tb.summary[0][1], tb.summary[1][1]);
+    bounds[2] = min(tb.summary[0][2], tb.summary[1][2]); bounds[3] = max(tb.summary[0][3], tb.summary[1][3]);
+    bounds[4] = tb.summary[2][0]; bounds[5] = tb.summary[2][1]; bounds[6] = tb.summary[2][2]; bounds[7] = tb.summary[2][3];
+    const bool all_inside = tb.summary[0][5] && tb.summary[1][5] && tb.summary[2][5];
 
     // ---- phase 1: stage the touched source rectangle -------------------------------------
-    const bool any = tb.bounds[1] > tb.bounds[0] && tb.bounds[5] > tb.bounds[4];
+    const bool any = bounds[1] > bounds[0] && bounds[5] > bounds[4];
     bool staged = false;
     int ycol0 = 0, ccol0 = 0, yr0 = 0, cr0 = 0;
     if (any) {
-        const int ylo = tb.bounds[0], yhi = tb.bounds[1], clo = tb.bounds[2], chi = tb.bounds[3];
+        const int ylo = bounds[0], yhi = bounds[1], clo = bounds[2], chi = bounds[3];
         ycol0 = max(ylo, 0) & ~15;                       // luma: byte == texel, 16 per vector
         ccol0 = max(clo, 0) & ~7;                        // chroma: 8 texels per 16-byte vector
         const int ynv = (min(yhi, SY.w - 1) - ycol0) / 16 + 1;
         const int cnv = (min(chi, SC.w - 1) - ccol0) / 8 + 1;
-        yr0 = tb.bounds[4]; cr0 = tb.bounds[6];
-        const int yr = tb.bounds[5] - yr0 + 1, cr = tb.bounds[7] - cr0 + 1;
+        yr0 = bounds[4]; cr0 = bounds[6];
+        const int yr = bounds[5] - yr0 + 1, cr = bounds[7] - cr0 + 1;
         staged = (ynv + 2) * 16 <= ypitch && yr <= yrows && (cnv + 2) * 64 <= cpitch && cr <= crows;
         if (staged) {
             // interior tiles: every tap and every staged 16-byte vector lies inside the planes
             // (taps outside the picture need the replicated edge texels; a vector that runs past
             // the payload of the plane's last row must not be read as 16 bytes)
-            const bool yedge = ylo < 0 || yhi >= SY.w || yr0 < 0 || tb.bounds[5] >= SY.h - 1 + (int)(ycol0 + ynv * 16 <= SY.w);
-            const bool cedge = clo < 0 || chi >= SC.w || cr0 < 0 || tb.bounds[7] >= SC.h - 1 + (int)(ccol0 + cnv * 8 <= SC.w);
+            const bool yedge = ylo < 0 || yhi >= SY.w || yr0 < 0 || bounds[5] >= SY.h - 1 + (int)(ycol0 + ynv * 16 <= SY.w);
+            const bool cedge = clo < 0 || chi >= SC.w || cr0 < 0 || bounds[7] >= SC.h - 1 + (int)(ccol0 + cnv * 8 <= SC.w);
             stage_plane_u8(smem + ybase, ypitch, SY, yr0, yr, ycol0, ynv, yedge, tid);
             stage_plane_rg_f32(smem + cbase, cpitch, SC, cr0, cr, ccol0, cnv, cedge, tid);
         }
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
     const bool full4 = xq + 3 < T.W;
     const CscFolded csc = csc_fold(kCsc[L.csc & 3]);
     const bool opaque = (L.flags & LF_OPAQUE) != 0;
-    const bool uniform_inside = tb.flags_and == AX_ALL && staged;
+    const bool uniform_inside = all_inside && staged;
 
     // column entries of this thread's four pixels (shared by its rows); when staged,
     // turned into LDS byte offsets inside a tile row
