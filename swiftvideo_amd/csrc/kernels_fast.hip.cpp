@@ -31,13 +31,19 @@ namespace chv {
 enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_COUNT };
 
 constexpr int TW = 128;          // tile width  (output pixels)
-constexpr int TH = 16;           // tile height (output rows)
+#ifndef CHV_TH
+#define CHV_TH 16
+#endif
+constexpr int TH = CHV_TH;       // tile height (output rows)
+constexpr int RPT = TH / 8;      // rows per thread
 constexpr int NTHREADS = 256;    // 32 x 8 threads, each 4 px x 2 rows
 constexpr int LDS_BUDGET = 64 * 1024;
 
 enum { AX_BORDER = 1, AX_TX = 2, AX_UV = 4, AX_ALL = 7 };
 
-// Per-tile tables, structure-of-arrays so that lane-adjacent reads are conflict free.
+constexpr int KT = 4;             // tiles per block: a vertical strip of KT tiles shares its column tables
+
+// Per-strip tables, structure-of-arrays so that lane-adjacent reads are conflict free.
 // Tap positions are the UNCLAMPED i0 = floor(u - 0.5) of the linear filter (tap 1 is
 // i0 + 1): the staged tile replicates the edge texels, so CLAMP_TO_EDGE costs nothing
 // in the inner loop and tap 1 always sits right next to tap 0.
@@ -45,25 +51,30 @@ struct TileTables {
     int cy[TW]; float cya[TW];     // luma column:   tap-0 position, weight of tap 1
     int cc[TW]; float cca[TW];     // chroma column
     int cfl[TW];
-    int ry[TH]; float rya[TH];     // luma row
-    int rc[TH]; float rca[TH];     // chroma row
-    int rfl[TH];
-    // per computing wave (0,1: columns; 2: rows): {min luma, max luma + 1, min chroma, max chroma + 1,
-    // any entry fully inside, every in-canvas entry fully inside, -, -}
-    int summary[3][8];
+    int ry[KT * TH]; float rya[KT * TH];     // luma rows of the KT tiles
+    int rc[KT * TH]; float rca[KT * TH];     // chroma rows
+    int rfl[KT * TH];
+    // {min luma, max luma + 1, min chroma, max chroma + 1, any entry fully inside,
+    //  every in-canvas entry fully inside, -, -}
+    int csum[2][8];                // per column wave
+    int rsum[KT][8];               // per tile of the strip
 };
 
-// Summarise one wave's entries.  Positions are monotone in the pixel index (every step of
-// the coordinate arithmetic is a monotone rounding of a monotone function) and the "fully
-// inside" entries form an interval, so the extremes sit at its first and last lane.
-CHV_DEV void wave_summary(int *out, bool in_canvas, int fl, int iy, int ic) {
-    const unsigned long long valid = __ballot(in_canvas && fl == AX_ALL);
-    const unsigned long long partial = __ballot(in_canvas && fl != AX_ALL);
-    int first = valid ? __ffsll((long long)valid) - 1 : 0;
-    int last = valid ? 63 - __clzll((long long)valid) : 0;
+// Summarise a group of `1 << gshift` consecutive lanes (one wave of columns: 64; one tile's
+// rows: 16).  Positions are monotone in the pixel index (every step of the coordinate
+// arithmetic is a monotone rounding of a monotone function) and the "fully inside"
+// entries form an interval, so the extremes sit at its first and last lane.
+CHV_DEV void group_summary(int *out, int gshift, bool in_canvas, int fl, int iy, int ic) {
+    const int lane = threadIdx.x & 63;
+    const int g0 = (lane >> gshift) << gshift;
+    const unsigned long long gmask = (gshift == 6) ? ~0ull : (((1ull << (1 << gshift)) - 1ull) << g0);
+    const unsigned long long valid = __ballot(in_canvas && fl == AX_ALL) & gmask;
+    const unsigned long long partial = __ballot(in_canvas && fl != AX_ALL) & gmask;
+    int first = valid ? __ffsll((long long)valid) - 1 : g0;
+    int last = valid ? 63 - __clzll((long long)valid) : g0;
     int y_a = __shfl(iy, first), y_b = __shfl(iy, last);
     int c_a = __shfl(ic, first), c_b = __shfl(ic, last);
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == g0) {
         out[0] = valid ? min(y_a, y_b) : 0x7fffffff;
         out[1] = valid ? max(y_a, y_b) + 1 : -0x7fffffff;
         out[2] = valid ? min(c_a, c_b) : 0x7fffffff;
@@ -164,57 +175,63 @@ CHV_DEV uint4 patch_edges(uint4 val, const DPlane &P, int row, int off) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// Thread -> (row, vector) mapping of the staging loops without an integer division:
-// the low `shift` bits of the thread id walk the vectors of a row.
+// Staging of one plane's source rectangle, split in two so that the global loads of the
+// NEXT tile are in flight while the current tile is being computed:
+//   stage_load : raw 16-byte vectors -> registers (no dependent instruction)
+//   stage_store: CLAMP_TO_EDGE patching, unorm8 -> float (chroma), LDS write
+// Slot i = tid + n * NTHREADS maps to row i >> sh, vector (i & mask) of that row; LDS row r
+// holds source row clamp(r_lo + r).  With `edge` (block-uniform: the rectangle touches a
+// picture edge) vectors -1 .. nvec are staged, with the outside texels replicated.
+struct StageGeom {
+    int r_lo, rows;     // first (unclamped) source row, number of LDS rows
+    int b0;             // first source byte of vector 0 (16-byte aligned)
+    int nvec;           // vectors that hold picture bytes
+    int sh;             // log2 of slots per row
+    int edge;
+};
 CHV_DEV int stage_shift(int nv) { return nv <= 16 ? 4 : (nv <= 32 ? 5 : 6); }
+CHV_DEV int stage_slots(const StageGeom &g) { return g.rows << g.sh; }
 
-// Stage a byte plane as bytes.  LDS row r holds source row clamp(r_lo + r); LDS byte
-// 16 + k of a row holds source byte b0 + k (b0 a multiple of 16; one padding vector in
-// front so that position b0 - 1 exists).  `edge` (block-uniform): the tile touches a
-// picture edge, so vectors -1 .. nvec are written with the outside texels replicated.
-CHV_DEV void stage_plane_u8(uint8_t *lds, int lds_pitch, const DPlane &P, int r_lo, int rows, int b0, int nvec,
-                            bool edge, int tid) {
-    if (!edge) {
-        const int sh = stage_shift(nvec);
-        for (int r = tid >> sh; r < rows; r += NTHREADS >> sh)
-            for (int v = tid & ((1 << sh) - 1); v < nvec; v += 1 << sh)
-                *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) =
-                    *(const uint4 *)(P.ptr + (size_t)(r_lo + r) * P.pitch + b0 + v * 16);
-        return;
-    }
-    const int nv = nvec + 2, sh = stage_shift(nv);
-    for (int r = tid >> sh; r < rows; r += NTHREADS >> sh) {
-        int row = min(max(r_lo + r, 0), P.h - 1);
-        for (int vv = tid & ((1 << sh) - 1); vv < nv; vv += 1 << sh) {
-            int v = vv - 1, off = b0 + v * 16;
-            *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = patch_edges<1>(load_row_vec(P, row, off), P, row, off);
+template <int N>
+CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, int tid) {
+    const int nv = g.edge ? g.nvec + 2 : g.nvec;
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        int i = tid + n * NTHREADS;
+        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
+        regs[n] = make_uint4(0, 0, 0, 0);
+        if (r < g.rows && vv < nv) {
+            int row = min(max(g.r_lo + r, 0), P.h - 1);
+            int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
+            regs[n] = g.edge ? load_row_vec(P, row, off) : *(const uint4 *)(P.ptr + (size_t)row * P.pitch + off);
         }
     }
 }
 
-// Stage a 2-byte-per-texel plane (NV12 chroma) as normalised float pairs: LDS texel
-// slot 8 + k of a row holds source texel t0 + k (t0 a multiple of 8); edges as above.
-CHV_DEV void stage_plane_rg_f32(uint8_t *lds, int lds_pitch, const DPlane &P, int r_lo, int rows, int t0, int nvec,
-                                bool edge, int tid) {
-    float4 f0, f1, f2, f3;
-    if (!edge) {
-        const int sh = stage_shift(nvec);
-        for (int r = tid >> sh; r < rows; r += NTHREADS >> sh)
-            for (int v = tid & ((1 << sh) - 1); v < nvec; v += 1 << sh) {
-                unorm16(*(const uint4 *)(P.ptr + (size_t)(r_lo + r) * P.pitch + (t0 + v * 8) * 2), f0, f1, f2, f3);
+// BPT = 1: bytes kept as bytes (LDS byte 16 + k of a row = source byte b0 + k)
+// BPT = 2: byte pairs normalised to float pairs (LDS texel slot 8 + k = source texel b0/2 + k)
+template <int BPT, int N>
+CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid) {
+    const int nv = g.edge ? g.nvec + 2 : g.nvec;
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        int i = tid + n * NTHREADS;
+        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
+        if (r < g.rows && vv < nv) {
+            int v = g.edge ? vv - 1 : vv;
+            uint4 val = regs[n];
+            if (g.edge) {
+                int row = min(max(g.r_lo + r, 0), P.h - 1);
+                val = patch_edges<BPT>(val, P, row, g.b0 + v * 16);
+            }
+            if (BPT == 1) {
+                *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
+            } else {
+                float4 f0, f1, f2, f3;
+                unorm16(val, f0, f1, f2, f3);
                 float4 *d = (float4 *)(lds + r * lds_pitch + 64 + v * 64);
                 d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
             }
-        return;
-    }
-    const int nv = nvec + 2, sh = stage_shift(nv);
-    for (int r = tid >> sh; r < rows; r += NTHREADS >> sh) {
-        int row = min(max(r_lo + r, 0), P.h - 1);
-        for (int vv = tid & ((1 << sh) - 1); vv < nv; vv += 1 << sh) {
-            int v = vv - 1, off = (t0 + v * 8) * 2;
-            unorm16(patch_edges<2>(load_row_vec(P, row, off), P, row, off), f0, f1, f2, f3);
-            float4 *d = (float4 *)(lds + r * lds_pitch + 64 + v * 64);
-            d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
         }
     }
 }
@@ -273,12 +290,18 @@ CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, int ix, int 
 
 // ---------------------------------------------------------------------------
 // FP_NV12_BGRA_TILED: one LK_BGRA_FROM_NV12 layer per tick, axis aligned.
+// A block walks a vertical strip of KT tiles: column tables once, row tables for all KT
+// tiles at once, then per tile  [LDS write of the prefetched rectangle | barrier | issue
+// the next tile's global loads | compute + store | barrier].
 // CLEAR: canvas starts as img_clear_bgra's value instead of being read.
 // ---------------------------------------------------------------------------
+constexpr int NYV = 3;   // prefetch registers (16-byte vectors) per thread, luma
+constexpr int NCV = 2;   // chroma
+
 template <bool CLEAR>
 __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__restrict__ ticks,
                                                                   const DLayer *__restrict__ layers,
-                                                                  int n_ticks, int tiles_x, int tiles_y,
+                                                                  int n_ticks, int tiles_x, int strips_y,
                                                                   int ypitch, int yrows, int cpitch, int crows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     TileTables &tb = *(TileTables *)smem;
@@ -286,148 +309,170 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
     const int cbase = ybase + yrows * ypitch;           // [crows][cpitch] chroma float pairs
 
     // XCD-aware numbering: consecutive blocks go to consecutive XCDs, so give each
-    // XCD whole frames: block -> (xcd, slot) -> (tick = group*8 + xcd, tile)
+    // XCD whole frames: block -> (xcd, slot) -> (tick = group*8 + xcd, strip)
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
-    const int tiles = tiles_x * tiles_y;
-    const int tick = (slot / tiles) * 8 + xcd;
+    const int strips = tiles_x * strips_y;
+    const int tick = (slot / strips) * 8 + xcd;
     if (tick >= n_ticks) return;
-    const int tile = slot % tiles;
+    const int strip = slot % strips;
     const DTick &T = ticks[tick];
-    const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
-    if (x0 >= T.W || y0 >= T.H) return;
+    const int x0 = (strip % tiles_x) * TW, ys0 = (strip / tiles_x) * (KT * TH);
+    if (x0 >= T.W || ys0 >= T.H) return;
+    const int ntiles = min(KT, (T.H - ys0 + TH - 1) / TH);
     const DLayer &L = layers[T.first_layer];
     const float *U = L.u;
     const DPlane &SY = L.src.pl[0];
     const DPlane &SC = L.src.pl[1];
+    const DPlane &D = T.dst.pl[0];
     const int tid = threadIdx.x;
     const float sx = (float)T.W, sy = (float)T.H;
 
-    // ---- phase 0: per-column / per-row entries ----------------------------------------
+    // ---- phase 0: column entries of the strip, row entries of all its tiles ------------
     if (tid < TW) {
         int x = x0 + tid;
         int iy, ic, fl; float ay, ac;
         axis_entry_x(U, min(x, T.W - 1), sx, sy, SY.w, SC.w, iy, ay, ic, ac, fl);
-        wave_summary(tb.summary[tid >> 6], x < T.W, fl, iy, ic);
+        group_summary(tb.csum[tid >> 6], 6, x < T.W, fl, iy, ic);
         if (x >= T.W) fl = AX_ALL;   // past the canvas edge: never stored; copy of the last column
         tb.cy[tid] = iy; tb.cya[tid] = ay; tb.cc[tid] = ic; tb.cca[tid] = ac; tb.cfl[tid] = fl;
-    } else if (tid < TW + 64) {
-        int j = tid - TW, y = y0 + j;
+    } else if (tid < TW + KT * TH) {
+        int j = tid - TW, y = ys0 + j;
         int iy, ic, fl; float ay, ac;
         axis_entry_y(U, min(y, T.H - 1), sx, sy, SY.h, SC.h, iy, ay, ic, ac, fl);
-        wave_summary(tb.summary[2], j < TH && y < T.H, fl, iy, ic);
+        group_summary(tb.rsum[j >> 4], 4, y < T.H, fl, iy, ic);
         if (y >= T.H) fl = AX_ALL;
-        if (j < TH) { tb.ry[j] = iy; tb.rya[j] = ay; tb.rc[j] = ic; tb.rca[j] = ac; tb.rfl[j] = fl; }
-    }
-    __syncthreads();
-    int bounds[8];
-    bounds[0] = min(tb.summary[0][0], tb.summary[1][0]); bounds[1] = max(tb.summary[0][1], tb.summary[1][1]);
-    bounds[2] = min(tb.summary[0][2], tb.summary[1][2]); bounds[3] = max(tb.summary[0][3], tb.summary[1][3]);
-    bounds[4] = tb.summary[2][0]; bounds[5] = tb.summary[2][1]; bounds[6] = tb.summary[2][2]; bounds[7] = tb.summary[2][3];
-    const bool all_inside = tb.summary[0][5] && tb.summary[1][5] && tb.summary[2][5];
-
-    // ---- phase 1: stage the touched source rectangle -------------------------------------
-    const bool any = bounds[1] > bounds[0] && bounds[5] > bounds[4];
-    bool staged = false;
-    int ycol0 = 0, ccol0 = 0, yr0 = 0, cr0 = 0;
-    if (any) {
-        const int ylo = bounds[0], yhi = bounds[1], clo = bounds[2], chi = bounds[3];
-        ycol0 = max(ylo, 0) & ~15;                       // luma: byte == texel, 16 per vector
-        ccol0 = max(clo, 0) & ~7;                        // chroma: 8 texels per 16-byte vector
-        const int ynv = (min(yhi, SY.w - 1) - ycol0) / 16 + 1;
-        const int cnv = (min(chi, SC.w - 1) - ccol0) / 8 + 1;
-        yr0 = bounds[4]; cr0 = bounds[6];
-        const int yr = bounds[5] - yr0 + 1, cr = bounds[7] - cr0 + 1;
-        staged = (ynv + 2) * 16 <= ypitch && yr <= yrows && (cnv + 2) * 64 <= cpitch && cr <= crows;
-        if (staged) {
-            // interior tiles: every tap and every staged 16-byte vector lies inside the planes
-            // (taps outside the picture need the replicated edge texels; a vector that runs past
-            // the payload of the plane's last row must not be read as 16 bytes)
-            const bool yedge = ylo < 0 || yhi >= SY.w || yr0 < 0 || bounds[5] >= SY.h - 1 + (int)(ycol0 + ynv * 16 <= SY.w);
-            const bool cedge = clo < 0 || chi >= SC.w || cr0 < 0 || bounds[7] >= SC.h - 1 + (int)(ccol0 + cnv * 8 <= SC.w);
-            stage_plane_u8(smem + ybase, ypitch, SY, yr0, yr, ycol0, ynv, yedge, tid);
-            stage_plane_rg_f32(smem + cbase, cpitch, SC, cr0, cr, ccol0, cnv, cedge, tid);
-        }
+        tb.ry[j] = iy; tb.rya[j] = ay; tb.rc[j] = ic; tb.rca[j] = ac; tb.rfl[j] = fl;
     }
     __syncthreads();
 
-    // ---- phase 2: 4 px x 2 rows per thread ------------------------------------------------
+    // column geometry of the staged rectangle (the same for every tile of the strip)
+    const int ylo = min(tb.csum[0][0], tb.csum[1][0]), yhi = max(tb.csum[0][1], tb.csum[1][1]);
+    const int clo = min(tb.csum[0][2], tb.csum[1][2]), chi = max(tb.csum[0][3], tb.csum[1][3]);
+    const bool cols_any = yhi > ylo;
+    const bool cols_inside = tb.csum[0][5] && tb.csum[1][5];
+    const int ycol0 = max(ylo, 0) & ~15;                       // luma: byte == texel, 16 per vector
+    const int ccol0 = max(clo, 0) & ~7;                        // chroma: 8 texels per 16-byte vector
+    const int ynv = (min(yhi, SY.w - 1) - ycol0) / 16 + 1;
+    const int cnv = (min(chi, SC.w - 1) - ccol0) / 8 + 1;
+    const bool cols_fit = (ynv + 2) * 16 <= ypitch && (cnv + 2) * 64 <= cpitch;
+
+    // per-tile staging geometry from the tile's row summary
+    auto tile_geom = [&](int j, StageGeom &gy, StageGeom &gc) -> bool {
+        const int *rs = tb.rsum[j];
+        if (!(cols_any && rs[1] > rs[0])) return false;
+        gy.r_lo = rs[0]; gy.rows = rs[1] - rs[0] + 1; gy.b0 = ycol0; gy.nvec = ynv;
+        gc.r_lo = rs[2]; gc.rows = rs[3] - rs[2] + 1; gc.b0 = ccol0 * 2; gc.nvec = cnv;
+        // interior rectangles: every tap and every 16-byte vector lies inside the planes
+        gy.edge = ylo < 0 || yhi >= SY.w || rs[0] < 0 || rs[1] >= SY.h - 1 + (int)(ycol0 + ynv * 16 <= SY.w);
+        gc.edge = clo < 0 || chi >= SC.w || rs[2] < 0 || rs[3] >= SC.h - 1 + (int)(ccol0 + cnv * 8 <= SC.w);
+        gy.sh = stage_shift(gy.edge ? ynv + 2 : ynv);
+        gc.sh = stage_shift(gc.edge ? cnv + 2 : cnv);
+        return cols_fit && gy.rows <= yrows && gc.rows <= crows &&
+               stage_slots(gy) <= NYV * NTHREADS && stage_slots(gc) <= NCV * NTHREADS;
+    };
+
+    uint4 yregs[NYV], cregs[NCV];
+    StageGeom gy, gc, ngy, ngc;
+    bool staged = tile_geom(0, gy, gc);
+    if (staged) { stage_load(yregs, SY, gy, tid); stage_load(cregs, SC, gc, tid); }
+
+    // column entries of this thread's four pixels (shared by all its rows); LDS byte
+    // offsets inside a staged tile row
     const int txi = tid & 31, tyi = tid >> 5;
-    const DPlane &D = T.dst.pl[0];
     const int xq = x0 + txi * 4;
-    if (xq >= T.W) return;
     const bool full4 = xq + 3 < T.W;
-    const CscFolded csc = csc_fold(kCsc[L.csc & 3]);
-    const bool opaque = (L.flags & LF_OPAQUE) != 0;
-    const bool uniform_inside = all_inside && staged;
-
-    // column entries of this thread's four pixels (shared by its rows); when staged,
-    // turned into LDS byte offsets inside a tile row
-    int cy[4], cc[4], cfl[4];
+    int cyp[4], ccp[4], cyo[4], cco[4], cfl[4];
     float cya[4], icya[4], cca[4], icca[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         int c = txi * 4 + k;
-        cy[k] = tb.cy[c]; cya[k] = tb.cya[c]; icya[k] = 1.0f - cya[k];
-        cc[k] = tb.cc[c]; cca[k] = tb.cca[c]; icca[k] = 1.0f - cca[k];
+        cyp[k] = tb.cy[c]; cya[k] = tb.cya[c]; icya[k] = 1.0f - cya[k];
+        ccp[k] = tb.cc[c]; cca[k] = tb.cca[c]; icca[k] = 1.0f - cca[k];
         cfl[k] = tb.cfl[c];
-        if (staged) { cy[k] = cy[k] - ycol0 + 16; cc[k] = (cc[k] - ccol0 + 8) * 8; }
+        cyo[k] = cyp[k] - ycol0 + 16; cco[k] = (ccp[k] - ccol0 + 8) * 8;
     }
+    const CscFolded csc = csc_fold(kCsc[L.csc & 3]);
+    const CscFolded cscb = csc_fold_biased(kCsc[L.csc & 3]);
+    const bool opaque = (L.flags & LF_OPAQUE) != 0;
 
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int ly = tyi + rr * 8;
-        const int y = y0 + ly;
-        if (y >= T.H) continue;
-        uint8_t *drow = D.ptr + (size_t)y * D.pitch;
-        const int ry = tb.ry[ly], rc = tb.rc[ly], rfl = tb.rfl[ly];
-        const float yb = tb.rya[ly], iyb = 1.0f - yb, cb = tb.rca[ly], icb = 1.0f - cb;
-        const int yrow = ybase + (ry - yr0) * ypitch, crow = cbase + (rc - cr0) * cpitch;   // staged only
-        uint32_t outw[4];
+    for (int j = 0; j < ntiles; j++) {
+        // ---- phase 1: the prefetched rectangle of tile j goes to LDS ------------------------
+        if (staged) {
+            stage_store<1>(yregs, smem + ybase, ypitch, SY, gy, tid);
+            stage_store<2>(cregs, smem + cbase, cpitch, SC, gc, tid);
+        }
+        __syncthreads();
+        // ---- prefetch tile j+1 while tile j is computed ---------------------------------------
+        bool nstaged = false;
+        if (j + 1 < ntiles) {
+            nstaged = tile_geom(j + 1, ngy, ngc);
+            if (nstaged) { stage_load(yregs, SY, ngy, tid); stage_load(cregs, SC, ngc, tid); }
+        }
 
-        if (uniform_inside && opaque) {
-            // every pixel of the tile is inside the picture and the layer is opaque:
-            // result = cur*0 + px*1 = px exactly and to_code(unorm8(c)) == c, so the
-            // colour-matrix word is the output (no canvas read, no float round trip)
+        // ---- phase 2: 4 px x 2 rows per thread ------------------------------------------------
+        const bool uniform_inside = staged && cols_inside && tb.rsum[j][5];
+        const int yr0 = gy.r_lo, cr0 = gc.r_lo;
+        if (xq < T.W) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float fy, fu, fv;
-                sample_nv12_lds(smem, yrow + cy[k], ypitch, crow + cc[k], cpitch,
-                                icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
-                                icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
-                outw[k] = yuv_to_bgra_word(csc, (int)to_code_unit(fy), (int)to_code_unit(fu), (int)to_code_unit(fv));
-            }
-        } else {
-            uint32_t cur[4];
-            if (CLEAR) { cur[0] = cur[1] = cur[2] = cur[3] = 0xFF000000u; }
-            else if (full4) { uint4 c = *(const uint4 *)(drow + (size_t)xq * 4); cur[0] = c.x; cur[1] = c.y; cur[2] = c.z; cur[3] = c.w; }
-            else { for (int k = 0; k < 4; k++) cur[k] = (xq + k < T.W) ? *(const uint32_t *)(drow + (size_t)(xq + k) * 4) : 0; }
+            for (int rr = 0; rr < RPT; rr++) {
+                const int ly = j * TH + tyi + rr * 8;
+                const int y = ys0 + ly;
+                if (y >= T.H) continue;
+                uint8_t *drow = D.ptr + (size_t)y * D.pitch;
+                const int ry = tb.ry[ly], rc = tb.rc[ly], rfl = tb.rfl[ly];
+                const float yb = tb.rya[ly], iyb = 1.0f - yb, cb = tb.rca[ly], icb = 1.0f - cb;
+                const int yrow = ybase + (ry - yr0) * ypitch, crow = cbase + (rc - cr0) * cpitch;   // staged only
+                uint32_t outw[4];
+
+                if (uniform_inside && opaque) {
+                    // every pixel of the tile is inside the picture and the layer is opaque:
+                    // result = cur*0 + px*1 = px exactly and to_code(unorm8(c)) == c, so the
+                    // colour-matrix word is the output (no canvas read, no float round trip)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int fl = cfl[k] & rfl;
-                uint32_t c = cur[k];
-                if (fl & AX_BORDER) {
-                    const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
-                    uint32_t w = 0;
-                    if (in_pic) {
+                    for (int k = 0; k < 4; k++) {
                         float fy, fu, fv;
-                        if (staged)
-                            sample_nv12_lds(smem, yrow + cy[k], ypitch, crow + cc[k], cpitch,
-                                            icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
-                                            icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
-                        else
-                            sample_nv12_global(SY, SC, cy[k], ry, cc[k], rc,
-                                               icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
-                                               icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
-                        w = yuv_to_bgra_word(csc, (int)to_code(fy), (int)to_code(fu), (int)to_code(fv));
+                        sample_nv12_lds(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
+                                        icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                        icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                        outw[k] = yuv_to_bgra_word(cscb, (int)to_code_unit_biased(fy), (int)to_code_unit_biased(fu),
+                                                   (int)to_code_unit_biased(fv));
                     }
-                    c = blend_bgra_general(c, U, in_pic, w);
+                } else {
+                    uint32_t cur[4];
+                    if (CLEAR) { cur[0] = cur[1] = cur[2] = cur[3] = 0xFF000000u; }
+                    else if (full4) { uint4 c = *(const uint4 *)(drow + (size_t)xq * 4); cur[0] = c.x; cur[1] = c.y; cur[2] = c.z; cur[3] = c.w; }
+                    else { for (int k = 0; k < 4; k++) cur[k] = (xq + k < T.W) ? *(const uint32_t *)(drow + (size_t)(xq + k) * 4) : 0; }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int fl = cfl[k] & rfl;
+                        uint32_t c = cur[k];
+                        if (fl & AX_BORDER) {
+                            const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
+                            uint32_t w = 0;
+                            if (in_pic) {
+                                float fy, fu, fv;
+                                if (staged)
+                                    sample_nv12_lds(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
+                                                    icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                                    icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                                else
+                                    sample_nv12_global(SY, SC, cyp[k], ry, ccp[k], rc,
+                                                       icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                                       icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                                w = yuv_to_bgra_word(csc, (int)to_code(fy), (int)to_code(fu), (int)to_code(fv));
+                            }
+                            c = blend_bgra_general(c, U, in_pic, w);
+                        }
+                        outw[k] = c;
+                    }
                 }
-                outw[k] = c;
+                if (full4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+                else for (int k = 0; k < 4; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
             }
         }
-        if (full4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-        else for (int k = 0; k < 4; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
+        __syncthreads();   // tile j's LDS rectangle is free again
+        staged = nstaged; gy = ngy; gc = ngc;
     }
 }
 
@@ -499,7 +544,7 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
         m.crows = std::max(1, (int)((LDS_BUDGET - sizeof(TileTables)) / 2 / m.cpitch));
         lds = sizeof(TileTables) + (size_t)m.ypitch * m.yrows + (size_t)m.cpitch * m.crows;
     }
-    int tiles_x = (maxW + TW - 1) / TW, tiles_y = (maxH + TH - 1) / TH;
+    int tiles_x = (maxW + TW - 1) / TW, tiles_y = (maxH + KT * TH - 1) / (KT * TH);   // strips of KT tiles
     int groups = (n_ticks + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * tiles_x * tiles_y));
     if (ticks_host[0].clear_first)

@@ -51,6 +51,13 @@ CHV_DEV uint32_t to_code_raw(float v) {
 CHV_DEV uint32_t to_code_unit(float f) {
     return (uint32_t)__builtin_rintf(f * 255.0f);
 }
+// The same rounding through the float adder: x + 1.5*2^23 is rounded to nearest-even at
+// unit spacing, so the low mantissa bits of the sum are rint(x) for 0 <= x < 2^22.
+// Returns the raw bits 0x4B400000 + rint(f*255): two full-rate ops, no v_rndne/v_cvt.
+CHV_DEV uint32_t to_code_unit_biased(float f) {
+    return __float_as_uint(f * 255.0f + 12582912.0f);
+}
+constexpr uint32_t kCodeBias = 0x4B400000u;
 
 CHV_DEV float clampf(float v, float lo, float hi) {
     return __builtin_fminf(__builtin_fmaxf(v, lo), hi);
@@ -177,6 +184,17 @@ CHV_DEV CscFolded csc_fold(const Csc &k) {
     f.kr = base - 128 * k.crv;
     f.kg = base + 128 * (k.cgu + k.cgv);
     f.kb = base - 128 * k.cbu;
+    return f;
+}
+// Operands carry the bias of to_code_unit_biased: v_mul_i32_i24 reads only bits [23:0]
+// (= 2^22 + code, still a positive 24-bit number) and the resulting constant
+// 2^22 * coefficient is folded into the channel offsets, in wrap-around arithmetic.
+CHV_DEV CscFolded csc_fold_biased(const Csc &k) {
+    CscFolded f = csc_fold(k);
+    const uint32_t b = 1u << 22;
+    f.kr = (int32_t)((uint32_t)f.kr - b * (uint32_t)f.cy - b * (uint32_t)f.crv);
+    f.kg = (int32_t)((uint32_t)f.kg - b * (uint32_t)f.cy - b * (uint32_t)f.ncgu - b * (uint32_t)f.ncgv);
+    f.kb = (int32_t)((uint32_t)f.kb - b * (uint32_t)f.cy - b * (uint32_t)f.cbu);
     return f;
 }
 CHV_DEV uint32_t yuv_to_bgra_word(const CscFolded &k, int y, int u, int v) {
