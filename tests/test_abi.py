@@ -1,0 +1,79 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol that
+include/chipvideo.h declares; struct layouts match the header; device-less calls fail with
+an error code instead of crashing."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from swiftvideo_amd import chipvideo as cv
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = (ROOT / "include" / "chipvideo.h").read_text()
+
+
+def declared_functions():
+    names = re.findall(r"\b(chv_[a-z0-9_]+)\s*\(", HEADER)
+    return sorted(set(names))
+
+
+def test_every_declared_symbol_is_exported(built):
+    lib = C.CDLL(str(cv.LIB_PATH))
+    declared = declared_functions()
+    assert len(declared) >= 30
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, f"declared in chipvideo.h but not exported: {missing}"
+
+
+def test_binding_covers_the_header(built):
+    assert sorted(cv._SIGNATURES) == declared_functions()
+    cv.load()
+
+
+def test_struct_layouts():
+    assert C.sizeof(cv.Uniforms) == 236                      # ImageUniforms, compute.swift:76-86
+    assert cv.Uniforms.fill_color.offset == 192 and cv.Uniforms.input_size.offset == 208
+    assert cv.Uniforms.output_size.offset == 216 and cv.Uniforms.opacity.offset == 224
+    assert cv.Uniforms.image_time.offset == 228 and cv.Uniforms.target_time.offset == 232
+    assert C.sizeof(cv.Plane) == 32 and C.sizeof(cv.Image) == 16 + 3 * 32
+    assert C.sizeof(cv.KernelOpts) == 16
+    assert C.sizeof(cv.Layer) == 8 + C.sizeof(cv.Image) + 236 + 16 - 4 or C.sizeof(cv.Layer) % 8 == 0
+
+
+def test_status_strings_follow_compute_error(built):
+    lib = cv.load()
+    cases = {0: "success", 1: "invalidValue", 2: "outOfMemory", 3: "invalidContext", 4: "badTarget",
+             5: "badInputData", 6: "notImplemented", 7: "computeKernelNotFound", 8: "deviceNotAvailable",
+             9: "invalidDevice", 10: "invalidOperation", 11: "badContextState", 12: "invalidPlatform", 13: "unknownError"}
+    for code, name in cases.items():
+        assert lib.chv_error_string(code).decode() == name
+        assert cv.STATUS_NAMES[code] == name
+    assert lib.chv_version() == 0x000100
+
+
+def test_null_and_bad_handles_return_codes_not_crashes(built):
+    lib = cv.load()
+    assert lib.chv_context_destroy(None) == 3
+    assert lib.chv_pass_begin(None) == 3
+    assert lib.chv_pass_end(None, 1) == 3
+    assert lib.chv_buffer_free(None) == 1
+    assert lib.chv_batch_destroy(None) == 1
+    assert lib.chv_event_destroy(None) == 1
+    assert lib.chv_device_count(None) == 1
+    k = C.c_int(0)
+    assert lib.chv_kernel_from_string(None, C.byref(k)) == 1
+    assert lib.chv_kernel_name(99) is None
+    out = C.c_void_p()
+    assert lib.chv_buffer_alloc(None, 16, C.byref(out)) == 3 and not out.value
+
+
+def test_no_device_is_an_error_not_a_fallback(built):
+    """On a box without a usable gfx950 device the product refuses to create a context; there is
+    no CPU pixel path (ComputeError.deviceNotAvailable, compute.swift:121-129)."""
+    from swiftvideo_amd import compute as sv
+    if sv.hasAvailableComputeDevices("GPU"):
+        pytest.skip("a GPU is present")
+    with pytest.raises(sv.ComputeError) as e:
+        sv.makeComputeContext(forType="GPU")
+    assert e.value.case == "deviceNotAvailable"

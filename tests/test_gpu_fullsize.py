@@ -1,0 +1,149 @@
+"""BASELINE.json's configurations at full size: direct comparison with the (multi-threaded) oracle where
+it finishes in seconds, plus size-independent properties (idempotent replay, fused == sequential,
+opacity-0 identity, constant images stay constant, replication of a frame gives replicated outputs)."""
+import os
+
+import numpy as np
+import pytest
+
+import gpuutil as G
+import util
+from oracle import oracle as O
+from swiftvideo_amd import compute as sv
+
+pytestmark = pytest.mark.gpu
+CORES = os.cpu_count() or 4
+
+
+def test_cfg1_720p_nv12_to_bgra(ctx):
+    """configs[0]: single 1280x720 NV12 -> BGRA convert (no scaling)."""
+    w, h = 1280, 720
+    src = util.alloc_image("nv12", w, h, seed=0x5EED0000 + 16)
+    u = util.full_canvas_uniforms((w, h), (w, h))
+    exp = util.alloc_image("bgra", w, h)
+    assert O.run_kernel("img_clear_bgra", exp, threads=CORES) == 0
+    assert O.run_kernel("img_nv12_bgra", exp, src, u, threads=CORES) == 0
+    gs, gd = G.to_gpu(ctx, "nv12", w, h, src), G.to_gpu(ctx, "bgra", w, h, util.alloc_image("bgra", w, h, seed=1))
+    sv.usingContext(ctx, lambda c: sv.compositeTick(c, gd, [(sv.ComputeKernel.img_nv12_bgra, gs, u, 0)], True))
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", w, h), exp, "cfg1")
+
+
+@pytest.mark.parametrize("csc", [0, 1])
+def test_cfg2_1080p_nv12_to_720p_bgra(ctx, csc):
+    """configs[1]: 1920x1080 NV12 -> BGRA + bilinear downscale to 1280x720 (the bench workload)."""
+    sw, sh, dw, dh = 1920, 1080, 1280, 720
+    src = util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 32)
+    u = util.full_canvas_uniforms((dw, dh), (sw, sh))
+    exp = util.alloc_image("bgra", dw, dh)
+    assert O.run_kernel("img_clear_bgra", exp, threads=CORES) == 0
+    assert O.run_kernel("img_nv12_bgra", exp, src, u, csc=csc, threads=CORES) == 0
+    gs = G.to_gpu(ctx, "nv12", sw, sh, src)
+    gd = G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=2))
+    h, name, keep = G.make_batch(ctx, [(gd, True, [(sv.ComputeKernel.img_nv12_bgra, gs, u, csc)])])
+    assert name == "tick_nv12_bgra_tiled"
+    G.run_batch(ctx, h)
+    first = G.from_gpu(ctx, gd, "bgra", dw, dh)
+    G.assert_same(first, exp, "cfg2")
+    G.run_batch(ctx, h)                                   # idempotent replay
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", dw, dh), exp, "cfg2 replay")
+    G.destroy_batch(h)
+
+
+def test_cfg3_four_1080p_bgra_layers(ctx):
+    """configs[2]: VideoMixer with four 1080p BGRA layers (opacity 1, .75, .5, .25) onto a 1080p canvas."""
+    w, h = 1920, 1080
+    layers = [util.alloc_image("bgra", w, h, seed=0x5EED0000 + 48 + i) for i in range(4)]
+    us = [util.full_canvas_uniforms((w, h), (w, h), opacity=o) for o in (1.0, 0.75, 0.5, 0.25)]
+    exp = util.alloc_image("bgra", w, h)
+    assert O.run_kernel("img_clear_bgra", exp, threads=CORES) == 0
+    for l, u in zip(layers, us):
+        assert O.run_kernel("img_bgra_bgra_tx", exp, l, u, threads=CORES) == 0
+    mixer = sv.VideoMixer("ws", 1 / 30, (w, h), outputFormat=sv.PixelFormat.BGRA, computeContext=ctx, fused=True)
+    up = sv.GPUBarrierUpload(ctx)
+    M = util.ortho(w, h) @ util._mat_scale(w, h)
+    for z, (l, o) in enumerate(zip(layers, (1.0, 0.75, 0.5, 0.25))):
+        tag, s = up(sv.pictureFromArrays(sv.PixelFormat.BGRA, (w, h), l, matrix=M, opacity=o, zIndex=z, assetId=f"in{z}"))
+        assert tag == "just"
+        assert mixer.push(s)[0] == "nothing"
+    out = mixer.mix(at=0.0)
+    assert out is not None, mixer.result
+    G.assert_same(G.from_gpu(ctx, out, "bgra", w, h), exp, "cfg3 fused mixer tick")
+    # the reference's own call sequence (clear + 4 x applyComputeImage) gives the same bytes
+    mixer2 = sv.VideoMixer("ws", 1 / 30, (w, h), outputFormat=sv.PixelFormat.BGRA, computeContext=ctx, fused=False)
+    for z, (l, o) in enumerate(zip(layers, (1.0, 0.75, 0.5, 0.25))):
+        mixer2.push(up(sv.pictureFromArrays(sv.PixelFormat.BGRA, (w, h), l, matrix=M, opacity=o, zIndex=z, assetId=f"in{z}"))[1])
+    out2 = mixer2.mix(at=0.0)
+    G.assert_same(G.from_gpu(ctx, out2, "bgra", w, h), exp, "cfg3 sequential mixer tick")
+
+
+def test_cfg4_streams_are_independent(ctx):
+    """configs[3] on one device: 8 streams in one launch; every stream's output equals that stream's
+    single-tick output (no cross-talk between ticks of a batch)."""
+    sw, sh, dw, dh = 1920, 1080, 1280, 720
+    u = util.full_canvas_uniforms((dw, dh), (sw, sh))
+    srcs = [util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 64 + s) for s in range(2)]
+    exps = []
+    for s in srcs:
+        e = util.alloc_image("bgra", dw, dh)
+        assert O.run_kernel("img_clear_bgra", e, threads=CORES) == 0
+        assert O.run_kernel("img_nv12_bgra", e, s, u, threads=CORES) == 0
+        exps.append(e)
+    ticks, gds = [], []
+    for i in range(8):
+        gs = G.to_gpu(ctx, "nv12", sw, sh, srcs[i % 2])
+        gd = G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=70 + i))
+        ticks.append((gd, True, [(sv.ComputeKernel.img_nv12_bgra, gs, u, 0)]))
+        gds.append(gd)
+    h, name, keep = G.make_batch(ctx, ticks)
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    for i, gd in enumerate(gds):
+        G.assert_same(G.from_gpu(ctx, gd, "bgra", dw, dh), exps[i % 2], f"stream {i}")
+
+
+def test_cfg5_4k_eight_layers_then_lanczos(ctx):
+    """configs[4]: 8 x 3840x2160 BGRA layers composited onto a 2160p canvas, Lanczos-3 down to 1080p."""
+    w, h, ow, oh = 3840, 2160, 1920, 1080
+    base = [util.alloc_image("bgra", w, h, seed=0x5EED0000 + 80 + i) for i in range(2)]
+    ops = (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3)
+    us = [util.full_canvas_uniforms((w, h), (w, h), opacity=o) for o in ops]
+    exp = util.alloc_image("bgra", w, h)
+    assert O.run_kernel("img_clear_bgra", exp, threads=CORES) == 0
+    for i, u in enumerate(us):
+        assert O.run_kernel("img_bgra_bgra_tx", exp, base[i % 2], u, threads=CORES) == 0
+    exp_small = util.alloc_image("bgra", ow, oh)
+    assert O.lanczos_bgra(exp_small[0], exp[0], threads=CORES) == 0
+    gl = [G.to_gpu(ctx, "bgra", w, h, b) for b in base]
+    canvas = G.to_gpu(ctx, "bgra", w, h, util.alloc_image("bgra", w, h))
+    small = G.to_gpu(ctx, "bgra", ow, oh, util.alloc_image("bgra", ow, oh))
+    layers = [(sv.ComputeKernel.img_bgra_bgra_tx, gl[i % 2], u, 0) for i, u in enumerate(us)]
+
+    def body(c):
+        c = sv.compositeTick(c, canvas, layers, True)
+        return sv.scaleLanczos(c, small, canvas)
+    sv.usingContext(ctx, body)
+    G.assert_same(G.from_gpu(ctx, canvas, "bgra", w, h), exp, "cfg5 composite")
+    G.assert_same(G.from_gpu(ctx, small, "bgra", ow, oh), exp_small, "cfg5 lanczos")
+
+
+def test_opacity_zero_layer_is_identity_and_constant_stays_constant(ctx):
+    w, h = 1920, 1080
+    canvas0 = util.alloc_image("nv12", w, h, seed=5)
+    src = util.alloc_image("bgra", 640, 360, seed=6)
+    gd = G.to_gpu(ctx, "nv12", w, h, canvas0)
+    gs = G.to_gpu(ctx, "bgra", 640, 360, src)
+    u = util.make_uniforms((w, h), rect=(100, 100, 1280, 720), opacity=0.0, in_size=(640, 360))
+    sv.usingContext(ctx, lambda c: sv.runComputeKernel(c, images=[gs], target=gd, kernel=sv.ComputeKernel.img_bgra_nv12,
+                                                       uniforms=u, blends=True))
+    G.assert_same(G.from_gpu(ctx, gd, "nv12", w, h), canvas0, "opacity 0")
+    # a constant NV12 picture stays constant through bilinear scaling + integer conversion
+    const = [np.full((1080, 1920), 120, np.uint8), np.full((540, 960, 2), 128, np.uint8)]
+    const[1][..., 0] = 90
+    const[1][..., 1] = 200
+    gc = G.to_gpu(ctx, "nv12", 1920, 1080, const)
+    out = G.to_gpu(ctx, "bgra", 1280, 720, util.alloc_image("bgra", 1280, 720))
+    sv.usingContext(ctx, lambda c: sv.compositeTick(c, out, [(sv.ComputeKernel.img_nv12_bgra, gc,
+                                                                util.full_canvas_uniforms((1280, 720), (1920, 1080)), 0)], True))
+    got = G.from_gpu(ctx, out, "bgra", 1280, 720)[0]
+    r, g, b = O.yuv2rgb_int(0, 120, 90, 200)
+    assert np.all(got == np.array([b, g, r, 255], dtype=np.uint8))

@@ -1,0 +1,70 @@
+"""VideoMixer semantics (mix.video.swift:95-165): backing ring of 10, z-order, carry-over of the last
+tick's samples, fused and reference-sequence ticks give the same bytes, errors surface as events."""
+import numpy as np
+import pytest
+
+import gpuutil as G
+import util
+from oracle import oracle as O
+from swiftvideo_amd import compute as sv
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(ctx, fmt, w, h, seed, canvas, rect, z, opacity=1.0, asset="cam"):
+    M = util.ortho(*canvas) @ util._mat_translate(rect[0], rect[1]) @ util._mat_scale(rect[2], rect[3])
+    p = sv.pictureFromArrays(G.FMT[fmt], (w, h), util.alloc_image(fmt, w, h, seed=seed), matrix=M, opacity=opacity,
+                             zIndex=z, assetId=asset)
+    return sv.uploadComputePicture(ctx, p)
+
+
+@pytest.mark.parametrize("fmt", ["nv12", "y420p"])
+def test_mixer_tick_matches_oracle_in_z_order(ctx, fmt):
+    canvas = (96, 54)
+    mixer = sv.VideoMixer("ws", 1 / 30, canvas, outputFormat=G.FMT[fmt], computeContext=ctx, fused=True)
+    seq = sv.VideoMixer("ws", 1 / 30, canvas, outputFormat=G.FMT[fmt], computeContext=ctx, fused=False)
+    specs = [("bgra", 40, 30, 11, (30, 10, 50, 30), 2, 0.8), (fmt, 64, 36, 12, (0, 0, 96, 54), 0, 1.0),
+             ("rgba", 20, 20, 13, (5, 5, 30, 30), 1, 0.6)]
+    for m in (mixer, seq):
+        for s, w, h, seed, rect, z, op in specs:            # pushed out of z order on purpose
+            assert m.push(_layer(ctx, s, w, h, seed, canvas, rect, z, op))[0] == "nothing"
+    exp = util.alloc_image(fmt, *canvas)
+    assert O.run_kernel(f"img_clear_{fmt}", exp) == 0
+    for s, w, h, seed, rect, z, op in sorted(specs, key=lambda t: t[5]):
+        u = util.make_uniforms(canvas, rect=rect, opacity=op, in_size=(w, h))
+        assert O.run_kernel(f"img_{s}_{fmt}", exp, util.alloc_image(s, w, h, seed=seed), u) == 0
+    out, out2 = mixer.mix(at=1.0), seq.mix(at=1.0)
+    assert out is not None and out2 is not None, (mixer.result, seq.result)
+    G.assert_same(G.from_gpu(ctx, out, fmt, *canvas), exp, "fused tick")
+    G.assert_same(G.from_gpu(ctx, out2, fmt, *canvas), exp, "sequential tick")
+    # next tick without new samples re-uses last tick's (samples[1]); the one after that is just the clear
+    out3 = mixer.mix(at=2.0)
+    G.assert_same(G.from_gpu(ctx, out3, fmt, *canvas), exp, "carry-over tick")
+    out4 = mixer.mix(at=3.0)
+    clr = util.alloc_image(fmt, *canvas)
+    assert O.run_kernel(f"img_clear_{fmt}", clr) == 0
+    G.assert_same(G.from_gpu(ctx, out4, fmt, *canvas), clr, "empty tick")
+
+
+def test_backing_ring_has_ten_images(ctx):
+    mixer = sv.VideoMixer("ws", 1 / 30, (32, 18), outputFormat=sv.PixelFormat.nv12, computeContext=ctx)
+    seen = []
+    for t in range(23):
+        out = mixer.mix(at=float(t))
+        seen.append(id(out.imageBuffer().computeTextures[0]))
+    assert len(set(seen)) == 10                       # numberBackingImages, mix.video.swift:167
+    assert seen[10:20] == seen[0:10] and seen[20:23] == seen[0:3]
+
+
+def test_sample_from_own_asset_passes_through_and_errors_become_events(ctx):
+    mixer = sv.VideoMixer("ws", 1 / 30, (32, 18), outputFormat=sv.PixelFormat.y420p, computeContext=ctx, assetId="mixer")
+    own = sv.createPictureSample((32, 18), sv.PixelFormat.y420p, assetId="mixer")
+    assert mixer.push(own) == ("just", own)           # mix.video.swift:66-73
+    # an NV12 layer onto a y420p canvas: findKernel synthesises img_nv12_y420p -> invalidValue -> event error
+    bad = _layer(ctx, "nv12", 16, 8, 3, (32, 18), (0, 0, 32, 18), 0)
+    mixer.push(bad)
+    assert mixer.mix(at=0.0) is None
+    assert mixer.result[0] == "error" and mixer.result[1][0] == "mix.video" and mixer.result[1][1] == -2
+    # the mixer keeps working on the next tick once the bad sample has aged out
+    mixer.mix(at=1.0)
+    assert mixer.mix(at=2.0) is not None

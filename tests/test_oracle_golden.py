@@ -1,0 +1,218 @@
+"""The oracle against the committed golden vectors, against the compiled reference kernel
+strings (when oracle/_ref/libclref.so is available), and its primitives against their
+definitions.  CPU only."""
+from fractions import Fraction
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import scenarios as S
+import util
+from oracle import oracle as O
+
+GOLD = Path(__file__).resolve().parent / "golden" / "vectors.npz"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _outs(gold, key):
+    outs, i = [], 0
+    while f"{key}/out{i}" in gold:
+        outs.append(gold[f"{key}/out{i}"])
+        i += 1
+    return outs
+
+
+def test_golden_file_covers_every_kernel_and_scenario(gold):
+    index = set(gold["index"].tolist())
+    for k in S.LAYER_KERNELS_REF + S.LAYER_KERNELS_OWN + ["img_bgra_bgra"]:
+        for sc in S.SCENARIOS:
+            assert f"{k}/{sc}" in index
+    assert len(index) >= 117
+
+
+def test_oracle_reproduces_golden_vectors(gold):
+    for key in gold["index"].tolist():
+        kernel = key.split("/")[0]
+        cw, ch, iw, ih, seed = gold[key + "/meta"].tolist()
+        exp = _outs(gold, key)
+        if kernel == "lanczos3":
+            src = util.alloc_image("bgra", iw, ih, seed=seed)
+            dst = util.alloc_image("bgra", cw, ch)
+            assert O.lanczos_bgra(dst[0], src[0], threads=2) == 0
+            got = dst
+        elif kernel.startswith("img_clear"):
+            got = util.alloc_image(kernel.split("_")[2], cw, ch, seed=seed)
+            assert O.run_kernel(kernel, got) == 0
+        else:
+            _, s, d = kernel.split("_")[:3]
+            src = util.alloc_image(s, iw, ih, seed=seed)
+            got = util.alloc_image(d, cw, ch, seed=seed + 1000)
+            assert O.run_kernel(kernel, got, src, gold[key + "/uniforms"], threads=3) == 0
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e), key
+
+
+def test_oracle_equals_compiled_reference_kernels():
+    """Kernel-body arithmetic of the restatement == the reference's OpenCL-C source compiled for
+    x86-64 (a cross-check, not a reference build: the image builtins are ours, oracle/clref/cl_shim.c)."""
+    if O.clref() is None:
+        pytest.skip("oracle/_ref/libclref.so not built (needs /root/reference)")
+    rng_geo = [dict(rect=(3, 1, 50, 30), rotation=0.9, opacity=0.45, fill=(0.3, 0.9, 0.2, 0.65), border=(4, 0, 1, 6)),
+               dict(rect=(-30, -10, 140, 70), opacity=1.0, tex=(0.3, 0.4, 0.3, 0.2)),
+               dict(rect=(40, 20, 10, 8), opacity=0.2, fill=(1, 1, 1, 1), border=(30, 15, 10, 5))]
+    for kernel in S.LAYER_KERNELS_REF:
+        _, s, d = kernel.split("_")
+        for gi, geo in enumerate(rng_geo):
+            u = util.make_uniforms((64, 36), in_size=(48, 28), **geo)
+            src = util.alloc_image(s, 48, 28, seed=300 + gi)
+            c0 = util.alloc_image(d, 64, 36, seed=400 + gi)
+            a, b = util.copy_image(c0), util.copy_image(c0)
+            assert O.run_kernel(kernel, a, src, u) == 0
+            assert O.run_clref(kernel, b, src, u) == 0
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), f"{kernel} geometry {gi}"
+
+
+def test_threaded_oracle_equals_single_thread():
+    u = util.make_uniforms((130, 47), rect=(5, 3, 100, 40), rotation=0.1, opacity=0.7, in_size=(64, 36))
+    for kernel in ["img_bgra_nv12", "img_y420p_y420p", "img_nv12_bgra"]:
+        _, s, d = kernel.split("_")
+        src = util.alloc_image(s, 64, 36, seed=8)
+        c0 = util.alloc_image(d, 130, 47, seed=9)
+        a, b = util.copy_image(c0), util.copy_image(c0)
+        assert O.run_kernel(kernel, a, src, u, threads=1) == 0
+        assert O.run_kernel(kernel, b, src, u, threads=7) == 0
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+# ---- primitives -------------------------------------------------------------------------------
+def test_unorm8_load_is_correctly_rounded_division():
+    lib = O.lib()
+    for c in range(256):
+        got = np.float32(lib.orc_load_unorm8(c))
+        assert got == np.float32(c) / np.float32(255)
+        # correctly rounded: the exact quotient lies within half an ulp
+        exact = Fraction(c, 255)
+        ulp = Fraction(float(np.spacing(got))) if c else Fraction(0)
+        assert abs(Fraction(float(got)) - exact) <= ulp / 2
+
+
+def test_two_op_unorm8_formula_is_exact():
+    """pixel_math.hip.h computes c/255 as fma(c, r_hi, c*r_lo); prove it in exact arithmetic."""
+    def rn32(x):
+        return Fraction(float(np.float32(float(x)))) if x.denominator.bit_length() < 60 else None
+    r_hi = Fraction(float(np.float32(1) / np.float32(255)))
+    r_lo = Fraction(float.fromhex("-0x1.fdfdfep-33"))
+    for c in range(256):
+        t = Fraction(float(np.float32(float(c * r_lo))))          # c*r_lo is exactly representable in double
+        s = c * r_hi + t                                            # exact
+        # round the exact sum to float32: both terms are dyadic, double holds the sum exactly here
+        assert np.float32(float(s)) == np.float32(c) / np.float32(255)
+
+
+def test_unorm8_store_rounding():
+    lib = O.lib()
+    assert lib.orc_store_unorm8(0.5) == 128            # 127.5 -> even
+    assert lib.orc_store_unorm8(0.0) == 0 and lib.orc_store_unorm8(1.0) == 255
+    assert lib.orc_store_unorm8(-3.0) == 0 and lib.orc_store_unorm8(7.0) == 255
+    assert lib.orc_store_unorm8(float("nan")) == 0
+    assert lib.orc_store_unorm8(float("inf")) == 255 and lib.orc_store_unorm8(float("-inf")) == 0
+    assert lib.orc_store_unorm8(2.5 / 255) == 2 and lib.orc_store_unorm8(3.5 / 255) == 4
+    for c in range(256):                                 # round trip: store(load(c)) == c
+        assert lib.orc_store_unorm8(lib.orc_load_unorm8(c)) == c
+
+
+def test_integer_yuv2rgb_known_answers():
+    # BT.601 limited: black, white, and the primaries' well-known code points
+    assert O.yuv2rgb_int(0, 16, 128, 128) == (0, 0, 0)
+    assert O.yuv2rgb_int(0, 235, 128, 128) == (255, 255, 255)
+    # the 8-bit code points of the primaries come back within one code
+    for yuv, rgb in (((81, 90, 240), (255, 0, 0)), ((145, 54, 34), (0, 255, 0)), ((41, 240, 110), (0, 0, 255))):
+        got = O.yuv2rgb_int(0, *yuv)
+        assert all(abs(g - e) <= 1 for g, e in zip(got, rgb)), (yuv, got)
+    assert O.yuv2rgb_int(0, 0, 0, 0) == (0, 136, 0)       # negative sums: arithmetic shift, then clip
+    # full range: identity on grey
+    for y in (0, 1, 127, 128, 254, 255):
+        assert O.yuv2rgb_int(2, y, 128, 128) == (y, y, y)
+        assert O.yuv2rgb_int(3, y, 128, 128) == (y, y, y)
+    # against a float64 evaluation of the same fixed-point definition, all (y,u,v) on a grid
+    k = {0: (16, 76309, 104597, 25675, 53279, 132201), 1: (16, 76309, 117489, 13975, 34925, 138438),
+         2: (0, 65536, 91881, 22553, 46802, 116130), 3: (0, 65536, 103206, 12276, 30679, 121609)}
+    for csc, (yo, cy, crv, cgu, cgv, cbu) in k.items():
+        for y in range(0, 256, 17):
+            for u in range(0, 256, 15):
+                for v in range(0, 256, 15):
+                    c = cy * (y - yo) + 32768
+                    exp = tuple(min(max(x >> 16, 0), 255) for x in
+                                (c + crv * (v - 128), c - cgu * (u - 128) - cgv * (v - 128), c + cbu * (u - 128)))
+                    assert O.yuv2rgb_int(csc, y, u, v) == exp
+
+
+def test_lanczos_table_properties():
+    for (i, o) in ((1920, 1920), (3840, 1920), (100, 37), (37, 100)):
+        taps, first, w = O.lanczos_table(i, o)
+        assert taps == 2 * int(np.ceil(3 * max(i / o, 1.0)))
+        assert np.allclose(w.sum(axis=1), 1.0, atol=1e-6)
+        assert np.all(np.diff(first) >= 0)
+    # identity size: the centre tap carries all the weight
+    taps, first, w = O.lanczos_table(64, 64)
+    assert np.all(w.max(axis=1) > 0.9999)
+
+
+def test_lanczos_constant_image_stays_constant():
+    src = np.full((40, 60, 4), 173, dtype=np.uint8)
+    dst = np.zeros((20, 30, 4), dtype=np.uint8)
+    assert O.lanczos_bgra(dst, src) == 0
+    assert np.all(dst == 173)
+
+
+def test_reference_quirks_are_preserved():
+    """Bit-level quirks of the reference called out in SURVEY section 2.2."""
+    # same-size full-canvas composite is a half-pixel box filter, not a copy (out_uv = gid/size, no +0.5)
+    src = util.alloc_image("nv12", 16, 8, seed=1)
+    dst = util.alloc_image("nv12", 16, 8)
+    assert O.run_kernel("img_clear_nv12", dst) == 0
+    assert O.run_kernel("img_nv12_nv12", dst, src, util.full_canvas_uniforms((16, 8), (16, 8))) == 0
+    assert dst[0][0, 0] == src[0][0, 0]                      # clamped corner
+    assert not np.array_equal(dst[0], src[0])
+    y = src[0].astype(np.float64)
+    box = (y[2, 4] + y[2, 5] + y[3, 4] + y[3, 5]) / 4
+    assert abs(int(dst[0][3, 5]) - box) <= 1
+    # clear: Y = 0, chroma = 0.5 -> 128 (round half to even)
+    assert np.all(dst[1] != 0)
+    c = util.alloc_image("y420p", 8, 4, seed=2)
+    assert O.run_kernel("img_clear_y420p", c) == 0
+    assert np.all(c[0] == 0) and np.all(c[1] == 128) and np.all(c[2] == 128)
+    # pure blue through img_bgra_nv12: Y = 0.113 * 255 -> 29 (the reference's 0.113, not 0.114)
+    blue = np.zeros((8, 16, 4), dtype=np.uint8)
+    blue[..., 0] = 255
+    blue[..., 3] = 255
+    nv = util.alloc_image("nv12", 16, 8)
+    assert O.run_kernel("img_clear_nv12", nv) == 0
+    assert O.run_kernel("img_bgra_nv12", nv, [blue], util.full_canvas_uniforms((16, 8), (16, 8))) == 0
+    assert np.all(nv[0] == 29) and np.all(nv[1][..., 0] == 255) and np.all(nv[1][..., 1] == 107)
+    # RGB-source kernels write nothing outside tx in [0,1]^2, YUV-source kernels paint the border
+    u = util.make_uniforms((32, 16), rect=(8, 4, 16, 8), border=(4, 2, 4, 2), fill=(1, 0, 0, 1), in_size=(16, 8))
+    c0 = util.alloc_image("nv12", 32, 16, seed=3)
+    a, b = util.copy_image(c0), util.copy_image(c0)
+    assert O.run_kernel("img_bgra_nv12", a, util.alloc_image("bgra", 16, 8, seed=4), u) == 0
+    assert O.run_kernel("img_nv12_nv12", b, util.alloc_image("nv12", 16, 8, seed=4), u) == 0
+    assert np.array_equal(a[0][2:4, 4:28], c0[0][2:4, 4:28])          # border rows untouched by the RGB kernel
+    assert not np.array_equal(b[0][2:4, 4:28], c0[0][2:4, 4:28])       # painted by the YUV kernel
+    assert np.array_equal(b[0][:2], c0[0][:2])                          # outside the border quad: untouched
+
+
+def test_oracle_argument_checks():
+    nv = util.alloc_image("nv12", 16, 8)
+    bg = util.alloc_image("bgra", 16, 8)
+    u = util.full_canvas_uniforms((16, 8), (16, 8))
+    assert O.run_kernel("img_clear_yuvs", nv) == 6          # enum case without a kernel
+    assert O.run_kernel("img_bgra_nv12", bg, bg, u) == 4    # bad target
+    assert O.run_kernel("img_bgra_nv12", nv, nv, u) == 5    # bad input
+    assert O.run_kernel("img_bgra_nv12", nv, bg, None) == 1
