@@ -1,0 +1,342 @@
+/*
+   compute.hip.swift — SwiftVideo compute backend over CHIPVideo (AMD MI355X / gfx950).
+
+   Drop-in for Sources/SwiftVideo/compute.cl.swift: it defines the same types
+   (ComputeDevice, ComputeBuffer, ComputeContext) and the same free functions, so
+   compute.swift, mix.video.swift and sample.pict.linux.swift compile unchanged when the
+   package is built with the GPGPU_HIP define (see INTEGRATION.md for the Package.swift
+   hunk).  All pixel work happens in libchipvideo.so; this file only marshals
+   PictureSample / ImageBuffer values into chv_image descriptors and maps status codes
+   to ComputeError.
+
+   NOTE: written against the backend contract of compute.cl.swift:36-499; it cannot be
+   compiled in the container this repository is developed in (no Swift toolchain), so the
+   call sequences it relies on are exercised through the same C ABI by tests/ instead.
+*/
+#if GPGPU_HIP
+import Foundation
+import CHIPVideo
+import VectorMath
+import Logging
+
+// MARK: - Types (compute.cl.swift:36-105)
+
+struct ComputeDevice {
+    let deviceId: Int32
+    let available: Bool
+    let deviceType: ComputeDeviceType?
+    let vendorId: Int?
+    let vendorName: String?
+    let supportsImages: Bool
+}
+
+public class ComputeBuffer {
+    fileprivate let handle: OpaquePointer
+    fileprivate let size: Int
+    fileprivate let pitch: Int
+    fileprivate init(_ handle: OpaquePointer, size: Int, pitch: Int = 0) {
+        self.handle = handle
+        self.size = size
+        self.pitch = pitch
+    }
+    deinit {
+        // callable from any thread: the library makes the owning device current
+        _ = chv_buffer_free(handle)
+    }
+}
+
+public struct ComputeContext {
+    fileprivate let handle: OpaquePointer
+    let device: ComputeDevice
+    let logger: Logger
+    fileprivate init(_ handle: OpaquePointer, device: ComputeDevice, logger: Logger) {
+        self.handle = handle
+        self.device = device
+        self.logger = logger
+    }
+}
+
+// MARK: - Error mapping (the role of checkCLError, compute.cl.swift:683-702)
+
+private func check(_ status: Int32, kernel: ComputeKernel? = nil) throws {
+    guard status != 0 else { return }
+    let detail = String(cString: chv_last_error_detail())
+    switch chv_status(UInt32(status)) {
+    case CHV_ERR_INVALID_VALUE: throw ComputeError.invalidValue
+    case CHV_ERR_OUT_OF_MEMORY: throw ComputeError.outOfMemory
+    case CHV_ERR_INVALID_CONTEXT: throw ComputeError.invalidContext
+    case CHV_ERR_BAD_TARGET: throw ComputeError.badTarget
+    case CHV_ERR_BAD_INPUT: throw ComputeError.badInputData(description: detail)
+    case CHV_ERR_NOT_IMPLEMENTED: throw ComputeError.notImplemented
+    case CHV_ERR_KERNEL_NOT_FOUND: throw ComputeError.computeKernelNotFound(kernel ?? .custom(name: detail))
+    case CHV_ERR_DEVICE_NOT_AVAILABLE: throw ComputeError.deviceNotAvailable
+    case CHV_ERR_INVALID_DEVICE: throw ComputeError.invalidDevice
+    case CHV_ERR_INVALID_OPERATION: throw ComputeError.invalidOperation
+    case CHV_ERR_BAD_CONTEXT_STATE: throw ComputeError.badContextState(description: detail)
+    case CHV_ERR_INVALID_PLATFORM: throw ComputeError.invalidPlatform
+    default: throw ComputeError.unknownError
+    }
+}
+
+private func kernelId(_ kernel: ComputeKernel) throws -> Int32 {
+    var id: Int32 = -1
+    if case .custom(let name) = kernel {
+        // "img_nv12_bgra", "img_bgra_bgra_tx", ... resolve through the library's name table
+        try check(chv_kernel_from_string(name, &id), kernel: kernel)
+        return id
+    }
+    try check(chv_kernel_from_string(String(describing: kernel), &id), kernel: kernel)
+    return id
+}
+
+// MARK: - Devices and contexts (compute.cl.swift:107-151)
+
+func availableComputeDevices() -> [ComputeDevice] {
+    var count: Int32 = 0
+    guard chv_device_count(&count) == 0 else { return [] }
+    return (0..<count).compactMap { idx in
+        var info = chv_device_info()
+        guard chv_device_info_get(idx, &info) == 0 else { return nil }
+        let name = withUnsafePointer(to: &info.name) {
+            $0.withMemoryRebound(to: CChar.self, capacity: 128) { String(cString: $0) }
+        }
+        return ComputeDevice(deviceId: idx, available: info.available != 0, deviceType: .GPU,
+                             vendorId: Int(info.vendor_id), vendorName: name,
+                             supportsImages: info.supports_images != 0)
+    }
+}
+
+func createComputeContext(sharing ctx: ComputeContext) -> ComputeContext? {
+    var out: OpaquePointer?
+    guard chv_context_share(ctx.handle, &out) == 0, let handle = out else { return nil }
+    return ComputeContext(handle, device: ctx.device, logger: ctx.logger)
+}
+
+func createComputeContext(_ device: ComputeDevice,
+                          logger: Logger = Logger(label: "SwiftVideo")) throws -> ComputeContext? {
+    var out: OpaquePointer?
+    try check(chv_context_create(device.deviceId, &out))
+    // all kernels are part of the library: nothing to build here (the OpenCL backend compiles
+    // every OpenCLKernel case at this point, compute.cl.swift:139-144)
+    return out.map { ComputeContext($0, device: device, logger: logger) }
+}
+
+func destroyComputeContext( _ context: ComputeContext) throws {
+    try check(chv_context_destroy(context.handle))
+}
+
+func buildComputeKernel(_ context: ComputeContext, name: String, source: String) throws -> ComputeContext {
+    // runtime-compiled user kernels (.custom) are not part of the picture path
+    throw ComputeError.notImplemented
+}
+
+// MARK: - Passes and kernels (compute.cl.swift:234-359)
+
+func beginComputePass(_ context: ComputeContext) -> ComputeContext {
+    _ = chv_pass_begin(context.handle)
+    return context
+}
+
+func endComputePass(_ context: ComputeContext, _ waitForCompletion: Bool) -> ComputeContext {
+    _ = chv_pass_end(context.handle, waitForCompletion ? 1 : 0)
+    return context
+}
+
+private func describe(_ image: ImageBuffer, maxPlanes: Int) -> chv_image? {
+    guard image.bufferType == .gpu, image.computeTextures.count > 0 else { return nil }
+    var desc = chv_image()
+    desc.format = Int32(pixelFormatCode(image.pixelFormat))
+    desc.width = Int32(image.size.x)
+    desc.height = Int32(image.size.y)
+    let count = min(image.computeTextures.count, maxPlanes)
+    desc.n_planes = Int32(count)
+    withUnsafeMutablePointer(to: &desc.planes) {
+        $0.withMemoryRebound(to: chv_plane.self, capacity: 3) { planes in
+            for idx in 0..<count {
+                let plane = image.planes[idx]
+                let comps = plane.components.count >= 3 ? 4 : plane.components.count
+                planes[idx] = chv_plane(buffer: image.computeTextures[idx].handle, offset: 0,
+                                        width: Int32(plane.size.x), height: Int32(plane.size.y),
+                                        pitch: Int32(image.computeTextures[idx].pitch),
+                                        components: Int32(comps))
+            }
+        }
+    }
+    return desc
+}
+
+private func pixelFormatCode(_ fmt: PixelFormat) -> Int {
+    switch fmt {
+    case .nv12: return Int(CHV_FMT_NV12.rawValue)
+    case .nv21: return Int(CHV_FMT_NV21.rawValue)
+    case .yuvs: return Int(CHV_FMT_YUVS.rawValue)
+    case .zvuy: return Int(CHV_FMT_ZVUY.rawValue)
+    case .y420p: return Int(CHV_FMT_Y420P.rawValue)
+    case .y422p: return Int(CHV_FMT_Y422P.rawValue)
+    case .y444p: return Int(CHV_FMT_Y444P.rawValue)
+    case .RGBA: return Int(CHV_FMT_RGBA.rawValue)
+    case .BGRA: return Int(CHV_FMT_BGRA.rawValue)
+    default: return Int(CHV_FMT_INVALID.rawValue)
+    }
+}
+
+func runComputeKernel(_ context: ComputeContext,
+                      images: [PictureSample],
+                      target: PictureSample,
+                      kernel: ComputeKernel,
+                      maxPlanes: Int = 3,
+                      requiredMemory: Int? = nil) throws -> ComputeContext {
+    return try runComputeKernel(context, images: images, target: target, kernel: kernel,
+                                maxPlanes: maxPlanes, uniforms: Void?.none)
+}
+
+func runComputeKernel<T>(_ context: ComputeContext,
+                         images: [PictureSample],
+                         target: PictureSample,
+                         kernel: ComputeKernel,
+                         maxPlanes: Int = 3,
+                         requiredMemory: Int? = nil,
+                         uniforms: T? = nil,
+                         blends: Bool = false) throws -> ComputeContext {
+    guard let targetImage = target.imageBuffer(), var targetDesc = describe(targetImage, maxPlanes: 3) else {
+        throw ComputeError.badTarget
+    }
+    var inputs = try images.map { sample -> chv_image in
+        // a CPU sample is uploaded on the fly, as createTexture does (compute.cl.swift:280-286)
+        let gpu = try uploadComputePicture(context, pict: sample, maxPlanes: maxPlanes)
+        guard let image = gpu.imageBuffer(), let desc = describe(image, maxPlanes: maxPlanes) else {
+            throw ComputeError.badInputData(description: "Bad input image")
+        }
+        return desc
+    }
+    let id = try kernelId(kernel)
+    let status: Int32
+    if var uniforms = uniforms {
+        status = withUnsafeBytes(of: &uniforms) { raw in
+            chv_run_kernel(context.handle, id, &targetDesc, &inputs, Int32(inputs.count),
+                           raw.baseAddress, MemoryLayout<T>.size, blends ? 1 : 0, nil)
+        }
+    } else {
+        status = chv_run_kernel(context.handle, id, &targetDesc, &inputs, Int32(inputs.count),
+                                nil, 0, blends ? 1 : 0, nil)
+    }
+    try check(status, kernel: kernel)
+    return context
+}
+
+// MARK: - Transfers (compute.cl.swift:361-498)
+
+func uploadComputeBuffer(_ ctx: ComputeContext, src: Data, dst: ComputeBuffer?) throws -> ComputeBuffer {
+    let buffer: ComputeBuffer
+    if let dst = dst {
+        buffer = dst
+    } else {
+        var out: OpaquePointer?
+        try check(chv_buffer_alloc(ctx.handle, src.count, &out))
+        buffer = ComputeBuffer(out!, size: src.count)
+    }
+    guard buffer.size >= src.count else {
+        throw ComputeError.badInputData(description: "Compute buffer needs to be >= to data.count")
+    }
+    try src.withUnsafeBytes {
+        try check(chv_upload(ctx.handle, buffer.handle, 0, src.count, $0.baseAddress, src.count, src.count, 1, 0))
+    }
+    return buffer
+}
+
+func downloadComputeBuffer(_ ctx: ComputeContext, src: ComputeBuffer, dst: Data?) throws -> Data {
+    var dst = dst ?? Data(count: src.size)
+    guard dst.count >= src.size else {
+        throw ComputeError.badInputData(description: "Destination data buffer must be >= buffer.size")
+    }
+    try dst.withUnsafeMutableBytes {
+        try check(chv_download(ctx.handle, $0.baseAddress, src.size, src.handle, 0, src.size, src.size, 1))
+    }
+    return dst
+}
+
+func uploadComputePicture(_ ctx: ComputeContext,
+                          pict: PictureSample,
+                          maxPlanes: Int = 3,
+                          retainCpuBuffer: Bool = true) throws -> PictureSample {
+    guard pict.bufferType() == .cpu else { return pict }
+    guard let imageBuffer = pict.imageBuffer() else {
+        throw ComputeError.badInputData(description: "Missing image buffer")
+    }
+    let planeCount = imageBuffer.planes.count
+    guard 3 >= planeCount && 0 < planeCount else {
+        throw ComputeError.badInputData(description: "Input image must have 1, 2, or 3 planes")
+    }
+    guard planeCount == imageBuffer.buffers.count else {
+        throw ComputeError.badInputData(description: "Input image must have the same number of buffers as planes")
+    }
+    let textures = try (0..<min(planeCount, maxPlanes)).map { idx -> ComputeBuffer in
+        let plane = imageBuffer.planes[idx]
+        let comps = plane.components.count >= 3 ? 4 : plane.components.count
+        var out: OpaquePointer?
+        var pitch = 0
+        try check(chv_plane_alloc(ctx.handle, Int32(plane.size.x), Int32(plane.size.y), Int32(comps), &out, &pitch))
+        let texture = ComputeBuffer(out!, size: pitch * Int(plane.size.y), pitch: pitch)
+        try imageBuffer.buffers[idx].withUnsafeBytes {
+            // async = 1: bytes are staged into pinned memory before the call returns, the copy
+            // is ordered on the context's stream in front of the kernels that read the plane
+            try check(chv_upload(ctx.handle, texture.handle, 0, pitch, $0.baseAddress, plane.stride,
+                                 Int(plane.size.x) * comps, Int(plane.size.y), 1))
+        }
+        return texture
+    }
+    let image = ImageBuffer(imageBuffer, computeTextures: textures,
+                            buffers: !retainCpuBuffer ? [] : nil, bufferType: .gpu)
+    return PictureSample(pict, img: image)
+}
+
+func downloadComputePicture(_ ctx: ComputeContext,
+                            pict: PictureSample,
+                            retainGpuBuffer: Bool = false) throws -> PictureSample {
+    guard pict.bufferType() == .gpu else { return pict }
+    guard let imageBuffer = pict.imageBuffer() else {
+        throw ComputeError.badInputData(description: "Missing image buffer")
+    }
+    let buffers = try (0..<imageBuffer.computeTextures.count).map { idx -> Data in
+        let plane = imageBuffer.planes[idx]
+        let comps = plane.components.count >= 3 ? 4 : plane.components.count
+        var buffer = imageBuffer.buffers[safe: idx] ?? Data(count: Int(plane.size.y) * plane.stride)
+        let texture = imageBuffer.computeTextures[idx]
+        try buffer.withUnsafeMutableBytes {
+            try check(chv_download(ctx.handle, $0.baseAddress, plane.stride, texture.handle, 0, texture.pitch,
+                                   Int(plane.size.x) * comps, Int(plane.size.y)))
+        }
+        return buffer
+    }
+    let image = ImageBuffer(imageBuffer, computeTextures: !retainGpuBuffer ? [] : nil,
+                            buffers: buffers, bufferType: .cpu)
+    return PictureSample(pict, img: image)
+}
+
+// MARK: - One mixer tick in one launch (optional fast path for VideoMixer.mix)
+
+/// Equivalent of `usingContext { clear; images.reduce { applyComputeImage } }` (mix.video.swift:116-124)
+/// issued as a single chv_composite launch; byte-identical output.
+func compositeTick(_ context: ComputeContext,
+                   layers: [(PictureSample, ComputeKernel, ImageUniforms)],
+                   target: PictureSample) throws -> ComputeContext {
+    guard let targetImage = target.imageBuffer(), var targetDesc = describe(targetImage, maxPlanes: 3) else {
+        throw ComputeError.badTarget
+    }
+    var descs = try layers.map { (sample, kernel, uniforms) -> chv_layer in
+        guard let image = sample.imageBuffer(), let desc = describe(image, maxPlanes: 3) else {
+            throw ComputeError.badInputData(description: "Bad input image")
+        }
+        var layer = chv_layer()
+        layer.kernel = try kernelId(kernel)
+        layer.image = desc
+        var u = uniforms
+        withUnsafeBytes(of: &u) { src in
+            withUnsafeMutableBytes(of: &layer.uniforms) { $0.copyMemory(from: UnsafeRawBufferPointer(rebasing: src[0..<236])) }
+        }
+        return layer
+    }
+    try check(chv_composite(context.handle, &targetDesc, 1, &descs, Int32(descs.count)))
+    return context
+}
+#endif
