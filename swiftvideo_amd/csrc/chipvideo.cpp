@@ -526,7 +526,9 @@ static int32_t layer_flags(const float *u) {
     // uv = textureTx . tx uses all four tx components: tx.z/tx.w must not depend on x or y
     bool tzw_const = T[8] == 0.f && T[9] == 0.f && T[12] == 0.f && T[13] == 0.f;
     if (axis(T) && axis(B) && axis(X) && tzw_const) f |= LF_AXIS_ALIGNED;
-    if (u[U_OPACITY] * u[U_FILL + 3] == 0.f) f |= LF_NO_FILL;
+    // no fill contribution: alpha is exactly zero AND the colour is finite (0 * inf would be NaN)
+    bool fill_finite = (u[U_FILL] - u[U_FILL] == 0.f) && (u[U_FILL + 1] - u[U_FILL + 1] == 0.f) && (u[U_FILL + 2] - u[U_FILL + 2] == 0.f);
+    if (u[U_OPACITY] * u[U_FILL + 3] == 0.f && fill_finite) f |= LF_NO_FILL;
     if (u[U_OPACITY] == 1.f) f |= LF_OPAQUE;
     return f;
 }

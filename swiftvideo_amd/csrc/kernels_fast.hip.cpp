@@ -19,7 +19,7 @@
 //
 // Every path here produces exactly the bytes of kernels_general.hip.cpp; the host
 // picks a path per batch (select_fast_path) and falls back to the general kernel.
-#include "pixel_math.hip.h"
+#include "tile_common.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -28,18 +28,25 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_COUNT };
 
-constexpr int TW = 128;          // tile width  (output pixels)
+// kernels_fast_rgb.hip.cpp
+bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
+hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
+                             int n_ticks, int maxW, int maxH, hipStream_t stream);
+
+#ifndef CHV_TW
+#define CHV_TW 128
+#endif
+constexpr int TW = CHV_TW;       // tile width  (output pixels), a multiple of 64
+constexpr int TXT = TW / 4;      // threads across a tile row (4 px each)
+constexpr int TYT = NTHREADS / TXT;   // tile rows covered per pass
 #ifndef CHV_TH
 #define CHV_TH 16
 #endif
 constexpr int TH = CHV_TH;       // tile height (output rows)
-constexpr int RPT = TH / 8;      // rows per thread
-constexpr int NTHREADS = 256;    // 32 x 8 threads, each 4 px x 2 rows
-constexpr int LDS_BUDGET = 64 * 1024;
-
-enum { AX_BORDER = 1, AX_TX = 2, AX_UV = 4, AX_ALL = 7 };
+constexpr int RPT = TH / TYT;    // rows per thread
+// NTHREADS = 256: 32 x 8 threads, each 4 px x 2 rows per tile
 
 constexpr int KT = 4;             // tiles per block: a vertical strip of KT tiles shares its column tables
 
@@ -56,41 +63,9 @@ struct TileTables {
     int rfl[KT * TH];
     // {min luma, max luma + 1, min chroma, max chroma + 1, any entry fully inside,
     //  every in-canvas entry fully inside, -, -}
-    int csum[2][8];                // per column wave
+    int csum[TW / 64][8];          // per column wave
     int rsum[KT][8];               // per tile of the strip
 };
-
-// Summarise a group of `1 << gshift` consecutive lanes (one wave of columns: 64; one tile's
-// rows: 16).  Positions are monotone in the pixel index (every step of the coordinate
-// arithmetic is a monotone rounding of a monotone function) and the "fully inside"
-// entries form an interval, so the extremes sit at its first and last lane.
-CHV_DEV void group_summary(int *out, int gshift, bool in_canvas, int fl, int iy, int ic) {
-    const int lane = threadIdx.x & 63;
-    const int g0 = (lane >> gshift) << gshift;
-    const unsigned long long gmask = (gshift == 6) ? ~0ull : (((1ull << (1 << gshift)) - 1ull) << g0);
-    const unsigned long long valid = __ballot(in_canvas && fl == AX_ALL) & gmask;
-    const unsigned long long partial = __ballot(in_canvas && fl != AX_ALL) & gmask;
-    int first = valid ? __ffsll((long long)valid) - 1 : g0;
-    int last = valid ? 63 - __clzll((long long)valid) : g0;
-    int y_a = __shfl(iy, first), y_b = __shfl(iy, last);
-    int c_a = __shfl(ic, first), c_b = __shfl(ic, last);
-    if (lane == g0) {
-        out[0] = valid ? min(y_a, y_b) : 0x7fffffff;
-        out[1] = valid ? max(y_a, y_b) + 1 : -0x7fffffff;
-        out[2] = valid ? min(c_a, c_b) : 0x7fffffff;
-        out[3] = valid ? max(c_a, c_b) + 1 : -0x7fffffff;
-        out[4] = valid != 0;
-        out[5] = partial == 0;
-    }
-}
-
-// unclamped tap-0 position and weight of one axis of the linear filter (cf. lin_axis)
-CHV_DEV void lin_axis_raw(float s, int w, int &i0, float &a) {
-    float um = s * (float)w - 0.5f;
-    float fl = __builtin_floorf(um);
-    a = um - fl;
-    i0 = (int)fl;
-}
 
 // x-dependent half of `geometry` + the sampler's x axis, evaluated at row 0 (under axis
 // alignment the x components do not depend on y; signs of zero apart, which no later
@@ -124,116 +99,6 @@ CHV_DEV void axis_entry_y(const float *__restrict__ U, int y, float sx, float sy
             ((v >= 0.f && v <= 1.f) ? AX_UV : 0);
     lin_axis_raw(v, hy, iy, ay);
     lin_axis_raw(v, hc, ic, ac);
-}
-
-// 16 source bytes -> 16 normalised floats
-CHV_DEV void unorm16(const uint4 &v, float4 &f0, float4 &f1, float4 &f2, float4 &f3) {
-    f0 = make_float4(unorm8(v.x & 255), unorm8((v.x >> 8) & 255), unorm8((v.x >> 16) & 255), unorm8(v.x >> 24));
-    f1 = make_float4(unorm8(v.y & 255), unorm8((v.y >> 8) & 255), unorm8((v.y >> 16) & 255), unorm8(v.y >> 24));
-    f2 = make_float4(unorm8(v.z & 255), unorm8((v.z >> 8) & 255), unorm8((v.z >> 16) & 255), unorm8(v.z >> 24));
-    f3 = make_float4(unorm8(v.w & 255), unorm8((v.w >> 8) & 255), unorm8((v.w >> 16) & 255), unorm8(v.w >> 24));
-}
-
-// 16 bytes at byte offset `off` of row `row` of a plane whose base and pitch are 16-byte
-// aligned (host-checked).  A vector that would run past the end of the LAST row is read
-// bytewise; bytes past the row's payload are don't-care.
-CHV_DEV uint4 load_row_vec(const DPlane &P, int row, int off) {
-    const int row_bytes = P.w * P.comps;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (off < 0 || off >= row_bytes) return val;
-    const uint8_t *s = P.ptr + (size_t)row * P.pitch + off;
-    if (row < P.h - 1 || off + 16 <= row_bytes) return *(const uint4 *)s;
-    uint32_t w[4] = { 0, 0, 0, 0 };
-    for (int k = 0; k < 16 && off + k < row_bytes; k++) w[k >> 2] |= (uint32_t)s[k] << ((k & 3) * 8);
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// Replace the texels of a 16-byte vector that lie outside the row (left of texel 0 when
-// the vector is the padding vector, at or beyond the row end otherwise) by the nearest
-// edge texel: CLAMP_TO_EDGE resolved once at staging time.  BPT = bytes per texel (1, 2).
-template <int BPT>
-CHV_DEV uint4 patch_edges(uint4 val, const DPlane &P, int row, int off) {
-    const int row_bytes = P.w * BPT;
-    if (off >= 0 && off + 16 <= row_bytes) return val;
-    const uint8_t *s = P.ptr + (size_t)row * P.pitch;
-    uint32_t w[4] = { val.x, val.y, val.z, val.w };
-    if (off < 0) {
-        // padding vector in front of texel 0: only its last texel slot is ever addressed
-        uint32_t e = BPT == 1 ? (uint32_t)s[0] << 24 : (uint32_t)(*(const uint16_t *)s) << 16;
-        w[3] = (w[3] & (BPT == 1 ? 0x00FFFFFFu : 0x0000FFFFu)) | e;
-    } else {
-        uint32_t e = BPT == 1 ? (uint32_t)s[row_bytes - 1] * 0x01010101u
-                              : (uint32_t)(*(const uint16_t *)(s + row_bytes - 2)) * 0x00010001u;
-        int nvalid = max(row_bytes - off, 0);     // bytes of this vector inside the row
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            int nb = min(max(nvalid - 4 * d, 0), 4);
-            uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
-            w[d] = (w[d] & mask) | (e & ~mask);
-        }
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// Staging of one plane's source rectangle, split in two so that the global loads of the
-// NEXT tile are in flight while the current tile is being computed:
-//   stage_load : raw 16-byte vectors -> registers (no dependent instruction)
-//   stage_store: CLAMP_TO_EDGE patching, unorm8 -> float (chroma), LDS write
-// Slot i = tid + n * NTHREADS maps to row i >> sh, vector (i & mask) of that row; LDS row r
-// holds source row clamp(r_lo + r).  With `edge` (block-uniform: the rectangle touches a
-// picture edge) vectors -1 .. nvec are staged, with the outside texels replicated.
-struct StageGeom {
-    int r_lo, rows;     // first (unclamped) source row, number of LDS rows
-    int b0;             // first source byte of vector 0 (16-byte aligned)
-    int nvec;           // vectors that hold picture bytes
-    int sh;             // log2 of slots per row
-    int edge;
-};
-CHV_DEV int stage_shift(int nv) { return nv <= 16 ? 4 : (nv <= 32 ? 5 : 6); }
-CHV_DEV int stage_slots(const StageGeom &g) { return g.rows << g.sh; }
-
-template <int N>
-CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, int tid) {
-    const int nv = g.edge ? g.nvec + 2 : g.nvec;
-#pragma unroll
-    for (int n = 0; n < N; n++) {
-        int i = tid + n * NTHREADS;
-        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
-        regs[n] = make_uint4(0, 0, 0, 0);
-        if (r < g.rows && vv < nv) {
-            int row = min(max(g.r_lo + r, 0), P.h - 1);
-            int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
-            regs[n] = g.edge ? load_row_vec(P, row, off) : *(const uint4 *)(P.ptr + (size_t)row * P.pitch + off);
-        }
-    }
-}
-
-// BPT = 1: bytes kept as bytes (LDS byte 16 + k of a row = source byte b0 + k)
-// BPT = 2: byte pairs normalised to float pairs (LDS texel slot 8 + k = source texel b0/2 + k)
-template <int BPT, int N>
-CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid) {
-    const int nv = g.edge ? g.nvec + 2 : g.nvec;
-#pragma unroll
-    for (int n = 0; n < N; n++) {
-        int i = tid + n * NTHREADS;
-        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
-        if (r < g.rows && vv < nv) {
-            int v = g.edge ? vv - 1 : vv;
-            uint4 val = regs[n];
-            if (g.edge) {
-                int row = min(max(g.r_lo + r, 0), P.h - 1);
-                val = patch_edges<BPT>(val, P, row, g.b0 + v * 16);
-            }
-            if (BPT == 1) {
-                *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
-            } else {
-                float4 f0, f1, f2, f3;
-                unorm16(val, f0, f1, f2, f3);
-                float4 *d = (float4 *)(lds + r * lds_pitch + 64 + v * 64);
-                d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
-            }
-        }
-    }
 }
 
 // One pixel of the BGRA-target family from already-sampled, quantised YUV.
@@ -295,7 +160,10 @@ CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, int ix, int 
 // the next tile's global loads | compute + store | barrier].
 // CLEAR: canvas starts as img_clear_bgra's value instead of being read.
 // ---------------------------------------------------------------------------
-constexpr int NYV = 3;   // prefetch registers (16-byte vectors) per thread, luma
+#ifndef CHV_NYV
+#define CHV_NYV 3
+#endif
+constexpr int NYV = CHV_NYV;   // prefetch registers (16-byte vectors) per thread, luma
 constexpr int NCV = 2;   // chroma
 
 template <bool CLEAR>
@@ -333,7 +201,7 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
         int x = x0 + tid;
         int iy, ic, fl; float ay, ac;
         axis_entry_x(U, min(x, T.W - 1), sx, sy, SY.w, SC.w, iy, ay, ic, ac, fl);
-        group_summary(tb.csum[tid >> 6], 6, x < T.W, fl, iy, ic);
+        group_summary(tb.csum[tid >> 6], 6, x < T.W, fl, iy, ic);   // TW / 64 column waves
         if (x >= T.W) fl = AX_ALL;   // past the canvas edge: never stored; copy of the last column
         tb.cy[tid] = iy; tb.cya[tid] = ay; tb.cc[tid] = ic; tb.cca[tid] = ac; tb.cfl[tid] = fl;
     } else if (tid < TW + KT * TH) {
@@ -347,10 +215,15 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
     __syncthreads();
 
     // column geometry of the staged rectangle (the same for every tile of the strip)
-    const int ylo = min(tb.csum[0][0], tb.csum[1][0]), yhi = max(tb.csum[0][1], tb.csum[1][1]);
-    const int clo = min(tb.csum[0][2], tb.csum[1][2]), chi = max(tb.csum[0][3], tb.csum[1][3]);
+    int ylo = tb.csum[0][0], yhi = tb.csum[0][1], clo = tb.csum[0][2], chi = tb.csum[0][3];
+    bool cols_inside = tb.csum[0][5] != 0;
+#pragma unroll
+    for (int w = 1; w < TW / 64; w++) {
+        ylo = min(ylo, tb.csum[w][0]); yhi = max(yhi, tb.csum[w][1]);
+        clo = min(clo, tb.csum[w][2]); chi = max(chi, tb.csum[w][3]);
+        cols_inside = cols_inside && tb.csum[w][5];
+    }
     const bool cols_any = yhi > ylo;
-    const bool cols_inside = tb.csum[0][5] && tb.csum[1][5];
     const int ycol0 = max(ylo, 0) & ~15;                       // luma: byte == texel, 16 per vector
     const int ccol0 = max(clo, 0) & ~7;                        // chroma: 8 texels per 16-byte vector
     const int ynv = (min(yhi, SY.w - 1) - ycol0) / 16 + 1;
@@ -379,18 +252,17 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
 
     // column entries of this thread's four pixels (shared by all its rows); LDS byte
     // offsets inside a staged tile row
-    const int txi = tid & 31, tyi = tid >> 5;
+    const int txi = tid % TXT, tyi = tid / TXT;
     const int xq = x0 + txi * 4;
     const bool full4 = xq + 3 < T.W;
-    int cyp[4], ccp[4], cyo[4], cco[4], cfl[4];
+    int cyo[4], cco[4];
     float cya[4], icya[4], cca[4], icca[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         int c = txi * 4 + k;
-        cyp[k] = tb.cy[c]; cya[k] = tb.cya[c]; icya[k] = 1.0f - cya[k];
-        ccp[k] = tb.cc[c]; cca[k] = tb.cca[c]; icca[k] = 1.0f - cca[k];
-        cfl[k] = tb.cfl[c];
-        cyo[k] = cyp[k] - ycol0 + 16; cco[k] = (ccp[k] - ccol0 + 8) * 8;
+        cya[k] = tb.cya[c]; icya[k] = 1.0f - cya[k];
+        cca[k] = tb.cca[c]; icca[k] = 1.0f - cca[k];
+        cyo[k] = tb.cy[c] - ycol0 + 16; cco[k] = (tb.cc[c] - ccol0 + 8) * 8;
     }
     const CscFolded csc = csc_fold(kCsc[L.csc & 3]);
     const CscFolded cscb = csc_fold_biased(kCsc[L.csc & 3]);
@@ -416,7 +288,7 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
         if (xq < T.W) {
 #pragma unroll
             for (int rr = 0; rr < RPT; rr++) {
-                const int ly = j * TH + tyi + rr * 8;
+                const int ly = j * TH + tyi + rr * TYT;
                 const int y = ys0 + ly;
                 if (y >= T.H) continue;
                 uint8_t *drow = D.ptr + (size_t)y * D.pitch;
@@ -439,33 +311,36 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
                                                    (int)to_code_unit_biased(fv));
                     }
                 } else {
-                    uint32_t cur[4];
-                    if (CLEAR) { cur[0] = cur[1] = cur[2] = cur[3] = 0xFF000000u; }
-                    else if (full4) { uint4 c = *(const uint4 *)(drow + (size_t)xq * 4); cur[0] = c.x; cur[1] = c.y; cur[2] = c.z; cur[3] = c.w; }
-                    else { for (int k = 0; k < 4; k++) cur[k] = (xq + k < T.W) ? *(const uint32_t *)(drow + (size_t)(xq + k) * 4) : 0; }
-#pragma unroll
+                    // tiles on a picture/border edge, translucent layers, unstaged tiles: one pixel at a
+                    // time, entries re-read from the tables (this branch is rare; keeping it narrow keeps
+                    // the kernel's register allocation that of the branch above)
+#pragma unroll 1
                     for (int k = 0; k < 4; k++) {
-                        const int fl = cfl[k] & rfl;
-                        uint32_t c = cur[k];
+                        if (xq + k >= T.W) break;
+                        const int c = txi * 4 + k;
+                        const int fl = tb.cfl[c] & rfl;
+                        uint32_t *dp = (uint32_t *)(drow + (size_t)(xq + k) * 4);
+                        uint32_t cpx = CLEAR ? 0xFF000000u : *dp;
                         if (fl & AX_BORDER) {
                             const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
                             uint32_t w = 0;
                             if (in_pic) {
+                                const int pyx = tb.cy[c], pcx = tb.cc[c];
+                                const float ya = tb.cya[c], iya = 1.0f - ya, ca = tb.cca[c], ica = 1.0f - ca;
                                 float fy, fu, fv;
                                 if (staged)
-                                    sample_nv12_lds(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
-                                                    icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
-                                                    icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                                    sample_nv12_lds(smem, yrow + (pyx - ycol0 + 16), ypitch, crow + (pcx - ccol0 + 8) * 8, cpitch,
+                                                    iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
                                 else
-                                    sample_nv12_global(SY, SC, cyp[k], ry, ccp[k], rc,
-                                                       icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
-                                                       icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                                    sample_nv12_global(SY, SC, pyx, ry, pcx, rc,
+                                                       iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
                                 w = yuv_to_bgra_word(csc, (int)to_code(fy), (int)to_code(fu), (int)to_code(fv));
                             }
-                            c = blend_bgra_general(c, U, in_pic, w);
+                            cpx = blend_bgra_general(cpx, U, in_pic, w);
                         }
-                        outw[k] = c;
+                        *dp = cpx;
                     }
+                    continue;
                 }
                 if (full4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
                 else for (int k = 0; k < 4; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
@@ -508,12 +383,15 @@ static bool aligned16(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 &
 const char *fast_path_name(int path) {
     switch (path) {
     case FP_NV12_BGRA_TILED: return "tick_nv12_bgra_tiled";
+    case FP_RGB_LAYERS_TILED: return "tick_rgb_layers_tiled";
     default: return "none";
     }
 }
 
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
     if (target_format != TF_BGRA || n_ticks <= 0) return FP_NONE;
+    if (ticks[0].n_layers >= 1 && layers[ticks[0].first_layer].kind == LK_BGRA_FROM_RGB)
+        return rgb_layers_eligible(ticks, layers, n_ticks) ? FP_RGB_LAYERS_TILED : FP_NONE;
     for (int i = 0; i < n_ticks; i++) {
         const DTick &T = ticks[i];
         if (T.n_layers != 1 || T.clear_first != ticks[0].clear_first) return FP_NONE;
@@ -529,6 +407,7 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
+    if (path == FP_RGB_LAYERS_TILED) return launch_rgb_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path != FP_NV12_BGRA_TILED) return hipErrorNotSupported;
     TileDims m = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < n_ticks; i++) {

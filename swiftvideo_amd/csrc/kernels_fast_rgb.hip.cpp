@@ -1,0 +1,317 @@
+// kernels_fast_rgb.hip.cpp — axis-aligned, LDS-tiled tick kernel for BGRA canvases whose
+// layers are all BGRA/RGBA pictures (img_bgra_bgra_tx / img_rgba_bgra_tx; BASELINE
+// configs 3 and 5: N full-size layers alpha-composited in one pass).
+//
+// A block owns a 64x16 tile of the canvas and keeps its pixels (4 per thread) in
+// registers across all layers, so the canvas is written once and every layer is read
+// once: the per-tick HBM traffic is the algorithmic minimum (layers + canvas).
+//   phase 0  per-layer column/row tables of the reference's coordinate arithmetic
+//            (same instruction sequence as the general kernel => same bits)
+//   per layer: [store the prefetched source rectangle to LDS as float4 texels (c/255 once
+//            per texel, edge texels replicated) | barrier | issue the next layer's global
+//            loads | sample 2x2 taps from LDS, blend, re-quantise | barrier]
+// Between layers the value is re-quantised through the float adder exactly as the
+// per-layer kernels do through their UNORM8 canvas.
+#include "tile_common.hip.h"
+
+#include <algorithm>
+#include <cmath>
+
+#pragma clang fp contract(off)
+
+namespace chv {
+
+constexpr int RTW = 64;           // tile width  (output pixels): 16 threads x 4 px (columns txi + 16k, so that
+                                  // lane-adjacent LDS reads hit adjacent 16-byte texels: no bank conflicts)
+constexpr int RTH = 16;           // tile height (output rows):   16 thread rows
+constexpr int RMAXL = 8;          // layers per tick this path accepts
+constexpr int RNV = 3;            // prefetch registers (16-byte vectors) per thread
+
+struct RgbLayerTable {
+    int cp[RTW]; float ca[RTW]; int cfl[RTW];     // column: unclamped tap-0 texel, weight of tap 1, flags
+    int rp[RTH]; float ra[RTH]; int rfl[RTH];     // row
+    int csum[8];                                  // {min, max+1, -, -, any inside, all inside, -, -}
+    int rsum[8];
+};
+
+CHV_DEV void axis_entry_x1(const float *__restrict__ U, int x, float sx, float sy, int w, int &ip, float &a, int &flags) {
+    float ou = (float)x / sx, ov = 0.0f / sy;
+    float nx = ou * 2.f - 1.f, ny = ov * 2.f - 1.f;
+    float t0 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 0);
+    float t1 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 4);
+    float t2 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 8);
+    float t3 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 12);
+    float b0 = dot4(nx, ny, 0.f, 1.f, U + U_BORDER + 0);
+    float u = dot4(t0, t1, t2, t3, U + U_TEXTURE + 0);
+    flags = ((b0 >= 0.f && b0 <= 1.f) ? AX_BORDER : 0) | ((t0 >= 0.f && t0 <= 1.f) ? AX_TX : 0) |
+            ((u >= 0.f && u <= 1.f) ? AX_UV : 0);
+    lin_axis_raw(u, w, ip, a);
+}
+CHV_DEV void axis_entry_y1(const float *__restrict__ U, int y, float sx, float sy, int h, int &ip, float &a, int &flags) {
+    float ou = 0.0f / sx, ov = (float)y / sy;
+    float nx = ou * 2.f - 1.f, ny = ov * 2.f - 1.f;
+    float t0 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 0);
+    float t1 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 4);
+    float t2 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 8);
+    float t3 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 12);
+    float b1 = dot4(nx, ny, 0.f, 1.f, U + U_BORDER + 4);
+    float v = dot4(t0, t1, t2, t3, U + U_TEXTURE + 4);
+    flags = ((b1 >= 0.f && b1 <= 1.f) ? AX_BORDER : 0) | ((t1 >= 0.f && t1 <= 1.f) ? AX_TX : 0) |
+            ((v >= 0.f && v <= 1.f) ? AX_UV : 0);
+    lin_axis_raw(v, h, ip, a);
+}
+
+// rint(x) for 0 <= x < 2^22 through the float adder (ties to even), kept as a float
+CHV_DEV float rint_small(float x) { return (x + 12582912.0f) - 12582912.0f; }
+// to_code as a float code value in [0, 255]: convert_uchar_sat_rte(f * 255), NaN -> 0
+CHV_DEV float to_codef(float f) {
+    float v = __builtin_rintf(f * 255.0f);
+    return __builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);
+}
+
+template <bool CLEAR>
+__global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *__restrict__ ticks,
+                                                                   const DLayer *__restrict__ layers,
+                                                                   int n_ticks, int tiles_x, int tiles_y,
+                                                                   int tpitch, int trows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    RgbLayerTable *tabs = (RgbLayerTable *)smem;                 // [RMAXL]
+    int *scratch = (int *)(smem + sizeof(RgbLayerTable) * RMAXL);  // sink for summaries of absent layers
+    const int tbase = (int)(sizeof(RgbLayerTable) * RMAXL) + 64; // [trows][tpitch] float4 texels
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int tiles = tiles_x * tiles_y;
+    const int tick = (slot / tiles) * 8 + xcd;                   // whole frames per XCD (block b runs on XCD b % 8)
+    if (tick >= n_ticks) return;
+    const int tile = slot % tiles;
+    const DTick &T = ticks[tick];
+    const int x0 = (tile % tiles_x) * RTW, y0 = (tile / tiles_x) * RTH;
+    if (x0 >= T.W || y0 >= T.H) return;
+    const DLayer *L = layers + T.first_layer;
+    const int nl = T.n_layers;
+    const DPlane &D = T.dst.pl[0];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float sx = (float)T.W, sy = (float)T.H;
+
+    // ---- phase 0: tables of every layer ---------------------------------------------------
+    for (int l = wave; l < nl; l += 4) {                         // one wave = the 64 columns of one layer
+        const DPlane &S = L[l].src.pl[0];
+        int x = x0 + lane, ip, fl; float a;
+        axis_entry_x1(L[l].u, min(x, T.W - 1), sx, sy, S.w, ip, a, fl);
+        group_summary(tabs[l].csum, 6, x < T.W, fl, ip, ip);
+        if (x >= T.W) fl = AX_ALL;
+        tabs[l].cp[lane] = ip; tabs[l].ca[lane] = a; tabs[l].cfl[lane] = fl;
+    }
+    for (int l4 = wave * 4; l4 < nl; l4 += 16) {                 // one wave = the 16 rows of four layers
+        int l = l4 + (lane >> 4), j = lane & 15;
+        int lc = min(l, nl - 1);
+        const DPlane &S = L[lc].src.pl[0];
+        int y = y0 + j, ip, fl; float a;
+        axis_entry_y1(L[lc].u, min(y, T.H - 1), sx, sy, S.h, ip, a, fl);
+        group_summary(l < nl ? tabs[l].rsum : scratch, 4, l < nl && y < T.H, fl, ip, ip);
+        if (y >= T.H) fl = AX_ALL;
+        if (l < nl) { tabs[l].rp[j] = ip; tabs[l].ra[j] = a; tabs[l].rfl[j] = fl; }
+    }
+    __syncthreads();
+
+    // staging geometry of layer l's source rectangle for this tile
+    auto layer_geom = [&](int l, StageGeom &g, int &col0) -> bool {
+        const RgbLayerTable &t = tabs[l];
+        const DPlane &S = L[l].src.pl[0];
+        if (!(t.csum[1] > t.csum[0] && t.rsum[1] > t.rsum[0])) return false;
+        const int lo = t.csum[0], hi = t.csum[1];
+        col0 = max(lo, 0) & ~3;                                  // 4 texels per 16-byte vector
+        const int nvec = (min(hi, S.w - 1) - col0) / 4 + 1;
+        g.r_lo = t.rsum[0]; g.rows = t.rsum[1] - t.rsum[0] + 1; g.b0 = col0 * 4; g.nvec = nvec;
+        g.edge = lo < 0 || hi >= S.w || t.rsum[0] < 0 || t.rsum[1] >= S.h - 1 + (int)(col0 + nvec * 4 <= S.w);
+        g.sh = stage_shift(g.edge ? nvec + 2 : nvec);
+        return (nvec + 2) * 64 <= tpitch && g.rows <= trows && stage_slots(g) <= RNV * NTHREADS;
+    };
+
+    // ---- canvas pixels of this thread, as float code values -----------------------------------
+    const int txi = tid & 15, ly = tid >> 4;
+    const int xq = x0 + txi, y = y0 + ly;              // this thread's pixels: xq + 16*k
+    const bool active = xq < T.W && y < T.H;
+    uint8_t *drow = D.ptr + (size_t)(active ? y : 0) * D.pitch;
+    float cb[4], cg[4], cr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { cb[k] = 0.f; cg[k] = 0.f; cr[k] = 0.f; }   // img_clear_bgra: (0,0,0,1)
+    bool touched[4] = { CLEAR, CLEAR, CLEAR, CLEAR };   // untouched pixels keep their original alpha byte
+    uint32_t orig_a[4] = { 0, 0, 0, 0 };
+    if (!CLEAR && active) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t cur = (xq + 16 * k < T.W) ? *(const uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) : 0;
+            cb[k] = (float)(cur & 255); cg[k] = (float)((cur >> 8) & 255); cr[k] = (float)((cur >> 16) & 255);
+            orig_a[k] = cur & 0xFF000000u;
+        }
+    }
+
+    uint4 regs[RNV];
+    StageGeom g, ng;
+    int col0 = 0, ncol0 = 0;
+    bool staged = nl > 0 && layer_geom(0, g, col0);
+    if (staged) stage_load(regs, L[0].src.pl[0], g, tid);
+
+    for (int l = 0; l < nl; l++) {
+        const DLayer &Ly = L[l];
+        const DPlane &S = Ly.src.pl[0];
+        const RgbLayerTable &t = tabs[l];
+        if (staged) stage_store<4>(regs, smem + tbase, tpitch, S, g, tid);
+        __syncthreads();
+        bool nstaged = false;
+        if (l + 1 < nl) {
+            nstaged = layer_geom(l + 1, ng, ncol0);
+            if (nstaged) stage_load(regs, L[l + 1].src.pl[0], ng, tid);
+        }
+        if (active) {
+            const float *U = Ly.u;
+            const float opacity = U[U_OPACITY];
+            const bool nofill = (Ly.flags & LF_NO_FILL) != 0;
+            // opacity in [0,1] and no fill: every blend is a convex combination of values in
+            // [0,1], so neither the clamp of the fill step nor the saturation of the store can
+            // trigger; with every pixel of the tile inside the picture the loop is branch-free
+            const bool fast = staged && t.csum[5] && t.rsum[5] && nofill && opacity >= 0.f && opacity <= 1.f;
+            const float b = t.ra[ly], ib = 1.0f - b;
+            const int rowoff = tbase + (t.rp[ly] - g.r_lo) * tpitch + (4 - col0) * 16;
+            if (fast) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int c = txi + 16 * k;
+                    const float a = t.ca[c], ia = 1.0f - a;
+                    const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
+                    const float4 *p0 = (const float4 *)(smem + rowoff + t.cp[c] * 16);
+                    const float4 *p1 = (const float4 *)(smem + rowoff + tpitch + t.cp[c] * 16);
+                    const float4 t00 = p0[0], t10 = p0[1], t01 = p1[0], t11 = p1[1];
+                    const float q0 = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+                    const float q1 = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+                    const float q2 = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+                    const float q3 = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+                    const float al = q3 * opacity, ial = 1.f - al;
+                    const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
+                    cb[k] = rint_small((unorm8f(cb[k]) * ial + pb * al) * 255.0f);
+                    cg[k] = rint_small((unorm8f(cg[k]) * ial + q1 * al) * 255.0f);
+                    cr[k] = rint_small((unorm8f(cr[k]) * ial + pr * al) * 255.0f);
+                    touched[k] = true;
+                }
+            } else {
+                const float af = opacity * U[U_FILL + 3], iaf = 1.f - af;
+                const float f_b = U[U_FILL + 2], f_g = U[U_FILL + 1], f_r = U[U_FILL + 0];
+                const int rfl = t.rfl[ly];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int c = txi + 16 * k;
+                    const int fl = t.cfl[c] & rfl;
+                    if (!(fl & AX_BORDER)) continue;
+                    touched[k] = true;
+                    const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
+                    float r0 = clampf(unorm8f(cb[k]) * iaf + f_b * af, 0.f, 1.f);
+                    float r1 = clampf(unorm8f(cg[k]) * iaf + f_g * af, 0.f, 1.f);
+                    float r2 = clampf(unorm8f(cr[k]) * iaf + f_r * af, 0.f, 1.f);
+                    if (in_pic) {
+                        const float a = t.ca[c], ia = 1.0f - a;
+                        const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
+                        float4 t00, t10, t01, t11;
+                        if (staged) {
+                            const float4 *p0 = (const float4 *)(smem + rowoff + t.cp[c] * 16);
+                            const float4 *p1 = (const float4 *)(smem + rowoff + tpitch + t.cp[c] * 16);
+                            t00 = p0[0]; t10 = p0[1]; t01 = p1[0]; t11 = p1[1];
+                        } else {
+                            int xa = min(max(t.cp[c], 0), S.w - 1), xb = min(max(t.cp[c] + 1, 0), S.w - 1);
+                            int ya = min(max(t.rp[ly], 0), S.h - 1), yb = min(max(t.rp[ly] + 1, 0), S.h - 1);
+                            auto ld = [&](int xx, int yy) {
+                                uint32_t v = *(const uint32_t *)(S.ptr + (size_t)yy * S.pitch + (size_t)xx * 4);
+                                return make_float4(unorm8(v & 255), unorm8((v >> 8) & 255), unorm8((v >> 16) & 255), unorm8(v >> 24));
+                            };
+                            t00 = ld(xa, ya); t10 = ld(xb, ya); t01 = ld(xa, yb); t11 = ld(xb, yb);
+                        }
+                        float q0 = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+                        float q1 = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+                        float q2 = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+                        float q3 = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+                        const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
+                        const float al = q3 * opacity, ial = 1.f - al;
+                        r0 = r0 * ial + pb * al;
+                        r1 = r1 * ial + q1 * al;
+                        r2 = r2 * ial + pr * al;
+                    }
+                    cb[k] = to_codef(r0); cg[k] = to_codef(r1); cr[k] = to_codef(r2);
+                }
+            }
+        }
+        __syncthreads();
+        staged = nstaged; g = ng; col0 = ncol0;
+    }
+
+    if (active) {
+        uint32_t outw[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            outw[k] = (uint32_t)cb[k] | ((uint32_t)cg[k] << 8) | ((uint32_t)cr[k] << 16) | (touched[k] ? 0xFF000000u : orig_a[k]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (xq + 16 * k < T.W) *(uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) = outw[k];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static bool finite16r(const float *m) {
+    for (int i = 0; i < 16; i++) if (!(m[i] - m[i] == 0.f)) return false;
+    return true;
+}
+static bool aligned16r(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0; }
+
+static void rgb_tile_dims(const DTick &T, const DLayer &L, int *pitch, int *rows) {
+    const float *U = L.u;
+    double sxr = std::fabs((double)U[U_TEXTURE + 0] * (double)U[U_TRANSFORM + 0] * 2.0 / (double)T.W);
+    double syr = std::fabs((double)U[U_TEXTURE + 5] * (double)U[U_TRANSFORM + 5] * 2.0 / (double)T.H);
+    int span = (int)std::ceil(RTW * sxr * L.src.pl[0].w) + 4;
+    *pitch = ((span + 3) / 4 + 3) * 64;                 // float4 texels, 4 per vector, alignment + 2 pad vectors
+    *rows = (int)std::ceil(RTH * syr * L.src.pl[0].h) + 5;
+}
+
+bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks) {
+    for (int i = 0; i < n_ticks; i++) {
+        const DTick &T = ticks[i];
+        if (T.n_layers < 1 || T.n_layers > RMAXL || T.clear_first != ticks[0].clear_first) return false;
+        if (!aligned16r(T.dst.pl[0])) return false;
+        for (int l = 0; l < T.n_layers; l++) {
+            const DLayer &L = layers[T.first_layer + l];
+            if (L.kind != LK_BGRA_FROM_RGB || !(L.flags & LF_AXIS_ALIGNED)) return false;
+            if (!finite16r(L.u + U_TRANSFORM) || !finite16r(L.u + U_TEXTURE) || !finite16r(L.u + U_BORDER)) return false;
+            if (!aligned16r(L.src.pl[0])) return false;
+            int pitch, rows;
+            rgb_tile_dims(T, L, &pitch, &rows);
+            if (sizeof(RgbLayerTable) * RMAXL + 64 + (size_t)pitch * rows > (size_t)LDS_BUDGET) return false;
+        }
+    }
+    return true;
+}
+
+hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
+                             int n_ticks, int maxW, int maxH, hipStream_t stream) {
+    int pitch = 0, rows = 0;
+    for (int i = 0; i < n_ticks; i++)
+        for (int l = 0; l < ticks_host[i].n_layers; l++) {
+            int p, r;
+            rgb_tile_dims(ticks_host[i], layers_host[ticks_host[i].first_layer + l], &p, &r);
+            pitch = std::max(pitch, p); rows = std::max(rows, r);
+        }
+    size_t lds = sizeof(RgbLayerTable) * RMAXL + 64 + (size_t)pitch * rows;
+    if (lds > (size_t)LDS_BUDGET) {
+        rows = std::max(1, (int)((LDS_BUDGET - sizeof(RgbLayerTable) * RMAXL - 64) / pitch));
+        lds = sizeof(RgbLayerTable) * RMAXL + 64 + (size_t)pitch * rows;
+    }
+    int tiles_x = (maxW + RTW - 1) / RTW, tiles_y = (maxH + RTH - 1) / RTH;
+    int groups = (n_ticks + 7) / 8;
+    dim3 grid((unsigned)(groups * 8 * tiles_x * tiles_y));
+    if (ticks_host[0].clear_first)
+        hipLaunchKernelGGL(tick_rgb_layers_tiled<true>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, tiles_x, tiles_y, pitch, rows);
+    else
+        hipLaunchKernelGGL(tick_rgb_layers_tiled<false>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, tiles_x, tiles_y, pitch, rows);
+    return hipGetLastError();
+}
+
+}  // namespace chv

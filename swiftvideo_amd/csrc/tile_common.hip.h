@@ -1,0 +1,161 @@
+// tile_common.hip.h — building blocks shared by the axis-aligned LDS-tiled kernels
+// (kernels_fast.hip.cpp: NV12 -> BGRA; kernels_fast_rgb.hip.cpp: BGRA/RGBA layers -> BGRA).
+#pragma once
+#include "pixel_math.hip.h"
+
+#pragma clang fp contract(off)
+
+namespace chv {
+
+constexpr int NTHREADS = 256;
+constexpr int LDS_BUDGET = 64 * 1024;
+
+enum { AX_BORDER = 1, AX_TX = 2, AX_UV = 4, AX_ALL = 7 };
+
+
+// Summarise a group of `1 << gshift` consecutive lanes (one wave of columns: 64; one tile's
+// rows: 16).  Positions are monotone in the pixel index (every step of the coordinate
+// arithmetic is a monotone rounding of a monotone function) and the "fully inside"
+// entries form an interval, so the extremes sit at its first and last lane.
+CHV_DEV void group_summary(int *out, int gshift, bool in_canvas, int fl, int iy, int ic) {
+    const int lane = threadIdx.x & 63;
+    const int g0 = (lane >> gshift) << gshift;
+    const unsigned long long gmask = (gshift == 6) ? ~0ull : (((1ull << (1 << gshift)) - 1ull) << g0);
+    const unsigned long long valid = __ballot(in_canvas && fl == AX_ALL) & gmask;
+    const unsigned long long partial = __ballot(in_canvas && fl != AX_ALL) & gmask;
+    int first = valid ? __ffsll((long long)valid) - 1 : g0;
+    int last = valid ? 63 - __clzll((long long)valid) : g0;
+    int y_a = __shfl(iy, first), y_b = __shfl(iy, last);
+    int c_a = __shfl(ic, first), c_b = __shfl(ic, last);
+    if (lane == g0) {
+        out[0] = valid ? min(y_a, y_b) : 0x7fffffff;
+        out[1] = valid ? max(y_a, y_b) + 1 : -0x7fffffff;
+        out[2] = valid ? min(c_a, c_b) : 0x7fffffff;
+        out[3] = valid ? max(c_a, c_b) + 1 : -0x7fffffff;
+        out[4] = valid != 0;
+        out[5] = partial == 0;
+    }
+}
+
+// unclamped tap-0 position and weight of one axis of the linear filter (cf. lin_axis)
+CHV_DEV void lin_axis_raw(float s, int w, int &i0, float &a) {
+    float um = s * (float)w - 0.5f;
+    float fl = __builtin_floorf(um);
+    a = um - fl;
+    i0 = (int)fl;
+}
+
+// 16 source bytes -> 16 normalised floats
+CHV_DEV void unorm16(const uint4 &v, float4 &f0, float4 &f1, float4 &f2, float4 &f3) {
+    f0 = make_float4(unorm8(v.x & 255), unorm8((v.x >> 8) & 255), unorm8((v.x >> 16) & 255), unorm8(v.x >> 24));
+    f1 = make_float4(unorm8(v.y & 255), unorm8((v.y >> 8) & 255), unorm8((v.y >> 16) & 255), unorm8(v.y >> 24));
+    f2 = make_float4(unorm8(v.z & 255), unorm8((v.z >> 8) & 255), unorm8((v.z >> 16) & 255), unorm8(v.z >> 24));
+    f3 = make_float4(unorm8(v.w & 255), unorm8((v.w >> 8) & 255), unorm8((v.w >> 16) & 255), unorm8(v.w >> 24));
+}
+
+// 16 bytes at byte offset `off` of row `row` of a plane whose base and pitch are 16-byte
+// aligned (host-checked).  A vector that would run past the end of the LAST row is read
+// bytewise; bytes past the row's payload are don't-care.
+CHV_DEV uint4 load_row_vec(const DPlane &P, int row, int off) {
+    const int row_bytes = P.w * P.comps;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (off < 0 || off >= row_bytes) return val;
+    const uint8_t *s = P.ptr + (size_t)row * P.pitch + off;
+    if (row < P.h - 1 || off + 16 <= row_bytes) return *(const uint4 *)s;
+    uint32_t w[4] = { 0, 0, 0, 0 };
+    for (int k = 0; k < 16 && off + k < row_bytes; k++) w[k >> 2] |= (uint32_t)s[k] << ((k & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Replace the texels of a 16-byte vector that lie outside the row (left of texel 0 when
+// the vector is the padding vector, at or beyond the row end otherwise) by the nearest
+// edge texel: CLAMP_TO_EDGE resolved once at staging time.  BPT = bytes per texel (1, 2, 4).
+template <int BPT>
+CHV_DEV uint4 patch_edges(uint4 val, const DPlane &P, int row, int off) {
+    const int row_bytes = P.w * BPT;
+    if (off >= 0 && off + 16 <= row_bytes) return val;
+    const uint8_t *s = P.ptr + (size_t)row * P.pitch;
+    uint32_t w[4] = { val.x, val.y, val.z, val.w };
+    if (off < 0) {
+        // padding vector in front of texel 0: only its last texel slot is ever addressed
+        uint32_t e = BPT == 1 ? (uint32_t)s[0] << 24 : BPT == 2 ? (uint32_t)(*(const uint16_t *)s) << 16 : *(const uint32_t *)s;
+        w[3] = (w[3] & (BPT == 1 ? 0x00FFFFFFu : BPT == 2 ? 0x0000FFFFu : 0u)) | e;
+    } else {
+        uint32_t e = BPT == 1 ? (uint32_t)s[row_bytes - 1] * 0x01010101u
+                   : BPT == 2 ? (uint32_t)(*(const uint16_t *)(s + row_bytes - 2)) * 0x00010001u
+                              : *(const uint32_t *)(s + row_bytes - 4);
+        int nvalid = max(row_bytes - off, 0);     // bytes of this vector inside the row
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            int nb = min(max(nvalid - 4 * d, 0), 4);
+            uint32_t mask = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+            w[d] = (w[d] & mask) | (e & ~mask);
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Staging of one plane's source rectangle, split in two so that the global loads of the
+// NEXT tile are in flight while the current tile is being computed:
+//   stage_load : raw 16-byte vectors -> registers (no dependent instruction)
+//   stage_store: CLAMP_TO_EDGE patching, unorm8 -> float (chroma), LDS write
+// Slot i = tid + n * NTHREADS maps to row i >> sh, vector (i & mask) of that row; LDS row r
+// holds source row clamp(r_lo + r).  With `edge` (block-uniform: the rectangle touches a
+// picture edge) vectors -1 .. nvec are staged, with the outside texels replicated.
+struct StageGeom {
+    int r_lo, rows;     // first (unclamped) source row, number of LDS rows
+    int b0;             // first source byte of vector 0 (16-byte aligned)
+    int nvec;           // vectors that hold picture bytes
+    int sh;             // log2 of slots per row
+    int edge;
+};
+CHV_DEV int stage_shift(int nv) { return nv <= 16 ? 4 : (nv <= 32 ? 5 : 6); }
+CHV_DEV int stage_slots(const StageGeom &g) { return g.rows << g.sh; }
+
+template <int N>
+CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, int tid) {
+    const int nv = g.edge ? g.nvec + 2 : g.nvec;
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        int i = tid + n * NTHREADS;
+        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
+        regs[n] = make_uint4(0, 0, 0, 0);
+        if (r < g.rows && vv < nv) {
+            int row = min(max(g.r_lo + r, 0), P.h - 1);
+            int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
+            regs[n] = g.edge ? load_row_vec(P, row, off) : *(const uint4 *)(P.ptr + (size_t)row * P.pitch + off);
+        }
+    }
+}
+
+// BPT = 1: bytes kept as bytes (LDS byte 16 + k of a row = source byte b0 + k)
+// BPT = 2: byte pairs normalised to float pairs (LDS texel slot 8 + k = source texel b0/2 + k)
+// BPT = 4: 4-byte texels normalised to float4   (LDS texel slot 4 + k = source texel b0/4 + k)
+template <int BPT, int N>
+CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid) {
+    const int nv = g.edge ? g.nvec + 2 : g.nvec;
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        int i = tid + n * NTHREADS;
+        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
+        if (r < g.rows && vv < nv) {
+            int v = g.edge ? vv - 1 : vv;
+            uint4 val = regs[n];
+            if (g.edge) {
+                int row = min(max(g.r_lo + r, 0), P.h - 1);
+                val = patch_edges<BPT>(val, P, row, g.b0 + v * 16);
+            }
+            if (BPT == 1) {
+                *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
+            } else {   // 16 source bytes -> 64 LDS bytes for both 2- and 4-byte texels
+                float4 f0, f1, f2, f3;
+                unorm16(val, f0, f1, f2, f3);
+                float4 *d = (float4 *)(lds + r * lds_pitch + 64 + v * 64);
+                d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
+            }
+        }
+    }
+}
+
+
+}  // namespace chv

@@ -1,0 +1,493 @@
+// swiftvideo_hip.hpp — C++17 host-side mirror of SwiftVideo's compute/picture operator
+// surface over the CHIPVideo C ABI (include/chipvideo.h).
+//
+// The reference is compiled Swift; with no Swift toolchain available, this header is the
+// native spelling of the backend contract (compute.cl.swift:36-499) and of the operators
+// that sit directly on it (compute.swift, mix.video.swift, sample.pict.linux.swift): same
+// names, argument meaning and error behaviour, so that native callers and tests read like
+// the reference's call sites:
+//
+//     auto ctx  = sv::makeComputeContext(sv::ComputeDeviceType::GPU);
+//     auto gpu  = sv::uploadComputePicture(ctx, pict);
+//     ctx = sv::usingContext(ctx, [&](sv::ComputeContext c) {
+//         return sv::applyComputeImage(c, gpu, backing, sv::ComputeKernel::img_bgra_nv12); });
+//     auto out  = sv::downloadComputePicture(ctx, backing);
+//
+// Header-only; link with -lchipvideo.  No pixel is touched on the host.
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/chipvideo.h"
+
+namespace sv {
+
+// ---- ComputeError (compute.swift:22-39) -------------------------------------------------------
+struct ComputeError : std::runtime_error {
+    int status;              // chv_status
+    std::string caseName;    // Swift case name
+    ComputeError(int s, const std::string &detail)
+        : std::runtime_error(std::string("ComputeError.") + chv_error_string(s) + (detail.empty() ? "" : ": " + detail)),
+          status(s), caseName(chv_error_string(s)) {}
+};
+inline void check(int status) {
+    if (status != CHV_OK) throw ComputeError(status, chv_last_error_detail());
+}
+
+enum class ComputeDeviceType { GPU, CPU, Accelerator, Default };   // compute.swift:41-46
+
+// ---- ComputeKernel (compute.swift:49-74) ---------------------------------------------------------
+enum class ComputeKernel : int {
+    img_nv12_nv12 = CHV_K_IMG_NV12_NV12, img_bgra_nv12 = CHV_K_IMG_BGRA_NV12, img_rgba_nv12 = CHV_K_IMG_RGBA_NV12,
+    img_bgra_bgra = CHV_K_IMG_BGRA_BGRA, img_y420p_y420p = CHV_K_IMG_Y420P_Y420P, img_y420p_nv12 = CHV_K_IMG_Y420P_NV12,
+    img_clear_nv12 = CHV_K_IMG_CLEAR_NV12, img_clear_yuvs = CHV_K_IMG_CLEAR_YUVS, img_clear_bgra = CHV_K_IMG_CLEAR_BGRA,
+    img_clear_y420p = CHV_K_IMG_CLEAR_Y420P, img_clear_rgba = CHV_K_IMG_CLEAR_RGBA, img_rgba_y420p = CHV_K_IMG_RGBA_Y420P,
+    img_bgra_y420p = CHV_K_IMG_BGRA_Y420P, snd_s16i_s16i = CHV_K_SND_S16I_S16I, me_fullsearch = CHV_K_ME_FULLSEARCH,
+    img_nv12_bgra = CHV_K_IMG_NV12_BGRA, img_y420p_bgra = CHV_K_IMG_Y420P_BGRA,
+    img_bgra_bgra_tx = CHV_K_IMG_BGRA_BGRA_TX, img_rgba_bgra_tx = CHV_K_IMG_RGBA_BGRA_TX
+};
+inline std::string describing(ComputeKernel k) {           // String(describing:)
+    const char *n = chv_kernel_name((int)k);
+    return n ? n : "";
+}
+// compute.swift:90-110; throws ComputeError.invalidValue
+inline ComputeKernel defaultComputeKernelFromString(const std::string &str) {
+    int k = -1;
+    check(chv_kernel_from_string(str.c_str(), &k));
+    return (ComputeKernel)k;
+}
+
+// ---- pixel formats and planes (sample.pict.swift:20-58) --------------------------------------
+enum class PixelFormat : int {
+    nv12 = CHV_FMT_NV12, nv21 = CHV_FMT_NV21, yuvs = CHV_FMT_YUVS, zvuy = CHV_FMT_ZVUY, y420p = CHV_FMT_Y420P,
+    y422p = CHV_FMT_Y422P, y444p = CHV_FMT_Y444P, RGBA = CHV_FMT_RGBA, BGRA = CHV_FMT_BGRA, invalid = CHV_FMT_INVALID
+};
+inline std::string lowercasedName(PixelFormat f) {        // String(describing:).lowercased(), mix.video.swift:143-144
+    switch (f) {
+    case PixelFormat::nv12: return "nv12"; case PixelFormat::nv21: return "nv21"; case PixelFormat::yuvs: return "yuvs";
+    case PixelFormat::zvuy: return "zvuy"; case PixelFormat::y420p: return "y420p"; case PixelFormat::y422p: return "y422p";
+    case PixelFormat::y444p: return "y444p"; case PixelFormat::RGBA: return "rgba"; case PixelFormat::BGRA: return "bgra";
+    default: return "invalid";
+    }
+}
+enum class BufferType { shared, cpu, gpu, invalid };
+struct Vector2 { float x = 0, y = 0; };
+struct Vector4 { float x = 0, y = 0, z = 0, w = 0; };
+struct Plane {
+    Vector2 size; int stride = 0; int bitDepth = 8; int components = 1;
+};
+
+// ---- Matrix4: what applyComputeImage needs from VectorMath (compute.swift:151-155) ---------------
+// Column-vector convention: (M v)_i = sum_j m[i][j] v_j; translation in m[i][3].
+struct Matrix4 {
+    std::array<double, 16> m{ 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+    static Matrix4 identity() { return Matrix4(); }
+    static Matrix4 translation(double x, double y, double z = 0) { Matrix4 r; r.m[3] = x; r.m[7] = y; r.m[11] = z; return r; }
+    static Matrix4 scale(double x, double y, double z = 1) { Matrix4 r; r.m[0] = x; r.m[5] = y; r.m[10] = z; return r; }
+    static Matrix4 rotationZ(double t) { Matrix4 r; r.m[0] = std::cos(t); r.m[1] = -std::sin(t); r.m[4] = std::sin(t); r.m[5] = std::cos(t); return r; }
+    // Matrix4(ortho), animator.pic.swift:326-332: canvas pixels -> NDC
+    static Matrix4 ortho(double w, double h) { Matrix4 r; r.m[0] = 2 / w; r.m[5] = 2 / h; r.m[3] = -1; r.m[7] = -1; r.m[11] = 1; return r; }
+    Matrix4 operator*(const Matrix4 &b) const {
+        Matrix4 r;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += m[i * 4 + k] * b.m[k * 4 + j];
+            r.m[i * 4 + j] = s;
+        }
+        return r;
+    }
+    Matrix4 inverse() const {            // Gauss-Jordan with partial pivoting
+        double a[4][8];
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { a[i][j] = m[i * 4 + j]; a[i][j + 4] = i == j ? 1.0 : 0.0; }
+        for (int c = 0; c < 4; c++) {
+            int p = c;
+            for (int r = c + 1; r < 4; r++) if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
+            if (a[p][c] == 0.0) throw ComputeError(CHV_ERR_INVALID_VALUE, "singular matrix");
+            if (p != c) for (int j = 0; j < 8; j++) std::swap(a[p][j], a[c][j]);
+            double d = a[c][c];
+            for (int j = 0; j < 8; j++) a[c][j] /= d;
+            for (int r = 0; r < 4; r++) if (r != c) {
+                double f = a[r][c];
+                if (f != 0.0) for (int j = 0; j < 8; j++) a[r][j] -= f * a[c][j];
+            }
+        }
+        Matrix4 r;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r.m[i * 4 + j] = a[i][j + 4];
+        return r;
+    }
+    // the 16 floats a kernel reads for this matrix: row i of M^-1 at [4i..4i+3]
+    // (VectorMath's M.inverse.transpose stored column-major is exactly that)
+    void kernelRows(float out[16]) const {
+        Matrix4 inv = inverse();
+        for (int i = 0; i < 16; i++) out[i] = (float)inv.m[i];
+    }
+};
+
+// ---- devices / contexts (compute.cl.swift:36-151) --------------------------------------------------
+struct ComputeDevice {
+    int deviceId = 0; bool available = false; ComputeDeviceType deviceType = ComputeDeviceType::GPU;
+    int vendorId = 0; std::string vendorName, arch; bool supportsImages = false;
+};
+inline std::vector<ComputeDevice> availableComputeDevices() {
+    std::vector<ComputeDevice> out;
+    int n = 0;
+    if (chv_device_count(&n) != CHV_OK) return out;
+    for (int i = 0; i < n; i++) {
+        chv_device_info info;
+        if (chv_device_info_get(i, &info) != CHV_OK) continue;
+        ComputeDevice d;
+        d.deviceId = i; d.available = info.available != 0; d.vendorId = info.vendor_id; d.vendorName = info.name;
+        d.arch = info.arch; d.supportsImages = info.supports_images != 0;
+        out.push_back(d);
+    }
+    return out;
+}
+
+// value type holding a shared handle, like the Swift struct (compute.cl.swift:75-105)
+struct ComputeContext {
+    std::shared_ptr<chv_context> handle;
+    ComputeDevice device;
+    chv_context *get() const {
+        if (!handle) throw ComputeError(CHV_ERR_INVALID_CONTEXT, "context destroyed");
+        return handle.get();
+    }
+};
+inline ComputeContext wrapContext(chv_context *c, const ComputeDevice &d) {
+    // destroyComputeContext() releases explicitly; the deleter covers contexts that are just dropped
+    return ComputeContext{ std::shared_ptr<chv_context>(c, [](chv_context *p) { if (p) chv_context_destroy(p); }), d };
+}
+inline ComputeContext createComputeContext(const ComputeDevice &device) {
+    chv_context *c = nullptr;
+    check(chv_context_create(device.deviceId, &c));
+    return wrapContext(c, device);
+}
+inline ComputeContext createComputeContext(const ComputeContext &sharing) {      // createComputeContext(sharing:)
+    chv_context *c = nullptr;
+    check(chv_context_share(sharing.get(), &c));
+    return wrapContext(c, sharing.device);
+}
+inline bool hasAvailableComputeDevices(ComputeDeviceType t) {
+    for (auto &d : availableComputeDevices()) if (d.deviceType == t && d.available) return true;
+    return false;
+}
+inline ComputeContext makeComputeContext(ComputeDeviceType forType, int index = 0) {   // compute.swift:121-129
+    int seen = 0;
+    for (auto &d : availableComputeDevices())
+        if (d.deviceType == forType && d.available && seen++ == index) return createComputeContext(d);
+    throw ComputeError(CHV_ERR_DEVICE_NOT_AVAILABLE, "no available compute device of the requested type");
+}
+inline void destroyComputeContext(ComputeContext &ctx) { ctx.handle.reset(); }
+inline ComputeContext beginComputePass(ComputeContext ctx) { check(chv_pass_begin(ctx.get())); return ctx; }
+inline ComputeContext endComputePass(ComputeContext ctx, bool waitForCompletion) {
+    check(chv_pass_end(ctx.get(), waitForCompletion ? 1 : 0));
+    return ctx;
+}
+// compute.swift:131-134
+inline ComputeContext usingContext(ComputeContext ctx, const std::function<ComputeContext(ComputeContext)> &fun) {
+    return endComputePass(fun(beginComputePass(ctx)), true);
+}
+
+// ---- buffers and samples (compute.cl.swift:46-58, sample.pict.linux.swift:23-311) ---------------
+struct ComputeBuffer {
+    chv_buffer *handle = nullptr; size_t size = 0; size_t pitch = 0;
+    ComputeBuffer(chv_buffer *h, size_t s, size_t p) : handle(h), size(s), pitch(p) {}
+    ComputeBuffer(const ComputeBuffer &) = delete;
+    ~ComputeBuffer() { if (handle) chv_buffer_free(handle); }
+};
+using ComputeBufferRef = std::shared_ptr<ComputeBuffer>;
+using Data = std::vector<uint8_t>;
+
+struct ImageBuffer {
+    PixelFormat pixelFormat = PixelFormat::invalid;
+    BufferType bufferType = BufferType::invalid;
+    Vector2 size;
+    std::vector<ComputeBufferRef> computeTextures;
+    std::vector<std::shared_ptr<Data>> buffers;     // one per plane, stride * rows bytes
+    std::vector<Plane> planes;
+};
+
+// sample.pict.linux.swift:275-294
+inline std::vector<Plane> planesForFormat(PixelFormat f, Vector2 size) {
+    int w = (int)size.x;
+    Vector2 half{ (float)((int)size.x / 2), (float)((int)size.y / 2) };
+    switch (f) {
+    case PixelFormat::nv12: return { Plane{ size, w, 8, 1 }, Plane{ half, w, 8, 2 } };
+    case PixelFormat::BGRA: case PixelFormat::RGBA: return { Plane{ size, w * 4, 8, 4 } };
+    case PixelFormat::y420p: return { Plane{ size, w, 8, 1 }, Plane{ half, w / 2, 8, 1 }, Plane{ half, w / 2, 8, 1 } };
+    default: throw ComputeError(CHV_ERR_BAD_INPUT, "Invalid pixel format");
+    }
+}
+
+struct PictureSample {
+    std::shared_ptr<ImageBuffer> img;
+    Matrix4 matrix, textureMatrix, borderMatrix;
+    Vector4 fillColor; float opacity = 1.0f; int zIndex = 0;
+    std::string assetId, workspaceId, revision;
+    double time = 0, pts = 0;
+    PixelFormat pixelFormat() const { return img->pixelFormat; }
+    BufferType bufferType() const { return img->bufferType; }
+    Vector2 size() const { return img->size; }
+};
+
+// sample.pict.linux.swift:254-273
+inline PictureSample createPictureSample(Vector2 size, PixelFormat format, const std::string &assetId = "",
+                                         const std::string &workspaceId = "") {
+    if (!(size.x > 0 && size.y > 0)) throw ComputeError(CHV_ERR_INVALID_OPERATION, "size must be positive");
+    auto img = std::make_shared<ImageBuffer>();
+    img->pixelFormat = format; img->bufferType = BufferType::cpu; img->size = size;
+    img->planes = planesForFormat(format, size);
+    for (auto &p : img->planes) img->buffers.push_back(std::make_shared<Data>((size_t)p.stride * std::max(1, (int)p.size.y), 0));
+    PictureSample s;
+    s.img = img; s.assetId = assetId; s.workspaceId = workspaceId; s.borderMatrix = s.matrix;
+    return s;
+}
+
+inline int planeComponents(const Plane &p) { return p.components >= 3 ? 4 : p.components; }
+
+// compute.cl.swift:421-459
+inline PictureSample uploadComputePicture(const ComputeContext &ctx, const PictureSample &pict, int maxPlanes = 3,
+                                          bool retainCpuBuffer = true, bool asynchronous = false) {
+    if (pict.bufferType() != BufferType::cpu) return pict;
+    const ImageBuffer &image = *pict.img;
+    size_t n = image.planes.size();
+    if (!(n > 0 && n <= 3)) throw ComputeError(CHV_ERR_BAD_INPUT, "Input image must have 1, 2, or 3 planes");
+    if (n != image.buffers.size()) throw ComputeError(CHV_ERR_BAD_INPUT, "Input image must have the same number of buffers as planes");
+    auto out = std::make_shared<ImageBuffer>(image);
+    out->computeTextures.clear();
+    beginComputePass(ctx);
+    for (size_t i = 0; i < std::min(n, (size_t)maxPlanes); i++) {
+        const Plane &p = image.planes[i];
+        int comps = planeComponents(p);
+        chv_buffer *h = nullptr; size_t pitch = 0;
+        check(chv_plane_alloc(ctx.get(), (int)p.size.x, (int)p.size.y, comps, &h, &pitch));
+        auto tex = std::make_shared<ComputeBuffer>(h, pitch * (size_t)p.size.y, pitch);
+        out->computeTextures.push_back(tex);
+        check(chv_upload(ctx.get(), h, 0, pitch, image.buffers[i]->data(), (size_t)p.stride, (size_t)p.size.x * comps,
+                         (size_t)p.size.y, asynchronous ? 1 : 0));
+    }
+    endComputePass(ctx, true);
+    out->bufferType = BufferType::gpu;
+    if (!retainCpuBuffer) out->buffers.clear();
+    PictureSample r = pict;
+    r.img = out;
+    return r;
+}
+
+// compute.cl.swift:461-498
+inline PictureSample downloadComputePicture(const ComputeContext &ctx, const PictureSample &pict, bool retainGpuBuffer = false) {
+    if (pict.bufferType() != BufferType::gpu) return pict;
+    const ImageBuffer &image = *pict.img;
+    auto out = std::make_shared<ImageBuffer>(image);
+    out->buffers.clear();
+    beginComputePass(ctx);
+    for (size_t i = 0; i < image.computeTextures.size(); i++) {
+        const Plane &p = image.planes[i];
+        int comps = planeComponents(p);
+        auto buf = i < image.buffers.size() ? image.buffers[i] : std::make_shared<Data>((size_t)p.stride * (size_t)p.size.y, 0);
+        check(chv_download(ctx.get(), buf->data(), (size_t)p.stride, image.computeTextures[i]->handle, 0,
+                           image.computeTextures[i]->pitch, (size_t)p.size.x * comps, (size_t)p.size.y));
+        out->buffers.push_back(buf);
+    }
+    endComputePass(ctx, true);
+    out->bufferType = BufferType::cpu;
+    if (!retainGpuBuffer) out->computeTextures.clear();
+    PictureSample r = pict;
+    r.img = out;
+    return r;
+}
+
+// ---- kernels (compute.swift:76-86,145-170; compute.cl.swift:250-344) ------------------------------
+using ImageUniforms = chv_uniforms;        // 236 bytes, same layout as the Swift struct
+
+inline bool describe(const PictureSample &s, chv_image *d, int maxPlanes = 3) {
+    if (!s.img || s.img->bufferType != BufferType::gpu || s.img->computeTextures.empty()) return false;
+    std::memset(d, 0, sizeof *d);
+    d->format = (int)s.img->pixelFormat; d->width = (int)s.img->size.x; d->height = (int)s.img->size.y;
+    int n = std::min((int)s.img->computeTextures.size(), maxPlanes);
+    d->n_planes = n;
+    for (int i = 0; i < n; i++) {
+        const Plane &p = s.img->planes[i];
+        d->planes[i] = chv_plane{ s.img->computeTextures[i]->handle, 0, (int)p.size.x, (int)p.size.y,
+                                  (int)s.img->computeTextures[i]->pitch, planeComponents(p) };
+    }
+    return true;
+}
+
+inline ComputeContext runComputeKernel(ComputeContext ctx, const std::vector<PictureSample> &images, const PictureSample &target,
+                                       ComputeKernel kernel, int maxPlanes = 3, const ImageUniforms *uniforms = nullptr,
+                                       bool blends = false, int colorspace = CHV_CSC_BT601_LIMITED) {
+    chv_image t;
+    if (!describe(target, &t)) throw ComputeError(CHV_ERR_BAD_TARGET, "target has no GPU image buffer");
+    std::vector<chv_image> in(images.size());
+    for (size_t i = 0; i < images.size(); i++)
+        if (!describe(images[i], &in[i], maxPlanes)) throw ComputeError(CHV_ERR_BAD_INPUT, "Bad input image");
+    chv_kernel_opts opts{ colorspace, { 0, 0, 0 } };
+    check(chv_run_kernel(ctx.get(), (int)kernel, &t, in.data(), (int)in.size(), uniforms, uniforms ? sizeof(ImageUniforms) : 0,
+                         blends ? 1 : 0, &opts));
+    return ctx;
+}
+
+inline ImageUniforms imageUniformsFor(const PictureSample &image, const PictureSample &target) {   // compute.swift:147-161
+    ImageUniforms u;
+    std::memset(&u, 0, sizeof u);
+    image.matrix.kernelRows(u.transform);
+    image.textureMatrix.kernelRows(u.texture_transform);
+    image.borderMatrix.kernelRows(u.border_matrix);
+    u.fill_color[0] = image.fillColor.x; u.fill_color[1] = image.fillColor.y; u.fill_color[2] = image.fillColor.z; u.fill_color[3] = image.fillColor.w;
+    u.input_size[0] = image.size().x; u.input_size[1] = image.size().y;
+    u.output_size[0] = target.size().x; u.output_size[1] = target.size().y;
+    u.opacity = image.opacity; u.image_time = (float)image.time; u.target_time = (float)target.time;
+    return u;
+}
+
+inline ComputeContext applyComputeImage(ComputeContext ctx, const PictureSample &image, const PictureSample &target,
+                                        ComputeKernel kernel, int colorspace = CHV_CSC_BT601_LIMITED) {
+    ImageUniforms u = imageUniformsFor(image, target);
+    return runComputeKernel(ctx, { image }, target, kernel, 3, &u, true, colorspace);
+}
+
+struct TickLayer { ComputeKernel kernel; PictureSample image; ImageUniforms uniforms; int colorspace = CHV_CSC_BT601_LIMITED; };
+
+// one mixer tick in one launch (chv_composite)
+inline ComputeContext compositeTick(ComputeContext ctx, const PictureSample &target, const std::vector<TickLayer> &layers,
+                                    bool clearFirst = true) {
+    chv_image t;
+    if (!describe(target, &t)) throw ComputeError(CHV_ERR_BAD_TARGET, "target has no GPU image buffer");
+    std::vector<chv_layer> ls(layers.size());
+    for (size_t i = 0; i < layers.size(); i++) {
+        std::memset(&ls[i], 0, sizeof ls[i]);
+        ls[i].kernel = (int)layers[i].kernel;
+        if (!describe(layers[i].image, &ls[i].image)) throw ComputeError(CHV_ERR_BAD_INPUT, "Bad input image");
+        ls[i].uniforms = layers[i].uniforms;
+        ls[i].opts.colorspace = layers[i].colorspace;
+    }
+    check(chv_composite(ctx.get(), &t, clearFirst ? 1 : 0, ls.data(), (int)ls.size()));
+    return ctx;
+}
+
+// ---- pipeline operators (compute.swift:175-255) -------------------------------------------------------
+struct EventError { std::string source; int code = 0; std::string description; std::string assetId; };
+template <typename T> struct EventBox {          // event.swift:63-95: .just / .nothing / .error / .gone
+    enum Kind { just, nothing, error, gone } kind = nothing;
+    T value{}; EventError err;
+};
+
+class GPUBarrierUpload {
+public:
+    explicit GPUBarrierUpload(const ComputeContext &context, bool retainCpuBuffer = true)
+        : context_(createComputeContext(context)), retain_(retainCpuBuffer) {}
+    EventBox<PictureSample> operator()(const PictureSample &s) const {
+        EventBox<PictureSample> r;
+        if (s.bufferType() == BufferType::cpu) {
+            try { r.value = uploadComputePicture(context_, s, 3, retain_); r.kind = r.just; }
+            catch (const ComputeError &e) { r.kind = r.error; r.err = EventError{ "barrier.upload", -1, e.what(), s.assetId }; }
+        } else { r.value = s; r.kind = r.just; }
+        return r;
+    }
+private:
+    ComputeContext context_; bool retain_;
+};
+
+class GPUBarrierDownload {
+public:
+    explicit GPUBarrierDownload(const ComputeContext &context, bool retainGpuBuffer = true)
+        : context_(createComputeContext(context)), retain_(retainGpuBuffer) {}
+    EventBox<PictureSample> operator()(const PictureSample &s) const {
+        EventBox<PictureSample> r;
+        if (s.bufferType() == BufferType::gpu) {
+            try { r.value = downloadComputePicture(context_, s, retain_); r.kind = r.just; }
+            catch (const ComputeError &e) { r.kind = r.error; r.err = EventError{ "barrier.download", -1, e.what(), s.assetId }; }
+        } else { r.value = s; r.kind = r.just; }
+        return r;
+    }
+private:
+    ComputeContext context_; bool retain_;
+};
+
+// ---- VideoMixer (mix.video.swift:21-184) without the clock: push() is the Source's set closure
+//      (:57-75), mix(at) one tick (:95-140) ------------------------------------------------------------
+class VideoMixer {
+public:
+    static constexpr int numberBackingImages = 10;     // mix.video.swift:167
+    VideoMixer(const std::string &workspaceId, Vector2 outputSize, PixelFormat outputFormat, const ComputeContext &computeContext,
+               const std::string &assetId = "mixer", bool fused = true, bool bgraTransformAware = true)
+        : clContext_(createComputeContext(computeContext)), backingSize_(outputSize), backingFormat_(outputFormat),
+          idWorkspace_(workspaceId), idAsset_(assetId), fused_(fused), bgraTx_(bgraTransformAware) {}
+
+    const std::string &assetId() const { return idAsset_; }
+
+    EventBox<PictureSample> push(const PictureSample &pic) {
+        EventBox<PictureSample> r;
+        if (pic.assetId != idAsset_) { samples_[0][pic.revision] = pic; r.kind = r.nothing; }
+        else { r.kind = r.just; r.value = pic; }
+        return r;
+    }
+
+    ComputeKernel findKernel(const PictureSample *image, const PictureSample &target) const {   // mix.video.swift:142-146
+        std::string inp = image ? lowercasedName(image->pixelFormat()) : "clear";
+        std::string outp = lowercasedName(target.pixelFormat());
+        std::string name = "img_" + inp + "_" + outp;
+        if (bgraTx_ && image && outp == "bgra" && (inp == "bgra" || inp == "rgba")) name += "_tx";
+        return defaultComputeKernelFromString(name);
+    }
+
+    EventBox<PictureSample> mix(double at) {
+        EventBox<PictureSample> out;
+        try {
+            PictureSample backing = getBacking();
+            std::map<std::string, PictureSample> merged = samples_[1];
+            for (auto &kv : samples_[0]) merged[kv.first] = kv.second;       // lhs wins, mix.video.swift:114
+            std::vector<PictureSample> images;
+            for (auto &kv : merged) images.push_back(kv.second);
+            std::stable_sort(images.begin(), images.end(), [](const PictureSample &a, const PictureSample &b) { return a.zIndex < b.zIndex; });
+            if (fused_) {
+                std::vector<TickLayer> layers;
+                for (auto &im : images) layers.push_back(TickLayer{ findKernel(&im, backing), im, imageUniformsFor(im, backing) });
+                usingContext(clContext_, [&](ComputeContext c) { return compositeTick(c, backing, layers, true); });
+            } else {
+                usingContext(clContext_, [&](ComputeContext c) {
+                    c = runComputeKernel(c, {}, backing, findKernel(nullptr, backing));
+                    for (auto &im : images) c = applyComputeImage(c, im, backing, findKernel(&im, backing));
+                    return c;
+                });
+            }
+            out.kind = out.just; out.value = backing; out.value.pts = at; out.value.time = at; out.value.assetId = idAsset_;
+        } catch (const ComputeError &e) {
+            out.kind = out.error; out.err = EventError{ "mix.video", -2, std::string("Compute error ") + e.what(), idAsset_ };
+        }
+        samples_[1] = samples_[0];
+        samples_[0].clear();
+        return out;
+    }
+
+private:
+    PictureSample getBacking() {                      // mix.video.swift:148-165
+        if ((int)backing_.size() < numberBackingImages) {
+            PictureSample image = createPictureSample(backingSize_, backingFormat_, idAsset_, idWorkspace_);
+            backing_.push_back(uploadComputePicture(clContext_, image));
+            return backing_.back();
+        }
+        PictureSample image = backing_[currentBacking_];
+        currentBacking_ = (currentBacking_ + 1) % (int)backing_.size();
+        return image;
+    }
+    ComputeContext clContext_;
+    std::vector<PictureSample> backing_;
+    int currentBacking_ = 0;
+    Vector2 backingSize_; PixelFormat backingFormat_;
+    std::string idWorkspace_, idAsset_;
+    bool fused_, bgraTx_;
+    std::map<std::string, PictureSample> samples_[2];
+};
+
+}  // namespace sv

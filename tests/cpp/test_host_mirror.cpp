@@ -1,0 +1,186 @@
+// tests/cpp/test_host_mirror.cpp — the C++ host mirror (swiftvideo_amd/host/swiftvideo_hip.hpp)
+// driven the way the reference's Swift call sites drive the backend, checked against the oracle.
+//   ./test_host_mirror cpu   — no device needed: name table, matrices, uniforms, layouts, error on no device
+//   ./test_host_mirror gpu   — mixer ticks, barriers, kernels == oracle byte for byte
+// Built and run by tests/test_cpp_host_mirror.py.  The oracle is linked here as the checker only.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "../../oracle/ref_kernels.h"
+#include "../../swiftvideo_amd/host/swiftvideo_hip.hpp"
+
+static int g_fail = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); g_fail++; } } while (0)
+
+// splitmix64 low bytes, as tests/util.py
+static void fill(sv::Data &d, uint64_t seed) {
+    uint64_t x = seed;
+    for (auto &b : d) {
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        b = (uint8_t)z;
+    }
+}
+
+static sv::PictureSample randomPicture(sv::PixelFormat f, int w, int h, uint64_t seed) {
+    sv::PictureSample s = sv::createPictureSample({ (float)w, (float)h }, f, "cam" + std::to_string(seed));
+    for (size_t i = 0; i < s.img->buffers.size(); i++) fill(*s.img->buffers[i], seed * 16 + i);
+    s.revision = "rev" + std::to_string(seed);
+    return s;
+}
+
+static std::vector<orc_plane> oraclePlanes(const sv::PictureSample &s) {
+    std::vector<orc_plane> out;
+    for (size_t i = 0; i < s.img->planes.size(); i++) {
+        const sv::Plane &p = s.img->planes[i];
+        out.push_back(orc_plane{ s.img->buffers[i]->data(), (int)p.size.x, (int)p.size.y, p.stride, sv::planeComponents(p) });
+    }
+    return out;
+}
+
+static bool samePlanes(const sv::PictureSample &a, const sv::PictureSample &b) {
+    for (size_t i = 0; i < a.img->planes.size(); i++) {
+        const sv::Plane &p = a.img->planes[i];
+        size_t row = (size_t)p.size.x * sv::planeComponents(p);
+        for (int y = 0; y < (int)p.size.y; y++)
+            if (std::memcmp(a.img->buffers[i]->data() + (size_t)y * p.stride, b.img->buffers[i]->data() + (size_t)y * p.stride, row)) return false;
+    }
+    return true;
+}
+
+static void cpuTests() {
+    // computeTests.swift:9-39
+    const char *names[] = { "img_nv12_nv12", "img_bgra_nv12", "img_rgba_nv12", "img_bgra_bgra", "img_y420p_y420p", "img_y420p_nv12",
+                            "img_clear_nv12", "img_clear_yuvs", "img_clear_bgra", "img_clear_rgba", "img_rgba_y420p", "img_bgra_y420p",
+                            "img_clear_y420p" };
+    for (const char *n : names) {
+        std::string got = sv::describing(sv::defaultComputeKernelFromString(n));
+        EXPECT(got == (std::string(n) == "img_clear_rgba" ? "img_clear_bgra" : n));
+    }
+    try { sv::defaultComputeKernelFromString("img_nv21_nv12"); EXPECT(false); }
+    catch (const sv::ComputeError &e) { EXPECT(e.caseName == "invalidValue"); }
+    // matrices: M = ortho * T * S, kernel rows = rows of M^-1 (compute.swift:151-155)
+    sv::Matrix4 M = sv::Matrix4::ortho(1280, 720) * sv::Matrix4::translation(100, 50) * sv::Matrix4::scale(640, 360);
+    float rows[16];
+    M.kernelRows(rows);
+    auto apply = [&](double px, double py, int r) {
+        double v[4] = { px / 1280 * 2 - 1, py / 720 * 2 - 1, 0, 1 }, s = 0;
+        for (int j = 0; j < 4; j++) s += rows[r * 4 + j] * v[j];
+        return s;
+    };
+    EXPECT(std::fabs(apply(100, 50, 0)) < 1e-5 && std::fabs(apply(100, 50, 1)) < 1e-5);
+    EXPECT(std::fabs(apply(740, 410, 0) - 1) < 1e-5 && std::fabs(apply(740, 410, 1) - 1) < 1e-5);
+    sv::Matrix4 I = M * M.inverse();
+    for (int i = 0; i < 16; i++) EXPECT(std::fabs(I.m[i] - (i % 5 == 0 ? 1.0 : 0.0)) < 1e-9);
+    sv::Matrix4 full = sv::Matrix4::ortho(64, 36) * sv::Matrix4::scale(64, 36);
+    full.kernelRows(rows);
+    const float expect[16] = { .5f, 0, 0, .5f, 0, .5f, 0, .5f, 0, 0, 1, -1, 0, 0, 0, 1 };
+    for (int i = 0; i < 16; i++) EXPECT(std::fabs(rows[i] - expect[i]) < 1e-6);
+    // layouts
+    auto p = sv::planesForFormat(sv::PixelFormat::nv12, { 1920, 1080 });
+    EXPECT(p.size() == 2 && p[1].stride == 1920 && p[1].size.x == 960 && p[1].components == 2);
+    auto q = sv::planesForFormat(sv::PixelFormat::y420p, { 1280, 720 });
+    EXPECT(q.size() == 3 && q[2].stride == 640);
+    EXPECT(sizeof(sv::ImageUniforms) == 236);
+    try { sv::createPictureSample({ 0, 4 }, sv::PixelFormat::nv12); EXPECT(false); }
+    catch (const sv::ComputeError &e) { EXPECT(e.caseName == "invalidOperation"); }
+    if (!sv::hasAvailableComputeDevices(sv::ComputeDeviceType::GPU)) {
+        try { sv::makeComputeContext(sv::ComputeDeviceType::GPU); EXPECT(false); }
+        catch (const sv::ComputeError &e) { EXPECT(e.caseName == "deviceNotAvailable"); }
+    }
+}
+
+static void gpuTests() {
+    auto ctx = sv::makeComputeContext(sv::ComputeDeviceType::GPU);
+    const int CW = 96, CH = 54;
+    for (sv::PixelFormat fmt : { sv::PixelFormat::nv12, sv::PixelFormat::y420p }) {
+        const char *fname = fmt == sv::PixelFormat::nv12 ? "nv12" : "y420p";
+        sv::GPUBarrierUpload up(ctx);
+        sv::GPUBarrierDownload down(ctx, true);
+        sv::VideoMixer fused("ws", { (float)CW, (float)CH }, fmt, ctx, "mixer", true);
+        sv::VideoMixer seq("ws", { (float)CW, (float)CH }, fmt, ctx, "mixer", false);
+        struct Spec { sv::PixelFormat f; const char *name; int w, h; uint64_t seed; double x, y, rw, rh; int z; float op; };
+        Spec specs[] = { { sv::PixelFormat::BGRA, "bgra", 40, 30, 11, 30, 10, 50, 30, 2, 0.8f },
+                         { fmt, fname, 64, 36, 12, 0, 0, 96, 54, 0, 1.0f },
+                         { sv::PixelFormat::RGBA, "rgba", 20, 20, 13, 5, 5, 30, 30, 1, 0.6f } };
+        std::vector<sv::PictureSample> cpu;
+        for (auto &sp : specs) {
+            sv::PictureSample s = randomPicture(sp.f, sp.w, sp.h, sp.seed);
+            s.matrix = sv::Matrix4::ortho(CW, CH) * sv::Matrix4::translation(sp.x, sp.y) * sv::Matrix4::scale(sp.rw, sp.rh);
+            s.borderMatrix = s.matrix; s.opacity = sp.op; s.zIndex = sp.z;
+            cpu.push_back(s);
+            auto g = up(s);
+            EXPECT(g.kind == g.just && g.value.bufferType() == sv::BufferType::gpu);
+            EXPECT(fused.push(g.value).kind == sv::EventBox<sv::PictureSample>::nothing);
+            seq.push(g.value);
+        }
+        // oracle: clear + layers in z order (mix.video.swift:114-124)
+        sv::PictureSample exp = sv::createPictureSample({ (float)CW, (float)CH }, fmt);
+        auto tp = oraclePlanes(exp);
+        EXPECT(orc_run_kernel(fmt == sv::PixelFormat::nv12 ? ORC_IMG_CLEAR_NV12 : ORC_IMG_CLEAR_Y420P, tp.data(), (int)tp.size(), nullptr, 0, nullptr, 0, 1) == 0);
+        int order[] = { 1, 2, 0 };
+        for (int i : order) {
+            sv::ImageUniforms u = sv::imageUniformsFor(cpu[i], exp);
+            auto ip = oraclePlanes(cpu[i]);
+            int kid = (int)sv::defaultComputeKernelFromString(std::string("img_") + specs[i].name + "_" + fname);
+            EXPECT(orc_run_kernel(kid, tp.data(), (int)tp.size(), ip.data(), (int)ip.size(), (const orc_uniforms *)&u, 0, 2) == 0);
+        }
+        auto a = fused.mix(1.0), b = seq.mix(1.0);
+        EXPECT(a.kind == a.just && b.kind == b.just);
+        if (a.kind == a.just && b.kind == b.just) {
+            auto da = down(a.value), db = down(b.value);
+            EXPECT(da.kind == da.just && samePlanes(da.value, exp));
+            EXPECT(db.kind == db.just && samePlanes(db.value, exp));
+        }
+        // a layer format the target has no kernel for surfaces as an event error (mix.video.swift:133-137)
+        if (fmt == sv::PixelFormat::y420p) {
+            auto g = up(randomPicture(sv::PixelFormat::nv12, 16, 8, 99));
+            fused.push(g.value);
+            auto r = fused.mix(2.0);
+            EXPECT(r.kind == r.error && r.err.source == "mix.video" && r.err.code == -2);
+        }
+    }
+    // NV12 -> BGRA convert + scale through applyComputeImage on a cleared canvas
+    {
+        sv::PictureSample src = randomPicture(sv::PixelFormat::nv12, 192, 108, 21);
+        src.matrix = sv::Matrix4::ortho(128, 72) * sv::Matrix4::scale(128, 72);
+        src.borderMatrix = src.matrix;
+        auto gsrc = sv::uploadComputePicture(ctx, src);
+        auto canvas = sv::uploadComputePicture(ctx, sv::createPictureSample({ 128, 72 }, sv::PixelFormat::BGRA));
+        ctx = sv::usingContext(ctx, [&](sv::ComputeContext c) {
+            c = sv::runComputeKernel(c, {}, canvas, sv::ComputeKernel::img_clear_bgra);
+            return sv::applyComputeImage(c, gsrc, canvas, sv::ComputeKernel::img_nv12_bgra);
+        });
+        auto got = sv::downloadComputePicture(ctx, canvas, true);
+        sv::PictureSample exp = sv::createPictureSample({ 128, 72 }, sv::PixelFormat::BGRA);
+        auto tp = oraclePlanes(exp); auto ip = oraclePlanes(src);
+        sv::ImageUniforms u = sv::imageUniformsFor(src, exp);
+        orc_run_kernel(ORC_IMG_CLEAR_BGRA, tp.data(), 1, nullptr, 0, nullptr, 0, 1);
+        orc_run_kernel(ORC_IMG_NV12_BGRA, tp.data(), 1, ip.data(), 2, (const orc_uniforms *)&u, 0, 1);
+        EXPECT(samePlanes(got, exp));
+        // error behaviour: wrong target structure -> badTarget; context stays usable
+        try { sv::applyComputeImage(ctx, gsrc, gsrc, sv::ComputeKernel::img_nv12_bgra); EXPECT(false); }
+        catch (const sv::ComputeError &e) { EXPECT(e.caseName == "badTarget"); }
+        try { sv::runComputeKernel(ctx, {}, canvas, sv::ComputeKernel::img_clear_yuvs); EXPECT(false); }
+        catch (const sv::ComputeError &e) { EXPECT(e.caseName == "computeKernelNotFound"); }
+        ctx = sv::usingContext(ctx, [&](sv::ComputeContext c) { return sv::runComputeKernel(c, {}, canvas, sv::ComputeKernel::img_clear_bgra); });
+    }
+    sv::destroyComputeContext(ctx);
+}
+
+int main(int argc, char **argv) {
+    std::string mode = argc > 1 ? argv[1] : "cpu";
+    try {
+        cpuTests();
+        if (mode == "gpu") gpuTests();
+    } catch (const std::exception &e) {
+        std::printf("FAIL uncaught: %s\n", e.what());
+        g_fail++;
+    }
+    std::printf("%s: %s (%d failures)\n", mode.c_str(), g_fail ? "FAILED" : "ok", g_fail);
+    return g_fail ? 1 : 0;
+}

@@ -82,3 +82,63 @@ def test_batch_of_mixed_sizes(ctx):
     G.destroy_batch(h)
     for i, ((gd, cw, ch), exp) in enumerate(zip(gds, exps)):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"tick {i}")
+
+
+# ---- BGRA/RGBA layers onto a BGRA canvas (tick_rgb_layers_tiled) -------------------------------------
+RGB_CASES = {
+    # name: (canvas w, h, clear_first, [(kernel, src w, h, make_uniforms kwargs)])
+    "one_full":      (200, 60, True, [("img_bgra_bgra_tx", 200, 60, dict())]),
+    "cfg3_small":    (192, 108, True, [("img_bgra_bgra_tx", 192, 108, dict(opacity=o)) for o in (1.0, 0.75, 0.5, 0.25)]),
+    "mixed_scale":   (260, 70, True, [("img_bgra_bgra_tx", 96, 54, dict()), ("img_rgba_bgra_tx", 400, 120, dict(opacity=0.6)),
+                                        ("img_bgra_bgra_tx", 33, 17, dict(rect=(20, 10, 100, 40), opacity=0.9))]),
+    "borders_fill":  (260, 70, True, [("img_bgra_bgra_tx", 64, 36, dict(rect=(33, 9, 180, 40), border=(5, 3, 7, 2), fill=(0.9, 0.2, 0.1, 0.6), opacity=0.8)),
+                                        ("img_rgba_bgra_tx", 64, 36, dict(rect=(-20, -10, 120, 60), fill=(0.1, 0.5, 0.9, 1.0), border=(40, 40, 40, 40), opacity=0.35))]),
+    "noclear":       (131, 39, False, [("img_bgra_bgra_tx", 50, 20, dict(rect=(10, 5, 80, 30), opacity=0.5)),
+                                        ("img_bgra_bgra_tx", 50, 20, dict(rect=(60, 2, 60, 36)))]),
+    "tex_flip":      (192, 40, True, [("img_bgra_bgra_tx", 96, 54, dict(tex=(1.0, 0.0, -1.0, 1.0))), ("img_rgba_bgra_tx", 96, 54, dict(tex=(0.2, 0.1, 0.5, 0.7), opacity=0.5))]),
+    "eight_layers":  (128, 48, True, [("img_bgra_bgra_tx" if i % 2 else "img_rgba_bgra_tx", 128, 48, dict(opacity=1.0 - 0.1 * i)) for i in range(8)]),
+    "odd_tiny":      (5, 3, True, [("img_bgra_bgra_tx", 7, 5, dict()), ("img_bgra_bgra_tx", 3, 3, dict(opacity=0.5))]),
+    "opacity_gt_1":  (100, 30, True, [("img_bgra_bgra_tx", 100, 30, dict(opacity=1.7)), ("img_bgra_bgra_tx", 100, 30, dict(opacity=-0.3))]),
+}
+
+
+@pytest.mark.parametrize("case", list(RGB_CASES))
+def test_rgb_layers_tiled_matches_oracle(ctx, case):
+    cw, ch, clear, specs = RGB_CASES[case]
+    canvas0 = util.alloc_image("bgra", cw, ch, seed=61)
+    exp = util.copy_image(canvas0)
+    if clear:
+        assert O.run_kernel("img_clear_bgra", exp) == 0
+    layers = []
+    for i, (k, sw, sh, kw) in enumerate(specs):
+        u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+        s = k.split("_")[1]
+        src = util.alloc_image(s, sw, sh, seed=70 + i)
+        assert O.run_kernel(k, exp, src, u, threads=4) == 0
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, 0))
+    gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+    h, name, keep = G.make_batch(ctx, [(gd, clear, layers)])
+    if case != "mixed_scale":     # a 1.5x-downscaled float4 tile exceeds the LDS budget -> general kernel
+        assert name == "tick_rgb_layers_tiled", name
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"{case} via {name}")
+
+
+def test_rgb_layers_fallbacks(ctx):
+    """More than 8 layers, a rotated layer or a YUV layer in the mix -> general kernel, same bytes."""
+    cw, ch = 96, 54
+    src = util.alloc_image("bgra", 48, 27, seed=5)
+    gs = G.to_gpu(ctx, "bgra", 48, 27, src)
+    u = util.make_uniforms((cw, ch), in_size=(48, 27), opacity=0.9)
+    many = [(sv.ComputeKernel.img_bgra_bgra_tx, gs, u, 0)] * 9
+    exp = util.alloc_image("bgra", cw, ch)
+    assert O.run_kernel("img_clear_bgra", exp) == 0
+    for _ in range(9):
+        assert O.run_kernel("img_bgra_bgra_tx", exp, src, u) == 0
+    gd = G.to_gpu(ctx, "bgra", cw, ch, util.alloc_image("bgra", cw, ch, seed=1))
+    h, name, keep = G.make_batch(ctx, [(gd, True, many)])
+    assert name == "tick_general_bgra"
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, "nine layers")
