@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--with-upload", action="store_true",
+                    help="end-to-end mode: every step also uploads its source frames from pinned host memory on a side "
+                         "stream (PCIe-inclusive rate; reported for DESIGN.md, never the headline value)")
     return ap.parse_args()
 
 
@@ -198,6 +201,74 @@ def cpu_baseline(wl, w, budget_s):
                       f"compositing whole ticks (clear + {len(us)} layer kernel(s) per tick, as the reference issues them)"}
 
 
+def run_with_upload(args, sv, cv, lib, ctx, wl, rank, n_gpus, dist):
+    """PCIe-inclusive pipeline for cfg2: two frame sets; while set A is converted on the compute
+    context's stream, set B's NV12 planes are uploaded (hipMemcpy2DAsync from pinned memory) on a
+    sharing context's stream.  Ordering: per-buffer upload events (kernel waits for its inputs) and a
+    per-set 'batch done' event (the next upload into the set waits for the kernel that read it)."""
+    import util
+    assert wl["layers"] == 1, "--with-upload is implemented for the convert+scale workload"
+    up = sv.createComputeContext(sharing=ctx)
+    sw, sh = wl["sw"], wl["sh"]
+    ysz, csz = sw * sh, sw * sh // 2
+    distinct = 4
+    pinned = C.c_void_p()
+    cv.check(lib.chv_host_alloc(up.handle, distinct * (ysz + csz), C.byref(pinned)))
+    host = np.ctypeslib.as_array((C.c_uint8 * (distinct * (ysz + csz))).from_address(pinned.value))
+    for i in range(distinct):
+        img = util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 32 + i)
+        host[i * (ysz + csz): i * (ysz + csz) + ysz] = img[0].reshape(-1)
+        host[i * (ysz + csz) + ysz: (i + 1) * (ysz + csz)] = img[1].reshape(-1)
+    sets = [build_workload(sv, ctx, wl, args.frames, seed_base=0x5EED0000 + 32) for _ in range(2)]
+    done = []
+    for _ in sets:
+        e = C.c_void_p()
+        cv.check(lib.chv_event_create(ctx.handle, C.byref(e)))
+        cv.check(lib.chv_event_record(ctx.handle, e))
+        done.append(e)
+
+    def upload_set(k):
+        cv.check(lib.chv_event_wait(up.handle, done[k]))          # the kernel that last read this set is finished
+        keep = sets[k]["keep"]
+        for f in range(args.frames):
+            src = keep[2 * f].imageBuffer()
+            base = pinned.value + (f % distinct) * (ysz + csz)
+            cv.check(lib.chv_upload(up.handle, src.computeTextures[0]._h, 0, src.gpuPitches[0], base, sw, sw, sh, 2))
+            cv.check(lib.chv_upload(up.handle, src.computeTextures[1]._h, 0, src.gpuPitches[1], base + ysz, sw, sw, sh // 2, 2))
+
+    def convert_set(k):
+        cv.check(lib.chv_batch_run(ctx.handle, sets[k]["batch"]))  # waits for the set's upload events on its stream
+        cv.check(lib.chv_event_record(ctx.handle, done[k]))
+
+    def sync():
+        cv.check(lib.chv_device_synchronize(ctx.handle))
+
+    for w in range(args.warmup):
+        upload_set(w % 2); convert_set(w % 2)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        upload_set(k % 2); convert_set(k % 2)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = reduce_max(dist, time.perf_counter() - t0)
+    if rank == 0:
+        px = args.frames * wl["dw"] * wl["dh"]
+        h2d = args.frames * (ysz + csz) * args.steps / elapsed / 1e9
+        print(json.dumps({
+            "metric": "Gpix/s + achieved HBM GB/s, 1080p NV12→BGRA+scale+4-layer composite, 1/2/4/8 GPU",
+            "value": whole_job_gpix(n_gpus, px, args.steps, elapsed), "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "mode": "END-TO-END incl. H2D upload of every source frame "
+                       "from pinned host memory on a side stream (not the headline mode)", "frames_per_step_per_gpu": args.frames,
+                       "h2d_GBps_per_gpu": h2d, "kernel": sets[0]["kernel"]}}), flush=True)
+    cv.check(lib.chv_host_free(up.handle, pinned))
+
+
 def main():
     args = parse_args()
     rank, local, world, dist = dist_setup(args.gpus)
@@ -210,6 +281,11 @@ def main():
     lib = cv.load()
     ctx = sv.makeComputeContext(forType="GPU", index=local)
     wl = WORKLOADS[args.workload]
+    if args.with_upload:
+        run_with_upload(args, sv, cv, lib, ctx, wl, rank, n_gpus, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     w = build_workload(sv, ctx, wl, args.frames, seed_base=0x5EED0000 + 16 * 2 + rank)
 
     def step():

@@ -152,10 +152,21 @@ int chv_plane_alloc(chv_context *ctx, int width, int height, int components,
  * uploadComputePicture (compute.cl.swift:361-379, 434-452): pitched H2D copy.
  * async = 0: returns when the copy is complete (reference behaviour).
  * async = 1: the host bytes are staged into pinned memory before returning, so
- * `src` is only borrowed for the call; the copy is ordered on the context's
- * stream. */
+ *            `src` is only borrowed for the call; the copy is ordered on the
+ *            context's stream.
+ * async = 2: `src` is pinned memory from chv_host_alloc that the caller leaves
+ *            unchanged until the context's stream has passed the copy (e.g. the
+ *            next chv_pass_end(wait)); no staging copy is made — the path for
+ *            decoders that write straight into pinned frames.
+ * After an asynchronous upload, kernels launched from ANY context of the device
+ * that read the plane wait for the copy on their own stream (an event per
+ * buffer); no host-side wait is needed between upload and use. */
 int chv_upload(chv_context *ctx, chv_buffer *dst, size_t dst_offset, size_t dst_pitch,
                const void *src, size_t src_pitch, size_t width_bytes, size_t rows, int async);
+/* Pinned (page-locked) host memory for async = 2 uploads. */
+int chv_host_alloc(chv_context *ctx, size_t bytes, void **out);
+int chv_host_free(chv_context *ctx, void *ptr);
+
 /* downloadComputeBuffer / downloadComputePicture (compute.cl.swift:381-396,
  * 461-498): pitched D2H copy, always complete on return. */
 int chv_download(chv_context *ctx, void *dst, size_t dst_pitch, chv_buffer *src,
@@ -259,6 +270,8 @@ int chv_scale_lanczos(chv_context *ctx, const chv_image *dst, const chv_image *s
 typedef struct chv_event chv_event;
 int chv_event_create(chv_context *ctx, chv_event **out);
 int chv_event_record(chv_context *ctx, chv_event *ev);
+/* Make all later work of `ctx`'s stream wait for `ev` (recorded on any context of the device). */
+int chv_event_wait(chv_context *ctx, chv_event *ev);
 int chv_event_synchronize(chv_event *ev);
 int chv_event_elapsed_ms(chv_event *start, chv_event *stop, float *ms);
 int chv_event_destroy(chv_event *ev);

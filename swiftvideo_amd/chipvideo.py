@@ -100,6 +100,8 @@ _SIGNATURES = {
     "chv_buffer_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "chv_plane_alloc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "chv_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]),
+    "chv_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "chv_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "chv_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     "chv_pass_begin": (C.c_int, [C.c_void_p]),
     "chv_run_kernel": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Image), C.POINTER(Image), C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(KernelOpts)]),
@@ -112,6 +114,7 @@ _SIGNATURES = {
     "chv_scale_lanczos": (C.c_int, [C.c_void_p, C.POINTER(Image), C.POINTER(Image)]),
     "chv_event_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "chv_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "chv_event_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "chv_event_synchronize": (C.c_int, [C.c_void_p]),
     "chv_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "chv_event_destroy": (C.c_int, [C.c_void_p]),

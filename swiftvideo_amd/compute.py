@@ -332,7 +332,9 @@ def uploadComputePicture(ctx, pict, maxPlanes=3, retainCpuBuffer=True, asynchron
         comps = 4 if comps >= 3 else comps
         cv.check(lib.chv_upload(ctx.handle, tex._h, 0, pitch, buf.ctypes.data, plane.stride,
                                 plane.size[0] * comps, plane.size[1], 1 if asynchronous else 0))
-    endComputePass(ctx, True)
+    # asynchronous: the bytes are already staged in pinned memory and the copies are ordered on this
+    # context's stream; kernels on other contexts wait on the planes' upload events, so no host stall
+    endComputePass(ctx, not asynchronous)
     img = image.withChanges(computeTextures=texs, gpuPitches=pitches,
                             buffers=image.buffers if retainCpuBuffer else [], bufferType="gpu")
     return pict.derive(img=img)

@@ -202,6 +202,12 @@ struct chv_buffer {
     size_t size = 0;
     int device = 0;
     bool owned = true;
+    // cross-context ordering: an asynchronous upload records `ready` on the uploading
+    // context's stream; a kernel launched from another context's stream waits on it first
+    // (the reference gets this ordering from blocking copies, compute.cl.swift:440-450)
+    hipEvent_t ready = nullptr;
+    hipStream_t ready_stream = nullptr;
+    uint64_t ready_seq = 0;
 };
 
 struct chv_event {
@@ -217,6 +223,7 @@ struct chv_batch {
     int fast_path = -1;
     DTick *d_ticks = nullptr;
     DLayer *d_layers = nullptr;
+    std::vector<std::pair<chv_buffer *, uint64_t>> deps;   // buffers the descriptors point into + last upload seen
     std::vector<DTick> h_ticks;    // host copies: launch geometry of the fast paths
     std::vector<DLayer> h_layers;
     std::string kernel_name;
@@ -358,6 +365,7 @@ extern "C" int chv_buffer_free(chv_buffer *b) {
         (void)hipSetDevice(b->device);
         (void)hipFree(b->ptr);  // hipFree waits for in-flight work on the allocation
     }
+    if (b->ready) { (void)hipSetDevice(b->device); (void)hipEventDestroy(b->ready); b->ready = nullptr; }
     b->magic = 0;
     b->ptr = nullptr;
     delete b;
@@ -405,6 +413,16 @@ extern "C" int chv_upload(chv_context *c, chv_buffer *dst, size_t dst_offset, si
     if (!async) {
         HIP_TRY(hipMemcpy2DAsync(d, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        dst->ready_stream = nullptr;   // complete: nobody has to wait
+        return CHV_OK;
+    }
+    if (async == 2) {
+        // caller-owned pinned memory (chv_host_alloc): no staging copy
+        HIP_TRY(hipMemcpy2DAsync(d, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->stream));
+        if (!dst->ready) HIP_TRY(hipEventCreateWithFlags(&dst->ready, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(dst->ready, c->stream));
+        dst->ready_stream = c->stream;
+        dst->ready_seq++;
         return CHV_OK;
     }
     // stage into pinned memory so the caller's bytes are only borrowed for this call
@@ -426,6 +444,28 @@ extern "C" int chv_upload(chv_context *c, chv_buffer *dst, size_t dst_offset, si
     HIP_TRY(hipMemcpy2DAsync(d, dst_pitch, hp, width_bytes, width_bytes, rows, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipEventRecord(s.done, c->stream));
     s.pending = true;
+    if (!dst->ready) HIP_TRY(hipEventCreateWithFlags(&dst->ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(dst->ready, c->stream));
+    dst->ready_stream = c->stream;
+    dst->ready_seq++;
+    return CHV_OK;
+}
+
+extern "C" int chv_host_alloc(chv_context *c, size_t bytes, void **out) {
+    if (!out) return fail(CHV_ERR_INVALID_VALUE, "null argument");
+    *out = nullptr;
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (bytes == 0) return fail(CHV_ERR_INVALID_VALUE, "zero-sized allocation");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return CHV_OK;
+}
+
+extern "C" int chv_host_free(chv_context *c, void *ptr) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!ptr) return fail(CHV_ERR_INVALID_VALUE, "null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostFree(ptr));
     return CHV_OK;
 }
 
@@ -485,6 +525,31 @@ static int kernel_shape(int kernel, KernelShape *s) {
     return CHV_OK;
 }
 
+// buffers referenced by the descriptors being built (for upload -> kernel ordering)
+static thread_local std::vector<chv_buffer *> *g_deps = nullptr;
+
+struct DepScope {
+    std::vector<chv_buffer *> bufs;
+    DepScope() { g_deps = &bufs; }
+    ~DepScope() { g_deps = nullptr; }
+    std::vector<std::pair<chv_buffer *, uint64_t>> pairs() const {
+        std::vector<std::pair<chv_buffer *, uint64_t>> out;
+        for (chv_buffer *b : bufs) out.emplace_back(b, (uint64_t)-1);
+        return out;
+    }
+};
+
+static int wait_for_uploads(hipStream_t stream, std::vector<std::pair<chv_buffer *, uint64_t>> &deps) {
+    for (auto &d : deps) {
+        chv_buffer *b = d.first;
+        if (b->ready_stream && b->ready_stream != stream && b->ready_seq != d.second) {
+            HIP_TRY(hipStreamWaitEvent(stream, b->ready, 0));
+            d.second = b->ready_seq;
+        }
+    }
+    return CHV_OK;
+}
+
 static int plane_to_device(const chv_plane &p, int comps, int device, DPlane *out, int err, const char *what, int idx) {
     if (!buf_ok(p.buffer)) return fail(err, "%s plane %d: no device buffer", what, idx);
     if (p.buffer->device != device) return fail(err, "%s plane %d lives on device %d, context on %d", what, idx, p.buffer->device, device);
@@ -497,6 +562,7 @@ static int plane_to_device(const chv_plane &p, int comps, int device, DPlane *ou
         return fail(err, "%s plane %d: 4-component planes must be 4-byte aligned", what, idx);
     out->ptr = (uint8_t *)p.buffer->ptr + p.offset;
     out->w = p.width; out->h = p.height; out->pitch = p.pitch; out->comps = comps;
+    if (g_deps) g_deps->push_back(p.buffer);
     return CHV_OK;
 }
 
@@ -672,7 +738,11 @@ extern "C" int chv_run_kernel(chv_context *c, int kernel, const chv_image *targe
     DTick dt;
     std::vector<DLayer> dl;
     int tf = -1;
+    DepScope deps;
     rc = tick_to_device(t, c->device, s.is_clear ? s.target_format : -1, &dt, &dl, &tf);
+    if (rc) return rc;
+    auto dp = deps.pairs();
+    rc = wait_for_uploads(c->stream, dp);
     if (rc) return rc;
     return launch_transient(c, dt, dl, tf);
 }
@@ -690,7 +760,11 @@ extern "C" int chv_composite(chv_context *c, const chv_image *target, int clear_
     DTick dt;
     std::vector<DLayer> dl;
     int tf = -1;
+    DepScope deps;
     int rc = tick_to_device(t, c->device, -1, &dt, &dl, &tf);
+    if (rc) return rc;
+    auto dp = deps.pairs();
+    rc = wait_for_uploads(c->stream, dp);
     if (rc) return rc;
     return launch_transient(c, dt, dl, tf);
 }
@@ -707,6 +781,7 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
     std::vector<DTick> dts((size_t)n_ticks);
     std::vector<DLayer> dls;
     int tf0 = -1, maxW = 0, maxH = 0;
+    DepScope deps;
     for (int i = 0; i < n_ticks; i++) {
         int tf = -1;
         int rc = tick_to_device(ticks[i], c->device, -1, &dts[i], &dls, &tf);
@@ -730,6 +805,7 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
     b->fast_path = select_fast_path(tf0, dts.data(), dls.data(), n_ticks);
     b->h_ticks = dts;
     b->h_layers = dls;
+    b->deps = deps.pairs();
     if (b->fast_path >= 0) b->kernel_name = fast_path_name(b->fast_path);
     else b->kernel_name = tf0 == TF_BGRA ? "tick_general_bgra" : (tf0 == TF_NV12 ? "tick_general_yuv<nv12>" : "tick_general_yuv<y420p>");
     *out = b.release();
@@ -741,6 +817,8 @@ extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
     if (!b || !b->d_ticks) return fail(CHV_ERR_INVALID_VALUE, "bad batch");
     if (b->device != c->device) return fail(CHV_ERR_INVALID_CONTEXT, "batch belongs to device %d", b->device);
     HIP_TRY(hipSetDevice(c->device));
+    int wrc = wait_for_uploads(c->stream, b->deps);
+    if (wrc) return wrc;
     hipError_t e = b->fast_path >= 0
         ? launch_tick_fast(b->fast_path, b->h_ticks.data(), b->h_layers.data(), b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
         : launch_tick_general(b->target_format, b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
@@ -825,11 +903,15 @@ extern "C" int chv_scale_lanczos(chv_context *c, const chv_image *dst, const chv
     if (!dst || dst->n_planes != 1) return fail(CHV_ERR_BAD_TARGET, "Lanczos target must be one 4-component plane");
     if (!src || src->n_planes != 1) return fail(CHV_ERR_BAD_INPUT, "Lanczos source must be one 4-component plane");
     DPlane d, s;
+    DepScope deps;
     int rc = plane_to_device(dst->planes[0], 4, c->device, &d, CHV_ERR_BAD_TARGET, "target", 0);
     if (rc) return rc;
     rc = plane_to_device(src->planes[0], 4, c->device, &s, CHV_ERR_BAD_INPUT, "input", 0);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    auto dp = deps.pairs();
+    rc = wait_for_uploads(c->stream, dp);
+    if (rc) return rc;
     LanczosTable tx, ty;
     rc = lanczos_table(c, s.w, d.w, &tx);
     if (rc) return rc;
@@ -860,6 +942,14 @@ extern "C" int chv_event_record(chv_context *c, chv_event *ev) {
     if (!ev || !ev->ev) return fail(CHV_ERR_INVALID_VALUE, "bad event");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(ev->ev, c->stream));
+    return CHV_OK;
+}
+extern "C" int chv_event_wait(chv_context *c, chv_event *ev) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!ev || !ev->ev) return fail(CHV_ERR_INVALID_VALUE, "bad event");
+    if (ev->device != c->device) return fail(CHV_ERR_INVALID_VALUE, "event belongs to device %d", ev->device);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamWaitEvent(c->stream, ev->ev, 0));
     return CHV_OK;
 }
 extern "C" int chv_event_synchronize(chv_event *ev) {

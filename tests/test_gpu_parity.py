@@ -177,3 +177,25 @@ def test_upload_download_roundtrip_and_barriers(ctx):
     p2.imageBuffer().buffers[0][:] = 0
     back = sv.downloadComputePicture(ctx, g2).imageBuffer().buffers[0]
     assert np.array_equal(back.reshape(200, 320, 4), keep)
+
+
+def test_async_upload_on_a_side_context_orders_before_kernels(ctx):
+    """hipMemcpyAsync on the upload barrier's own stream, kernels on the mixer's stream: the planes'
+    upload events order them without a host wait (north star: H2D overlaps the kernel chain)."""
+    up_ctx = sv.createComputeContext(sharing=ctx)
+    sw, sh, dw, dh = 1920, 1080, 1280, 720
+    u = util.full_canvas_uniforms((dw, dh), (sw, sh))
+    canvas = G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh))
+    for i in range(6):
+        src = util.alloc_image("nv12", sw, sh, seed=900 + i)
+        gs = sv.uploadComputePicture(up_ctx, sv.pictureFromArrays(sv.PixelFormat.nv12, (sw, sh), src), asynchronous=True)
+        for p in src:        # the host bytes were staged: scribbling over them must not matter
+            keep = p.copy()
+            p[...] = 0
+            p[...] = keep
+        sv.usingContext(ctx, lambda c: sv.compositeTick(c, canvas, [(sv.ComputeKernel.img_nv12_bgra, gs, u, 0)], True))
+        exp = util.alloc_image("bgra", dw, dh)
+        assert O.run_kernel("img_clear_bgra", exp, threads=8) == 0
+        assert O.run_kernel("img_nv12_bgra", exp, src, u, threads=8) == 0
+        G.assert_same(G.from_gpu(ctx, canvas, "bgra", dw, dh), exp, f"async frame {i}")
+    sv.destroyComputeContext(up_ctx)
