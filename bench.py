@@ -36,6 +36,8 @@ WORKLOADS = {
                  sw=1920, sh=1080, dw=1280, dh=720, layers=1, bytes=3110400 + 3686400),
     "cfg3": dict(desc="4 x 1080p BGRA layers (opacity 1/.75/.5/.25) alpha-composited onto a 1080p BGRA canvas",
                  sw=1920, sh=1080, dw=1920, dh=1080, layers=4, bytes=4 * 8294400 + 8294400),
+    "cfg5": dict(desc="8 x 3840x2160 BGRA layers composited onto a 2160p canvas, then Lanczos-3 down to 1920x1080",
+                 sw=3840, sh=2160, dw=3840, dh=2160, layers=8, bytes=8 * 33177600 + 8294400, lanczos=(1920, 1080)),
 }
 
 
@@ -100,6 +102,7 @@ def build_workload(sv, ctx, wl, frames, seed_base):
     keep = []  # keep PictureSamples alive (they own the device memory)
     ticks = (cv.Tick * frames)()
     layer_arrays = []
+    lanczos_pairs = []
     if wl["layers"] == 1:
         for i in range(distinct):
             host_src.append(util.alloc_image("nv12", sw, sh, seed=seed_base + i))
@@ -120,7 +123,8 @@ def build_workload(sv, ctx, wl, frames, seed_base):
         nl = wl["layers"]
         for i in range(distinct):
             host_src.append(util.alloc_image("bgra", sw, sh, seed=seed_base + i))
-        us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in (1.0, 0.75, 0.5, 0.25)[:nl]]
+        ops = (1.0, 0.75, 0.5, 0.25) if nl <= 4 else (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3)
+        us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in ops[:nl]]
         for f in range(frames):
             layers = []
             for l in range(nl):
@@ -130,6 +134,9 @@ def build_workload(sv, ctx, wl, frames, seed_base):
                 layers.append((sv.ComputeKernel.img_bgra_bgra_tx, src, us[l], 0))
             dst = sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False)
             keep.append(dst)
+            if "lanczos" in wl:
+                small = sv.uploadComputePicture(ctx, sv.createPictureSample(wl["lanczos"], sv.PixelFormat.BGRA), retainCpuBuffer=False)
+                lanczos_pairs.append((small, dst))
             arr = sv._layer_array(layers)
             layer_arrays.append(arr)
             ticks[f].target = sv._image_desc(dst)
@@ -141,7 +148,8 @@ def build_workload(sv, ctx, wl, frames, seed_base):
     cv.check(lib.chv_batch_create(ctx.handle, ticks, frames, C.byref(batch)))
     name = C.create_string_buffer(128)
     cv.check(lib.chv_batch_describe(batch, name, 128, None))
-    return dict(batch=batch, keep=keep, layer_arrays=layer_arrays, ticks=ticks, kernel=name.value.decode(), verify=verify)
+    return dict(batch=batch, keep=keep, layer_arrays=layer_arrays, ticks=ticks, kernel=name.value.decode(), verify=verify,
+                lanczos=lanczos_pairs)
 
 
 def verify_frame(sv, ctx, wl, w, frame=0):
@@ -290,6 +298,8 @@ def main():
 
     def step():
         cv.check(lib.chv_batch_run(ctx.handle, w["batch"]))
+        for small, big in w["lanczos"]:
+            sv.scaleLanczos(ctx, small, big)
 
     def sync():
         cv.check(lib.chv_device_synchronize(ctx.handle))

@@ -181,9 +181,11 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int strips = tiles_x * strips_y;
-    const int tick = (slot / strips) * 8 + xcd;
-    if (tick >= n_ticks) return;
-    const int strip = slot % strips;
+    const int total = strips * n_ticks, per_xcd = (total + 7) >> 3;
+    const int index = xcd * per_xcd + slot;          // one contiguous range of strips per XCD
+    if (slot >= per_xcd || index >= total) return;
+    const int tick = index / strips;
+    const int strip = index - tick * strips;
     const DTick &T = ticks[tick];
     const int x0 = (strip % tiles_x) * TW, ys0 = (strip / tiles_x) * (KT * TH);
     if (x0 >= T.W || ys0 >= T.H) return;
@@ -424,8 +426,8 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
         lds = sizeof(TileTables) + (size_t)m.ypitch * m.yrows + (size_t)m.cpitch * m.crows;
     }
     int tiles_x = (maxW + TW - 1) / TW, tiles_y = (maxH + KT * TH - 1) / (KT * TH);   // strips of KT tiles
-    int groups = (n_ticks + 7) / 8;
-    dim3 grid((unsigned)(groups * 8 * tiles_x * tiles_y));
+    int per_xcd = (n_ticks * tiles_x * tiles_y + 7) / 8;
+    dim3 grid((unsigned)(per_xcd * 8));
     if (ticks_host[0].clear_first)
         hipLaunchKernelGGL(tick_nv12_bgra_tiled<true>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks,
                            tiles_x, tiles_y, m.ypitch, m.yrows, m.cpitch, m.crows);

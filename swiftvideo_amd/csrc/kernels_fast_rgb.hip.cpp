@@ -79,12 +79,16 @@ __global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *_
     int *scratch = (int *)(smem + sizeof(RgbLayerTable) * RMAXL);  // sink for summaries of absent layers
     const int tbase = (int)(sizeof(RgbLayerTable) * RMAXL) + 64; // [trows][tpitch] float4 texels
 
+    // XCD-aware numbering: block b runs on XCD b % 8; give every XCD one contiguous range of the
+    // launch's tiles (whole frames when there are >= 8 ticks) so that halos are shared through its L2
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int tiles = tiles_x * tiles_y;
-    const int tick = (slot / tiles) * 8 + xcd;                   // whole frames per XCD (block b runs on XCD b % 8)
-    if (tick >= n_ticks) return;
-    const int tile = slot % tiles;
+    const int total = tiles * n_ticks, per_xcd = (total + 7) >> 3;
+    const int index = xcd * per_xcd + slot;
+    if (slot >= per_xcd || index >= total) return;
+    const int tick = index / tiles;
+    const int tile = index - tick * tiles;
     const DTick &T = ticks[tick];
     const int x0 = (tile % tiles_x) * RTW, y0 = (tile / tiles_x) * RTH;
     if (x0 >= T.W || y0 >= T.H) return;
@@ -305,8 +309,8 @@ hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host,
         lds = sizeof(RgbLayerTable) * RMAXL + 64 + (size_t)pitch * rows;
     }
     int tiles_x = (maxW + RTW - 1) / RTW, tiles_y = (maxH + RTH - 1) / RTH;
-    int groups = (n_ticks + 7) / 8;
-    dim3 grid((unsigned)(groups * 8 * tiles_x * tiles_y));
+    int per_xcd = (n_ticks * tiles_x * tiles_y + 7) / 8;
+    dim3 grid((unsigned)(per_xcd * 8));
     if (ticks_host[0].clear_first)
         hipLaunchKernelGGL(tick_rgb_layers_tiled<true>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, tiles_x, tiles_y, pitch, rows);
     else
