@@ -6,7 +6,7 @@
 # and leaves CSVs under gpurun_out/prof_<tag>/ for profiles/summarize.py.
 set -u
 TAG=${1:-run}; shift || true
-ARGS=${@:-"--steps 10 --warmup 2 --no-cpu-baseline --no-verify"}
+ARGS=${@:-"--steps 50 --warmup 5 --no-cpu-baseline --no-verify"}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
