@@ -39,7 +39,11 @@ hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host,
 #define CHV_TW 128
 #endif
 constexpr int TW = CHV_TW;       // tile width  (output pixels), a multiple of 64
-constexpr int TXT = TW / 4;      // threads across a tile row (4 px each)
+#ifndef CHV_PXT
+#define CHV_PXT 2
+#endif
+constexpr int PXT = CHV_PXT;     // horizontally adjacent pixels per thread (4: one 16-byte store, 2: one 8-byte store)
+constexpr int TXT = TW / PXT;    // threads across a tile row
 constexpr int TYT = NTHREADS / TXT;   // tile rows covered per pass
 #ifndef CHV_TH
 #define CHV_TH 16
@@ -255,13 +259,13 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
     // column entries of this thread's four pixels (shared by all its rows); LDS byte
     // offsets inside a staged tile row
     const int txi = tid % TXT, tyi = tid / TXT;
-    const int xq = x0 + txi * 4;
-    const bool full4 = xq + 3 < T.W;
-    int cyo[4], cco[4];
-    float cya[4], icya[4], cca[4], icca[4];
+    const int xq = x0 + txi * PXT;
+    const bool full4 = xq + PXT - 1 < T.W;
+    int cyo[PXT], cco[PXT];
+    float cya[PXT], icya[PXT], cca[PXT], icca[PXT];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int c = txi * 4 + k;
+    for (int k = 0; k < PXT; k++) {
+        int c = txi * PXT + k;
         cya[k] = tb.cya[c]; icya[k] = 1.0f - cya[k];
         cca[k] = tb.cca[c]; icca[k] = 1.0f - cca[k];
         cyo[k] = tb.cy[c] - ycol0 + 16; cco[k] = (tb.cc[c] - ccol0 + 8) * 8;
@@ -297,14 +301,14 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
                 const int ry = tb.ry[ly], rc = tb.rc[ly], rfl = tb.rfl[ly];
                 const float yb = tb.rya[ly], iyb = 1.0f - yb, cb = tb.rca[ly], icb = 1.0f - cb;
                 const int yrow = ybase + (ry - yr0) * ypitch, crow = cbase + (rc - cr0) * cpitch;   // staged only
-                uint32_t outw[4];
+                uint32_t outw[PXT];
 
                 if (uniform_inside && opaque) {
                     // every pixel of the tile is inside the picture and the layer is opaque:
                     // result = cur*0 + px*1 = px exactly and to_code(unorm8(c)) == c, so the
                     // colour-matrix word is the output (no canvas read, no float round trip)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < PXT; k++) {
                         float fy, fu, fv;
                         sample_nv12_lds(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
                                         icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
@@ -317,9 +321,9 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
                     // time, entries re-read from the tables (this branch is rare; keeping it narrow keeps
                     // the kernel's register allocation that of the branch above)
 #pragma unroll 1
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < PXT; k++) {
                         if (xq + k >= T.W) break;
-                        const int c = txi * 4 + k;
+                        const int c = txi * PXT + k;
                         const int fl = tb.cfl[c] & rfl;
                         uint32_t *dp = (uint32_t *)(drow + (size_t)(xq + k) * 4);
                         uint32_t cpx = CLEAR ? 0xFF000000u : *dp;
@@ -344,8 +348,10 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
                     }
                     continue;
                 }
-                if (full4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-                else for (int k = 0; k < 4; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
+                if (full4) {
+                    if (PXT == 4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]);
+                    else *(uint2 *)(drow + (size_t)xq * 4) = make_uint2(outw[0], outw[PXT - 1]);
+                } else for (int k = 0; k < PXT; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
             }
         }
         __syncthreads();   // tile j's LDS rectangle is free again
