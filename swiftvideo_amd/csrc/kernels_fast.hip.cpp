@@ -28,7 +28,7 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_COUNT };
 
 // kernels_fast_rgb.hip.cpp
 bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
@@ -139,8 +139,9 @@ CHV_DEV void sample_nv12_lds(const uint8_t *smem, int ya, int ypitch, int ca, in
     fv = ((c00 * q00.y + c10 * q10.y) + c01 * q01.y) + c11 * q11.y;
 }
 
-// the same sample straight from the source planes (tile did not fit the LDS budget)
-CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, int ix, int iy, int cx, int cy,
+// the same sample straight from the source planes (tile did not fit the LDS budget);
+// SV != nullptr: planar chroma (y420p: U from SC, V from SV), else interleaved (NV12)
+CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, const DPlane *SV, int ix, int iy, int cx, int cy,
                                 float w00, float w10, float w01, float w11,
                                 float c00, float c10, float c01, float c11,
                                 float &fy, float &fu, float &fv) {
@@ -151,14 +152,50 @@ CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, int ix, int 
     int u0 = min(max(cx, 0), SC.w - 1), u1 = min(max(cx + 1, 0), SC.w - 1);
     int v0 = min(max(cy, 0), SC.h - 1), v1 = min(max(cy + 1, 0), SC.h - 1);
     const uint8_t *q0 = SC.ptr + (size_t)v0 * SC.pitch, *q1 = SC.ptr + (size_t)v1 * SC.pitch;
-    uint32_t a00 = *(const uint16_t *)(q0 + u0 * 2), a10 = *(const uint16_t *)(q0 + u1 * 2);
-    uint32_t a01 = *(const uint16_t *)(q1 + u0 * 2), a11 = *(const uint16_t *)(q1 + u1 * 2);
+    uint32_t a00, a10, a01, a11;
+    if (SV) {
+        const uint8_t *z0 = SV->ptr + (size_t)v0 * SV->pitch, *z1 = SV->ptr + (size_t)v1 * SV->pitch;
+        a00 = q0[u0] | (z0[u0] << 8); a10 = q0[u1] | (z0[u1] << 8);
+        a01 = q1[u0] | (z1[u0] << 8); a11 = q1[u1] | (z1[u1] << 8);
+    } else {
+        a00 = *(const uint16_t *)(q0 + u0 * 2); a10 = *(const uint16_t *)(q0 + u1 * 2);
+        a01 = *(const uint16_t *)(q1 + u0 * 2); a11 = *(const uint16_t *)(q1 + u1 * 2);
+    }
     fu = ((c00 * unorm8(a00 & 255) + c10 * unorm8(a10 & 255)) + c01 * unorm8(a01 & 255)) + c11 * unorm8(a11 & 255);
     fv = ((c00 * unorm8(a00 >> 8) + c10 * unorm8(a10 >> 8)) + c01 * unorm8(a01 >> 8)) + c11 * unorm8(a11 >> 8);
 }
 
+// Planar chroma (y420p): one 16-byte vector of the U plane and the matching one of the V plane
+// become 16 (u, v) float pairs = 128 bytes of LDS; slot 16 + k of a row holds source texel t0 + k.
+template <int N>
+CHV_DEV void stage_store_uv_planar(const uint4 (&uregs)[N], const uint4 (&vregs)[N], uint8_t *lds, int lds_pitch,
+                                   const DPlane &PU, const DPlane &PV, const StageGeom &g, int tid) {
+    const int nv = g.edge ? g.nvec + 2 : g.nvec;
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        int i = tid + n * NTHREADS;
+        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
+        if (r < g.rows && vv < nv) {
+            int v = g.edge ? vv - 1 : vv;
+            uint4 uu = uregs[n], vw = vregs[n];
+            if (g.edge) {
+                int row = min(max(g.r_lo + r, 0), PU.h - 1);
+                uu = patch_edges<1>(uu, PU, row, g.b0 + v * 16);
+                vw = patch_edges<1>(vw, PV, row, g.b0 + v * 16);
+            }
+            float4 *d = (float4 *)(lds + r * lds_pitch + 128 + v * 128);
+            const uint32_t us[4] = { uu.x, uu.y, uu.z, uu.w }, vs[4] = { vw.x, vw.y, vw.z, vw.w };
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                d[2 * q] = make_float4(unorm8(us[q] & 255), unorm8(vs[q] & 255), unorm8((us[q] >> 8) & 255), unorm8((vs[q] >> 8) & 255));
+                d[2 * q + 1] = make_float4(unorm8((us[q] >> 16) & 255), unorm8((vs[q] >> 16) & 255), unorm8(us[q] >> 24), unorm8(vs[q] >> 24));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
-// FP_NV12_BGRA_TILED: one LK_BGRA_FROM_NV12 layer per tick, axis aligned.
+// FP_NV12_BGRA_TILED / FP_Y420P_BGRA_TILED: one LK_BGRA_FROM_{NV12,Y420P} layer per tick, axis aligned.
 // A block walks a vertical strip of KT tiles: column tables once, row tables for all KT
 // tiles at once, then per tile  [LDS write of the prefetched rectangle | barrier | issue
 // the next tile's global loads | compute + store | barrier].
@@ -170,8 +207,8 @@ CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, int ix, int 
 constexpr int NYV = CHV_NYV;   // prefetch registers (16-byte vectors) per thread, luma
 constexpr int NCV = 2;   // chroma
 
-template <bool CLEAR>
-__global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__restrict__ ticks,
+template <bool CLEAR, bool PLANAR>
+__global__ __launch_bounds__(NTHREADS) void tick_yuv_bgra_tiled(const DTick *__restrict__ ticks,
                                                                   const DLayer *__restrict__ layers,
                                                                   int n_ticks, int tiles_x, int strips_y,
                                                                   int ypitch, int yrows, int cpitch, int crows) {
@@ -198,6 +235,8 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
     const float *U = L.u;
     const DPlane &SY = L.src.pl[0];
     const DPlane &SC = L.src.pl[1];
+    const DPlane &SV = L.src.pl[PLANAR ? 2 : 1];
+    constexpr int CVEC = PLANAR ? 16 : 8;           // chroma texels per 16-byte source vector
     const DPlane &D = T.dst.pl[0];
     const int tid = threadIdx.x;
     const float sx = (float)T.W, sy = (float)T.H;
@@ -231,30 +270,33 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
     }
     const bool cols_any = yhi > ylo;
     const int ycol0 = max(ylo, 0) & ~15;                       // luma: byte == texel, 16 per vector
-    const int ccol0 = max(clo, 0) & ~7;                        // chroma: 8 texels per 16-byte vector
+    const int ccol0 = max(clo, 0) & ~(CVEC - 1);               // chroma: CVEC texels per 16-byte vector
     const int ynv = (min(yhi, SY.w - 1) - ycol0) / 16 + 1;
-    const int cnv = (min(chi, SC.w - 1) - ccol0) / 8 + 1;
-    const bool cols_fit = (ynv + 2) * 16 <= ypitch && (cnv + 2) * 64 <= cpitch;
+    const int cnv = (min(chi, SC.w - 1) - ccol0) / CVEC + 1;
+    const bool cols_fit = (ynv + 2) * 16 <= ypitch && (cnv + 2) * CVEC * 8 <= cpitch;
 
     // per-tile staging geometry from the tile's row summary
     auto tile_geom = [&](int j, StageGeom &gy, StageGeom &gc) -> bool {
         const int *rs = tb.rsum[j];
         if (!(cols_any && rs[1] > rs[0])) return false;
         gy.r_lo = rs[0]; gy.rows = rs[1] - rs[0] + 1; gy.b0 = ycol0; gy.nvec = ynv;
-        gc.r_lo = rs[2]; gc.rows = rs[3] - rs[2] + 1; gc.b0 = ccol0 * 2; gc.nvec = cnv;
+        gc.r_lo = rs[2]; gc.rows = rs[3] - rs[2] + 1; gc.b0 = ccol0 * (PLANAR ? 1 : 2); gc.nvec = cnv;
         // interior rectangles: every tap and every 16-byte vector lies inside the planes
         gy.edge = ylo < 0 || yhi >= SY.w || rs[0] < 0 || rs[1] >= SY.h - 1 + (int)(ycol0 + ynv * 16 <= SY.w);
-        gc.edge = clo < 0 || chi >= SC.w || rs[2] < 0 || rs[3] >= SC.h - 1 + (int)(ccol0 + cnv * 8 <= SC.w);
+        gc.edge = clo < 0 || chi >= SC.w || rs[2] < 0 || rs[3] >= SC.h - 1 + (int)(ccol0 + cnv * CVEC <= SC.w);
         gy.sh = stage_shift(gy.edge ? ynv + 2 : ynv);
         gc.sh = stage_shift(gc.edge ? cnv + 2 : cnv);
         return cols_fit && gy.rows <= yrows && gc.rows <= crows &&
                stage_slots(gy) <= NYV * NTHREADS && stage_slots(gc) <= NCV * NTHREADS;
     };
 
-    uint4 yregs[NYV], cregs[NCV];
+    uint4 yregs[NYV], cregs[NCV], vregs[PLANAR ? NCV : 1];
     StageGeom gy, gc, ngy, ngc;
     bool staged = tile_geom(0, gy, gc);
-    if (staged) { stage_load(yregs, SY, gy, tid); stage_load(cregs, SC, gc, tid); }
+    if (staged) {
+        stage_load(yregs, SY, gy, tid); stage_load(cregs, SC, gc, tid);
+        if (PLANAR) stage_load(vregs, SV, gc, tid);
+    }
 
     // column entries of this thread's four pixels (shared by all its rows); LDS byte
     // offsets inside a staged tile row
@@ -268,7 +310,7 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
         int c = txi * PXT + k;
         cya[k] = tb.cya[c]; icya[k] = 1.0f - cya[k];
         cca[k] = tb.cca[c]; icca[k] = 1.0f - cca[k];
-        cyo[k] = tb.cy[c] - ycol0 + 16; cco[k] = (tb.cc[c] - ccol0 + 8) * 8;
+        cyo[k] = tb.cy[c] - ycol0 + 16; cco[k] = (tb.cc[c] - ccol0 + CVEC) * 8;
     }
     const CscFolded csc = csc_fold(kCsc[L.csc & 3]);
     const CscFolded cscb = csc_fold_biased(kCsc[L.csc & 3]);
@@ -278,14 +320,18 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
         // ---- phase 1: the prefetched rectangle of tile j goes to LDS ------------------------
         if (staged) {
             stage_store<1>(yregs, smem + ybase, ypitch, SY, gy, tid);
-            stage_store<2>(cregs, smem + cbase, cpitch, SC, gc, tid);
+            if constexpr (PLANAR) stage_store_uv_planar(cregs, vregs, smem + cbase, cpitch, SC, SV, gc, tid);
+            else stage_store<2>(cregs, smem + cbase, cpitch, SC, gc, tid);
         }
         __syncthreads();
         // ---- prefetch tile j+1 while tile j is computed ---------------------------------------
         bool nstaged = false;
         if (j + 1 < ntiles) {
             nstaged = tile_geom(j + 1, ngy, ngc);
-            if (nstaged) { stage_load(yregs, SY, ngy, tid); stage_load(cregs, SC, ngc, tid); }
+            if (nstaged) {
+                stage_load(yregs, SY, ngy, tid); stage_load(cregs, SC, ngc, tid);
+                if (PLANAR) stage_load(vregs, SV, ngc, tid);
+            }
         }
 
         // ---- phase 2: 4 px x 2 rows per thread ------------------------------------------------
@@ -335,10 +381,10 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
                                 const float ya = tb.cya[c], iya = 1.0f - ya, ca = tb.cca[c], ica = 1.0f - ca;
                                 float fy, fu, fv;
                                 if (staged)
-                                    sample_nv12_lds(smem, yrow + (pyx - ycol0 + 16), ypitch, crow + (pcx - ccol0 + 8) * 8, cpitch,
+                                    sample_nv12_lds(smem, yrow + (pyx - ycol0 + 16), ypitch, crow + (pcx - ccol0 + CVEC) * 8, cpitch,
                                                     iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
                                 else
-                                    sample_nv12_global(SY, SC, pyx, ry, pcx, rc,
+                                    sample_nv12_global(SY, SC, PLANAR ? &SV : nullptr, pyx, ry, pcx, rc,
                                                        iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
                                 w = yuv_to_bgra_word(csc, (int)to_code(fy), (int)to_code(fu), (int)to_code(fv));
                             }
@@ -350,7 +396,8 @@ __global__ __launch_bounds__(NTHREADS) void tick_nv12_bgra_tiled(const DTick *__
                 }
                 if (full4) {
                     if (PXT == 4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]);
-                    else *(uint2 *)(drow + (size_t)xq * 4) = make_uint2(outw[0], outw[PXT - 1]);
+                    else if (PXT == 2) *(uint2 *)(drow + (size_t)xq * 4) = make_uint2(outw[0], outw[PXT - 1]);
+                    else *(uint32_t *)(drow + (size_t)xq * 4) = outw[0];
                 } else for (int k = 0; k < PXT; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
             }
         }
@@ -379,9 +426,11 @@ static TileDims tile_dims(const DTick &T, const DLayer &L) {
     int yspan = (int)std::ceil(TW * sxr * L.src.pl[0].w) + 4;   // texels incl. tap 1 and rounding slack
     int cspan = (int)std::ceil(TW * sxr * L.src.pl[1].w) + 4;
     d.ypitch = ((yspan + 15) / 16 + 3) * 16;                    // luma bytes: vectors + alignment + 2 pad vectors
-    d.cpitch = ((cspan + 7) / 8 + 3) * 64;                      // chroma float pairs
-    d.yrows = (int)std::ceil(TH * syr * L.src.pl[0].h) + 5;
-    d.crows = (int)std::ceil(TH * syr * L.src.pl[1].h) + 5;
+    const bool planar = L.kind == LK_BGRA_FROM_Y420P;
+    d.cpitch = planar ? ((cspan + 15) / 16 + 3) * 128 : ((cspan + 7) / 8 + 3) * 64;   // chroma float pairs
+    // rows a tile's taps span: <= ceil((TH-1)*scale) + 2 (tap 1 of the last row) <= ceil(TH*scale) + 2
+    d.yrows = (int)std::ceil(TH * syr * L.src.pl[0].h) + 3;
+    d.crows = (int)std::ceil(TH * syr * L.src.pl[1].h) + 3;
     d.lds = sizeof(TileTables) + (size_t)d.ypitch * d.yrows + (size_t)d.cpitch * d.crows;
     return d;
 }
@@ -392,6 +441,7 @@ const char *fast_path_name(int path) {
     switch (path) {
     case FP_NV12_BGRA_TILED: return "tick_nv12_bgra_tiled";
     case FP_RGB_LAYERS_TILED: return "tick_rgb_layers_tiled";
+    case FP_Y420P_BGRA_TILED: return "tick_y420p_bgra_tiled";
     default: return "none";
     }
 }
@@ -404,19 +454,21 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
         const DTick &T = ticks[i];
         if (T.n_layers != 1 || T.clear_first != ticks[0].clear_first) return FP_NONE;
         const DLayer &L = layers[T.first_layer];
-        if (L.kind != LK_BGRA_FROM_NV12 || !(L.flags & LF_AXIS_ALIGNED)) return FP_NONE;
+        if ((L.kind != LK_BGRA_FROM_NV12 && L.kind != LK_BGRA_FROM_Y420P) || !(L.flags & LF_AXIS_ALIGNED)) return FP_NONE;
+        if (L.kind != layers[ticks[0].first_layer].kind) return FP_NONE;
+        if (L.kind == LK_BGRA_FROM_Y420P && !aligned16(L.src.pl[2])) return FP_NONE;
         if (!finite16(L.u + U_TRANSFORM) || !finite16(L.u + U_TEXTURE) || !finite16(L.u + U_BORDER)) return FP_NONE;
         if (!aligned16(T.dst.pl[0]) || !aligned16(L.src.pl[0]) || !aligned16(L.src.pl[1])) return FP_NONE;
         if (tile_dims(T, L).lds > (size_t)LDS_BUDGET) return FP_NONE;
     }
-    return FP_NV12_BGRA_TILED;
+    return layers[ticks[0].first_layer].kind == LK_BGRA_FROM_Y420P ? FP_Y420P_BGRA_TILED : FP_NV12_BGRA_TILED;
 }
 
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
     if (path == FP_RGB_LAYERS_TILED) return launch_rgb_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
-    if (path != FP_NV12_BGRA_TILED) return hipErrorNotSupported;
+    if (path != FP_NV12_BGRA_TILED && path != FP_Y420P_BGRA_TILED) return hipErrorNotSupported;
     TileDims m = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < n_ticks; i++) {
         TileDims d = tile_dims(ticks_host[i], layers_host[ticks_host[i].first_layer]);
@@ -434,12 +486,14 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
     int tiles_x = (maxW + TW - 1) / TW, tiles_y = (maxH + KT * TH - 1) / (KT * TH);   // strips of KT tiles
     int per_xcd = (n_ticks * tiles_x * tiles_y + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8));
-    if (ticks_host[0].clear_first)
-        hipLaunchKernelGGL(tick_nv12_bgra_tiled<true>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks,
-                           tiles_x, tiles_y, m.ypitch, m.yrows, m.cpitch, m.crows);
-    else
-        hipLaunchKernelGGL(tick_nv12_bgra_tiled<false>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks,
-                           tiles_x, tiles_y, m.ypitch, m.yrows, m.cpitch, m.crows);
+#define CHV_LAUNCH(C, P) hipLaunchKernelGGL((tick_yuv_bgra_tiled<C, P>), grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, \
+                                            tiles_x, tiles_y, m.ypitch, m.yrows, m.cpitch, m.crows)
+    const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;
+    if (clear && planar) CHV_LAUNCH(true, true);
+    else if (clear) CHV_LAUNCH(true, false);
+    else if (planar) CHV_LAUNCH(false, true);
+    else CHV_LAUNCH(false, false);
+#undef CHV_LAUNCH
     return hipGetLastError();
 }
 

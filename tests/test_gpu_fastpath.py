@@ -142,3 +142,38 @@ def test_rgb_layers_fallbacks(ctx):
     G.run_batch(ctx, h)
     G.destroy_batch(h)
     G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, "nine layers")
+
+
+# ---- y420p -> BGRA through the planar variant of the tiled kernel -------------------------------------
+@pytest.mark.parametrize("case", [c for c in NV12_BGRA_CASES if c not in ("huge_downscale", "down_2.5x", "tiny")])
+def test_y420p_bgra_tiled_matches_oracle(ctx, case):
+    cw, ch, sw, sh, kw, clear = NV12_BGRA_CASES[case]
+    u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+    src = util.alloc_image("y420p", sw, sh, seed=31)
+    canvas0 = util.alloc_image("bgra", cw, ch, seed=32)
+    exp = util.copy_image(canvas0)
+    if clear:
+        assert O.run_kernel("img_clear_bgra", exp) == 0
+    assert O.run_kernel("img_y420p_bgra", exp, src, u, csc=1, threads=4) == 0
+    gs = G.to_gpu(ctx, "y420p", sw, sh, src)
+    gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+    h, name, keep = G.make_batch(ctx, [(gd, clear, [(sv.ComputeKernel.img_y420p_bgra, gs, u, 1)])])
+    assert name == "tick_y420p_bgra_tiled", name
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"{case} via {name}")
+
+
+def test_y420p_1080p_to_720p_full_size(ctx):
+    sw, sh, dw, dh = 1920, 1080, 1280, 720
+    src = util.alloc_image("y420p", sw, sh, seed=41)
+    u = util.full_canvas_uniforms((dw, dh), (sw, sh))
+    exp = util.alloc_image("bgra", dw, dh)
+    assert O.run_kernel("img_clear_bgra", exp, threads=16) == 0
+    assert O.run_kernel("img_y420p_bgra", exp, src, u, threads=16) == 0
+    gs, gd = G.to_gpu(ctx, "y420p", sw, sh, src), G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=3))
+    h, name, keep = G.make_batch(ctx, [(gd, True, [(sv.ComputeKernel.img_y420p_bgra, gs, u, 0)])])
+    assert name == "tick_y420p_bgra_tiled"
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", dw, dh), exp, "y420p cfg2")
