@@ -36,6 +36,8 @@ WORKLOADS = {
                  sw=1920, sh=1080, dw=1280, dh=720, layers=1, bytes=3110400 + 3686400),
     "cfg3": dict(desc="4 x 1080p BGRA layers (opacity 1/.75/.5/.25) alpha-composited onto a 1080p BGRA canvas",
                  sw=1920, sh=1080, dw=1920, dh=1080, layers=4, bytes=4 * 8294400 + 8294400),
+    "mixer_y420p": dict(desc="reference-default canvas: 1080p y420p canvas <- full-canvas 1080p y420p layer + two 640x360 BGRA overlays (opacity .8/.6)",
+                 sw=1920, sh=1080, dw=1920, dh=1080, layers=3, bytes=3110400 + 3110400 + 2 * 921600, mixer="y420p"),
     "cfg5": dict(desc="8 x 3840x2160 BGRA layers composited onto a 2160p canvas, then Lanczos-3 down to 1920x1080",
                  sw=3840, sh=2160, dw=3840, dh=2160, layers=8, bytes=8 * 33177600 + 8294400, lanczos=(1920, 1080)),
 }
@@ -103,7 +105,31 @@ def build_workload(sv, ctx, wl, frames, seed_base):
     ticks = (cv.Tick * frames)()
     layer_arrays = []
     lanczos_pairs = []
-    if wl["layers"] == 1:
+    if "mixer" in wl:
+        fmt = wl["mixer"]
+        pf = sv.PixelFormat.y420p if fmt == "y420p" else sv.PixelFormat.nv12
+        for i in range(distinct):
+            host_src.append(util.alloc_image(fmt, sw, sh, seed=seed_base + i))
+        ov = [util.alloc_image("bgra", 640, 360, seed=seed_base + 100 + i) for i in range(2)]
+        us = [util.full_canvas_uniforms((dw, dh), (sw, sh)),
+              util.make_uniforms((dw, dh), rect=(64, 64, 640, 360), opacity=0.8, in_size=(640, 360)),
+              util.make_uniforms((dw, dh), rect=(1200, 640, 640, 360), opacity=0.6, in_size=(640, 360))]
+        k_main = sv.defaultComputeKernelFromString(f"img_{fmt}_{fmt}")
+        k_ov = sv.defaultComputeKernelFromString(f"img_bgra_{fmt}")
+        govs = [sv.uploadComputePicture(ctx, sv.pictureFromArrays(sv.PixelFormat.BGRA, (640, 360), o), retainCpuBuffer=False) for o in ov]
+        keep += govs
+        for f in range(frames):
+            src = sv.uploadComputePicture(ctx, sv.pictureFromArrays(pf, (sw, sh), host_src[f % distinct]), retainCpuBuffer=False)
+            dst = sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), pf), retainCpuBuffer=False)
+            keep += [src, dst]
+            arr = sv._layer_array([(k_main, src, us[0], 0), (k_ov, govs[0], us[1], 0), (k_ov, govs[1], us[2], 0)])
+            layer_arrays.append(arr)
+            ticks[f].target = sv._image_desc(dst)
+            ticks[f].clear_first = 1
+            ticks[f].n_layers = 3
+            ticks[f].layers = arr
+        verify = None
+    elif wl["layers"] == 1:
         for i in range(distinct):
             host_src.append(util.alloc_image("nv12", sw, sh, seed=seed_base + i))
         u = util.full_canvas_uniforms((dw, dh), (sw, sh))
@@ -318,7 +344,7 @@ def main():
         step()
     sync()
     verified = None
-    if not args.no_verify and rank == 0:
+    if not args.no_verify and rank == 0 and w["verify"] is not None:
         verified = verify_frame(sv, ctx, wl, w, frame=0) and verify_frame(sv, ctx, wl, w, frame=args.frames - 1)
 
     # per-launch HIP events on the stream the kernels run on
@@ -374,7 +400,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": w["kernel"], "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and w["verify"] is not None:
             out["cpu_baseline"] = cpu_baseline(wl, w, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     barrier()
