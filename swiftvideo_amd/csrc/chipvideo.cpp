@@ -599,6 +599,28 @@ static int32_t layer_flags(const float *u) {
     return f;
 }
 
+// Conservative bounding box of {pixels whose border coordinates lie in [0,1]^2}.  Axis-aligned
+// layers only (border.x depends on x alone); everything else gets the whole canvas.  The box is
+// computed in double with a 2-pixel margin, far more than the float evaluation can differ by.
+static void layer_bbox(DLayer *L, int W, int H) {
+    L->bbox[0] = 0; L->bbox[1] = 0; L->bbox[2] = W; L->bbox[3] = H;
+    if (!(L->flags & LF_AXIS_ALIGNED)) return;
+    const float *B = L->u + U_BORDER;
+    auto range = [](double k, double c, int n, int32_t *lo, int32_t *hi) {
+        // 0 <= k * (2*x/n - 1) + c <= 1
+        if (!(k - k == 0.0) || !(c - c == 0.0)) return;
+        if (k == 0.0) { if (c < -1e-3 || c > 1.0 + 1e-3) { *lo = 0; *hi = 0; } return; }
+        double a = ((0.0 - c) / k + 1.0) * n / 2.0, b = ((1.0 - c) / k + 1.0) * n / 2.0;
+        if (a > b) std::swap(a, b);
+        double l = std::floor(a) - 2.0, h = std::ceil(b) + 3.0;
+        *lo = (int32_t)std::min(std::max(l, 0.0), (double)n);
+        *hi = (int32_t)std::min(std::max(h, 0.0), (double)n);
+    };
+    // row 0: b0 = nx*B[0] + (ny*B[1] + 0*B[2]) + B[3] with B[1] = B[2] = 0
+    range((double)B[0], (double)B[3], W, &L->bbox[0], &L->bbox[2]);
+    range((double)B[5], (double)B[7], H, &L->bbox[1], &L->bbox[3]);
+}
+
 static int layer_to_device(const chv_layer &l, int device, int *target_format, DLayer *out) {
     KernelShape s;
     int rc = kernel_shape(l.kernel, &s);
@@ -652,6 +674,11 @@ static int tick_to_device(const chv_tick &t, int device, int forced_target_forma
     if (rc) return rc;
     dt->W = dt->dst.pl[0].w;
     dt->H = dt->dst.pl[0].h;
+    for (int i = first; i < (int)layers->size(); i++) {
+        DLayer &L = (*layers)[i];
+        if (L.kind == LK_BGRA_METAL) { L.bbox[0] = 0; L.bbox[1] = 0; L.bbox[2] = dt->W; L.bbox[3] = dt->H; }
+        else layer_bbox(&L, dt->W, dt->H);
+    }
     dt->clear_first = t.clear_first ? 1 : 0;
     dt->n_layers = t.n_layers;
     dt->first_layer = first;

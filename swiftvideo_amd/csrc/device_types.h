@@ -38,6 +38,10 @@ struct DLayer {
     int32_t swizzle;    // 1: exchange byte 0 and byte 2 of the sampled texel
     int32_t csc;        // chv_colorspace
     int32_t flags;      // LF_* below (host-side analysis; fast paths only)
+    // Conservative canvas-pixel bounding box [x0, x1) x [y0, y1) of the layer's border quad
+    // (host-side, a few pixels of margin): pixels outside it fail the border test for sure,
+    // so kernels may skip the layer there without evaluating the geometry.
+    int32_t bbox[4];
     int32_t pad;
 };
 

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -447,7 +448,13 @@ const char *fast_path_name(int path) {
 }
 
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
-    if (target_format != TF_BGRA || n_ticks <= 0) return FP_NONE;
+    if (n_ticks <= 0) return FP_NONE;
+    // A/B switch for measurements: CHV_FORCE_GENERAL=1 routes everything through the general kernels
+    static const bool force_general = [] { const char *e = getenv("CHV_FORCE_GENERAL"); return e && e[0] == '1'; }();
+    if (force_general) return FP_NONE;
+    // 4:2:0 canvases: the general quad kernel with per-layer bounding-box skipping measured faster than an
+    // LDS-tiled variant (profiles/r01_notes.md), so there is no tiled path for them yet
+    if (target_format != TF_BGRA) return FP_NONE;
     if (ticks[0].n_layers >= 1 && layers[ticks[0].first_layer].kind == LK_BGRA_FROM_RGB)
         return rgb_layers_eligible(ticks, layers, n_ticks) ? FP_RGB_LAYERS_TILED : FP_NONE;
     for (int i = 0; i < n_ticks; i++) {

@@ -152,22 +152,33 @@ __global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *_
         }
     }
 
+    // layers whose border quad cannot touch this tile are skipped (block-uniform test against the
+    // host-computed bounding box); `next_hit` walks the remaining ones in z order
+    auto next_hit = [&](int l) {
+        for (; l < nl; l++) {
+            const int *bb = L[l].bbox;
+            if (!(x0 + RTW <= bb[0] || x0 >= bb[2] || y0 + RTH <= bb[1] || y0 >= bb[3])) break;
+        }
+        return l;
+    };
     uint4 regs[RNV];
     StageGeom g, ng;
     int col0 = 0, ncol0 = 0;
-    bool staged = nl > 0 && layer_geom(0, g, col0);
-    if (staged) stage_load(regs, L[0].src.pl[0], g, tid);
+    int l = next_hit(0);
+    bool staged = l < nl && layer_geom(l, g, col0);
+    if (staged) stage_load(regs, L[l].src.pl[0], g, tid);
 
-    for (int l = 0; l < nl; l++) {
+    while (l < nl) {
         const DLayer &Ly = L[l];
         const DPlane &S = Ly.src.pl[0];
         const RgbLayerTable &t = tabs[l];
         if (staged) stage_store<4>(regs, smem + tbase, tpitch, S, g, tid);
         __syncthreads();
+        const int ln = next_hit(l + 1);
         bool nstaged = false;
-        if (l + 1 < nl) {
-            nstaged = layer_geom(l + 1, ng, ncol0);
-            if (nstaged) stage_load(regs, L[l + 1].src.pl[0], ng, tid);
+        if (ln < nl) {
+            nstaged = layer_geom(ln, ng, ncol0);
+            if (nstaged) stage_load(regs, L[ln].src.pl[0], ng, tid);
         }
         if (active) {
             const float *U = Ly.u;
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *_
             }
         }
         __syncthreads();
-        staged = nstaged; g = ng; col0 = ncol0;
+        staged = nstaged; g = ng; col0 = ncol0; l = ln;
     }
 
     if (active) {

@@ -97,7 +97,11 @@ __global__ __launch_bounds__(256) void tick_general_bgra(const DTick *__restrict
     uint32_t cur = T.clear_first ? 0xFF000000u : *dp;
     float sx = (float)T.W, sy = (float)T.H;
     const DLayer *L = layers + T.first_layer;
-    for (int l = 0; l < T.n_layers; l++) cur = apply_layer_bgra(L[l], x, y, sx, sy, cur);
+    for (int l = 0; l < T.n_layers; l++) {
+        const DLayer &Ly = L[l];
+        if (x < Ly.bbox[0] || x >= Ly.bbox[2] || y < Ly.bbox[1] || y >= Ly.bbox[3]) continue;   // fails the border test for sure
+        cur = apply_layer_bgra(Ly, x, y, sx, sy, cur);
+    }
     *dp = cur;
 }
 
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(256) void tick_general_yuv(const DTick *__restrict_
     const DLayer *L = layers + T.first_layer;
     for (int l = 0; l < T.n_layers; l++) {
         const DLayer &Ly = L[l];
+        if (x0 + 1 < Ly.bbox[0] || x0 >= Ly.bbox[2] || y0 + 1 < Ly.bbox[1] || y0 >= Ly.bbox[3]) continue;
         if (!cvalid) { s.u = 0; s.v = 0; }
         uint32_t du = 0, dv = 0;  // chroma of non-owner pixels: computed by the reference, never stored
 #pragma unroll

@@ -177,3 +177,82 @@ def test_y420p_1080p_to_720p_full_size(ctx):
     G.run_batch(ctx, h)
     G.destroy_batch(h)
     G.assert_same(G.from_gpu(ctx, gd, "bgra", dw, dh), exp, "y420p cfg2")
+
+
+# ---- 4:2:0 canvases (the reference's own kernels): batched multi-layer ticks, general quad kernel --------
+YUV_CASES = {
+    # name: (target fmt, canvas w, h, clear_first, [(kernel, src w, h, make_uniforms kwargs)])
+    "nv12_copy":      ("nv12", 128, 48, True, [("img_nv12_nv12", 128, 48, dict())]),
+    "nv12_scale":     ("nv12", 192, 108, True, [("img_nv12_nv12", 288, 162, dict(opacity=0.8))]),
+    "y420p_mixer":    ("y420p", 192, 108, True, [("img_y420p_y420p", 192, 108, dict()),
+                                                  ("img_bgra_y420p", 64, 36, dict(rect=(8, 8, 64, 36), opacity=0.8)),
+                                                  ("img_rgba_y420p", 64, 36, dict(rect=(100, 60, 80, 44), opacity=0.6, fill=(0.2, 0.9, 0.1, 0.5)))]),
+    "nv12_mixed":     ("nv12", 260, 70, True, [("img_y420p_nv12", 96, 54, dict(rect=(33, 9, 180, 40), border=(5, 3, 7, 2), fill=(0.9, 0.2, 0.1, 0.6), opacity=0.8)),
+                                                ("img_bgra_nv12", 50, 40, dict(rect=(-20, -10, 120, 60), fill=(0.1, 0.5, 0.9, 1.0), opacity=0.35)),
+                                                ("img_nv12_nv12", 64, 64, dict(rect=(150, 5, 90, 60), tex=(0.25, 0.0, 0.5, 1.0), fill=(1, 1, 0, 1)))]),
+    "y420p_noclear":  ("y420p", 130, 38, False, [("img_y420p_y420p", 50, 20, dict(rect=(10, 5, 80, 30), opacity=0.5)),
+                                                  ("img_bgra_y420p", 50, 20, dict(rect=(60, 2, 60, 36)))]),
+    "nv12_flip":      ("nv12", 192, 40, True, [("img_nv12_nv12", 96, 54, dict(tex=(1.0, 0.0, -1.0, 1.0))),
+                                                ("img_rgba_nv12", 96, 54, dict(tex=(0.2, 0.1, 0.5, 0.7), opacity=0.5))]),
+    "y420p_tiny":     ("y420p", 4, 2, True, [("img_y420p_y420p", 6, 4, dict()), ("img_bgra_y420p", 3, 3, dict(opacity=0.5))]),
+    "nv12_12_layers": ("nv12", 128, 32, True, [("img_bgra_nv12" if i % 3 else "img_nv12_nv12", 64, 16, dict(rect=(4 * i, i, 64, 16), opacity=1.0 - 0.05 * i)) for i in range(12)]),
+}
+
+
+@pytest.mark.parametrize("case", list(YUV_CASES))
+def test_yuv_layer_ticks_match_oracle(ctx, case):
+    d, cw, ch, clear, specs = YUV_CASES[case]
+    canvas0 = util.alloc_image(d, cw, ch, seed=81)
+    exp = util.copy_image(canvas0)
+    if clear:
+        assert O.run_kernel(f"img_clear_{d}", exp) == 0
+    layers = []
+    for i, (k, sw, sh, kw) in enumerate(specs):
+        u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+        s = k.split("_")[1]
+        src = util.alloc_image(s, sw, sh, seed=90 + i)
+        assert O.run_kernel(k, exp, src, u, threads=4) == 0
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, 0))
+    gd = G.to_gpu(ctx, d, cw, ch, canvas0)
+    h, name, keep = G.make_batch(ctx, [(gd, clear, layers)])
+    assert name == f"tick_general_yuv<{d}>", name
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, d, cw, ch), exp, f"{case} via {name}")
+
+
+def test_yuv_odd_canvas_uses_general_kernel(ctx):
+    gs = G.to_gpu(ctx, "bgra", 8, 8, util.alloc_image("bgra", 8, 8, seed=1))
+    gd = G.to_gpu(ctx, "nv12", 33, 17, util.alloc_image("nv12", 33, 17, seed=2))
+    u = util.make_uniforms((33, 17), in_size=(8, 8))
+    h, name, keep = G.make_batch(ctx, [(gd, True, [(sv.ComputeKernel.img_bgra_nv12, gs, u, 0)])])
+    G.destroy_batch(h)
+    assert name == "tick_general_yuv<nv12>"
+
+
+def test_bounding_box_skipping_keeps_results(ctx):
+    """Small overlays on a big canvas: layers are skipped per tile / per pixel by the host-side bounding box;
+    edges of the box (border quads with fractional coordinates, negative scales) must not lose pixels."""
+    cw, ch = 400, 120
+    rng = np.random.default_rng(7)
+    for d in ("bgra", "nv12"):
+        exp = util.alloc_image(d, cw, ch)
+        assert O.run_kernel(f"img_clear_{d}", exp) == 0
+        layers = []
+        for i in range(6):
+            sw, sh = 40, 24
+            rect = (float(rng.uniform(-30, cw - 10)), float(rng.uniform(-20, ch - 5)), float(rng.uniform(8, 120)), float(rng.uniform(6, 60)))
+            kw = dict(rect=rect, border=tuple(float(v) for v in rng.uniform(0, 9, 4)), fill=(0.3, 0.6, 0.9, 0.7), opacity=float(rng.uniform(0.3, 1)))
+            if i % 2:
+                kw["tex"] = (1.0, 0.0, -1.0, 1.0)
+            u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+            k = "img_bgra_bgra_tx" if d == "bgra" else "img_bgra_nv12"
+            src = util.alloc_image("bgra", sw, sh, seed=200 + i)
+            assert O.run_kernel(k, exp, src, u) == 0
+            layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, "bgra", sw, sh, src), u, 0))
+        # a rotated layer too (general kernel, whole-canvas box)
+        gd = G.to_gpu(ctx, d, cw, ch, util.alloc_image(d, cw, ch, seed=3))
+        h, name, keep = G.make_batch(ctx, [(gd, True, layers)])
+        G.run_batch(ctx, h)
+        G.destroy_batch(h)
+        G.assert_same(G.from_gpu(ctx, gd, d, cw, ch), exp, f"bbox {d} via {name}")
