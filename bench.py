@@ -46,13 +46,15 @@ WORKLOADS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=256, help="distinct frames (ticks) per launch per GPU")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--device", type=int, default=None,
+                    help="device index for every rank (default: LOCAL_RANK); lets the N>1 path be exercised on a 1-GPU box")
     ap.add_argument("--with-upload", action="store_true",
                     help="end-to-end mode: every step also uploads its source frames from pinned host memory on a side "
                          "stream (PCIe-inclusive rate; reported for DESIGN.md, never the headline value)")
@@ -313,7 +315,7 @@ def main():
     from swiftvideo_amd import chipvideo as cv
     from swiftvideo_amd import compute as sv
     lib = cv.load()
-    ctx = sv.makeComputeContext(forType="GPU", index=local)
+    ctx = sv.makeComputeContext(forType="GPU", index=local if args.device is None else args.device)
     wl = WORKLOADS[args.workload]
     if args.with_upload:
         run_with_upload(args, sv, cv, lib, ctx, wl, rank, n_gpus, dist)

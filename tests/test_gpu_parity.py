@@ -199,3 +199,54 @@ def test_async_upload_on_a_side_context_orders_before_kernels(ctx):
         assert O.run_kernel("img_nv12_bgra", exp, src, u, threads=8) == 0
         G.assert_same(G.from_gpu(ctx, canvas, "bgra", dw, dh), exp, f"async frame {i}")
     sv.destroyComputeContext(up_ctx)
+
+
+def test_descriptor_validation_through_the_c_abi(ctx):
+    """Malformed descriptors are rejected with the ComputeError case the reference would raise; no launch happens."""
+    import ctypes as C
+    from swiftvideo_amd import chipvideo as cv
+    lib = cv.load()
+    bgra = G.to_gpu(ctx, "bgra", 32, 16, util.alloc_image("bgra", 32, 16, seed=1))
+    nv12 = G.to_gpu(ctx, "nv12", 32, 16, util.alloc_image("nv12", 32, 16, seed=2))
+    u = util.full_canvas_uniforms((32, 16), (32, 16))
+    t = sv._image_desc(nv12)
+    i = sv._image_desc(bgra)
+
+    def run(target, inp, kernel=cv.K_IMG_BGRA_NV12, uniforms=u, size=236, blends=1):
+        arr = (cv.Image * 1)(inp)
+        return lib.chv_run_kernel(ctx.handle, kernel, C.byref(target), arr, 1, uniforms.ctypes.data if uniforms is not None else None,
+                                  size, blends, None)
+
+    assert run(t, i) == 0
+    bad = sv._image_desc(bgra); bad.planes[0].pitch = 32 * 4 - 4
+    assert run(t, bad) == 5                                  # pitch smaller than a row -> badInputData
+    bad = sv._image_desc(bgra); bad.planes[0].height = 4000
+    assert run(t, bad) == 5                                  # extent exceeds the device buffer
+    bad = sv._image_desc(bgra); bad.planes[0].offset = 2
+    assert run(t, bad) == 5                                  # 4-component plane not 4-byte aligned
+    bad = sv._image_desc(bgra); bad.planes[0].buffer = None
+    assert run(t, bad) == 5
+    badt = sv._image_desc(nv12); badt.planes[1].components = 1
+    assert run(badt, i) == 4                                 # chroma plane must be 2 components -> badTarget
+    badt = sv._image_desc(nv12); badt.n_planes = 1
+    assert run(badt, i) == 4
+    assert run(t, i, size=200) == 1                          # not the 236-byte ImageUniforms -> invalidValue
+    assert run(t, i, uniforms=None, size=0) == 1
+    assert run(t, i, blends=0) == 10                         # composite kernels read the target -> invalidOperation
+    assert run(t, i, kernel=99) == 7                         # unknown id -> computeKernelNotFound
+    # upload / download regions are checked against the buffer
+    buf = bgra.imageBuffer().computeTextures[0]
+    host = np.zeros(64, dtype=np.uint8)
+    assert lib.chv_upload(ctx.handle, buf._h, buf.size - 8, 64, host.ctypes.data, 64, 64, 1, 0) == 5
+    assert lib.chv_download(ctx.handle, host.ctypes.data, 64, buf._h, 0, 16, 64, 1) == 5   # pitch < row bytes
+    # too many layers, mixed target formats in a batch
+    layer = (sv.ComputeKernel.img_bgra_nv12, bgra, u, 0)
+    with pytest.raises(sv.ComputeError) as e:
+        sv.compositeTick(ctx, nv12, [layer] * 17, True)
+    assert e.value.case == "invalidValue"
+    with pytest.raises(sv.ComputeError) as e:
+        G.make_batch(ctx, [(nv12, True, [layer]), (bgra, True, [])])
+    assert e.value.case == "badTarget"
+    # everything still works afterwards
+    assert run(t, i) == 0
+    sv.endComputePass(ctx, True)
