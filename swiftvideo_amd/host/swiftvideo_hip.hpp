@@ -490,4 +490,89 @@ private:
     std::map<std::string, PictureSample> samples_[2];
 };
 
+
+// ---- PictureAnimator (animator.pic.swift:24-128, 207-272): the caller that produces the matrices ----
+// Elements without a parent (anchors only act relative to a parent's size change, :149-193).
+// The 4x4 algebra is VectorMath's in the reference (un-vendored, un-pinned); conventions as in Matrix4 above.
+enum class AspectMode { aspectNone, aspectFit, aspectFill };
+enum class PictureOrigin { originTopLeft, originCenter };
+
+struct ElementState {                       // Proto/Composition.proto:56-71, picture fields
+    double picPos[3] = { 0, 0, 0 };
+    double size[2] = { 0, 0 };
+    double textureOffset[2] = { 0, 0 };
+    double rotation = 0, transparency = 0;
+    AspectMode picAspect = AspectMode::aspectNone;
+    PictureOrigin picOrigin = PictureOrigin::originTopLeft;
+    bool hasFillColor = false;
+    double fillColor[4] = { 0, 0, 0, 0 };   // r g b a
+    double borderSize[4] = { 0, 0, 0, 0 };  // l t r b
+    bool hidden = false;
+};
+
+struct ComputedPictureState { Matrix4 matrix, textureMatrix, borderMatrix; Vector4 fillColor; float opacity = 1; };
+
+inline Matrix4 computeTextureMatrix(Vector2 sampleSize, const double geometrySize[2], const double textureOffset[2], AspectMode aspect) {
+    double origAspect = sampleSize.x / sampleSize.y, geomAspect = geometrySize[0] / geometrySize[1];
+    double scalex, scaley;
+    if (aspect == AspectMode::aspectFit) {
+        scalex = origAspect > geomAspect ? 1.0 : origAspect / geomAspect;
+        scaley = origAspect <= geomAspect ? 1.0 : geomAspect / origAspect;
+    } else if (aspect == AspectMode::aspectFill) {
+        scalex = origAspect <= geomAspect ? 1.0 : origAspect / geomAspect;
+        scaley = origAspect > geomAspect ? 1.0 : geomAspect / origAspect;
+    } else return Matrix4::identity();
+    return Matrix4::translation(textureOffset[0] + (1.0 - scalex) / 2, textureOffset[1] + (1.0 - scaley) / 2) * Matrix4::scale(scalex, scaley);
+}
+
+inline ElementState computeElementState(const ElementState &a, const ElementState &b, double pct) {   // :195-205
+    auto lerp = [pct](double x, double y) { return x + (y - x) * pct; };
+    ElementState r = a;
+    for (int i = 0; i < 3; i++) r.picPos[i] = lerp(a.picPos[i], b.picPos[i]);
+    for (int i = 0; i < 2; i++) { r.size[i] = lerp(a.size[i], b.size[i]); r.textureOffset[i] = lerp(a.textureOffset[i], b.textureOffset[i]); }
+    r.rotation = lerp(a.rotation, b.rotation); r.transparency = lerp(a.transparency, b.transparency);
+    r.picAspect = b.picAspect; r.picOrigin = b.picOrigin;
+    for (int i = 0; i < 4; i++) {
+        r.fillColor[i] = lerp(a.hasFillColor ? a.fillColor[i] : 0.0, b.hasFillColor ? b.fillColor[i] : 0.0);
+        r.borderSize[i] = lerp(a.borderSize[i], b.borderSize[i]);
+    }
+    r.hasFillColor = a.hasFillColor || b.hasFillColor;
+    return r;
+}
+
+inline ComputedPictureState computePictureState(Vector2 sampleSize, const ElementState &state) {   // :229-272, parent == nil
+    double ax = state.picOrigin == PictureOrigin::originTopLeft ? 0.0 : -state.size[0] / 2;
+    double ay = state.picOrigin == PictureOrigin::originTopLeft ? 0.0 : -state.size[1] / 2;
+    double px = state.picPos[0] + ax, py = state.picPos[1] + ay;
+    const double *b = state.borderSize;
+    ComputedPictureState c;
+    c.matrix = Matrix4::translation(px, py) * Matrix4::rotationZ(state.rotation) * Matrix4::scale(state.size[0], state.size[1]);
+    c.textureMatrix = computeTextureMatrix(sampleSize, state.size, state.textureOffset, state.picAspect);
+    c.borderMatrix = Matrix4::translation(px - b[0], py - b[1]) * Matrix4::rotationZ(state.rotation) *
+                     Matrix4::scale(b[0] + state.size[0] + b[2], b[1] + state.size[1] + b[3]);
+    if (state.hasFillColor) c.fillColor = Vector4{ (float)state.fillColor[0], (float)state.fillColor[1], (float)state.fillColor[2], (float)state.fillColor[3] };
+    c.opacity = (float)(1.0 - state.transparency);
+    return c;
+}
+
+class PictureAnimator {                     // Tx<PictureSample, PictureSample>, :107-128
+public:
+    PictureAnimator(Vector2 canvasSize, const ElementState &state, const std::string &revision = "")
+        : canvas_(canvasSize), state_(state), revision_(revision) {}
+    void setState(const ElementState &s) { state_ = s; }
+    EventBox<PictureSample> operator()(const PictureSample &sample) const {
+        EventBox<PictureSample> r;
+        if (state_.hidden) { r.kind = r.nothing; return r; }
+        ComputedPictureState cs = computePictureState(sample.size(), state_);
+        Matrix4 proj = Matrix4::ortho(canvas_.x, canvas_.y);
+        r.kind = r.just; r.value = sample;
+        r.value.matrix = proj * cs.matrix; r.value.textureMatrix = cs.textureMatrix; r.value.borderMatrix = proj * cs.borderMatrix;
+        r.value.fillColor = cs.fillColor; r.value.opacity = cs.opacity;
+        if (!revision_.empty()) r.value.revision = revision_;
+        return r;
+    }
+private:
+    Vector2 canvas_; ElementState state_; std::string revision_;
+};
+
 }  // namespace sv

@@ -88,6 +88,28 @@ static void cpuTests() {
     EXPECT(sizeof(sv::ImageUniforms) == 236);
     try { sv::createPictureSample({ 0, 4 }, sv::PixelFormat::nv12); EXPECT(false); }
     catch (const sv::ComputeError &e) { EXPECT(e.caseName == "invalidOperation"); }
+    // PictureAnimator (animator.pic.swift:207-272): aspect fit of a 4:3 picture in a 16:9 rect, border rect
+    {
+        sv::ElementState st;
+        st.picPos[0] = 100; st.picPos[1] = 50; st.size[0] = 640; st.size[1] = 360;
+        st.borderSize[0] = 4; st.borderSize[1] = 2; st.borderSize[2] = 6; st.borderSize[3] = 8;
+        st.picAspect = sv::AspectMode::aspectFit; st.transparency = 0.25; st.hasFillColor = true; st.fillColor[0] = 1; st.fillColor[3] = 0.5;
+        sv::ComputedPictureState cs = sv::computePictureState({ 640, 480 }, st);
+        double sxs = (640.0 / 480.0) / (640.0 / 360.0);
+        EXPECT(std::fabs(cs.textureMatrix.m[0] - sxs) < 1e-6 && std::fabs(cs.textureMatrix.m[3] - (1 - sxs) / 2) < 1e-6 && cs.textureMatrix.m[5] == 1.0);
+        EXPECT(cs.opacity == 0.75f && cs.fillColor.w == 0.5f);
+        EXPECT(cs.matrix.m[3] == 100 && cs.matrix.m[7] == 50 && cs.matrix.m[0] == 640 && cs.matrix.m[5] == 360);
+        EXPECT(cs.borderMatrix.m[3] == 96 && cs.borderMatrix.m[7] == 48 && cs.borderMatrix.m[0] == 650 && cs.borderMatrix.m[5] == 370);
+        sv::PictureSample pic = sv::createPictureSample({ 640, 480 }, sv::PixelFormat::nv12);
+        auto stamped = sv::PictureAnimator({ 1280, 720 }, st, "cam@1")(pic);
+        EXPECT(stamped.kind == stamped.just && stamped.value.revision == "cam@1" && stamped.value.opacity == 0.75f);
+        sv::ImageUniforms u = sv::imageUniformsFor(stamped.value, sv::createPictureSample({ 1280, 720 }, sv::PixelFormat::nv12));
+        // kernel rows map the rect's corners to tx = (0,0) / (1,1)
+        auto tx = [&](double px, double py, int r) { double v[4] = { px / 1280 * 2 - 1, py / 720 * 2 - 1, 0, 1 }, s = 0; for (int j = 0; j < 4; j++) s += u.transform[r * 4 + j] * v[j]; return s; };
+        EXPECT(std::fabs(tx(100, 50, 0)) < 1e-5 && std::fabs(tx(740, 410, 1) - 1) < 1e-5);
+        st.hidden = true;
+        EXPECT(sv::PictureAnimator({ 64, 36 }, st)(pic).kind == sv::EventBox<sv::PictureSample>::nothing);
+    }
     if (!sv::hasAvailableComputeDevices(sv::ComputeDeviceType::GPU)) {
         try { sv::makeComputeContext(sv::ComputeDeviceType::GPU); EXPECT(false); }
         catch (const sv::ComputeError &e) { EXPECT(e.caseName == "deviceNotAvailable"); }
