@@ -250,3 +250,44 @@ def test_descriptor_validation_through_the_c_abi(ctx):
     # everything still works afterwards
     assert run(t, i) == 0
     sv.endComputePass(ctx, True)
+
+
+def test_wrapped_decoder_surface_with_plane_offsets(ctx):
+    """Zero-copy hand-off of a decoder-style frame: ONE device allocation holding the Y and the interleaved
+    chroma plane with a 64-byte-aligned linesize (how FFmpeg lays out an AVFrame, dec.video.ffmpeg.swift:187-221),
+    adopted with chv_buffer_wrap and described by plane offsets."""
+    import ctypes as C
+    from swiftvideo_amd import chipvideo as cv
+    lib = cv.load()
+    sw, sh, dw, dh = 200, 90, 320, 144
+    linesize = 256                                             # > width, 64-byte aligned
+    src = util.alloc_image("nv12", sw, sh, seed=55)
+    frame = np.zeros(linesize * (sh + sh // 2), dtype=np.uint8)
+    frame[: linesize * sh].reshape(sh, linesize)[:, :sw] = src[0]
+    frame[linesize * sh:].reshape(sh // 2, linesize)[:, :sw] = src[1].reshape(sh // 2, sw)
+    owner = C.c_void_p()
+    cv.check(lib.chv_buffer_alloc(ctx.handle, frame.size, C.byref(owner)))
+    cv.check(lib.chv_upload(ctx.handle, owner, 0, frame.size, frame.ctypes.data, frame.size, frame.size, 1, 0))
+    devptr = C.c_void_p()
+    cv.check(lib.chv_buffer_info(owner, C.byref(devptr), None))
+    wrapped = C.c_void_p()
+    cv.check(lib.chv_buffer_wrap(ctx.handle, devptr, frame.size, C.byref(wrapped)))
+    img = cv.Image()
+    img.format, img.width, img.height, img.n_planes = cv.FMT_NV12, sw, sh, 2
+    img.planes[0] = cv.Plane(wrapped.value, 0, sw, sh, linesize, 1)
+    img.planes[1] = cv.Plane(wrapped.value, linesize * sh, sw // 2, sh // 2, linesize, 2)
+    canvas = G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=56))
+    u = util.make_uniforms((dw, dh), rect=(10, 7, 280, 120), opacity=0.9, in_size=(sw, sh))
+    tdesc = sv._image_desc(canvas)
+    arr = (cv.Image * 1)(img)
+    cv.check(lib.chv_pass_begin(ctx.handle))
+    cv.check(lib.chv_run_kernel(ctx.handle, cv.K_IMG_NV12_BGRA, C.byref(tdesc), arr, 1, u.ctypes.data, 236, 1, None))
+    cv.check(lib.chv_pass_end(ctx.handle, 1))
+    exp = util.alloc_image("bgra", dw, dh, seed=56)
+    assert O.run_kernel("img_nv12_bgra", exp, src, u) == 0
+    G.assert_same(G.from_gpu(ctx, canvas, "bgra", dw, dh), exp, "wrapped surface")
+    cv.check(lib.chv_buffer_free(wrapped))                     # does not free the adopted memory
+    back = np.zeros(16, dtype=np.uint8)
+    cv.check(lib.chv_download(ctx.handle, back.ctypes.data, 16, owner, 0, 16, 16, 1))
+    assert np.array_equal(back, frame[:16])
+    cv.check(lib.chv_buffer_free(owner))
