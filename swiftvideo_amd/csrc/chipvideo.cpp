@@ -26,6 +26,7 @@ hipError_t launch_tick_general(int target_format, const DTick *ticks, const DLay
                                int n_ticks, int maxW, int maxH, hipStream_t stream);
 hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
                            const float *den, float *out_q, int n, hipStream_t stream);
+hipError_t launch_selftest_pack(const int *b, const int *g, const int *r, uint32_t *out, int n, hipStream_t stream);
 // kernels_fast.hip.cpp
 const char *fast_path_name(int path);
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
@@ -1038,5 +1039,22 @@ extern "C" int chv_selftest_primitives(chv_context *c, float *unorm_out /*256*/,
         HIP_TRY(hipMemcpy(quot_out, d_q, n * sizeof(float), hipMemcpyDeviceToHost));
     }
     (void)hipFree(d_f); (void)hipFree(d_in); (void)hipFree(d_num); (void)hipFree(d_den); (void)hipFree(d_q); (void)hipFree(d_c);
+    return CHV_OK;
+}
+
+extern "C" int chv_selftest_pack(chv_context *c, const int *b, const int *g, const int *r, uint32_t *out /*2n*/, int n) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (n <= 0) return fail(CHV_ERR_INVALID_VALUE, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    int *d_b = nullptr, *d_g = nullptr, *d_r = nullptr; uint32_t *d_o = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_b, n * 4)); HIP_TRY(hipMalloc((void **)&d_g, n * 4)); HIP_TRY(hipMalloc((void **)&d_r, n * 4));
+    HIP_TRY(hipMalloc((void **)&d_o, n * 8));
+    HIP_TRY(hipMemcpy(d_b, b, n * 4, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(d_g, g, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_r, r, n * 4, hipMemcpyHostToDevice));
+    hipError_t e = launch_selftest_pack(d_b, d_g, d_r, d_o, n, c->stream);
+    if (e != hipSuccess) return hip_fail(e, "selftest launch");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, d_o, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_b); (void)hipFree(d_g); (void)hipFree(d_r); (void)hipFree(d_o);
     return CHV_OK;
 }

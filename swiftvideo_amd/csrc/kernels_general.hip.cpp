@@ -281,6 +281,15 @@ __global__ void selftest_kernel(float *out_f, const float *in_f, uint8_t *out_c,
         out_q[i] = num[i] / den[i];
     }
 }
+// out[i] = {pack_bgra_fixed(b,g,r), pack_bgra_fixed_pk(b,g,r)} for 16.16 channel sums
+__global__ void selftest_pack_kernel(const int *b, const int *g, const int *r, uint32_t *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[2 * i] = pack_bgra_fixed(b[i], g[i], r[i]); out[2 * i + 1] = pack_bgra_fixed_pk(b[i], g[i], r[i]); }
+}
+hipError_t launch_selftest_pack(const int *b, const int *g, const int *r, uint32_t *out, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(selftest_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b, g, r, out, n);
+    return hipGetLastError();
+}
 hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
                            const float *den, float *out_q, int n, hipStream_t stream) {
     int m = n > 256 ? n : 256;

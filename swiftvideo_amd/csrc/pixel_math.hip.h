@@ -165,6 +165,17 @@ CHV_DEV uint32_t pack_bgra_fixed(int32_t b16, int32_t g16, int32_t r16) {
     return (b >> 16) | ((g >> 8) & 0xFF00u) | (r & 0xFF0000u) | 0xFF000000u;
 }
 
+// The same packing with gfx950's v_ashr_pk_u8_i32 (shift right, saturate to u8, pack two
+// channels per instruction) and one v_perm_b32: {B,G} and {R,255} pairs, then a byte gather.
+// Only the low 16 bits of each pair are used (the instruction leaves the upper half undefined
+// for our purposes).  Checked against pack_bgra_fixed on device by tests/test_gpu_primitives.py.
+CHV_DEV uint32_t pack_bgra_fixed_pk(int32_t b16, int32_t g16, int32_t r16) {
+    uint32_t bg = (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(b16, g16, 16);        // byte0 = B, byte1 = G
+    uint32_t ra = (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(r16, 0x00FF0000, 16); // byte0 = R, byte1 = 255
+    // v_perm_b32(S0, S1, sel): selector bytes 0..3 pick from S1, 4..7 from S0
+    return __builtin_amdgcn_perm(ra, bg, 0x05040100u);
+}
+
 // returns memory-order BGRA word: B | G<<8 | R<<16 | 255<<24
 CHV_DEV uint32_t yuv_to_bgra_word(const Csc &k, int y, int u, int v) {
     int32_t c = k.cy * (y - k.yoff) + 32768;
@@ -201,7 +212,7 @@ CHV_DEV uint32_t yuv_to_bgra_word(const CscFolded &k, int y, int u, int v) {
     int32_t r = mad24(v, k.crv, mad24(y, k.cy, k.kr));
     int32_t g = mad24(v, k.ncgv, mad24(u, k.ncgu, mad24(y, k.cy, k.kg)));
     int32_t b = mad24(u, k.cbu, mad24(y, k.cy, k.kb));
-    return pack_bgra_fixed(b, g, r);
+    return pack_bgra_fixed_pk(b, g, r);
 }
 
 }  // namespace chv

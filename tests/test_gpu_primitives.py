@@ -45,3 +45,26 @@ def test_unorm8_store_and_division_match_oracle(ctx):
     assert bad.size == 0, f"to_code differs for {in_f[bad[:5]]}: {codes[bad[:5]]} vs {exp_codes[bad[:5]]}"
     assert np.array_equal(quot.view(np.uint32), (num / den).astype(np.float32).view(np.uint32)), \
         "device float division is not correctly rounded"
+
+
+def test_packed_saturating_shift_matches_plain_packing(ctx):
+    """pack_bgra_fixed_pk (v_ashr_pk_u8_i32 + v_perm_b32) == pack_bgra_fixed (clamp, shift, or) for 16.16 sums
+    over the whole range the colour matrices can produce, and == numpy."""
+    lib = cv.load()
+    fn = lib.chv_selftest_pack
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int]
+    rng = np.random.default_rng(3)
+    n = 200000
+    chans = [np.concatenate([rng.integers(-40_000_000, 60_000_000, n - 12),
+                             [0, 65535, 65536, -1, -65536, 255 * 65536, 255 * 65536 + 65535, 256 * 65536, 2**31 - 1, -2**31, 16777215, 16777216]]).astype(np.int32)
+             for _ in range(3)]
+    for c in chans:
+        rng.shuffle(c)
+    out = np.zeros(2 * n, dtype=np.uint32)
+    cv.check(fn(ctx.handle, chans[0].ctypes.data, chans[1].ctypes.data, chans[2].ctypes.data, out.ctypes.data, n))
+    clip = lambda v: np.clip(v.astype(np.int64) >> 16, 0, 255).astype(np.uint32)
+    exp = clip(chans[0]) | (clip(chans[1]) << 8) | (clip(chans[2]) << 16) | np.uint32(0xFF000000)
+    assert np.array_equal(out[0::2], exp), "pack_bgra_fixed"
+    bad = np.nonzero(out[1::2] != exp)[0]
+    assert bad.size == 0, f"pack_bgra_fixed_pk differs at {bad[:5]}: {[hex(v) for v in out[1::2][bad[:5]]]} vs {[hex(v) for v in exp[bad[:5]]]}"
