@@ -170,8 +170,11 @@ CHV_DEV uint32_t pack_bgra_fixed(int32_t b16, int32_t g16, int32_t r16) {
 // Only the low 16 bits of each pair are used (the instruction leaves the upper half undefined
 // for our purposes).  Checked against pack_bgra_fixed on device by tests/test_gpu_primitives.py.
 CHV_DEV uint32_t pack_bgra_fixed_pk(int32_t b16, int32_t g16, int32_t r16) {
-    uint32_t bg = (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(b16, g16, 16);        // byte0 = B, byte1 = G
-    uint32_t ra = (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(r16, 0x00FF0000, 16); // byte0 = R, byte1 = 255
+    // (inline asm rather than __builtin_amdgcn_ashr_pk_u8_i32: the builtin's 16-bit result type makes
+    // the compiler mask the register before the v_perm, which ignores the upper bytes anyway)
+    uint32_t bg, ra;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(bg) : "v"(b16), "v"(g16));          // byte0 = B, byte1 = G
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(ra) : "v"(r16), "v"(0x00FF0000));   // byte0 = R, byte1 = 255
     // v_perm_b32(S0, S1, sel): selector bytes 0..3 pick from S1, 4..7 from S0
     return __builtin_amdgcn_perm(ra, bg, 0x05040100u);
 }
