@@ -144,7 +144,7 @@ int chv_buffer_wrap(chv_context *ctx, void *device_ptr, size_t bytes, chv_buffer
 int chv_buffer_free(chv_buffer *buf);
 int chv_buffer_info(chv_buffer *buf, void **device_ptr, size_t *bytes);
 /* One plane of createTexture (compute.cl.swift:532-581): `components` bytes
- * per texel (1 = R8, 2 = RG8, 4 = RGBA8).  Linear, pitch is 256-byte aligned. */
+ * per texel (1 = R8, 2 = RG8, 4 = RGBA8).  Linear, pitch is 128-byte (cache line) aligned. */
 int chv_plane_alloc(chv_context *ctx, int width, int height, int components,
                     chv_buffer **out, size_t *pitch);
 

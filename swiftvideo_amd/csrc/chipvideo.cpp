@@ -386,8 +386,10 @@ extern "C" int chv_plane_alloc(chv_context *c, int width, int height, int compon
     if (width <= 0 || height <= 0) return fail(CHV_ERR_INVALID_OPERATION, "plane size %dx%d", width, height);
     if (components != 1 && components != 2 && components != 4)
         return fail(CHV_ERR_BAD_INPUT, "components must be 1, 2 or 4, got %d", components);
+    // rows start on a 128-byte cache line; widths that already are a multiple of 128 bytes stay packed,
+    // so a packed host plane of the same stride uploads as one linear copy
     size_t row = (size_t)width * components;
-    size_t p = (row + 255) & ~(size_t)255;
+    size_t p = (row + 127) & ~(size_t)127;
     *pitch = p;
     return chv_buffer_alloc(c, p * (size_t)height, out);
 }
@@ -411,15 +413,20 @@ extern "C" int chv_upload(chv_context *c, chv_buffer *dst, size_t dst_offset, si
     if (src_pitch < width_bytes) return fail(CHV_ERR_BAD_INPUT, "source pitch %zu < row bytes %zu", src_pitch, width_bytes);
     HIP_TRY(hipSetDevice(c->device));
     uint8_t *d = (uint8_t *)dst->ptr + dst_offset;
+    auto copy_h2d = [&](const void *from, size_t from_pitch) -> hipError_t {
+        // one contiguous block on both sides -> a linear copy
+        if (dst_pitch == width_bytes && from_pitch == width_bytes) return hipMemcpyAsync(d, from, width_bytes * rows, hipMemcpyHostToDevice, c->stream);
+        return hipMemcpy2DAsync(d, dst_pitch, from, from_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->stream);
+    };
     if (!async) {
-        HIP_TRY(hipMemcpy2DAsync(d, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(copy_h2d(src, src_pitch));
         HIP_TRY(hipStreamSynchronize(c->stream));
         dst->ready_stream = nullptr;   // complete: nobody has to wait
         return CHV_OK;
     }
     if (async == 2) {
         // caller-owned pinned memory (chv_host_alloc): no staging copy
-        HIP_TRY(hipMemcpy2DAsync(d, dst_pitch, src, src_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(copy_h2d(src, src_pitch));
         if (!dst->ready) HIP_TRY(hipEventCreateWithFlags(&dst->ready, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(dst->ready, c->stream));
         dst->ready_stream = c->stream;
@@ -442,7 +449,7 @@ extern "C" int chv_upload(chv_context *c, chv_buffer *dst, size_t dst_offset, si
     uint8_t *hp = (uint8_t *)s.host;
     if (src_pitch == width_bytes) memcpy(hp, sp, need);
     else for (size_t r = 0; r < rows; r++) memcpy(hp + r * width_bytes, sp + r * src_pitch, width_bytes);
-    HIP_TRY(hipMemcpy2DAsync(d, dst_pitch, hp, width_bytes, width_bytes, rows, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(copy_h2d(hp, width_bytes));
     HIP_TRY(hipEventRecord(s.done, c->stream));
     s.pending = true;
     if (!dst->ready) HIP_TRY(hipEventCreateWithFlags(&dst->ready, hipEventDisableTiming));
