@@ -171,12 +171,11 @@ CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, const DPlane
 template <int N>
 CHV_DEV void stage_store_uv_planar(const uint4 (&uregs)[N], const uint4 (&vregs)[N], uint8_t *lds, int lds_pitch,
                                    const DPlane &PU, const DPlane &PV, const StageGeom &g, int tid) {
-    const int nv = g.edge ? g.nvec + 2 : g.nvec;
 #pragma unroll
     for (int n = 0; n < N; n++) {
-        int i = tid + n * NTHREADS;
-        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
-        if (r < g.rows && vv < nv) {
+        int i = tid + n * NTHREADS, r, vv;
+        stage_slot(g, i, r, vv);
+        if (i < 1024 && r < g.rows) {
             int v = g.edge ? vv - 1 : vv;
             uint4 uu = uregs[n], vw = vregs[n];
             if (g.edge) {
@@ -285,8 +284,8 @@ __global__ __launch_bounds__(NTHREADS) void tick_yuv_bgra_tiled(const DTick *__r
         // interior rectangles: every tap and every 16-byte vector lies inside the planes
         gy.edge = ylo < 0 || yhi >= SY.w || rs[0] < 0 || rs[1] >= SY.h - 1 + (int)(ycol0 + ynv * 16 <= SY.w);
         gc.edge = clo < 0 || chi >= SC.w || rs[2] < 0 || rs[3] >= SC.h - 1 + (int)(ccol0 + cnv * CVEC <= SC.w);
-        gy.sh = stage_shift(gy.edge ? ynv + 2 : ynv);
-        gc.sh = stage_shift(gc.edge ? cnv + 2 : cnv);
+        stage_slots_init(gy);
+        stage_slots_init(gc);
         return cols_fit && gy.rows <= yrows && gc.rows <= crows &&
                stage_slots(gy) <= NYV * NTHREADS && stage_slots(gc) <= NCV * NTHREADS;
     };

@@ -25,7 +25,7 @@ constexpr int RTW = 64;           // tile width  (output pixels): 16 threads x 4
                                   // lane-adjacent LDS reads hit adjacent 16-byte texels: no bank conflicts)
 constexpr int RTH = 16;           // tile height (output rows):   16 thread rows
 constexpr int RMAXL = 8;          // layers per tick this path accepts
-constexpr int RNV = 3;            // prefetch registers (16-byte vectors) per thread
+constexpr int RNV = 2;            // prefetch registers (16-byte vectors) per thread
 
 struct RgbLayerTable {
     int cp[RTW]; float ca[RTW]; int cfl[RTW];     // column: unclamped tap-0 texel, weight of tap 1, flags
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *_
         const int nvec = (min(hi, S.w - 1) - col0) / 4 + 1;
         g.r_lo = t.rsum[0]; g.rows = t.rsum[1] - t.rsum[0] + 1; g.b0 = col0 * 4; g.nvec = nvec;
         g.edge = lo < 0 || hi >= S.w || t.rsum[0] < 0 || t.rsum[1] >= S.h - 1 + (int)(col0 + nvec * 4 <= S.w);
-        g.sh = stage_shift(g.edge ? nvec + 2 : nvec);
+        stage_slots_init(g);
         return (nvec + 2) * 64 <= tpitch && g.rows <= trows && stage_slots(g) <= RNV * NTHREADS;
     };
 

@@ -99,28 +99,35 @@ CHV_DEV uint4 patch_edges(uint4 val, const DPlane &P, int row, int off) {
 // NEXT tile are in flight while the current tile is being computed:
 //   stage_load : raw 16-byte vectors -> registers (no dependent instruction)
 //   stage_store: CLAMP_TO_EDGE patching, unorm8 -> float (chroma), LDS write
-// Slot i = tid + n * NTHREADS maps to row i >> sh, vector (i & mask) of that row; LDS row r
+// Slot i = tid + n * NTHREADS maps to row i / nslot, vector i % nslot of that row; LDS row r
 // holds source row clamp(r_lo + r).  With `edge` (block-uniform: the rectangle touches a
 // picture edge) vectors -1 .. nvec are staged, with the outside texels replicated.
 struct StageGeom {
     int r_lo, rows;     // first (unclamped) source row, number of LDS rows
     int b0;             // first source byte of vector 0 (16-byte aligned)
     int nvec;           // vectors that hold picture bytes
-    int sh;             // log2 of slots per row
+    int nslot;          // slots per row = vectors staged per row (nvec, or nvec + 2 with `edge`)
+    int inv20;          // ceil(2^20 / nslot): slot i -> row (i * inv20) >> 20, exact for i < 1024, nslot < 1024
     int edge;
 };
-CHV_DEV int stage_shift(int nv) { return nv <= 16 ? 4 : (nv <= 32 ? 5 : 6); }
-CHV_DEV int stage_slots(const StageGeom &g) { return g.rows << g.sh; }
+CHV_DEV void stage_slots_init(StageGeom &g) {
+    g.nslot = g.edge ? g.nvec + 2 : g.nvec;
+    g.inv20 = ((1 << 20) + g.nslot - 1) / g.nslot;
+}
+CHV_DEV int stage_slots(const StageGeom &g) { return g.rows * g.nslot; }
+CHV_DEV void stage_slot(const StageGeom &g, int i, int &r, int &vv) {
+    r = (int)(((unsigned)i * (unsigned)g.inv20) >> 20);
+    vv = i - r * g.nslot;
+}
 
 template <int N>
 CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, int tid) {
-    const int nv = g.edge ? g.nvec + 2 : g.nvec;
 #pragma unroll
     for (int n = 0; n < N; n++) {
-        int i = tid + n * NTHREADS;
-        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
+        int i = tid + n * NTHREADS, r, vv;
+        stage_slot(g, i, r, vv);
         regs[n] = make_uint4(0, 0, 0, 0);
-        if (r < g.rows && vv < nv) {
+        if (i < 1024 && r < g.rows) {
             int row = min(max(g.r_lo + r, 0), P.h - 1);
             int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
             regs[n] = g.edge ? load_row_vec(P, row, off) : *(const uint4 *)(P.ptr + (size_t)row * P.pitch + off);
@@ -133,12 +140,11 @@ CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, i
 // BPT = 4: 4-byte texels normalised to float4   (LDS texel slot 4 + k = source texel b0/4 + k)
 template <int BPT, int N>
 CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid) {
-    const int nv = g.edge ? g.nvec + 2 : g.nvec;
 #pragma unroll
     for (int n = 0; n < N; n++) {
-        int i = tid + n * NTHREADS;
-        int r = i >> g.sh, vv = i & ((1 << g.sh) - 1);
-        if (r < g.rows && vv < nv) {
+        int i = tid + n * NTHREADS, r, vv;
+        stage_slot(g, i, r, vv);
+        if (i < 1024 && r < g.rows) {
             int v = g.edge ? vv - 1 : vv;
             uint4 val = regs[n];
             if (g.edge) {
