@@ -53,7 +53,10 @@ constexpr int TH = CHV_TH;       // tile height (output rows)
 constexpr int RPT = TH / TYT;    // rows per thread
 // NTHREADS = 256: 32 x 8 threads, each 4 px x 2 rows per tile
 
-constexpr int KT = 4;             // tiles per block: a vertical strip of KT tiles shares its column tables
+#ifndef CHV_KT
+#define CHV_KT 4
+#endif
+constexpr int KT = CHV_KT;             // tiles per block: a vertical strip of KT tiles shares its column tables
 
 // Per-strip tables, structure-of-arrays so that lane-adjacent reads are conflict free.
 // Tap positions are the UNCLAMPED i0 = floor(u - 0.5) of the linear filter (tap 1 is
@@ -201,14 +204,17 @@ CHV_DEV void stage_store_uv_planar(const uint4 (&uregs)[N], const uint4 (&vregs)
 // the next tile's global loads | compute + store | barrier].
 // CLEAR: canvas starts as img_clear_bgra's value instead of being read.
 // ---------------------------------------------------------------------------
-#ifndef CHV_NYV
-#define CHV_NYV 3
+// NYV / NCV: prefetch registers (16-byte vectors) per thread for the luma / chroma rectangle of the next
+// tile.  The host picks the smallest pair the layer geometry needs: (2, 1) covers scale factors up to
+// about 1.7 (cfg2), (3, 2) the rest up to the LDS budget.
+// Occupancy: the kernel is VALU-issue bound and the SIMD's issue rate keeps rising with resident waves
+// (tools/ubench_issue.cpp), so the small-prefetch NV12 variant is held to 80 VGPRs = 6 waves per SIMD
+// (it fits without spilling); the others stay at 96 VGPRs = 5 waves.
+#ifndef CHV_MINW
+#define CHV_MINW ((NYV == 2 && !PLANAR) ? 6 : (NYV == 3 && PLANAR) ? 4 : 5)
 #endif
-constexpr int NYV = CHV_NYV;   // prefetch registers (16-byte vectors) per thread, luma
-constexpr int NCV = 2;   // chroma
-
-template <bool CLEAR, bool PLANAR>
-__global__ __launch_bounds__(NTHREADS) void tick_yuv_bgra_tiled(const DTick *__restrict__ ticks,
+template <bool CLEAR, bool PLANAR, int NYV, int NCV>
+__global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const DTick *__restrict__ ticks,
                                                                   const DLayer *__restrict__ layers,
                                                                   int n_ticks, int tiles_x, int strips_y,
                                                                   int ypitch, int yrows, int cpitch, int crows) {
@@ -337,68 +343,82 @@ __global__ __launch_bounds__(NTHREADS) void tick_yuv_bgra_tiled(const DTick *__r
         // ---- phase 2: 4 px x 2 rows per thread ------------------------------------------------
         const bool uniform_inside = staged && cols_inside && tb.rsum[j][5];
         const int yr0 = gy.r_lo, cr0 = gc.r_lo;
-        if (xq < T.W) {
+        // one row of the common case: every pixel of the tile is inside the picture and the layer is
+        // opaque, so result = cur*0 + px*1 = px exactly and to_code(unorm8(c)) == c: the colour-matrix
+        // word is the output (no canvas read, no float round trip)
+        auto fast_row = [&](int ly, uint32_t (&outw)[PXT]) {
+            const int ry = tb.ry[ly], rc = tb.rc[ly];
+            const float yb = tb.rya[ly], iyb = 1.0f - yb, cb = tb.rca[ly], icb = 1.0f - cb;
+            const int yrow = ybase + (ry - yr0) * ypitch, crow = cbase + (rc - cr0) * cpitch;
 #pragma unroll
+            for (int k = 0; k < PXT; k++) {
+                float fy, fu, fv;
+                sample_nv12_lds(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
+                                icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                outw[k] = yuv_to_bgra_word(cscb, (int)to_code_unit_biased(fy), (int)to_code_unit_biased(fu),
+                                           (int)to_code_unit_biased(fv));
+            }
+        };
+        auto store_row = [&](uint8_t *drow, const uint32_t (&outw)[PXT]) {
+            if (PXT == 4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]);
+            else if (PXT == 2) *(uint2 *)(drow + (size_t)xq * 4) = make_uint2(outw[0], outw[PXT - 1]);
+            else *(uint32_t *)(drow + (size_t)xq * 4) = outw[0];
+        };
+        const bool fast_tile = uniform_inside && opaque;
+        if (fast_tile && full4 && ys0 + (j + 1) * TH <= T.H) {
+            // whole tile on the common path: one straight-line block for all RPT rows, so the
+            // LDS reads of a later row are in flight while an earlier row is computed
+            uint32_t outw[RPT][PXT];
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) fast_row(j * TH + tyi + rr * TYT, outw[rr]);
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) store_row(D.ptr + (size_t)(ys0 + j * TH + tyi + rr * TYT) * D.pitch, outw[rr]);
+        } else if (xq < T.W) {
+#pragma unroll 1
             for (int rr = 0; rr < RPT; rr++) {
                 const int ly = j * TH + tyi + rr * TYT;
                 const int y = ys0 + ly;
                 if (y >= T.H) continue;
                 uint8_t *drow = D.ptr + (size_t)y * D.pitch;
+                uint32_t outw[PXT];
+                if (fast_tile) {
+                    fast_row(ly, outw);
+                    if (full4) store_row(drow, outw);
+                    else for (int k = 0; k < PXT; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
+                    continue;
+                }
+                // tiles on a picture/border edge, translucent layers, unstaged tiles: one pixel at a
+                // time, entries re-read from the tables
                 const int ry = tb.ry[ly], rc = tb.rc[ly], rfl = tb.rfl[ly];
                 const float yb = tb.rya[ly], iyb = 1.0f - yb, cb = tb.rca[ly], icb = 1.0f - cb;
                 const int yrow = ybase + (ry - yr0) * ypitch, crow = cbase + (rc - cr0) * cpitch;   // staged only
-                uint32_t outw[PXT];
-
-                if (uniform_inside && opaque) {
-                    // every pixel of the tile is inside the picture and the layer is opaque:
-                    // result = cur*0 + px*1 = px exactly and to_code(unorm8(c)) == c, so the
-                    // colour-matrix word is the output (no canvas read, no float round trip)
-#pragma unroll
-                    for (int k = 0; k < PXT; k++) {
-                        float fy, fu, fv;
-                        sample_nv12_lds(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
-                                        icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
-                                        icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
-                        outw[k] = yuv_to_bgra_word(cscb, (int)to_code_unit_biased(fy), (int)to_code_unit_biased(fu),
-                                                   (int)to_code_unit_biased(fv));
-                    }
-                } else {
-                    // tiles on a picture/border edge, translucent layers, unstaged tiles: one pixel at a
-                    // time, entries re-read from the tables (this branch is rare; keeping it narrow keeps
-                    // the kernel's register allocation that of the branch above)
 #pragma unroll 1
-                    for (int k = 0; k < PXT; k++) {
-                        if (xq + k >= T.W) break;
-                        const int c = txi * PXT + k;
-                        const int fl = tb.cfl[c] & rfl;
-                        uint32_t *dp = (uint32_t *)(drow + (size_t)(xq + k) * 4);
-                        uint32_t cpx = CLEAR ? 0xFF000000u : *dp;
-                        if (fl & AX_BORDER) {
-                            const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
-                            uint32_t w = 0;
-                            if (in_pic) {
-                                const int pyx = tb.cy[c], pcx = tb.cc[c];
-                                const float ya = tb.cya[c], iya = 1.0f - ya, ca = tb.cca[c], ica = 1.0f - ca;
-                                float fy, fu, fv;
-                                if (staged)
-                                    sample_nv12_lds(smem, yrow + (pyx - ycol0 + 16), ypitch, crow + (pcx - ccol0 + CVEC) * 8, cpitch,
-                                                    iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
-                                else
-                                    sample_nv12_global(SY, SC, PLANAR ? &SV : nullptr, pyx, ry, pcx, rc,
-                                                       iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
-                                w = yuv_to_bgra_word(csc, (int)to_code(fy), (int)to_code(fu), (int)to_code(fv));
-                            }
-                            cpx = blend_bgra_general(cpx, U, in_pic, w);
+                for (int k = 0; k < PXT; k++) {
+                    if (xq + k >= T.W) break;
+                    const int c = txi * PXT + k;
+                    const int fl = tb.cfl[c] & rfl;
+                    uint32_t *dp = (uint32_t *)(drow + (size_t)(xq + k) * 4);
+                    uint32_t cpx = CLEAR ? 0xFF000000u : *dp;
+                    if (fl & AX_BORDER) {
+                        const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
+                        uint32_t w = 0;
+                        if (in_pic) {
+                            const int pyx = tb.cy[c], pcx = tb.cc[c];
+                            const float ya = tb.cya[c], iya = 1.0f - ya, ca = tb.cca[c], ica = 1.0f - ca;
+                            float fy, fu, fv;
+                            if (staged)
+                                sample_nv12_lds(smem, yrow + (pyx - ycol0 + 16), ypitch, crow + (pcx - ccol0 + CVEC) * 8, cpitch,
+                                                iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
+                            else
+                                sample_nv12_global(SY, SC, PLANAR ? &SV : nullptr, pyx, ry, pcx, rc,
+                                                   iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
+                            w = yuv_to_bgra_word(csc, (int)to_code(fy), (int)to_code(fu), (int)to_code(fv));
                         }
-                        *dp = cpx;
+                        cpx = blend_bgra_general(cpx, U, in_pic, w);
                     }
-                    continue;
+                    *dp = cpx;
                 }
-                if (full4) {
-                    if (PXT == 4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]);
-                    else if (PXT == 2) *(uint2 *)(drow + (size_t)xq * 4) = make_uint2(outw[0], outw[PXT - 1]);
-                    else *(uint32_t *)(drow + (size_t)xq * 4) = outw[0];
-                } else for (int k = 0; k < PXT; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
             }
         }
         __syncthreads();   // tile j's LDS rectangle is free again
@@ -492,13 +512,17 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
     int tiles_x = (maxW + TW - 1) / TW, tiles_y = (maxH + KT * TH - 1) / (KT * TH);   // strips of KT tiles
     int per_xcd = (n_ticks * tiles_x * tiles_y + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8));
-#define CHV_LAUNCH(C, P) hipLaunchKernelGGL((tick_yuv_bgra_tiled<C, P>), grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, \
-                                            tiles_x, tiles_y, m.ypitch, m.yrows, m.cpitch, m.crows)
+#define CHV_LAUNCH(C, P, NY, NC) hipLaunchKernelGGL((tick_yuv_bgra_tiled<C, P, NY, NC>), grid, dim3(NTHREADS), lds, stream, ticks, layers, \
+                                                    n_ticks, tiles_x, tiles_y, m.ypitch, m.yrows, m.cpitch, m.crows)
+#define CHV_LAUNCH_N(C, P) do { if (small) CHV_LAUNCH(C, P, 2, 1); else CHV_LAUNCH(C, P, 3, 2); } while (0)
     const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;
-    if (clear && planar) CHV_LAUNCH(true, true);
-    else if (clear) CHV_LAUNCH(true, false);
-    else if (planar) CHV_LAUNCH(false, true);
-    else CHV_LAUNCH(false, false);
+    // upper bounds of the staging slots a tile can need (rows x vectors per row incl. the two edge vectors)
+    const bool small = m.yrows * (m.ypitch / 16) <= 2 * NTHREADS && m.crows * (m.cpitch / (planar ? 128 : 64)) <= NTHREADS;
+    if (clear && planar) CHV_LAUNCH_N(true, true);
+    else if (clear) CHV_LAUNCH_N(true, false);
+    else if (planar) CHV_LAUNCH_N(false, true);
+    else CHV_LAUNCH_N(false, false);
+#undef CHV_LAUNCH_N
 #undef CHV_LAUNCH
     return hipGetLastError();
 }

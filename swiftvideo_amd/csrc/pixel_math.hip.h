@@ -190,6 +190,13 @@ CHV_DEV uint32_t yuv_to_bgra_word(const Csc &k, int y, int u, int v) {
 // multiplies (v_mad_i32_i24, full rate): all intermediate sums stay below 2^27, so the
 // regrouping is exact integer arithmetic.
 CHV_DEV int32_t mad24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }
+// v_mad_i32_i24 spelled out: left to itself hipcc 7.2 splits multiply-adds into v_mul_i32_i24 + v_add3_u32,
+// one more multiplier-pipe instruction per term; `coef` must be wave-uniform (an SGPR)
+CHV_DEV int32_t mad24_uniform(int32_t a, int32_t coef, int32_t c) {
+    int32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(coef), "v"(c));
+    return d;
+}
 struct CscFolded { int32_t cy, crv, ncgu, ncgv, cbu, kr, kg, kb; };
 CHV_DEV CscFolded csc_fold(const Csc &k) {
     CscFolded f;
@@ -212,9 +219,13 @@ CHV_DEV CscFolded csc_fold_biased(const Csc &k) {
     return f;
 }
 CHV_DEV uint32_t yuv_to_bgra_word(const CscFolded &k, int y, int u, int v) {
-    int32_t r = mad24(v, k.crv, mad24(y, k.cy, k.kr));
-    int32_t g = mad24(v, k.ncgv, mad24(u, k.ncgu, mad24(y, k.cy, k.kg)));
-    int32_t b = mad24(u, k.cbu, mad24(y, k.cy, k.kb));
+    // one luma product shared by the three channels, chroma terms as 24-bit multiply-adds
+    // (v_mad_i32_i24), channel offsets as plain adds: 5 multiplier-pipe ops + 3 adds per pixel
+    int32_t t = __mul24(y, k.cy);
+    int32_t r, g, b;
+    r = mad24_uniform(v, k.crv, t) + k.kr;
+    g = mad24_uniform(v, k.ncgv, mad24_uniform(u, k.ncgu, t)) + k.kg;
+    b = mad24_uniform(u, k.cbu, t) + k.kb;
     return pack_bgra_fixed_pk(b, g, r);
 }
 
