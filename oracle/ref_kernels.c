@@ -56,6 +56,9 @@ INL uint8_t st8(float f) {
 }
 uint8_t orc_store_unorm8(float f) { return st8(f); }
 
+/* RN(1/255), the alpha scale of the code-scale family */
+#define ORC_INV255 0x1.010102p-8f
+
 /* Same conversion for a value already on the 0..255 code scale. */
 INL uint8_t st8_code(float v) {
     if (!(v == v)) return 0;
@@ -293,7 +296,28 @@ INL void px_bgra_bgra_metal(const job_t *j, int x, int y) {
 /* BGRA-target family (spec owned by this repo):
  * the structure of the reference's YUV-source kernels (kernels.cl.swift:78-105)
  * with the canvas in BGRA, per-pixel source alpha as in kernels.metal:59 and
- * the YUV->RGB step done in integer on the quantised sample. */
+ * the YUV->RGB step done in integer on the quantised sample.
+ *
+ * Arithmetic of this family is specified on the 0..255 CODE scale with fused
+ * multiply-adds (one rounding each, fmaf), not on the unit scale of the
+ * reference's OpenCL kernels:
+ *   sample_c = fma(w11,T11, fma(w01,T01, fma(w10,T10, w00*T00)))   T = texel bytes as floats,
+ *              geometry, tap addresses and weights exactly those of the LINEAR sampler above
+ *   YUV sources: codes = RTE(sample) per plane -> integer matrix -> p_c = B,G,R bytes
+ *   RGB sources: p_c = sample_c (not rounded), a = sample_A * (opacity * (1/255))
+ *   fill:   r_c = clamp(fma(fill_c*255, af, cur_c*(1-af)), 0, 255),  af = opacity*fill_A
+ *   blend:  r_c = fma(p_c, a, r_c*(1-a))
+ *   store:  RTE, saturated, NaN -> 0; alpha byte 255
+ * It differs from the unit-scale evaluation (c/255 per tap, sequential roundings,
+ * *255 at the store) by at most one code of the sampled value, at rounding ties
+ * (tests/test_oracle_golden.py::test_code_scale_sampler_vs_unit_scale). */
+INL float cs_fetch(const orc_plane *p, const lin2 *l, int c) {
+    float t00 = (float)texel(p, l->x.i0, l->y.i0)[c];
+    float t10 = (float)texel(p, l->x.i1, l->y.i0)[c];
+    float t01 = (float)texel(p, l->x.i0, l->y.i1)[c];
+    float t11 = (float)texel(p, l->x.i1, l->y.i1)[c];
+    return fmaf(l->w11, t11, fmaf(l->w01, t01, fmaf(l->w10, t10, l->w00 * t00)));
+}
 INL void px_to_bgra(int SRC, const job_t *j, int x, int y) {
     geom_t g = geometry(j, x, y);
     if (!g.in_border) return;
@@ -301,39 +325,39 @@ INL void px_to_bgra(int SRC, const job_t *j, int x, int y) {
     /* fill colour under the picture / on the border, straight alpha (:96-105) */
     float af = j->u->opacity * j->u->fillColor[3];
     float iaf = 1.f - af;
-    float r0 = clampf(ld8(d[0]) * iaf + j->u->fillColor[2] * af, 0.f, 1.f); /* B */
-    float r1 = clampf(ld8(d[1]) * iaf + j->u->fillColor[1] * af, 0.f, 1.f); /* G */
-    float r2 = clampf(ld8(d[2]) * iaf + j->u->fillColor[0] * af, 0.f, 1.f); /* R */
+    float r0 = clampf(fmaf(j->u->fillColor[2] * 255.0f, af, (float)d[0] * iaf), 0.f, 255.f); /* B */
+    float r1 = clampf(fmaf(j->u->fillColor[1] * 255.0f, af, (float)d[1] * iaf), 0.f, 255.f); /* G */
+    float r2 = clampf(fmaf(j->u->fillColor[0] * 255.0f, af, (float)d[2] * iaf), 0.f, 255.f); /* R */
     if (g.in_tx && g.in_uv) {
         float p0, p1, p2, a;
         if (SRC == SRC_BGRA || SRC == SRC_RGBA) {
             lin2 l = lin_setup(&j->in[0], g.uv.x, g.uv.y);
-            float q0 = lin_fetch(&j->in[0], &l, 0), q1 = lin_fetch(&j->in[0], &l, 1);
-            float q2 = lin_fetch(&j->in[0], &l, 2), q3 = lin_fetch(&j->in[0], &l, 3);
+            float q0 = cs_fetch(&j->in[0], &l, 0), q1 = cs_fetch(&j->in[0], &l, 1);
+            float q2 = cs_fetch(&j->in[0], &l, 2), q3 = cs_fetch(&j->in[0], &l, 3);
             p0 = SRC == SRC_BGRA ? q0 : q2; p1 = q1; p2 = SRC == SRC_BGRA ? q2 : q0;
-            a = q3 * j->u->opacity;
+            a = q3 * (j->u->opacity * ORC_INV255);
         } else {
             lin2 ly = lin_setup(&j->in[0], g.uv.x, g.uv.y);
             lin2 lc = lin_setup(&j->in[1], g.uv.x, g.uv.y);
-            float fy = lin_fetch(&j->in[0], &ly, 0), fu, fv;
-            if (SRC == SRC_NV12) { fu = lin_fetch(&j->in[1], &lc, 0); fv = lin_fetch(&j->in[1], &lc, 1); }
+            float fy = cs_fetch(&j->in[0], &ly, 0), fu, fv;
+            if (SRC == SRC_NV12) { fu = cs_fetch(&j->in[1], &lc, 0); fv = cs_fetch(&j->in[1], &lc, 1); }
             else {
-                fu = lin_fetch(&j->in[1], &lc, 0);
+                fu = cs_fetch(&j->in[1], &lc, 0);
                 lin2 lv = lin_setup(&j->in[2], g.uv.x, g.uv.y);
-                fv = lin_fetch(&j->in[2], &lv, 0);
+                fv = cs_fetch(&j->in[2], &lv, 0);
             }
-            /* quantise exactly as a write_imagef to an 8-bit YUV image would */
+            /* quantise as a store to an 8-bit YUV image would */
             uint8_t R, G, B;
-            yuv2rgb_int(&CSC[j->csc & 3], st8(fy), st8(fu), st8(fv), &R, &G, &B);
-            p0 = ld8(B); p1 = ld8(G); p2 = ld8(R);
+            yuv2rgb_int(&CSC[j->csc & 3], st8_code(fy), st8_code(fu), st8_code(fv), &R, &G, &B);
+            p0 = (float)B; p1 = (float)G; p2 = (float)R;
             a = 1.0f * j->u->opacity;
         }
         float ia = 1.f - a;
-        r0 = r0 * ia + p0 * a;
-        r1 = r1 * ia + p1 * a;
-        r2 = r2 * ia + p2 * a;
+        r0 = fmaf(p0, a, r0 * ia);
+        r1 = fmaf(p1, a, r1 * ia);
+        r2 = fmaf(p2, a, r2 * ia);
     }
-    d[0] = st8(r0); d[1] = st8(r1); d[2] = st8(r2); d[3] = st8(1.0f);
+    d[0] = st8_code(r0); d[1] = st8_code(r1); d[2] = st8_code(r2); d[3] = 255;
 }
 
 /* Clear kernels: img_clear_nv12 (kernels.cl.swift:38-46), img_clear_y420p

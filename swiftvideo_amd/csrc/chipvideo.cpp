@@ -601,7 +601,9 @@ static int32_t layer_flags(const float *u) {
     bool tzw_const = T[8] == 0.f && T[9] == 0.f && T[12] == 0.f && T[13] == 0.f;
     if (axis(T) && axis(B) && axis(X) && tzw_const) f |= LF_AXIS_ALIGNED;
     // no fill contribution: alpha is exactly zero AND the colour is finite (0 * inf would be NaN)
-    bool fill_finite = (u[U_FILL] - u[U_FILL] == 0.f) && (u[U_FILL + 1] - u[U_FILL + 1] == 0.f) && (u[U_FILL + 2] - u[U_FILL + 2] == 0.f);
+    // (checked on fill * 255, the code-scale value the BGRA-target family multiplies by the alpha)
+    auto finite255 = [](float c) { float v = c * 255.0f; return v - v == 0.f; };
+    bool fill_finite = finite255(u[U_FILL]) && finite255(u[U_FILL + 1]) && finite255(u[U_FILL + 2]);
     if (u[U_OPACITY] * u[U_FILL + 3] == 0.f && fill_finite) f |= LF_NO_FILL;
     if (u[U_OPACITY] == 1.f) f |= LF_OPAQUE;
     return f;

@@ -109,38 +109,37 @@ CHV_DEV void axis_entry_y(const float *__restrict__ U, int y, float sx, float sy
     lin_axis_raw(v, hc, ic, ac);
 }
 
-// One pixel of the BGRA-target family from already-sampled, quantised YUV.
+// One pixel of the BGRA-target family from already-sampled, quantised YUV (code-scale
+// arithmetic, pixel_math.hip.h): fill under the picture, then the picture itself.
 CHV_DEV uint32_t blend_bgra_general(uint32_t c, const float *__restrict__ U, bool in_pic, uint32_t w) {
     const float opacity = U[U_OPACITY];
     const float af = opacity * U[U_FILL + 3];
     const float iaf = 1.f - af;
-    float r0 = clampf(unorm8(c & 255) * iaf + U[U_FILL + 2] * af, 0.f, 1.f);
-    float r1 = clampf(unorm8((c >> 8) & 255) * iaf + U[U_FILL + 1] * af, 0.f, 1.f);
-    float r2 = clampf(unorm8((c >> 16) & 255) * iaf + U[U_FILL + 0] * af, 0.f, 1.f);
+    float r0 = clampf(__builtin_fmaf(U[U_FILL + 2] * 255.0f, af, (float)(c & 255) * iaf), 0.f, 255.f);
+    float r1 = clampf(__builtin_fmaf(U[U_FILL + 1] * 255.0f, af, (float)((c >> 8) & 255) * iaf), 0.f, 255.f);
+    float r2 = clampf(__builtin_fmaf(U[U_FILL + 0] * 255.0f, af, (float)((c >> 16) & 255) * iaf), 0.f, 255.f);
     if (in_pic) {
         const float a = 1.0f * opacity, ia = 1.f - a;
-        r0 = r0 * ia + unorm8(w & 255) * a;
-        r1 = r1 * ia + unorm8((w >> 8) & 255) * a;
-        r2 = r2 * ia + unorm8((w >> 16) & 255) * a;
+        r0 = __builtin_fmaf((float)(w & 255), a, r0 * ia);
+        r1 = __builtin_fmaf((float)((w >> 8) & 255), a, r1 * ia);
+        r2 = __builtin_fmaf((float)((w >> 16) & 255), a, r2 * ia);
     }
-    return to_code(r0) | (to_code(r1) << 8) | (to_code(r2) << 16) | 0xFF000000u;
+    return to_code_raw(r0) | (to_code_raw(r1) << 8) | (to_code_raw(r2) << 16) | 0xFF000000u;
 }
 
-// NV12 sample at one pixel from the staged tile: luma bytes (normalised per tap),
-// chroma float pairs; tap 1 is the next texel, the next row is one LDS pitch further.
+// NV12 sample at one pixel from the staged tile, on the code scale: luma bytes, chroma float
+// pairs; tap 1 is the next texel, the next row is one LDS pitch further.
 CHV_DEV void sample_nv12_lds(const uint8_t *smem, int ya, int ypitch, int ca, int cpitch,
                              float w00, float w10, float w01, float w11,
                              float c00, float c10, float c01, float c11,
                              float &fy, float &fu, float &fv) {
     const uint8_t *py = smem + ya;
-    float t00 = unorm8(py[0]), t10 = unorm8(py[1]);
-    float t01 = unorm8(py[ypitch]), t11 = unorm8(py[ypitch + 1]);
-    fy = ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;
+    fy = cs_mix(w00, w10, w01, w11, (float)py[0], (float)py[1], (float)py[ypitch], (float)py[ypitch + 1]);
     const float2 *pc0 = (const float2 *)(smem + ca);
     const float2 *pc1 = (const float2 *)(smem + ca + cpitch);
     float2 q00 = pc0[0], q10 = pc0[1], q01 = pc1[0], q11 = pc1[1];
-    fu = ((c00 * q00.x + c10 * q10.x) + c01 * q01.x) + c11 * q11.x;
-    fv = ((c00 * q00.y + c10 * q10.y) + c01 * q01.y) + c11 * q11.y;
+    fu = cs_mix(c00, c10, c01, c11, q00.x, q10.x, q01.x, q11.x);
+    fv = cs_mix(c00, c10, c01, c11, q00.y, q10.y, q01.y, q11.y);
 }
 
 // the same sample straight from the source planes (tile did not fit the LDS budget);
@@ -152,7 +151,7 @@ CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, const DPlane
     int x0 = min(max(ix, 0), SY.w - 1), x1 = min(max(ix + 1, 0), SY.w - 1);
     int y0 = min(max(iy, 0), SY.h - 1), y1 = min(max(iy + 1, 0), SY.h - 1);
     const uint8_t *p0 = SY.ptr + (size_t)y0 * SY.pitch, *p1 = SY.ptr + (size_t)y1 * SY.pitch;
-    fy = ((w00 * unorm8(p0[x0]) + w10 * unorm8(p0[x1])) + w01 * unorm8(p1[x0])) + w11 * unorm8(p1[x1]);
+    fy = cs_mix(w00, w10, w01, w11, (float)p0[x0], (float)p0[x1], (float)p1[x0], (float)p1[x1]);
     int u0 = min(max(cx, 0), SC.w - 1), u1 = min(max(cx + 1, 0), SC.w - 1);
     int v0 = min(max(cy, 0), SC.h - 1), v1 = min(max(cy + 1, 0), SC.h - 1);
     const uint8_t *q0 = SC.ptr + (size_t)v0 * SC.pitch, *q1 = SC.ptr + (size_t)v1 * SC.pitch;
@@ -165,8 +164,8 @@ CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, const DPlane
         a00 = *(const uint16_t *)(q0 + u0 * 2); a10 = *(const uint16_t *)(q0 + u1 * 2);
         a01 = *(const uint16_t *)(q1 + u0 * 2); a11 = *(const uint16_t *)(q1 + u1 * 2);
     }
-    fu = ((c00 * unorm8(a00 & 255) + c10 * unorm8(a10 & 255)) + c01 * unorm8(a01 & 255)) + c11 * unorm8(a11 & 255);
-    fv = ((c00 * unorm8(a00 >> 8) + c10 * unorm8(a10 >> 8)) + c01 * unorm8(a01 >> 8)) + c11 * unorm8(a11 >> 8);
+    fu = cs_mix(c00, c10, c01, c11, (float)(a00 & 255), (float)(a10 & 255), (float)(a01 & 255), (float)(a11 & 255));
+    fv = cs_mix(c00, c10, c01, c11, (float)(a00 >> 8), (float)(a10 >> 8), (float)(a01 >> 8), (float)(a11 >> 8));
 }
 
 // Planar chroma (y420p): one 16-byte vector of the U plane and the matching one of the V plane
@@ -190,8 +189,8 @@ CHV_DEV void stage_store_uv_planar(const uint4 (&uregs)[N], const uint4 (&vregs)
             const uint32_t us[4] = { uu.x, uu.y, uu.z, uu.w }, vs[4] = { vw.x, vw.y, vw.z, vw.w };
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                d[2 * q] = make_float4(unorm8(us[q] & 255), unorm8(vs[q] & 255), unorm8((us[q] >> 8) & 255), unorm8((vs[q] >> 8) & 255));
-                d[2 * q + 1] = make_float4(unorm8((us[q] >> 16) & 255), unorm8((vs[q] >> 16) & 255), unorm8(us[q] >> 24), unorm8(vs[q] >> 24));
+                d[2 * q] = make_float4((float)(us[q] & 255), (float)(vs[q] & 255), (float)((us[q] >> 8) & 255), (float)((vs[q] >> 8) & 255));
+                d[2 * q + 1] = make_float4((float)((us[q] >> 16) & 255), (float)((vs[q] >> 16) & 255), (float)(us[q] >> 24), (float)(vs[q] >> 24));
             }
         }
     }
@@ -344,8 +343,8 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
         const bool uniform_inside = staged && cols_inside && tb.rsum[j][5];
         const int yr0 = gy.r_lo, cr0 = gc.r_lo;
         // one row of the common case: every pixel of the tile is inside the picture and the layer is
-        // opaque, so result = cur*0 + px*1 = px exactly and to_code(unorm8(c)) == c: the colour-matrix
-        // word is the output (no canvas read, no float round trip)
+        // opaque, so result = fma(px, 1, cur*0) = px exactly: the colour-matrix word is the output
+        // (no canvas read, no float round trip)
         auto fast_row = [&](int ly, uint32_t (&outw)[PXT]) {
             const int ry = tb.ry[ly], rc = tb.rc[ly];
             const float yb = tb.rya[ly], iyb = 1.0f - yb, cb = tb.rca[ly], icb = 1.0f - cb;
@@ -356,8 +355,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
                 sample_nv12_lds(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
                                 icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
                                 icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
-                outw[k] = yuv_to_bgra_word(cscb, (int)to_code_unit_biased(fy), (int)to_code_unit_biased(fu),
-                                           (int)to_code_unit_biased(fv));
+                outw[k] = yuv_to_bgra_word(cscb, (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv));
             }
         };
         auto store_row = [&](uint8_t *drow, const uint32_t (&outw)[PXT]) {
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
                             else
                                 sample_nv12_global(SY, SC, PLANAR ? &SV : nullptr, pyx, ry, pcx, rc,
                                                    iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
-                            w = yuv_to_bgra_word(csc, (int)to_code(fy), (int)to_code(fu), (int)to_code(fv));
+                            w = yuv_to_bgra_word(csc, (int)to_code_raw(fy), (int)to_code_raw(fu), (int)to_code_raw(fv));
                         }
                         cpx = blend_bgra_general(cpx, U, in_pic, w);
                     }

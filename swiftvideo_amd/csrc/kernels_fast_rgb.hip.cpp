@@ -7,11 +7,11 @@
 // once: the per-tick HBM traffic is the algorithmic minimum (layers + canvas).
 //   phase 0  per-layer column/row tables of the reference's coordinate arithmetic
 //            (same instruction sequence as the general kernel => same bits)
-//   per layer: [store the prefetched source rectangle to LDS as float4 texels (c/255 once
-//            per texel, edge texels replicated) | barrier | issue the next layer's global
+//   per layer: [store the prefetched source rectangle to LDS as float4 texels on the code
+//            scale (edge texels replicated) | barrier | issue the next layer's global
 //            loads | sample 2x2 taps from LDS, blend, re-quantise | barrier]
-// Between layers the value is re-quantised through the float adder exactly as the
-// per-layer kernels do through their UNORM8 canvas.
+// Between layers the value is re-quantised (RTE through the float adder) exactly as the
+// per-layer kernels do through their 8-bit canvas.
 #include "tile_common.hip.h"
 
 #include <algorithm>
@@ -61,23 +61,27 @@ CHV_DEV void axis_entry_y1(const float *__restrict__ U, int y, float sx, float s
     lin_axis_raw(v, h, ip, a);
 }
 
-// rint(x) for 0 <= x < 2^22 through the float adder (ties to even), kept as a float
-CHV_DEV float rint_small(float x) { return (x + 12582912.0f) - 12582912.0f; }
-// to_code as a float code value in [0, 255]: convert_uchar_sat_rte(f * 255), NaN -> 0
-CHV_DEV float to_codef(float f) {
-    float v = __builtin_rintf(f * 255.0f);
+// store conversion of a code-scale value kept as a float: RTE, saturated, NaN -> 0
+CHV_DEV float to_codef(float v) {
+    v = __builtin_rintf(v);
     return __builtin_fminf(__builtin_fmaxf(v, 0.0f), 255.0f);
 }
 
+#ifndef CHV_RGB_MINW
+#define CHV_RGB_MINW 5
+#endif
+#ifndef CHV_RGB_ROWPAD
+#define CHV_RGB_ROWPAD 3
+#endif
 template <bool CLEAR>
-__global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *__restrict__ ticks,
+__global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(const DTick *__restrict__ ticks,
                                                                    const DLayer *__restrict__ layers,
                                                                    int n_ticks, int tiles_x, int tiles_y,
-                                                                   int tpitch, int trows) {
+                                                                   int tpitch, int trows, int max_layers) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    RgbLayerTable *tabs = (RgbLayerTable *)smem;                 // [RMAXL]
-    int *scratch = (int *)(smem + sizeof(RgbLayerTable) * RMAXL);  // sink for summaries of absent layers
-    const int tbase = (int)(sizeof(RgbLayerTable) * RMAXL) + 64; // [trows][tpitch] float4 texels
+    RgbLayerTable *tabs = (RgbLayerTable *)smem;                 // [max_layers] (the launch's deepest tick)
+    int *scratch = (int *)(smem + sizeof(RgbLayerTable) * max_layers);  // sink for summaries of absent layers
+    const int tbase = (int)(sizeof(RgbLayerTable) * max_layers) + 64; // [trows][tpitch] float4 texels
 
     // XCD-aware numbering: block b runs on XCD b % 8; give every XCD one contiguous range of the
     // launch's tiles (whole frames when there are >= 8 ticks) so that halos are shared through its L2
@@ -184,10 +188,11 @@ __global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *_
             const float *U = Ly.u;
             const float opacity = U[U_OPACITY];
             const bool nofill = (Ly.flags & LF_NO_FILL) != 0;
-            // opacity in [0,1] and no fill: every blend is a convex combination of values in
-            // [0,1], so neither the clamp of the fill step nor the saturation of the store can
-            // trigger; with every pixel of the tile inside the picture the loop is branch-free
+            // opacity in [0,1] and no fill: every blend is a convex combination of code values, so
+            // neither the clamp of the fill step nor the saturation of the store can trigger; with
+            // every pixel of the tile inside the picture the loop is branch-free
             const bool fast = staged && t.csum[5] && t.rsum[5] && nofill && opacity >= 0.f && opacity <= 1.f;
+            const float ka = opacity * kInv255;
             const float b = t.ra[ly], ib = 1.0f - b;
             const int rowoff = tbase + (t.rp[ly] - g.r_lo) * tpitch + (4 - col0) * 16;
             if (fast) {
@@ -199,20 +204,20 @@ __global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *_
                     const float4 *p0 = (const float4 *)(smem + rowoff + t.cp[c] * 16);
                     const float4 *p1 = (const float4 *)(smem + rowoff + tpitch + t.cp[c] * 16);
                     const float4 t00 = p0[0], t10 = p0[1], t01 = p1[0], t11 = p1[1];
-                    const float q0 = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
-                    const float q1 = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
-                    const float q2 = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
-                    const float q3 = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
-                    const float al = q3 * opacity, ial = 1.f - al;
+                    const float q0 = cs_mix(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x);
+                    const float q1 = cs_mix(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y);
+                    const float q2 = cs_mix(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z);
+                    const float q3 = cs_mix(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w);
+                    const float al = q3 * ka, ial = 1.f - al;
                     const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
-                    cb[k] = rint_small((unorm8f(cb[k]) * ial + pb * al) * 255.0f);
-                    cg[k] = rint_small((unorm8f(cg[k]) * ial + q1 * al) * 255.0f);
-                    cr[k] = rint_small((unorm8f(cr[k]) * ial + pr * al) * 255.0f);
+                    cb[k] = code_rintf(__builtin_fmaf(pb, al, cb[k] * ial));
+                    cg[k] = code_rintf(__builtin_fmaf(q1, al, cg[k] * ial));
+                    cr[k] = code_rintf(__builtin_fmaf(pr, al, cr[k] * ial));
                     touched[k] = true;
                 }
             } else {
                 const float af = opacity * U[U_FILL + 3], iaf = 1.f - af;
-                const float f_b = U[U_FILL + 2], f_g = U[U_FILL + 1], f_r = U[U_FILL + 0];
+                const float f_b = U[U_FILL + 2] * 255.0f, f_g = U[U_FILL + 1] * 255.0f, f_r = U[U_FILL + 0] * 255.0f;
                 const int rfl = t.rfl[ly];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -221,9 +226,9 @@ __global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *_
                     if (!(fl & AX_BORDER)) continue;
                     touched[k] = true;
                     const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
-                    float r0 = clampf(unorm8f(cb[k]) * iaf + f_b * af, 0.f, 1.f);
-                    float r1 = clampf(unorm8f(cg[k]) * iaf + f_g * af, 0.f, 1.f);
-                    float r2 = clampf(unorm8f(cr[k]) * iaf + f_r * af, 0.f, 1.f);
+                    float r0 = clampf(__builtin_fmaf(f_b, af, cb[k] * iaf), 0.f, 255.f);
+                    float r1 = clampf(__builtin_fmaf(f_g, af, cg[k] * iaf), 0.f, 255.f);
+                    float r2 = clampf(__builtin_fmaf(f_r, af, cr[k] * iaf), 0.f, 255.f);
                     if (in_pic) {
                         const float a = t.ca[c], ia = 1.0f - a;
                         const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
@@ -235,21 +240,18 @@ __global__ __launch_bounds__(NTHREADS) void tick_rgb_layers_tiled(const DTick *_
                         } else {
                             int xa = min(max(t.cp[c], 0), S.w - 1), xb = min(max(t.cp[c] + 1, 0), S.w - 1);
                             int ya = min(max(t.rp[ly], 0), S.h - 1), yb = min(max(t.rp[ly] + 1, 0), S.h - 1);
-                            auto ld = [&](int xx, int yy) {
-                                uint32_t v = *(const uint32_t *)(S.ptr + (size_t)yy * S.pitch + (size_t)xx * 4);
-                                return make_float4(unorm8(v & 255), unorm8((v >> 8) & 255), unorm8((v >> 16) & 255), unorm8(v >> 24));
-                            };
+                            auto ld = [&](int xx, int yy) { return codes4(*(const uint32_t *)(S.ptr + (size_t)yy * S.pitch + (size_t)xx * 4)); };
                             t00 = ld(xa, ya); t10 = ld(xb, ya); t01 = ld(xa, yb); t11 = ld(xb, yb);
                         }
-                        float q0 = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
-                        float q1 = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
-                        float q2 = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
-                        float q3 = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+                        const float q0 = cs_mix(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x);
+                        const float q1 = cs_mix(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y);
+                        const float q2 = cs_mix(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z);
+                        const float q3 = cs_mix(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w);
                         const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
-                        const float al = q3 * opacity, ial = 1.f - al;
-                        r0 = r0 * ial + pb * al;
-                        r1 = r1 * ial + q1 * al;
-                        r2 = r2 * ial + pr * al;
+                        const float al = q3 * ka, ial = 1.f - al;
+                        r0 = __builtin_fmaf(pb, al, r0 * ial);
+                        r1 = __builtin_fmaf(q1, al, r1 * ial);
+                        r2 = __builtin_fmaf(pr, al, r2 * ial);
                     }
                     cb[k] = to_codef(r0); cg[k] = to_codef(r1); cr[k] = to_codef(r2);
                 }
@@ -284,7 +286,8 @@ static void rgb_tile_dims(const DTick &T, const DLayer &L, int *pitch, int *rows
     double syr = std::fabs((double)U[U_TEXTURE + 5] * (double)U[U_TRANSFORM + 5] * 2.0 / (double)T.H);
     int span = (int)std::ceil(RTW * sxr * L.src.pl[0].w) + 4;
     *pitch = ((span + 3) / 4 + 3) * 64;                 // float4 texels, 4 per vector, alignment + 2 pad vectors
-    *rows = (int)std::ceil(RTH * syr * L.src.pl[0].h) + 5;
+    // rows a tile's taps span: <= ceil((RTH-1)*scale) + 2 (tap 1 of the last row) <= ceil(RTH*scale) + 2
+    *rows = (int)std::ceil(RTH * syr * L.src.pl[0].h) + CHV_RGB_ROWPAD;
 }
 
 bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks) {
@@ -307,25 +310,28 @@ bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks) 
 
 hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                              int n_ticks, int maxW, int maxH, hipStream_t stream) {
-    int pitch = 0, rows = 0;
-    for (int i = 0; i < n_ticks; i++)
+    int pitch = 0, rows = 0, max_layers = 1;
+    for (int i = 0; i < n_ticks; i++) {
+        max_layers = std::max(max_layers, ticks_host[i].n_layers);
         for (int l = 0; l < ticks_host[i].n_layers; l++) {
             int p, r;
             rgb_tile_dims(ticks_host[i], layers_host[ticks_host[i].first_layer + l], &p, &r);
             pitch = std::max(pitch, p); rows = std::max(rows, r);
         }
-    size_t lds = sizeof(RgbLayerTable) * RMAXL + 64 + (size_t)pitch * rows;
+    }
+    const size_t tab_bytes = sizeof(RgbLayerTable) * max_layers + 64;
+    size_t lds = tab_bytes + (size_t)pitch * rows;
     if (lds > (size_t)LDS_BUDGET) {
-        rows = std::max(1, (int)((LDS_BUDGET - sizeof(RgbLayerTable) * RMAXL - 64) / pitch));
-        lds = sizeof(RgbLayerTable) * RMAXL + 64 + (size_t)pitch * rows;
+        rows = std::max(1, (int)((LDS_BUDGET - tab_bytes) / pitch));
+        lds = tab_bytes + (size_t)pitch * rows;
     }
     int tiles_x = (maxW + RTW - 1) / RTW, tiles_y = (maxH + RTH - 1) / RTH;
     int per_xcd = (n_ticks * tiles_x * tiles_y + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8));
     if (ticks_host[0].clear_first)
-        hipLaunchKernelGGL(tick_rgb_layers_tiled<true>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, tiles_x, tiles_y, pitch, rows);
+        hipLaunchKernelGGL(tick_rgb_layers_tiled<true>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, tiles_x, tiles_y, pitch, rows, max_layers);
     else
-        hipLaunchKernelGGL(tick_rgb_layers_tiled<false>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, tiles_x, tiles_y, pitch, rows);
+        hipLaunchKernelGGL(tick_rgb_layers_tiled<false>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, tiles_x, tiles_y, pitch, rows, max_layers);
     return hipGetLastError();
 }
 

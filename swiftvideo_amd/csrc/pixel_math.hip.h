@@ -135,6 +135,27 @@ CHV_DEV float lin_fetch(const DPlane &p, const Lin2 &l, int c) {
     return lin_mix(l, unorm8(b[l.o00]), unorm8(b[l.o10]), unorm8(b[l.o01]), unorm8(b[l.o11]));
 }
 
+// ---- code-scale arithmetic of the BGRA-target family (spec owned by this repo) ----
+// Samples, fill and blend of img_{nv12,y420p,bgra,rgba}_bgra(_tx) are specified on the 0..255 code
+// scale with fused multiply-adds (one rounding each); geometry, tap addresses and weights are those
+// of the LINEAR sampler above.  oracle/ref_kernels.c::px_to_bgra is the statement of record.
+constexpr float kInv255 = 0x1.010102p-8f;   // RN(1/255): alpha scale of RGB sources
+CHV_DEV float cs_mix(float w00, float w10, float w01, float w11, float t00, float t10, float t01, float t11) {
+    return __builtin_fmaf(w11, t11, __builtin_fmaf(w01, t01, __builtin_fmaf(w10, t10, w00 * t00)));
+}
+CHV_DEV float cs_mix(const Lin2 &l, float t00, float t10, float t01, float t11) {
+    return cs_mix(l.w00, l.w10, l.w01, l.w11, t00, t10, t01, t11);
+}
+CHV_DEV float cs_fetch(const DPlane &p, const Lin2 &l, int c) {
+    const uint8_t *b = p.ptr + c;
+    return cs_mix(l, (float)b[l.o00], (float)b[l.o10], (float)b[l.o01], (float)b[l.o11]);
+}
+// RTE of a code-scale value known to lie in [0, 255 + a few ulp] and not NaN (a convex combination
+// of codes), through the float adder: returns the raw bits 0x4B400000 + rint(v)
+CHV_DEV uint32_t code_biased(float v) { return __float_as_uint(v + 12582912.0f); }
+// the same as a float code value
+CHV_DEV float code_rintf(float v) { return (v + 12582912.0f) - 12582912.0f; }
+
 // rgb2yuv rows, kernels.cl.swift:96-99 (0.113 is the reference's value).
 CHV_DEV void rgb2yuv(float r, float g, float b, float &y, float &u, float &v) {
     // dot((r,g,b,1), row): the .w lane multiplies 1.0 by the row's offset

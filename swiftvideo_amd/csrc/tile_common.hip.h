@@ -45,12 +45,13 @@ CHV_DEV void lin_axis_raw(float s, int w, int &i0, float &a) {
     i0 = (int)fl;
 }
 
-// 16 source bytes -> 16 normalised floats
-CHV_DEV void unorm16(const uint4 &v, float4 &f0, float4 &f1, float4 &f2, float4 &f3) {
-    f0 = make_float4(unorm8(v.x & 255), unorm8((v.x >> 8) & 255), unorm8((v.x >> 16) & 255), unorm8(v.x >> 24));
-    f1 = make_float4(unorm8(v.y & 255), unorm8((v.y >> 8) & 255), unorm8((v.y >> 16) & 255), unorm8(v.y >> 24));
-    f2 = make_float4(unorm8(v.z & 255), unorm8((v.z >> 8) & 255), unorm8((v.z >> 16) & 255), unorm8(v.z >> 24));
-    f3 = make_float4(unorm8(v.w & 255), unorm8((v.w >> 8) & 255), unorm8((v.w >> 16) & 255), unorm8(v.w >> 24));
+// 16 source bytes -> 16 floats on the code scale (0..255, exact): the BGRA-target family samples
+// code values (pixel_math.hip.h), so staging is a plain v_cvt_f32_ubyteN per byte
+CHV_DEV float4 codes4(uint32_t w) {
+    return make_float4((float)(w & 255), (float)((w >> 8) & 255), (float)((w >> 16) & 255), (float)(w >> 24));
+}
+CHV_DEV void codes16(const uint4 &v, float4 &f0, float4 &f1, float4 &f2, float4 &f3) {
+    f0 = codes4(v.x); f1 = codes4(v.y); f2 = codes4(v.z); f3 = codes4(v.w);
 }
 
 // 16 bytes at byte offset `off` of row `row` of a plane whose base and pitch are 16-byte
@@ -98,7 +99,7 @@ CHV_DEV uint4 patch_edges(uint4 val, const DPlane &P, int row, int off) {
 // Staging of one plane's source rectangle, split in two so that the global loads of the
 // NEXT tile are in flight while the current tile is being computed:
 //   stage_load : raw 16-byte vectors -> registers (no dependent instruction)
-//   stage_store: CLAMP_TO_EDGE patching, unorm8 -> float (chroma), LDS write
+//   stage_store: CLAMP_TO_EDGE patching, byte -> float code value (chroma, RGB texels), LDS write
 // Slot i = tid + n * NTHREADS maps to row i / nslot, vector i % nslot of that row; LDS row r
 // holds source row clamp(r_lo + r).  With `edge` (block-uniform: the rectangle touches a
 // picture edge) vectors -1 .. nvec are staged, with the outside texels replicated.
@@ -136,8 +137,8 @@ CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, i
 }
 
 // BPT = 1: bytes kept as bytes (LDS byte 16 + k of a row = source byte b0 + k)
-// BPT = 2: byte pairs normalised to float pairs (LDS texel slot 8 + k = source texel b0/2 + k)
-// BPT = 4: 4-byte texels normalised to float4   (LDS texel slot 4 + k = source texel b0/4 + k)
+// BPT = 2: byte pairs as float pairs on the code scale (LDS texel slot 8 + k = source texel b0/2 + k)
+// BPT = 4: 4-byte texels as float4 on the code scale   (LDS texel slot 4 + k = source texel b0/4 + k)
 template <int BPT, int N>
 CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid) {
 #pragma unroll
@@ -155,7 +156,7 @@ CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, co
                 *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
             } else {   // 16 source bytes -> 64 LDS bytes for both 2- and 4-byte texels
                 float4 f0, f1, f2, f3;
-                unorm16(val, f0, f1, f2, f3);
+                codes16(val, f0, f1, f2, f3);
                 float4 *d = (float4 *)(lds + r * lds_pitch + 64 + v * 64);
                 d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
             }

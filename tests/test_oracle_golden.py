@@ -172,6 +172,74 @@ def test_lanczos_constant_image_stays_constant():
     assert np.all(dst == 173)
 
 
+def test_code_scale_sampler_vs_unit_scale():
+    """The BGRA-target family (spec owned by this repo) samples on the 0..255 code scale with fused
+    multiply-adds; the reference's kernels sample on the unit scale through the Khronos LINEAR filter
+    (c/255 per tap, sequential roundings, *255 at the store).  north_star allows the float scaler
+    1 ULP.  Tolerance of this test: the two agree to within ONE CODE of the sampled value everywhere,
+    and they differ only where the exact filter value lies within 1e-3 of a rounding tie (x.5) — there
+    the unit-scale result is decided by its own rounding noise, the code-scale one by ties-to-even."""
+    W, H, w, h = 192, 108, 128, 72
+    f32 = np.float32
+    u = util.full_canvas_uniforms((w, h), (W, H))
+
+    def axis(n_out, n_in):
+        o = np.arange(n_out, dtype=f32) / f32(n_out)             # out_uv = gid / size
+        t = (o * f32(2) - f32(1)) * f32(.5) + f32(.5)             # transform row (.5, 0, 0, .5); textureTx = I
+        um = t * f32(n_in) - f32(.5)
+        fl = np.floor(um)
+        i0 = fl.astype(np.int32)
+        return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), (um - fl).astype(f32)
+
+    x0, x1, a = axis(w, W)
+    y0, y1, b = axis(h, H)
+    ia, ib = f32(1) - a, f32(1) - b
+    w00, w10 = ib[:, None] * ia[None, :], ib[:, None] * a[None, :]
+    w01, w11 = b[:, None] * ia[None, :], b[:, None] * a[None, :]
+
+    def taps(p):
+        return p[y0][:, x0], p[y0][:, x1], p[y1][:, x0], p[y1][:, x1]
+
+    def exact(p):       # the filter value in float64 (weights as the float32 values both paths use)
+        t00, t10, t01, t11 = (t.astype(np.float64) for t in taps(p))
+        return w00.astype(np.float64) * t00 + w10.astype(np.float64) * t10 + w01.astype(np.float64) * t01 + w11.astype(np.float64) * t11
+
+    def check(own, unit, p):
+        d = own.astype(np.int32) - unit.astype(np.int32)
+        assert np.abs(d).max() <= 1
+        e = exact(p)
+        tie_distance = np.abs(np.abs(e - np.floor(e)) - 0.5)
+        assert np.all(tie_distance[d != 0] < 1e-3)
+        assert np.all(np.abs(own.astype(np.float64) - e) <= 0.5 + 1e-3)   # and the owned result is a correct rounding
+
+    # (1) luma: img_nv12_bgra (full-range matrix, flat chroma => B = G = R = luma code) against the luma plane
+    # the reference kernel img_nv12_nv12 writes for the same picture and uniforms (checked against the
+    # compiled reference OpenCL source by test_oracle_equals_compiled_reference_kernels)
+    src = util.alloc_image("nv12", W, H, seed=77)
+    src[1][...] = 128
+    ref = util.alloc_image("nv12", w, h)
+    assert O.run_kernel("img_clear_nv12", ref) == 0
+    assert O.run_kernel("img_nv12_nv12", ref, src, u) == 0
+    own = util.alloc_image("bgra", w, h)
+    assert O.run_kernel("img_clear_bgra", own) == 0
+    assert O.run_kernel("img_nv12_bgra", own, src, u, csc=2) == 0
+    assert np.array_equal(own[0][..., 0], own[0][..., 1]) and np.array_equal(own[0][..., 0], own[0][..., 2])
+    check(own[0][..., 0], ref[0], src[0])
+    # (2) four-channel texels: img_bgra_bgra_tx of an opaque picture (alpha 255, opacity 1, cleared canvas)
+    # against a float32 numpy evaluation of the unit-scale filter
+    pic = util.alloc_image("bgra", W, H, seed=78)
+    pic[0][..., 3] = 255
+    own = util.alloc_image("bgra", w, h)
+    assert O.run_kernel("img_clear_bgra", own) == 0
+    assert O.run_kernel("img_bgra_bgra_tx", own, pic, u) == 0
+    for c in range(3):
+        t00, t10, t01, t11 = (t.astype(f32) / f32(255) for t in taps(pic[0][..., c]))
+        q = ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11
+        unit = np.clip(np.rint(q * f32(255)), 0, 255)
+        check(own[0][..., c], unit, pic[0][..., c])
+    assert np.all(own[0][..., 3] == 255)
+
+
 def test_reference_quirks_are_preserved():
     """Bit-level quirks of the reference called out in SURVEY section 2.2."""
     # same-size full-canvas composite is a half-pixel box filter, not a copy (out_uv = gid/size, no +0.5)
