@@ -329,9 +329,9 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     for (int j = 0; j < ntiles; j++) {
         // ---- phase 1: the prefetched rectangle of tile j goes to LDS ------------------------
         if (staged) {
-            stage_store<1>(yregs, smem + ybase, ypitch, SY, gy, tid);
+            stage_store<1, false>(yregs, smem + ybase, ypitch, SY, gy, tid);
             if constexpr (PLANAR) stage_store_uv_planar(cregs, vregs, smem + cbase, cpitch, SC, SV, gc, tid);
-            else stage_store<2>(cregs, smem + cbase, cpitch, SC, gc, tid);
+            else stage_store<2, true>(cregs, smem + cbase, cpitch, SC, gc, tid);
         }
         __syncthreads();
         // ---- prefetch tile j+1 while tile j is computed ---------------------------------------

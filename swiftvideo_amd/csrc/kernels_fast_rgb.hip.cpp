@@ -2,14 +2,16 @@
 // layers are all BGRA/RGBA pictures (img_bgra_bgra_tx / img_rgba_bgra_tx; BASELINE
 // configs 3 and 5: N full-size layers alpha-composited in one pass).
 //
-// A block owns a 64x16 tile of the canvas and keeps its pixels (4 per thread) in
+// A block owns a 64x32 tile of the canvas and keeps its pixels (8 per thread) in
 // registers across all layers, so the canvas is written once and every layer is read
 // once: the per-tick HBM traffic is the algorithmic minimum (layers + canvas).
 //   phase 0  per-layer column/row tables of the reference's coordinate arithmetic
 //            (same instruction sequence as the general kernel => same bits)
-//   per layer: [store the prefetched source rectangle to LDS as float4 texels on the code
-//            scale (edge texels replicated) | barrier | issue the next layer's global
-//            loads | sample 2x2 taps from LDS, blend, re-quantise | barrier]
+//   per layer: [store the prefetched source rectangle to LDS as it is (4-byte texels, edge
+//            texels replicated) | barrier | issue the next layer's global loads | read 2x2
+//            taps from LDS, convert (v_cvt_f32_ubyteN), blend, re-quantise | barrier]
+// The tile stays in bytes on purpose: float4 texels made the LDS rectangle 4x larger (4 px per
+// thread at 5 blocks per CU) and the kernel LDS- and latency-bound (profiles/r01_notes.md).
 // Between layers the value is re-quantised (RTE through the float adder) exactly as the
 // per-layer kernels do through their 8-bit canvas.
 #include "tile_common.hip.h"
@@ -22,10 +24,15 @@
 namespace chv {
 
 constexpr int RTW = 64;           // tile width  (output pixels): 16 threads x 4 px (columns txi + 16k, so that
-                                  // lane-adjacent LDS reads hit adjacent 16-byte texels: no bank conflicts)
-constexpr int RTH = 16;           // tile height (output rows):   16 thread rows
+                                  // lane-adjacent LDS reads hit adjacent texels: no bank conflicts)
+constexpr int RTH = 32;           // tile height (output rows):   16 thread rows x RROWS
+constexpr int RROWS = RTH / 16;   // rows per thread (ly + 16*r)
+constexpr int RCOLS = 4;          // columns per thread
 constexpr int RMAXL = 8;          // layers per tick this path accepts
-constexpr int RNV = 2;            // prefetch registers (16-byte vectors) per thread
+#ifndef CHV_RGB_RNV
+#define CHV_RGB_RNV 3
+#endif
+constexpr int RNV = CHV_RGB_RNV;  // prefetch registers (16-byte vectors) per thread
 
 struct RgbLayerTable {
     int cp[RTW]; float ca[RTW]; int cfl[RTW];     // column: unclamped tap-0 texel, weight of tap 1, flags
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     RgbLayerTable *tabs = (RgbLayerTable *)smem;                 // [max_layers] (the launch's deepest tick)
     int *scratch = (int *)(smem + sizeof(RgbLayerTable) * max_layers);  // sink for summaries of absent layers
-    const int tbase = (int)(sizeof(RgbLayerTable) * max_layers) + 64; // [trows][tpitch] float4 texels
+    const int tbase = (int)(sizeof(RgbLayerTable) * max_layers) + 64; // [trows][tpitch] source texels (bytes)
 
     // XCD-aware numbering: block b runs on XCD b % 8; give every XCD one contiguous range of the
     // launch's tiles (whole frames when there are >= 8 ticks) so that halos are shared through its L2
@@ -111,13 +118,16 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
         if (x >= T.W) fl = AX_ALL;
         tabs[l].cp[lane] = ip; tabs[l].ca[lane] = a; tabs[l].cfl[lane] = fl;
     }
-    for (int l4 = wave * 4; l4 < nl; l4 += 16) {                 // one wave = the 16 rows of four layers
-        int l = l4 + (lane >> 4), j = lane & 15;
+    constexpr int LPW = 64 / RTH;                                // layers whose rows one wave covers
+    constexpr int RSH = RTH == 32 ? 5 : 4;
+    static_assert(RTH == 16 || RTH == 32, "row tables: 16 or 32 rows per tile");
+    for (int l4 = wave * LPW; l4 < nl; l4 += 4 * LPW) {          // one wave = the RTH rows of LPW layers
+        int l = l4 + (lane >> RSH), j = lane & (RTH - 1);
         int lc = min(l, nl - 1);
         const DPlane &S = L[lc].src.pl[0];
         int y = y0 + j, ip, fl; float a;
         axis_entry_y1(L[lc].u, min(y, T.H - 1), sx, sy, S.h, ip, a, fl);
-        group_summary(l < nl ? tabs[l].rsum : scratch, 4, l < nl && y < T.H, fl, ip, ip);
+        group_summary(l < nl ? tabs[l].rsum : scratch, RSH, l < nl && y < T.H, fl, ip, ip);
         if (y >= T.H) fl = AX_ALL;
         if (l < nl) { tabs[l].rp[j] = ip; tabs[l].ra[j] = a; tabs[l].rfl[j] = fl; }
     }
@@ -134,25 +144,31 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
         g.r_lo = t.rsum[0]; g.rows = t.rsum[1] - t.rsum[0] + 1; g.b0 = col0 * 4; g.nvec = nvec;
         g.edge = lo < 0 || hi >= S.w || t.rsum[0] < 0 || t.rsum[1] >= S.h - 1 + (int)(col0 + nvec * 4 <= S.w);
         stage_slots_init(g);
-        return (nvec + 2) * 64 <= tpitch && g.rows <= trows && stage_slots(g) <= RNV * NTHREADS;
+        return (nvec + 2) * 16 <= tpitch && g.rows <= trows && stage_slots(g) <= RNV * NTHREADS;
     };
 
     // ---- canvas pixels of this thread, as float code values -----------------------------------
     const int txi = tid & 15, ly = tid >> 4;
-    const int xq = x0 + txi, y = y0 + ly;              // this thread's pixels: xq + 16*k
-    const bool active = xq < T.W && y < T.H;
-    uint8_t *drow = D.ptr + (size_t)(active ? y : 0) * D.pitch;
-    float cb[4], cg[4], cr[4];
+    const int xq = x0 + txi, yq = y0 + ly;              // this thread's pixels: (xq + 16*k, yq + 16*r)
+    const bool active = xq < T.W && yq < T.H;
+    float cb[RROWS][RCOLS], cg[RROWS][RCOLS], cr[RROWS][RCOLS];
+    uint32_t orig_a[RROWS][RCOLS];
+    unsigned touched = CLEAR ? ~0u : 0u;                // bit r*4+k; untouched pixels keep their original alpha byte
 #pragma unroll
-    for (int k = 0; k < 4; k++) { cb[k] = 0.f; cg[k] = 0.f; cr[k] = 0.f; }   // img_clear_bgra: (0,0,0,1)
-    bool touched[4] = { CLEAR, CLEAR, CLEAR, CLEAR };   // untouched pixels keep their original alpha byte
-    uint32_t orig_a[4] = { 0, 0, 0, 0 };
+    for (int r = 0; r < RROWS; r++)
+#pragma unroll
+        for (int k = 0; k < RCOLS; k++) { cb[r][k] = 0.f; cg[r][k] = 0.f; cr[r][k] = 0.f; orig_a[r][k] = 0; }   // img_clear_bgra: (0,0,0,1)
     if (!CLEAR && active) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t cur = (xq + 16 * k < T.W) ? *(const uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) : 0;
-            cb[k] = (float)(cur & 255); cg[k] = (float)((cur >> 8) & 255); cr[k] = (float)((cur >> 16) & 255);
-            orig_a[k] = cur & 0xFF000000u;
+        for (int r = 0; r < RROWS; r++) {
+            if (yq + 16 * r >= T.H) continue;
+            const uint8_t *drow = D.ptr + (size_t)(yq + 16 * r) * D.pitch;
+#pragma unroll
+            for (int k = 0; k < RCOLS; k++) {
+                uint32_t cur = (xq + 16 * k < T.W) ? *(const uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) : 0;
+                cb[r][k] = (float)(cur & 255); cg[r][k] = (float)((cur >> 8) & 255); cr[r][k] = (float)((cur >> 16) & 255);
+                orig_a[r][k] = cur & 0xFF000000u;
+            }
         }
     }
 
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
         const DLayer &Ly = L[l];
         const DPlane &S = Ly.src.pl[0];
         const RgbLayerTable &t = tabs[l];
-        if (staged) stage_store<4>(regs, smem + tbase, tpitch, S, g, tid);
+        if (staged) stage_store<4, false>(regs, smem + tbase, tpitch, S, g, tid);
         __syncthreads();
         const int ln = next_hit(l + 1);
         bool nstaged = false;
@@ -193,67 +209,82 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
             // every pixel of the tile inside the picture the loop is branch-free
             const bool fast = staged && t.csum[5] && t.rsum[5] && nofill && opacity >= 0.f && opacity <= 1.f;
             const float ka = opacity * kInv255;
-            const float b = t.ra[ly], ib = 1.0f - b;
-            const int rowoff = tbase + (t.rp[ly] - g.r_lo) * tpitch + (4 - col0) * 16;
+            // column entries of this thread's pixels (shared by its rows)
+            int cpo[RCOLS]; float ca[RCOLS], ica[RCOLS];
+#pragma unroll
+            for (int k = 0; k < RCOLS; k++) {
+                const int c = txi + 16 * k;
+                cpo[k] = (t.cp[c] - col0 + 4) * 4; ca[k] = t.ca[c]; ica[k] = 1.0f - ca[k];
+            }
             if (fast) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int c = txi + 16 * k;
-                    const float a = t.ca[c], ia = 1.0f - a;
-                    const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
-                    const float4 *p0 = (const float4 *)(smem + rowoff + t.cp[c] * 16);
-                    const float4 *p1 = (const float4 *)(smem + rowoff + tpitch + t.cp[c] * 16);
-                    const float4 t00 = p0[0], t10 = p0[1], t01 = p1[0], t11 = p1[1];
-                    const float q0 = cs_mix(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x);
-                    const float q1 = cs_mix(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y);
-                    const float q2 = cs_mix(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z);
-                    const float q3 = cs_mix(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w);
-                    const float al = q3 * ka, ial = 1.f - al;
-                    const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
-                    cb[k] = code_rintf(__builtin_fmaf(pb, al, cb[k] * ial));
-                    cg[k] = code_rintf(__builtin_fmaf(q1, al, cg[k] * ial));
-                    cr[k] = code_rintf(__builtin_fmaf(pr, al, cr[k] * ial));
-                    touched[k] = true;
-                }
-            } else {
-                const float af = opacity * U[U_FILL + 3], iaf = 1.f - af;
-                const float f_b = U[U_FILL + 2] * 255.0f, f_g = U[U_FILL + 1] * 255.0f, f_r = U[U_FILL + 0] * 255.0f;
-                const int rfl = t.rfl[ly];
+                for (int r = 0; r < RROWS; r++) {
+                    const int lr = ly + 16 * r;
+                    const float b = t.ra[lr], ib = 1.0f - b;
+                    const int rowoff = tbase + (t.rp[lr] - g.r_lo) * tpitch;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int c = txi + 16 * k;
-                    const int fl = t.cfl[c] & rfl;
-                    if (!(fl & AX_BORDER)) continue;
-                    touched[k] = true;
-                    const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
-                    float r0 = clampf(__builtin_fmaf(f_b, af, cb[k] * iaf), 0.f, 255.f);
-                    float r1 = clampf(__builtin_fmaf(f_g, af, cg[k] * iaf), 0.f, 255.f);
-                    float r2 = clampf(__builtin_fmaf(f_r, af, cr[k] * iaf), 0.f, 255.f);
-                    if (in_pic) {
-                        const float a = t.ca[c], ia = 1.0f - a;
-                        const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
-                        float4 t00, t10, t01, t11;
-                        if (staged) {
-                            const float4 *p0 = (const float4 *)(smem + rowoff + t.cp[c] * 16);
-                            const float4 *p1 = (const float4 *)(smem + rowoff + tpitch + t.cp[c] * 16);
-                            t00 = p0[0]; t10 = p0[1]; t01 = p1[0]; t11 = p1[1];
-                        } else {
-                            int xa = min(max(t.cp[c], 0), S.w - 1), xb = min(max(t.cp[c] + 1, 0), S.w - 1);
-                            int ya = min(max(t.rp[ly], 0), S.h - 1), yb = min(max(t.rp[ly] + 1, 0), S.h - 1);
-                            auto ld = [&](int xx, int yy) { return codes4(*(const uint32_t *)(S.ptr + (size_t)yy * S.pitch + (size_t)xx * 4)); };
-                            t00 = ld(xa, ya); t10 = ld(xb, ya); t01 = ld(xa, yb); t11 = ld(xb, yb);
-                        }
+                    for (int k = 0; k < RCOLS; k++) {
+                        const float w00 = ica[k] * ib, w10 = ca[k] * ib, w01 = ica[k] * b, w11 = ca[k] * b;
+                        const uint32_t *p0 = (const uint32_t *)(smem + rowoff + cpo[k]);
+                        const uint32_t *p1 = (const uint32_t *)(smem + rowoff + tpitch + cpo[k]);
+                        const float4 t00 = codes4(p0[0]), t10 = codes4(p0[1]), t01 = codes4(p1[0]), t11 = codes4(p1[1]);
                         const float q0 = cs_mix(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x);
                         const float q1 = cs_mix(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y);
                         const float q2 = cs_mix(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z);
                         const float q3 = cs_mix(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w);
-                        const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
                         const float al = q3 * ka, ial = 1.f - al;
-                        r0 = __builtin_fmaf(pb, al, r0 * ial);
-                        r1 = __builtin_fmaf(q1, al, r1 * ial);
-                        r2 = __builtin_fmaf(pr, al, r2 * ial);
+                        const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
+                        cb[r][k] = code_rintf(__builtin_fmaf(pb, al, cb[r][k] * ial));
+                        cg[r][k] = code_rintf(__builtin_fmaf(q1, al, cg[r][k] * ial));
+                        cr[r][k] = code_rintf(__builtin_fmaf(pr, al, cr[r][k] * ial));
                     }
-                    cb[k] = to_codef(r0); cg[k] = to_codef(r1); cr[k] = to_codef(r2);
+                }
+                touched = ~0u;
+            } else {
+                const float af = opacity * U[U_FILL + 3], iaf = 1.f - af;
+                const float f_b = U[U_FILL + 2] * 255.0f, f_g = U[U_FILL + 1] * 255.0f, f_r = U[U_FILL + 0] * 255.0f;
+#pragma unroll
+                for (int r = 0; r < RROWS; r++) {
+                    const int lr = ly + 16 * r;
+                    const float b = t.ra[lr], ib = 1.0f - b;
+                    const int rowoff = tbase + (t.rp[lr] - g.r_lo) * tpitch;
+                    const int rfl = t.rfl[lr];
+#pragma unroll
+                    for (int k = 0; k < RCOLS; k++) {
+                        const int c = txi + 16 * k;
+                        const int fl = t.cfl[c] & rfl;
+                        if (!(fl & AX_BORDER)) continue;
+                        touched |= 1u << (r * 4 + k);
+                        const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
+                        float r0 = clampf(__builtin_fmaf(f_b, af, cb[r][k] * iaf), 0.f, 255.f);
+                        float r1 = clampf(__builtin_fmaf(f_g, af, cg[r][k] * iaf), 0.f, 255.f);
+                        float r2 = clampf(__builtin_fmaf(f_r, af, cr[r][k] * iaf), 0.f, 255.f);
+                        if (in_pic) {
+                            const float w00 = ica[k] * ib, w10 = ca[k] * ib, w01 = ica[k] * b, w11 = ca[k] * b;
+                            uint32_t u00, u10, u01, u11;
+                            if (staged) {
+                                const uint32_t *p0 = (const uint32_t *)(smem + rowoff + cpo[k]);
+                                const uint32_t *p1 = (const uint32_t *)(smem + rowoff + tpitch + cpo[k]);
+                                u00 = p0[0]; u10 = p0[1]; u01 = p1[0]; u11 = p1[1];
+                            } else {
+                                int xa = min(max(t.cp[c], 0), S.w - 1), xb = min(max(t.cp[c] + 1, 0), S.w - 1);
+                                int ya = min(max(t.rp[lr], 0), S.h - 1), yb = min(max(t.rp[lr] + 1, 0), S.h - 1);
+                                auto ld = [&](int xx, int yy) { return *(const uint32_t *)(S.ptr + (size_t)yy * S.pitch + (size_t)xx * 4); };
+                                u00 = ld(xa, ya); u10 = ld(xb, ya); u01 = ld(xa, yb); u11 = ld(xb, yb);
+                            }
+                            const float4 t00 = codes4(u00), t10 = codes4(u10), t01 = codes4(u01), t11 = codes4(u11);
+                            const float q0 = cs_mix(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x);
+                            const float q1 = cs_mix(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y);
+                            const float q2 = cs_mix(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z);
+                            const float q3 = cs_mix(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w);
+                            const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
+                            const float al = q3 * ka, ial = 1.f - al;
+                            r0 = __builtin_fmaf(pb, al, r0 * ial);
+                            r1 = __builtin_fmaf(q1, al, r1 * ial);
+                            r2 = __builtin_fmaf(pr, al, r2 * ial);
+                        }
+                        cb[r][k] = to_codef(r0); cg[r][k] = to_codef(r1); cr[r][k] = to_codef(r2);
+                    }
                 }
             }
         }
@@ -262,12 +293,17 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
     }
 
     if (active) {
-        uint32_t outw[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            outw[k] = (uint32_t)cb[k] | ((uint32_t)cg[k] << 8) | ((uint32_t)cr[k] << 16) | (touched[k] ? 0xFF000000u : orig_a[k]);
+        for (int r = 0; r < RROWS; r++) {
+            if (yq + 16 * r >= T.H) continue;
+            uint8_t *drow = D.ptr + (size_t)(yq + 16 * r) * D.pitch;
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (xq + 16 * k < T.W) *(uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) = outw[k];
+            for (int k = 0; k < RCOLS; k++) {
+                const uint32_t a8 = ((touched >> (r * 4 + k)) & 1u) ? 0xFF000000u : orig_a[r][k];
+                const uint32_t w = (uint32_t)cb[r][k] | ((uint32_t)cg[r][k] << 8) | ((uint32_t)cr[r][k] << 16) | a8;
+                if (xq + 16 * k < T.W) *(uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) = w;
+            }
+        }
     }
 }
 
@@ -285,7 +321,7 @@ static void rgb_tile_dims(const DTick &T, const DLayer &L, int *pitch, int *rows
     double sxr = std::fabs((double)U[U_TEXTURE + 0] * (double)U[U_TRANSFORM + 0] * 2.0 / (double)T.W);
     double syr = std::fabs((double)U[U_TEXTURE + 5] * (double)U[U_TRANSFORM + 5] * 2.0 / (double)T.H);
     int span = (int)std::ceil(RTW * sxr * L.src.pl[0].w) + 4;
-    *pitch = ((span + 3) / 4 + 3) * 64;                 // float4 texels, 4 per vector, alignment + 2 pad vectors
+    *pitch = ((span + 3) / 4 + 3) * 16;                 // 4-byte texels, 4 per vector, alignment + 2 pad vectors
     // rows a tile's taps span: <= ceil((RTH-1)*scale) + 2 (tap 1 of the last row) <= ceil(RTH*scale) + 2
     *rows = (int)std::ceil(RTH * syr * L.src.pl[0].h) + CHV_RGB_ROWPAD;
 }

@@ -136,10 +136,12 @@ CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, i
     }
 }
 
-// BPT = 1: bytes kept as bytes (LDS byte 16 + k of a row = source byte b0 + k)
-// BPT = 2: byte pairs as float pairs on the code scale (LDS texel slot 8 + k = source texel b0/2 + k)
-// BPT = 4: 4-byte texels as float4 on the code scale   (LDS texel slot 4 + k = source texel b0/4 + k)
-template <int BPT, int N>
+// BPT = bytes per source texel (1, 2, 4; selects the edge patching).
+// TO_FLOAT = false: the 16 source bytes are kept as bytes (LDS byte 16 + k of a row = source byte b0 + k)
+// TO_FLOAT = true : bytes become floats on the code scale, 64 LDS bytes per vector
+//                   (BPT = 2: float pairs, LDS texel slot 8 + k = source texel b0/2 + k;
+//                    BPT = 4: float4 texels, LDS texel slot 4 + k = source texel b0/4 + k)
+template <int BPT, bool TO_FLOAT, int N>
 CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid) {
 #pragma unroll
     for (int n = 0; n < N; n++) {
@@ -152,9 +154,9 @@ CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, co
                 int row = min(max(g.r_lo + r, 0), P.h - 1);
                 val = patch_edges<BPT>(val, P, row, g.b0 + v * 16);
             }
-            if (BPT == 1) {
+            if (!TO_FLOAT) {
                 *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
-            } else {   // 16 source bytes -> 64 LDS bytes for both 2- and 4-byte texels
+            } else {
                 float4 f0, f1, f2, f3;
                 codes16(val, f0, f1, f2, f3);
                 float4 *d = (float4 *)(lds + r * lds_pitch + 64 + v * 64);
