@@ -339,4 +339,17 @@ func compositeTick(_ context: ComputeContext,
     try check(chv_composite(context.handle, &targetDesc, 1, &descs, Int32(descs.count)))
     return context
 }
+
+// MARK: - Lanczos-3 resample, BGRA -> BGRA (no reference counterpart; used by filter.pict.hip.swift)
+
+func scaleLanczos(_ context: ComputeContext, src: PictureSample, target: PictureSample) throws -> ComputeContext {
+    guard let targetImage = target.imageBuffer(), var targetDesc = describe(targetImage, maxPlanes: 1) else {
+        throw ComputeError.badTarget
+    }
+    guard let image = src.imageBuffer(), var desc = describe(image, maxPlanes: 1) else {
+        throw ComputeError.badInputData(description: "Bad input image")
+    }
+    try check(chv_scale_lanczos(context.handle, &targetDesc, &desc))
+    return context
+}
 #endif

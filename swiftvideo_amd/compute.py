@@ -29,7 +29,7 @@ __all__ = [
     "destroyComputeContext", "beginComputePass", "endComputePass", "usingContext", "runComputeKernel",
     "applyComputeImage", "uploadComputePicture", "downloadComputePicture", "uploadComputeBuffer",
     "downloadComputeBuffer", "createPictureSample", "GPUBarrierUpload", "GPUBarrierDownload", "VideoMixer",
-    "compositeTick", "scaleLanczos",
+    "compositeTick", "scaleLanczos", "PictureFilter",
 ]
 
 
@@ -538,6 +538,84 @@ class GPUBarrierDownload:
             except ComputeError as e:
                 return ("error", ("barrier.download", -1, str(e), sample.assetId()))
         return ("just", sample)
+
+
+class PictureFilter:
+    """Tx<PictureSample, PictureSample> that converts a picture to `outputFormat` at `outputSize` on the
+    device — the operator the reference sketches and leaves commented out (filter.pict.swift:20-47: same
+    constructor shape: a context of its own, sharing the given one).  One full-canvas layer through the
+    composite kernels: colour conversion + bilinear scale in one launch (`scaler="bilinear"`, any format
+    pair the kernel table has), or a separable Lanczos-3 resample (`scaler="lanczos"`, BGRA -> BGRA).
+    CPU samples are uploaded first; the sample's time stamps, ids and transform state are carried over.
+    Results land in a ring of `numberBackingImages` device images like the mixer's (mix.video.swift:148-167)."""
+
+    numberBackingImages = 10
+
+    def __init__(self, outputSize, outputFormat=PixelFormat.BGRA, computeContext=None, scaler="bilinear",
+                 colorspace=cv.CSC_BT601_LIMITED):
+        if scaler not in ("bilinear", "lanczos"):
+            raise ComputeError(0, f"unknown scaler {scaler!r}")
+        try:
+            self.context = createComputeContext(sharing=computeContext) if computeContext is not None \
+                else makeComputeContext(forType="GPU")
+        except ComputeError:
+            self.context = None                     # filter.pict.swift:31-33
+        self.outputSize, self.outputFormat = outputSize, outputFormat
+        self.scaler, self.colorspace = scaler, colorspace
+        self.backing, self.currentBacking = [], 0
+
+    def findKernel(self, image):
+        """same naming rule as VideoMixer.findKernel (mix.video.swift:142-146)"""
+        inp, outp = str(image.pixelFormat().name).lower(), str(PixelFormat(self.outputFormat).name).lower()
+        name = f"img_{inp}_{outp}"
+        if outp == "bgra" and inp in ("bgra", "rgba"):
+            name += "_tx"
+        return defaultComputeKernelFromString(name)
+
+    def _backing(self, like):
+        if len(self.backing) < self.numberBackingImages:
+            image = createPictureSample(self.outputSize, self.outputFormat, assetId=like.assetId(),
+                                        workspaceId=like.workspaceId())
+            self.backing.append(uploadComputePicture(self.context, image))
+            return self.backing[-1]
+        image = self.backing[self.currentBacking]
+        self.currentBacking = (self.currentBacking + 1) % len(self.backing)
+        return image
+
+    def __call__(self, sample):
+        if self.context is None:
+            return ("error", ("filter.pict", -1, "No Compute Context", sample.assetId()))
+        ctx = self.context
+        try:
+            src = uploadComputePicture(ctx, sample) if sample.bufferType() == "cpu" else sample
+            dst = self._backing(sample)
+            beginComputePass(ctx)
+            if self.scaler == "lanczos":
+                if src.pixelFormat() != PixelFormat.BGRA or self.outputFormat != PixelFormat.BGRA:
+                    raise ComputeError(9, "lanczos: BGRA -> BGRA only")
+                scaleLanczos(ctx, dst, src)
+            else:
+                # a full-canvas opaque layer: identity placement, no border, no fill
+                full = src.derive(matrix=_unit_quad_to_ndc(), textureMatrix=np.eye(4), borderMatrix=_unit_quad_to_ndc(),
+                                  fillColor=(0.0, 0.0, 0.0, 0.0), opacity=1.0)
+                compositeTick(ctx, dst, [(self.findKernel(src), full, imageUniformsFor(full, dst), self.colorspace)],
+                              clearFirst=True)
+            endComputePass(ctx, True)
+            return ("just", dst.derive(pts=sample.pts(), time=sample.time(), assetId=sample.assetId(),
+                                       workspaceId=sample.workspaceId(), matrix=sample.matrix(),
+                                       textureMatrix=sample.textureMatrix(), borderMatrix=sample.borderMatrix(),
+                                       fillColor=sample.fillColor(), opacity=sample.opacity(), zIndex=sample.zIndex(),
+                                       revision=sample.revision()))
+        except ComputeError as e:
+            return ("error", ("filter.pict", -2, f"Compute error {e}", sample.assetId()))
+
+
+def _unit_quad_to_ndc():
+    """the unit quad [0,1]^2 stretched over the whole canvas in NDC [-1,1]^2 (what PictureAnimator
+    produces for a picture at (0,0) with the canvas' size: ortho * T(0) * S(canvas))"""
+    m = np.eye(4)
+    m[0, 0], m[1, 1], m[0, 3], m[1, 3], m[2, 3] = 2.0, 2.0, -1.0, -1.0, 1.0
+    return m
 
 
 class VideoMixer:

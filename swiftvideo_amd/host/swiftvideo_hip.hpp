@@ -375,6 +375,15 @@ inline ComputeContext compositeTick(ComputeContext ctx, const PictureSample &tar
     return ctx;
 }
 
+// separable Lanczos-3 resample BGRA -> BGRA (chv_scale_lanczos; no reference counterpart)
+inline ComputeContext scaleLanczos(ComputeContext ctx, const PictureSample &dst, const PictureSample &src) {
+    chv_image d, s;
+    if (!describe(dst, &d)) throw ComputeError(CHV_ERR_BAD_TARGET, "target has no GPU image buffer");
+    if (!describe(src, &s)) throw ComputeError(CHV_ERR_BAD_INPUT, "Bad input image");
+    check(chv_scale_lanczos(ctx.get(), &d, &s));
+    return ctx;
+}
+
 // ---- pipeline operators (compute.swift:175-255) -------------------------------------------------------
 struct EventError { std::string source; int code = 0; std::string description; std::string assetId; };
 template <typename T> struct EventBox {          // event.swift:63-95: .just / .nothing / .error / .gone
@@ -491,11 +500,74 @@ private:
 };
 
 
-// ---- PictureAnimator (animator.pic.swift:24-128, 207-272): the caller that produces the matrices ----
-// Elements without a parent (anchors only act relative to a parent's size change, :149-193).
+// ---- PictureFilter: the Tx<PictureSample, PictureSample> the reference sketches and leaves commented out
+//      (filter.pict.swift:20-47).  Converts a picture to outputFormat at outputSize on the device: one
+//      full-canvas layer through the composite kernels (colour conversion + bilinear scale in one launch),
+//      or a separable Lanczos-3 resample (BGRA -> BGRA).  CPU samples are uploaded first; results land in a
+//      ring of device images like the mixer's (mix.video.swift:148-167). ------------------------------------
+class PictureFilter {
+public:
+    enum class Scaler { bilinear, lanczos };
+    static constexpr int numberBackingImages = 10;
+    PictureFilter(Vector2 outputSize, PixelFormat outputFormat, const ComputeContext &computeContext,
+                  Scaler scaler = Scaler::bilinear, int colorspace = CHV_CSC_BT601_LIMITED)
+        : context_(createComputeContext(computeContext)), size_(outputSize), format_(outputFormat), scaler_(scaler), colorspace_(colorspace) {}
+
+    ComputeKernel findKernel(const PictureSample &image) const {      // VideoMixer.findKernel's naming rule
+        std::string inp = lowercasedName(image.pixelFormat()), outp = lowercasedName(format_);
+        std::string name = "img_" + inp + "_" + outp;
+        if (outp == "bgra" && (inp == "bgra" || inp == "rgba")) name += "_tx";
+        return defaultComputeKernelFromString(name);
+    }
+
+    EventBox<PictureSample> operator()(const PictureSample &sample) {
+        EventBox<PictureSample> r;
+        try {
+            PictureSample src = sample.bufferType() == BufferType::cpu ? uploadComputePicture(context_, sample) : sample;
+            PictureSample dst = getBacking(sample);
+            if (scaler_ == Scaler::lanczos) {
+                if (src.pixelFormat() != PixelFormat::BGRA || format_ != PixelFormat::BGRA)
+                    throw ComputeError(CHV_ERR_NOT_IMPLEMENTED, "lanczos: BGRA -> BGRA only");
+                usingContext(context_, [&](ComputeContext c) { return scaleLanczos(c, dst, src); });
+            } else {
+                // a full-canvas opaque layer: the unit quad stretched over the canvas in NDC, no border, no fill
+                PictureSample full = src;
+                Matrix4 quad; quad.m[0] = 2; quad.m[5] = 2; quad.m[3] = -1; quad.m[7] = -1; quad.m[11] = 1;
+                full.matrix = quad; full.borderMatrix = quad; full.textureMatrix = Matrix4::identity();
+                full.fillColor = Vector4{}; full.opacity = 1.0f;
+                std::vector<TickLayer> layers{ TickLayer{ findKernel(src), full, imageUniformsFor(full, dst), colorspace_ } };
+                usingContext(context_, [&](ComputeContext c) { return compositeTick(c, dst, layers, true); });
+            }
+            r.kind = r.just; r.value = sample;            // time stamps, ids and transform state carry over
+            r.value.img = dst.img;
+        } catch (const ComputeError &e) {
+            r.kind = r.error; r.err = EventError{ "filter.pict", -2, std::string("Compute error ") + e.what(), sample.assetId };
+        }
+        return r;
+    }
+
+private:
+    PictureSample getBacking(const PictureSample &like) {
+        if ((int)backing_.size() < numberBackingImages) {
+            PictureSample image = createPictureSample(size_, format_, like.assetId, like.workspaceId);
+            backing_.push_back(uploadComputePicture(context_, image));
+            return backing_.back();
+        }
+        PictureSample image = backing_[current_];
+        current_ = (current_ + 1) % (int)backing_.size();
+        return image;
+    }
+    ComputeContext context_;
+    Vector2 size_; PixelFormat format_; Scaler scaler_; int colorspace_;
+    std::vector<PictureSample> backing_; int current_ = 0;
+};
+
+// ---- PictureAnimator (animator.pic.swift:28-128, 149-272): the caller that produces the matrices ----
+// Including elements attached to a parent element through parent anchors (:149-193).
 // The 4x4 algebra is VectorMath's in the reference (un-vendored, un-pinned); conventions as in Matrix4 above.
 enum class AspectMode { aspectNone, aspectFit, aspectFill };
 enum class PictureOrigin { originTopLeft, originCenter };
+enum PictureAnchor : unsigned { anchorTopLeft = 1, anchorTopRight = 2, anchorBottomLeft = 4, anchorBottomRight = 8 };   // bit set
 
 struct ElementState {                       // Proto/Composition.proto:56-71, picture fields
     double picPos[3] = { 0, 0, 0 };
@@ -508,6 +580,7 @@ struct ElementState {                       // Proto/Composition.proto:56-71, pi
     double fillColor[4] = { 0, 0, 0, 0 };   // r g b a
     double borderSize[4] = { 0, 0, 0, 0 };  // l t r b
     bool hidden = false;
+    unsigned parentAnchor = 0;              // PictureAnchor bits; 0 -> anchorTopLeft (:64)
 };
 
 struct ComputedPictureState { Matrix4 matrix, textureMatrix, borderMatrix; Vector4 fillColor; float opacity = 1; };
@@ -540,39 +613,98 @@ inline ElementState computeElementState(const ElementState &a, const ElementStat
     return r;
 }
 
-inline ComputedPictureState computePictureState(Vector2 sampleSize, const ElementState &state) {   // :229-272, parent == nil
+// :149-193 — position and size of an element whose corners follow its parent's corners.
+// parentPos: the parent's translation; d: parent size now minus parent size at attachment.
+inline void computePositionSize(const double basePos[2], const double baseSize[2], const double parentPos[2], const double d[2],
+                                unsigned anchors, double pos[2], double size[2]) {
+    const double rx = basePos[0] + parentPos[0], ry = basePos[1] + parentPos[1];
+    double v[3][2] = { { rx, ry }, { rx + baseSize[0], ry }, { rx, ry + baseSize[1] } };
+    if (anchors & anchorBottomRight) {
+        for (auto &q : v) { q[0] += d[0]; q[1] += d[1]; }
+        if (anchors & anchorBottomLeft) { v[0][0] = rx; v[2][0] = rx; }
+        if (anchors & anchorTopRight) { v[0][1] = ry; v[1][1] = ry; }
+        if (anchors & anchorTopLeft) {
+            v[0][0] = rx; v[0][1] = ry;
+            v[1][0] = rx + baseSize[0] + d[0]; v[1][1] = ry;
+            v[2][0] = rx; v[2][1] = ry + baseSize[1] + d[1];
+        }
+    } else if (anchors & anchorTopRight) {
+        v[1][0] += d[0];
+        if (!(anchors & anchorTopLeft) && !(anchors & anchorBottomLeft)) { v[0][0] += d[0]; v[2][0] += d[0]; }
+        else if (anchors & anchorBottomLeft) v[2][1] += d[1];
+    } else if (anchors & anchorBottomLeft) {
+        v[2][1] += d[1];
+        if (!(anchors & anchorTopLeft)) { v[1][1] += d[1]; v[0][1] += d[1]; }
+    }
+    pos[0] = v[0][0]; pos[1] = v[0][1];
+    size[0] = v[1][0] - v[0][0]; size[1] = v[2][1] - v[0][1];
+}
+
+// lengths of the first two columns' xy parts = the element's size under rotation (:243-249)
+inline void columnScale(const Matrix4 &m, double out[2]) {
+    out[0] = std::hypot(m.m[0], m.m[4]);
+    out[1] = std::hypot(m.m[1], m.m[5]);
+}
+
+// :229-272.  parent: the parent's (un-projected) matrix or nullptr; initialParent: the parent's state
+// when this element was attached, or nullptr.
+inline ComputedPictureState computePictureState(Vector2 sampleSize, const ElementState &state, const Matrix4 *parent = nullptr,
+                                                unsigned anchors = anchorTopLeft, const ComputedPictureState *initialParent = nullptr) {
+    double parentPos[2] = { 0, 0 }, parentSize[2] = { 0, 0 }, initialSize[2] = { 0, 0 };
+    if (parent) { parentPos[0] = parent->m[3]; parentPos[1] = parent->m[7]; columnScale(*parent, parentSize); }
+    if (initialParent) columnScale(initialParent->matrix, initialSize);
+    const double delta[2] = { parentSize[0] - initialSize[0], parentSize[1] - initialSize[1] };
     double ax = state.picOrigin == PictureOrigin::originTopLeft ? 0.0 : -state.size[0] / 2;
     double ay = state.picOrigin == PictureOrigin::originTopLeft ? 0.0 : -state.size[1] / 2;
-    double px = state.picPos[0] + ax, py = state.picPos[1] + ay;
+    double rel[2], size[2];
+    computePositionSize(state.picPos, state.size, parentPos, delta, anchors, rel, size);
+    double px = rel[0] + ax, py = rel[1] + ay;
     const double *b = state.borderSize;
     ComputedPictureState c;
-    c.matrix = Matrix4::translation(px, py) * Matrix4::rotationZ(state.rotation) * Matrix4::scale(state.size[0], state.size[1]);
-    c.textureMatrix = computeTextureMatrix(sampleSize, state.size, state.textureOffset, state.picAspect);
+    c.matrix = Matrix4::translation(px, py) * Matrix4::rotationZ(state.rotation) * Matrix4::scale(size[0], size[1]);
+    c.textureMatrix = computeTextureMatrix(sampleSize, size, state.textureOffset, state.picAspect);
     c.borderMatrix = Matrix4::translation(px - b[0], py - b[1]) * Matrix4::rotationZ(state.rotation) *
-                     Matrix4::scale(b[0] + state.size[0] + b[2], b[1] + state.size[1] + b[3]);
+                     Matrix4::scale(b[0] + size[0] + b[2], b[1] + size[1] + b[3]);
     if (state.hasFillColor) c.fillColor = Vector4{ (float)state.fillColor[0], (float)state.fillColor[1], (float)state.fillColor[2], (float)state.fillColor[3] };
     c.opacity = (float)(1.0 - state.transparency);
     return c;
 }
 
-class PictureAnimator {                     // Tx<PictureSample, PictureSample>, :107-128
+class PictureAnimator {                     // Tx<PictureSample, PictureSample>, :28-128
 public:
-    PictureAnimator(Vector2 canvasSize, const ElementState &state, const std::string &revision = "")
-        : canvas_(canvasSize), state_(state), revision_(revision) {}
-    void setState(const ElementState &s) { state_ = s; }
-    EventBox<PictureSample> operator()(const PictureSample &sample) const {
+    PictureAnimator(Vector2 canvasSize, const ElementState &state, const std::string &revision = "",
+                    const PictureAnimator *parent = nullptr, unsigned parentAnchors = anchorTopLeft)
+        : canvas_(canvasSize), state_(state), revision_(revision), parent_(parent), anchors_(parentAnchors) {}
+    void setParent(const PictureAnimator *p) { parent_ = p; }
+    // immediate switch (duration <= 0, :56-66): anchors follow the new state, the attachment is re-initialised
+    void setState(const ElementState &s) {
+        state_ = s; has_initial_ = false;
+        anchors_ = s.parentAnchor ? s.parentAnchor : (unsigned)anchorTopLeft;
+    }
+    ComputedPictureState computedState(const PictureSample &sample, const ComputedPictureState *parentState = nullptr) const {   // :84-105
+        return computePictureState(sample.size(), state_, parentState ? &parentState->matrix : nullptr, anchors_,
+                                   has_initial_ ? &initial_ : nullptr);
+    }
+    EventBox<PictureSample> operator()(const PictureSample &sample) {
         EventBox<PictureSample> r;
         if (state_.hidden) { r.kind = r.nothing; return r; }
-        ComputedPictureState cs = computePictureState(sample.size(), state_);
+        // the parent's state is computed without ITS parent (:112); the attachment state is recorded only
+        // after the first sample went through (:115-117)
+        ComputedPictureState ps;
+        if (parent_) ps = parent_->computedState(sample);
+        ComputedPictureState cs = computedState(sample, parent_ ? &ps : nullptr);
+        if (parent_ && !has_initial_) { initial_ = ps; has_initial_ = true; }
         Matrix4 proj = Matrix4::ortho(canvas_.x, canvas_.y);
         r.kind = r.just; r.value = sample;
         r.value.matrix = proj * cs.matrix; r.value.textureMatrix = cs.textureMatrix; r.value.borderMatrix = proj * cs.borderMatrix;
-        r.value.fillColor = cs.fillColor; r.value.opacity = cs.opacity;
+        r.value.fillColor = cs.fillColor; r.value.opacity = cs.opacity * (parent_ ? ps.opacity : 1.0f);
         if (!revision_.empty()) r.value.revision = revision_;
         return r;
     }
 private:
     Vector2 canvas_; ElementState state_; std::string revision_;
+    const PictureAnimator *parent_ = nullptr; unsigned anchors_ = anchorTopLeft;
+    ComputedPictureState initial_; bool has_initial_ = false;
 };
 
 }  // namespace sv

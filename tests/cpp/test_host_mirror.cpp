@@ -110,6 +110,43 @@ static void cpuTests() {
         st.hidden = true;
         EXPECT(sv::PictureAnimator({ 64, 36 }, st)(pic).kind == sv::EventBox<sv::PictureSample>::nothing);
     }
+    // parent anchors (animator.pic.swift:149-193): corners follow the parent's corners when it grows by (30, 16)
+    {
+        const double base[2] = { 10, 20 }, size[2] = { 100, 50 }, ppos[2] = { 5, 7 }, d[2] = { 30, 16 };
+        struct { unsigned a; double x, y, w, h; } cases[] = {
+            { sv::anchorTopLeft, 15, 27, 100, 50 }, { sv::anchorTopRight, 45, 27, 100, 50 },
+            { sv::anchorBottomLeft, 15, 43, 100, 50 }, { sv::anchorBottomRight, 45, 43, 100, 50 },
+            { sv::anchorTopLeft | sv::anchorTopRight, 15, 27, 130, 50 }, { sv::anchorTopLeft | sv::anchorBottomLeft, 15, 27, 100, 66 },
+            { sv::anchorTopLeft | sv::anchorBottomRight, 15, 27, 130, 66 }, { sv::anchorTopRight | sv::anchorBottomRight, 45, 27, 100, 66 },
+            { sv::anchorBottomLeft | sv::anchorBottomRight, 15, 43, 130, 50 },
+        };
+        for (auto &c : cases) {
+            double pos[2], sz[2];
+            sv::computePositionSize(base, size, ppos, d, c.a, pos, sz);
+            EXPECT(pos[0] == c.x && pos[1] == c.y && sz[0] == c.w && sz[1] == c.h);
+        }
+        sv::ElementState ps; ps.picPos[0] = 200; ps.picPos[1] = 100; ps.size[0] = 400; ps.size[1] = 300; ps.transparency = 0.5;
+        sv::ElementState cs; cs.picPos[0] = 10; cs.picPos[1] = 20; cs.size[0] = 100; cs.size[1] = 50; cs.transparency = 0.2;
+        cs.parentAnchor = sv::anchorBottomRight;
+        sv::PictureAnimator parent({ 1280, 720 }, ps);
+        sv::PictureAnimator child({ 1280, 720 }, sv::ElementState(), "", &parent);
+        child.setState(cs);
+        sv::PictureSample pic = sv::createPictureSample({ 64, 64 }, sv::PixelFormat::BGRA);
+        sv::Matrix4 inv = sv::Matrix4::ortho(1280, 720).inverse();
+        auto origin = [&](const sv::PictureSample &s, double out[2]) { sv::Matrix4 m = inv * s.matrix; out[0] = m.m[3]; out[1] = m.m[7]; };
+        double o[2];
+        auto first = child(pic);       // reference quirk: computed before the attachment state exists (:115-117)
+        origin(first.value, o);
+        EXPECT(std::fabs(o[0] - 610) < 1e-6 && std::fabs(o[1] - 420) < 1e-6 && std::fabs(first.value.opacity - 0.4f) < 1e-6);
+        auto second = child(pic);
+        origin(second.value, o);
+        EXPECT(std::fabs(o[0] - 210) < 1e-6 && std::fabs(o[1] - 120) < 1e-6);
+        ps.picPos[0] = 220; ps.picPos[1] = 90; ps.size[0] = 460; ps.size[1] = 330;
+        parent.setState(ps);
+        auto third = child(pic);       // rides the parent's bottom-right corner: +20 +60, -10 +30
+        origin(third.value, o);
+        EXPECT(std::fabs(o[0] - 290) < 1e-6 && std::fabs(o[1] - 140) < 1e-6);
+    }
     if (!sv::hasAvailableComputeDevices(sv::ComputeDeviceType::GPU)) {
         try { sv::makeComputeContext(sv::ComputeDeviceType::GPU); EXPECT(false); }
         catch (const sv::ComputeError &e) { EXPECT(e.caseName == "deviceNotAvailable"); }
@@ -190,6 +227,39 @@ static void gpuTests() {
         try { sv::runComputeKernel(ctx, {}, canvas, sv::ComputeKernel::img_clear_yuvs); EXPECT(false); }
         catch (const sv::ComputeError &e) { EXPECT(e.caseName == "computeKernelNotFound"); }
         ctx = sv::usingContext(ctx, [&](sv::ComputeContext c) { return sv::runComputeKernel(c, {}, canvas, sv::ComputeKernel::img_clear_bgra); });
+    }
+    // PictureFilter (filter.pict.swift:20-47): CPU y420p picture -> 128x72 BGRA, and BGRA -> NV12, against the oracle
+    {
+        sv::PictureSample src = randomPicture(sv::PixelFormat::y420p, 192, 108, 31);
+        src.time = 2.0; src.pts = 2.5; src.assetId = "cam"; src.zIndex = 4;
+        sv::PictureFilter filt({ 128, 72 }, sv::PixelFormat::BGRA, ctx);
+        auto out = filt(src);
+        EXPECT(out.kind == out.just && out.value.bufferType() == sv::BufferType::gpu && out.value.pixelFormat() == sv::PixelFormat::BGRA);
+        EXPECT(out.value.assetId == "cam" && out.value.time == 2.0 && out.value.pts == 2.5 && out.value.zIndex == 4);
+        sv::PictureSample exp = sv::createPictureSample({ 128, 72 }, sv::PixelFormat::BGRA);
+        sv::PictureSample full = src;
+        full.matrix = sv::Matrix4::ortho(128, 72) * sv::Matrix4::scale(128, 72); full.borderMatrix = full.matrix;
+        sv::ImageUniforms u = sv::imageUniformsFor(full, exp);
+        auto tp = oraclePlanes(exp); auto ip = oraclePlanes(src);
+        orc_run_kernel(ORC_IMG_CLEAR_BGRA, tp.data(), 1, nullptr, 0, nullptr, 0, 1);
+        orc_run_kernel(ORC_IMG_Y420P_BGRA, tp.data(), 1, ip.data(), 3, (const orc_uniforms *)&u, 0, 1);
+        if (out.kind == out.just) EXPECT(samePlanes(sv::downloadComputePicture(ctx, out.value, true), exp));
+        sv::PictureFilter toNv12({ 96, 54 }, sv::PixelFormat::nv12, ctx);
+        sv::PictureSample rgb = randomPicture(sv::PixelFormat::BGRA, 160, 90, 32);
+        auto o2 = toNv12(sv::uploadComputePicture(ctx, rgb));
+        sv::PictureSample e2 = sv::createPictureSample({ 96, 54 }, sv::PixelFormat::nv12);
+        sv::PictureSample f2 = rgb;
+        f2.matrix = sv::Matrix4::ortho(96, 54) * sv::Matrix4::scale(96, 54); f2.borderMatrix = f2.matrix;
+        sv::ImageUniforms u2 = sv::imageUniformsFor(f2, e2);
+        auto tp2 = oraclePlanes(e2); auto ip2 = oraclePlanes(rgb);
+        orc_run_kernel(ORC_IMG_CLEAR_NV12, tp2.data(), 2, nullptr, 0, nullptr, 0, 1);
+        orc_run_kernel(ORC_IMG_BGRA_NV12, tp2.data(), 2, ip2.data(), 1, (const orc_uniforms *)&u2, 0, 1);
+        EXPECT(o2.kind == o2.just);
+        if (o2.kind == o2.just) EXPECT(samePlanes(sv::downloadComputePicture(ctx, o2.value, true), e2));
+        // no kernel for the pair -> error event, not an exception
+        sv::PictureFilter bad({ 96, 54 }, sv::PixelFormat::RGBA, ctx);
+        auto o3 = bad(src);
+        EXPECT(o3.kind == o3.error && o3.err.source == "filter.pict");
     }
     sv::destroyComputeContext(ctx);
 }

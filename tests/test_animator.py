@@ -47,6 +47,64 @@ def test_picture_state_and_uniform_rows():
     assert an.PictureAnimator((64, 36), an.ElementState(hidden=True))(pic)[0] == "nothing"
 
 
+def test_parent_anchors_follow_the_parents_corners():
+    """animator.pic.swift:149-193: a child's corners follow the parent's corners named by its anchors
+    when the parent is resized after the child was attached.  dx, dy = growth of the parent."""
+    base, size, ppos, d = (10.0, 20.0, 0.0), (100.0, 50.0), (5.0, 7.0), (30.0, 16.0)
+    rel = (15.0, 27.0)
+    TL, TR, BL, BR = an.ANCHOR_TOP_LEFT, an.ANCHOR_TOP_RIGHT, an.ANCHOR_BOTTOM_LEFT, an.ANCHOR_BOTTOM_RIGHT
+    cases = {
+        (TL,): (rel, size),                                              # pinned to the parent's top-left: unchanged
+        (TR,): ((rel[0] + 30, rel[1]), size),                            # rides the right edge
+        (BL,): ((rel[0], rel[1] + 16), size),                            # rides the bottom edge
+        (BR,): ((rel[0] + 30, rel[1] + 16), size),                       # rides the bottom-right corner
+        (TL, TR): (rel, (130.0, 50.0)),                                  # stretches horizontally
+        (TL, BL): (rel, (100.0, 66.0)),                                  # stretches vertically
+        (TL, BR): (rel, (130.0, 66.0)),                                  # stretches both ways
+        (TR, BR): ((rel[0] + 30, rel[1]), (100.0, 66.0)),                # right edge, stretches vertically
+        (BL, BR): ((rel[0], rel[1] + 16), (130.0, 50.0)),                # bottom edge, stretches horizontally
+        (TL, TR, BL, BR): (rel, (130.0, 66.0)),
+    }
+    for anchors, (pos, sz) in cases.items():
+        got_pos, got_size = an.computePositionSize(base, size, ppos, d, anchors)
+        assert np.allclose(got_pos, pos) and np.allclose(got_size, sz), anchors
+    # without growth of the parent every anchor set gives the plain relative rectangle
+    for anchors in cases:
+        got_pos, got_size = an.computePositionSize(base, size, ppos, (0.0, 0.0), anchors)
+        assert np.allclose(got_pos, rel) and np.allclose(got_size, size)
+
+
+def test_child_animator_tracks_parent_state():
+    pic = sv.createPictureSample((64, 64), sv.PixelFormat.BGRA)
+    parent = an.PictureAnimator((1280, 720), an.ElementState(picPos=(200, 100, 0), size=(400, 300), transparency=0.5))
+    child = an.PictureAnimator((1280, 720), parent=parent)
+    assert child(pic)[0] == "nothing"                                     # no state yet
+    child.setState(an.ElementState(picPos=(10, 20, 0), size=(100, 50), transparency=0.2,
+                                   parentAnchor=(an.ANCHOR_BOTTOM_RIGHT,)))
+    assert child.anchors == (an.ANCHOR_BOTTOM_RIGHT,)
+    inv = np.linalg.inv(an.orthoMatrix((1280, 720)))
+    # reference quirk (animator.pic.swift:115-117, 250): the first sample is computed before the attachment
+    # state is recorded, so the parent's whole size counts as growth
+    tag, first = child(pic)
+    assert tag == "just" and child.initialParentState is not None
+    assert np.allclose((inv @ first.matrix()) @ [0, 0, 0, 1], [200 + 10 + 400, 100 + 20 + 300, 0, 1])
+    assert np.isclose(first.opacity(), 0.8 * 0.5)                         # own opacity x the parent's
+    # from the second sample on: relative to the parent's position, growth measured from the attachment
+    tag, second = child(pic)
+    assert np.allclose((inv @ second.matrix()) @ [0, 0, 0, 1], [210, 120, 0, 1])
+    assert np.allclose((inv @ second.matrix()) @ [1, 1, 0, 1], [310, 170, 0, 1])
+    parent.setState(an.ElementState(picPos=(220, 90, 0), size=(460, 330), transparency=0.5))
+    tag, third = child(pic)
+    assert np.allclose((inv @ third.matrix()) @ [0, 0, 0, 1], [220 + 10 + 60, 90 + 20 + 30, 0, 1])   # rides the corner
+    assert np.allclose((inv @ third.matrix()) @ [1, 1, 0, 1], [220 + 10 + 60 + 100, 90 + 20 + 30 + 50, 0, 1])
+    # a rotated parent: its size is read off the matrix columns (animator.pic.swift:243-245)
+    parent.setState(an.ElementState(picPos=(220, 90, 0), size=(460, 330), rotation=0.3))
+    assert np.allclose(an._col_scale(parent.computedState(pic).matrix), (460, 330))
+    # an immediate setState re-attaches (initialParentState reset, :56-66)
+    child.setState(an.ElementState(picPos=(0, 0, 0), size=(10, 10)))
+    assert child.initialParentState is None and child.anchors == (an.ANCHOR_TOP_LEFT,)
+
+
 @pytest.mark.gpu
 def test_animator_to_mixer_aspect_fit_letterbox(ctx):
     import gpuutil as G

@@ -68,3 +68,46 @@ def test_sample_from_own_asset_passes_through_and_errors_become_events(ctx):
     # the mixer keeps working on the next tick once the bad sample has aged out
     mixer.mix(at=1.0)
     assert mixer.mix(at=2.0) is not None
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt,kernel", [("nv12", "bgra", "img_nv12_bgra"), ("y420p", "bgra", "img_y420p_bgra"),
+                                                    ("bgra", "nv12", "img_bgra_nv12"), ("rgba", "y420p", "img_rgba_y420p"),
+                                                    ("y420p", "nv12", "img_y420p_nv12"), ("bgra", "bgra", "img_bgra_bgra_tx")])
+def test_picture_filter_converts_and_scales(ctx, src_fmt, dst_fmt, kernel):
+    """PictureFilter (the operator filter.pict.swift:20-47 sketches): one full-canvas layer = convert + bilinear
+    scale; equals the oracle's kernel run with the literal full-canvas uniforms after a clear."""
+    (W, H), (w, h) = (192, 108), (128, 72)
+    planes = util.alloc_image(src_fmt, W, H, seed=91)
+    cpu = sv.pictureFromArrays(G.FMT[src_fmt], (W, H), planes, assetId="cam", time=3.0, pts=3.5, zIndex=7)
+    filt = sv.PictureFilter((w, h), G.FMT[dst_fmt], computeContext=ctx)
+    tag, out = filt(cpu)                                   # CPU sample: uploaded by the filter
+    assert tag == "just", out
+    assert out.bufferType() == "gpu" and out.size() == (w, h) and out.pixelFormat() == G.FMT[dst_fmt]
+    assert (out.assetId(), out.time(), out.pts(), out.zIndex()) == ("cam", 3.0, 3.5, 7)
+    exp = util.alloc_image(dst_fmt, w, h)
+    assert O.run_kernel(f"img_clear_{dst_fmt}", exp) == 0
+    assert O.run_kernel(kernel, exp, planes, util.full_canvas_uniforms((w, h), (W, H))) == 0
+    G.assert_same(G.from_gpu(ctx, out, dst_fmt, w, h), exp, kernel)
+    tag2, out2 = filt(sv.uploadComputePicture(ctx, cpu))   # GPU sample: used in place, next image of the ring
+    assert tag2 == "just" and out2.imageBuffer().computeTextures[0] is not out.imageBuffer().computeTextures[0]
+    G.assert_same(G.from_gpu(ctx, out2, dst_fmt, w, h), exp, kernel + " (gpu input)")
+
+
+def test_picture_filter_lanczos_and_errors(ctx):
+    (W, H), (w, h) = (160, 90), (64, 36)
+    planes = util.alloc_image("bgra", W, H, seed=92)
+    pic = sv.pictureFromArrays(sv.PixelFormat.BGRA, (W, H), planes)
+    tag, out = sv.PictureFilter((w, h), sv.PixelFormat.BGRA, computeContext=ctx, scaler="lanczos")(pic)
+    assert tag == "just"
+    exp = util.alloc_image("bgra", w, h)
+    assert O.lanczos_bgra(exp[0], planes[0]) == 0
+    G.assert_same(G.from_gpu(ctx, out, "bgra", w, h), exp, "lanczos filter")
+    # no kernel for this pair (nv12 -> rgba is in no table): surfaces as an error event, the filter stays usable
+    nv = sv.pictureFromArrays(sv.PixelFormat.nv12, (W, H), util.alloc_image("nv12", W, H, seed=93))
+    f = sv.PictureFilter((w, h), sv.PixelFormat.RGBA, computeContext=ctx)
+    tag, err = f(nv)
+    assert tag == "error" and err[0] == "filter.pict"
+    tag, err = sv.PictureFilter((w, h), sv.PixelFormat.BGRA, computeContext=ctx, scaler="lanczos")(nv)
+    assert tag == "error"
+    with pytest.raises(sv.ComputeError):
+        sv.PictureFilter((w, h), scaler="bicubic")
