@@ -23,7 +23,10 @@
  * All coordinates/arith are IEEE binary32 with no fused contraction (build
  * with -ffp-contract=off), operations in reference source order, dot() summed
  * left to right ((x+y)+z)+w as in the reference's only explicit definition
- * (kernels.cuda.swift:45-47).
+ * (kernels.cuda.swift:45-47).  The kernels whose specification this repository
+ * owns (ids 32.., the BGRA-target family, and Lanczos-3) use explicit fmaf()
+ * where their specification says "fused" (DESIGN.md section 4): the BGRA-target
+ * family evaluates samples, fill and blend on the 0..255 code scale.
  */
 #ifndef ORACLE_REF_KERNELS_H
 #define ORACLE_REF_KERNELS_H
