@@ -152,22 +152,23 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
     const int xq = x0 + txi, yq = y0 + ly;              // this thread's pixels: (xq + 16*k, yq + 16*r)
     const bool active = xq < T.W && yq < T.H;
     float cb[RROWS][RCOLS], cg[RROWS][RCOLS], cr[RROWS][RCOLS];
-    uint32_t orig_a[RROWS][RCOLS];
+    uint32_t orig_a[RROWS];                             // the RCOLS original alpha bytes of a row, packed
     unsigned touched = CLEAR ? ~0u : 0u;                // bit r*4+k; untouched pixels keep their original alpha byte
 #pragma unroll
     for (int r = 0; r < RROWS; r++)
 #pragma unroll
-        for (int k = 0; k < RCOLS; k++) { cb[r][k] = 0.f; cg[r][k] = 0.f; cr[r][k] = 0.f; orig_a[r][k] = 0; }   // img_clear_bgra: (0,0,0,1)
+        for (int k = 0; k < RCOLS; k++) { cb[r][k] = 0.f; cg[r][k] = 0.f; cr[r][k] = 0.f; }   // img_clear_bgra: (0,0,0,1)
     if (!CLEAR && active) {
 #pragma unroll
         for (int r = 0; r < RROWS; r++) {
+            orig_a[r] = 0;
             if (yq + 16 * r >= T.H) continue;
             const uint8_t *drow = D.ptr + (size_t)(yq + 16 * r) * D.pitch;
 #pragma unroll
             for (int k = 0; k < RCOLS; k++) {
                 uint32_t cur = (xq + 16 * k < T.W) ? *(const uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) : 0;
                 cb[r][k] = (float)(cur & 255); cg[r][k] = (float)((cur >> 8) & 255); cr[r][k] = (float)((cur >> 16) & 255);
-                orig_a[r][k] = cur & 0xFF000000u;
+                orig_a[r] |= (cur >> 24) << (8 * k);
             }
         }
     }
@@ -209,13 +210,9 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
             // every pixel of the tile inside the picture the loop is branch-free
             const bool fast = staged && t.csum[5] && t.rsum[5] && nofill && opacity >= 0.f && opacity <= 1.f;
             const float ka = opacity * kInv255;
-            // column entries of this thread's pixels (shared by its rows)
-            int cpo[RCOLS]; float ca[RCOLS], ica[RCOLS];
-#pragma unroll
-            for (int k = 0; k < RCOLS; k++) {
-                const int c = txi + 16 * k;
-                cpo[k] = (t.cp[c] - col0 + 4) * 4; ca[k] = t.ca[c]; ica[k] = 1.0f - ca[k];
-            }
+            // column entries are re-read from the LDS tables per pixel: the LDS pipe is mostly idle in this
+            // kernel and holding them across the rows costs 12 VGPRs (spills at 96)
+            const int coloff = (4 - col0) * 4;
             if (fast) {
 #pragma unroll
                 for (int r = 0; r < RROWS; r++) {
@@ -224,9 +221,12 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
                     const int rowoff = tbase + (t.rp[lr] - g.r_lo) * tpitch;
 #pragma unroll
                     for (int k = 0; k < RCOLS; k++) {
-                        const float w00 = ica[k] * ib, w10 = ca[k] * ib, w01 = ica[k] * b, w11 = ca[k] * b;
-                        const uint32_t *p0 = (const uint32_t *)(smem + rowoff + cpo[k]);
-                        const uint32_t *p1 = (const uint32_t *)(smem + rowoff + tpitch + cpo[k]);
+                        const int c = txi + 16 * k;
+                        const float a = t.ca[c], ia = 1.0f - a;
+                        const int cpo = t.cp[c] * 4 + coloff;
+                        const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
+                        const uint32_t *p0 = (const uint32_t *)(smem + rowoff + cpo);
+                        const uint32_t *p1 = (const uint32_t *)(smem + rowoff + tpitch + cpo);
                         const float4 t00 = codes4(p0[0]), t10 = codes4(p0[1]), t01 = codes4(p1[0]), t11 = codes4(p1[1]);
                         const float q0 = cs_mix(w00, w10, w01, w11, t00.x, t10.x, t01.x, t11.x);
                         const float q1 = cs_mix(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y);
@@ -260,11 +260,13 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
                         float r1 = clampf(__builtin_fmaf(f_g, af, cg[r][k] * iaf), 0.f, 255.f);
                         float r2 = clampf(__builtin_fmaf(f_r, af, cr[r][k] * iaf), 0.f, 255.f);
                         if (in_pic) {
-                            const float w00 = ica[k] * ib, w10 = ca[k] * ib, w01 = ica[k] * b, w11 = ca[k] * b;
+                            const float a = t.ca[c], ia = 1.0f - a;
+                            const int cpo = t.cp[c] * 4 + coloff;
+                            const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
                             uint32_t u00, u10, u01, u11;
                             if (staged) {
-                                const uint32_t *p0 = (const uint32_t *)(smem + rowoff + cpo[k]);
-                                const uint32_t *p1 = (const uint32_t *)(smem + rowoff + tpitch + cpo[k]);
+                                const uint32_t *p0 = (const uint32_t *)(smem + rowoff + cpo);
+                                const uint32_t *p1 = (const uint32_t *)(smem + rowoff + tpitch + cpo);
                                 u00 = p0[0]; u10 = p0[1]; u01 = p1[0]; u11 = p1[1];
                             } else {
                                 int xa = min(max(t.cp[c], 0), S.w - 1), xb = min(max(t.cp[c] + 1, 0), S.w - 1);
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
             uint8_t *drow = D.ptr + (size_t)(yq + 16 * r) * D.pitch;
 #pragma unroll
             for (int k = 0; k < RCOLS; k++) {
-                const uint32_t a8 = ((touched >> (r * 4 + k)) & 1u) ? 0xFF000000u : orig_a[r][k];
+                const uint32_t a8 = ((touched >> (r * 4 + k)) & 1u) ? 0xFF000000u : (((orig_a[r] >> (8 * k)) & 255u) << 24);
                 const uint32_t w = (uint32_t)cb[r][k] | ((uint32_t)cg[r][k] << 8) | ((uint32_t)cr[r][k] << 16) | a8;
                 if (xq + 16 * k < T.W) *(uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) = w;
             }
