@@ -259,6 +259,49 @@ int chv_batch_destroy(chv_batch *batch);
 /* Name of the device kernel a batch dispatches to and its launch count (for profiling). */
 int chv_batch_describe(chv_batch *batch, char *kernel_name, size_t cap, int *n_launches);
 
+/* ---- custom kernels ------------------------------------------------------ */
+/* `ComputeKernel.custom(name:)` + buildComputeKernel (compute.swift:72-73,
+ * compute.cl.swift:153-195, getComputeKernel :218-232): user source compiled at
+ * run time and kept in the context's library under `name`.  Here the source
+ * is HIP C++ compiled with hipRTC for the context's device; it is prefixed
+ * with chv_custom_prelude() (the counterpart of kOpenCLKernelMatrixFuncs,
+ * kernels.cl.swift:25-35, plus the image builtins OpenCL gives a kernel for
+ * free) and must define
+ *     extern "C" __global__ void <name>(chv_custom_args a)
+ * The argument block carries what the reference binds positionally
+ * (compute.cl.swift:288-335): the target planes, the same planes again as
+ * `current` when `blends` (n_planes = 0 otherwise), the input images, the
+ * uniforms' bytes.  Launch domain: one thread per texel of target plane 0 in
+ * 16x16 blocks, rounded up — kernels test their coordinates (CHV_GUARD). */
+#define CHV_CUSTOM_MAX_INPUTS 4
+#define CHV_CUSTOM_MAX_UNIFORMS 256
+typedef struct chv_dev_plane {
+    uint8_t *ptr;                     /* device address of texel (0, 0) */
+    int32_t width, height, pitch, components;
+} chv_dev_plane;
+typedef struct chv_dev_image {
+    chv_dev_plane planes[3];
+    int32_t n_planes, format;
+} chv_dev_image;
+typedef struct chv_custom_args {
+    chv_dev_image target, current;
+    chv_dev_image inputs[CHV_CUSTOM_MAX_INPUTS];
+    int32_t n_inputs, uniforms_size;
+    uint8_t uniforms[CHV_CUSTOM_MAX_UNIFORMS];
+} chv_custom_args;
+/* The text every custom source is prefixed with (struct definitions above, vecmat4, unorm8 load/store,
+ * nearest and linear samplers with the semantics of the built-in kernels). */
+const char *chv_custom_prelude(void);
+/* buildComputeKernel.  Replaces an earlier kernel of the same name in this context's library; contexts made
+ * with chv_context_share afterwards inherit the library.  Compile or lookup failure:
+ * CHV_ERR_BAD_INPUT ("Unable to create kernel named ..."), build log in chv_last_error_detail(). */
+int chv_kernel_build(chv_context *ctx, const char *name, const char *source);
+/* runComputeKernel(kernel: .custom(name)).  CHV_ERR_KERNEL_NOT_FOUND if `name` is not in the library;
+ * at most CHV_CUSTOM_MAX_INPUTS images and CHV_CUSTOM_MAX_UNIFORMS uniform bytes. */
+int chv_run_custom(chv_context *ctx, const char *name, const chv_image *target,
+                   const chv_image *inputs, int n_inputs,
+                   const void *uniforms, size_t uniforms_size, int blends);
+
 /* ---- resampling --------------------------------------------------------- */
 /* Separable Lanczos-3 resize of a 4-component image (BGRA or RGBA) from `src`
  * to `dst` size.  No reference counterpart; DESIGN.md section 4.4. */

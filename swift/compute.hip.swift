@@ -125,9 +125,25 @@ func destroyComputeContext( _ context: ComputeContext) throws {
     try check(chv_context_destroy(context.handle))
 }
 
+/// compute.cl.swift:153-195.  `source` is HIP C++ here (compiled with hipRTC for the context's device, prefixed
+/// with chv_custom_prelude()) and must define `extern "C" __global__ void <name>(chv_custom_args a)`.
+/// The library lives in the native context; contexts created with createComputeContext(sharing:) afterwards
+/// inherit it, as `ComputeContext(other:)` copies `library` in the OpenCL backend (:82-87).
 func buildComputeKernel(_ context: ComputeContext, name: String, source: String) throws -> ComputeContext {
-    // runtime-compiled user kernels (.custom) are not part of the picture path
-    throw ComputeError.notImplemented
+    context.logger.info("buildComputeKernel")
+    let status = chv_kernel_build(context.handle, name, source)
+    if status != CHV_OK.rawValue, let detail = chv_last_error_detail() {
+        context.logger.info("Build log:\n\(String(cString: detail))")
+    }
+    try check(status)
+    return context
+}
+
+/// name of a user kernel: a `.custom` whose name the built-in table does not know
+private func userKernelName(_ kernel: ComputeKernel) -> String? {
+    guard case .custom(let name) = kernel else { return nil }
+    var id: Int32 = -1
+    return chv_kernel_from_string(name, &id) == CHV_OK.rawValue ? nil : name
 }
 
 // MARK: - Passes and kernels (compute.cl.swift:234-359)
@@ -209,8 +225,21 @@ func runComputeKernel<T>(_ context: ComputeContext,
         }
         return desc
     }
-    let id = try kernelId(kernel)
     let status: Int32
+    if let user = userKernelName(kernel) {
+        // getComputeKernel's `.custom` branch (compute.cl.swift:218-232): a kernel from the context's library
+        if var uniforms = uniforms {
+            status = withUnsafeBytes(of: &uniforms) { raw in
+                chv_run_custom(context.handle, user, &targetDesc, &inputs, Int32(inputs.count),
+                               raw.baseAddress, MemoryLayout<T>.size, blends ? 1 : 0)
+            }
+        } else {
+            status = chv_run_custom(context.handle, user, &targetDesc, &inputs, Int32(inputs.count), nil, 0, blends ? 1 : 0)
+        }
+        try check(status, kernel: kernel)
+        return context
+    }
+    let id = try kernelId(kernel)
     if var uniforms = uniforms {
         status = withUnsafeBytes(of: &uniforms) { raw in
             chv_run_kernel(context.handle, id, &targetDesc, &inputs, Int32(inputs.count),

@@ -29,7 +29,7 @@ __all__ = [
     "destroyComputeContext", "beginComputePass", "endComputePass", "usingContext", "runComputeKernel",
     "applyComputeImage", "uploadComputePicture", "downloadComputePicture", "uploadComputeBuffer",
     "downloadComputeBuffer", "createPictureSample", "GPUBarrierUpload", "GPUBarrierDownload", "VideoMixer",
-    "compositeTick", "scaleLanczos", "PictureFilter",
+    "compositeTick", "scaleLanczos", "PictureFilter", "CustomKernel", "buildComputeKernel",
 ]
 
 
@@ -434,6 +434,23 @@ def _uniform_blob(uniforms):
     return np.ascontiguousarray(uniforms, dtype=np.float32).reshape(-1)
 
 
+class CustomKernel:
+    """`ComputeKernel.custom(name:)`, compute.swift:72-73: a kernel built at run time with buildComputeKernel."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __str__(self):
+        return self.name
+
+
+def buildComputeKernel(ctx, name, source):
+    """compute.cl.swift:153-195: compile `source` (HIP C++ here, prefixed with cv.custom_prelude()) and put its
+    kernel `name` into the context's library; throws ComputeError.badInputData with the build log on failure."""
+    cv.check(cv.load().chv_kernel_build(ctx.handle, name.encode(), source.encode()))
+    return ctx
+
+
 def runComputeKernel(ctx, images, target, kernel, maxPlanes=3, requiredMemory=None, uniforms=None,
                      blends=False, colorspace=cv.CSC_BT601_LIMITED):
     """Both overloads of runComputeKernel, compute.cl.swift:250-344."""
@@ -446,6 +463,16 @@ def runComputeKernel(ctx, images, target, kernel, maxPlanes=3, requiredMemory=No
         if d is None:
             raise ComputeError(5, "Bad input image")
         descs[i] = d
+    if isinstance(kernel, CustomKernel):      # ComputeKernel.custom(name:), compute.swift:72-73
+        # uniforms: any value type in the reference (MemoryLayout<T>.size bytes are bound, compute.cl.swift:508-512)
+        if isinstance(uniforms, (bytes, bytearray)):
+            u = np.frombuffer(bytes(uniforms), dtype=np.uint8)
+        else:
+            u = _uniform_blob(uniforms)
+        cv.check(cv.load().chv_run_custom(ctx.handle, kernel.name.encode(), C.byref(tdesc), descs, len(images),
+                                          u.ctypes.data if u is not None else None,
+                                          u.nbytes if u is not None else 0, 1 if blends else 0))
+        return ctx
     u = _uniform_blob(uniforms)
     opts = cv.KernelOpts(colorspace=int(colorspace))
     cv.check(cv.load().chv_run_kernel(ctx.handle, int(kernel), C.byref(tdesc), descs, len(images),

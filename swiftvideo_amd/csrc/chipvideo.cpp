@@ -7,6 +7,7 @@
 #include "../../include/chipvideo.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <atomic>
 #include <cstdarg>
@@ -167,6 +168,16 @@ struct DeviceShared {
     }
 };
 
+// A run-time compiled kernel (`ComputeKernel.custom`): the module lives as long as any context's library names it.
+struct CustomKernel {
+    int device = 0;
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+    ~CustomKernel() {
+        if (module) { (void)hipSetDevice(device); (void)hipModuleUnload(module); }
+    }
+};
+
 struct StagingSlot {
     void *host = nullptr;
     size_t cap = 0;
@@ -195,6 +206,8 @@ struct chv_context {
     uint8_t *desc_host = nullptr;
     DescSlot desc[kDescSlots];
     int next_desc = 0;
+    // `library` of the reference's ComputeContext (compute.cl.swift:66-73): name -> built kernel
+    std::map<std::string, std::shared_ptr<CustomKernel>> library;
 };
 
 struct chv_buffer {
@@ -299,7 +312,9 @@ extern "C" int chv_context_share(chv_context *parent, chv_context **out) {
     if (!out) return fail(CHV_ERR_INVALID_VALUE, "null argument");
     *out = nullptr;
     if (!ctx_ok(parent)) return fail(CHV_ERR_INVALID_CONTEXT, "bad parent context");
-    return context_new(parent->device, parent->shared, out);
+    int rc = context_new(parent->device, parent->shared, out);
+    if (rc == CHV_OK) (*out)->library = parent->library;      // ComputeContext(other:) copies the library, compute.cl.swift:82-87
+    return rc;
 }
 
 extern "C" int chv_context_destroy(chv_context *c) {
@@ -714,6 +729,7 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     HIP_TRY(hipHostGetDevicePointer((void **)&dt, ht, 0));
     DLayer *dl = (DLayer *)((uint8_t *)dt + sizeof(DTick));
     int path = select_fast_path(tf, ht, hl, 1);
+    (void)hipGetLastError();   // the launchers report through hipGetLastError(): drop whatever an earlier, unrelated call left there
     hipError_t e = path >= 0 ? launch_tick_fast(path, ht, hl, dt, dl, 1, ht->W, ht->H, c->stream)
                              : launch_tick_general(tf, dt, dl, 1, ht->W, ht->H, c->stream);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -856,6 +872,7 @@ extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
     HIP_TRY(hipSetDevice(c->device));
     int wrc = wait_for_uploads(c->stream, b->deps);
     if (wrc) return wrc;
+    (void)hipGetLastError();   // see launch_transient
     hipError_t e = b->fast_path >= 0
         ? launch_tick_fast(b->fast_path, b->h_ticks.data(), b->h_layers.data(), b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
         : launch_tick_general(b->target_format, b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
@@ -883,6 +900,165 @@ extern "C" int chv_batch_describe(chv_batch *b, char *kernel_name, size_t cap, i
 // ---------------------------------------------------------------------------
 // Lanczos-3: tables in double on the host, resampling on the GPU
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// custom kernels (compute.swift:72-73, compute.cl.swift:153-232) through hipRTC
+// ---------------------------------------------------------------------------
+static const char kCustomPrelude[] = R"CHV(
+// ---- CHIPVideo custom-kernel prelude (prefixed to every source given to chv_kernel_build) ----
+typedef unsigned char uint8_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+struct chv_dev_plane { uint8_t *ptr; int32_t width, height, pitch, components; };
+struct chv_dev_image { chv_dev_plane planes[3]; int32_t n_planes, format; };
+struct chv_custom_args {
+    chv_dev_image target, current;
+    chv_dev_image inputs[4];
+    int32_t n_inputs, uniforms_size;
+    uint8_t uniforms[256];
+};
+// ImageUniforms, compute.swift:76-86 (236 bytes); each matrix holds the rows of M^-1
+struct ImageUniforms {
+    float transform[16], textureTransform[16], borderMatrix[16];
+    float fillColor[4], inputSize[2], outputSize[2];
+    float opacity, imageTime, targetTime;
+};
+#define CHV_GID_X ((int)(blockIdx.x * blockDim.x + threadIdx.x))
+#define CHV_GID_Y ((int)(blockIdx.y * blockDim.y + threadIdx.y))
+// the launch is rounded up to 16x16 blocks: leave when outside plane `p`
+#define CHV_GUARD(p) do { if (CHV_GID_X >= (p).width || CHV_GID_Y >= (p).height) return; } while (0)
+// vecmat4, kernels.cl.swift:27: (dot(v, row0), dot(v, row1), dot(v, row2), dot(v, row3))
+__device__ inline float4 chv_vecmat4(float4 v, const float *m) {
+    return make_float4(((v.x * m[0] + v.y * m[1]) + v.z * m[2]) + v.w * m[3], ((v.x * m[4] + v.y * m[5]) + v.z * m[6]) + v.w * m[7],
+                       ((v.x * m[8] + v.y * m[9]) + v.z * m[10]) + v.w * m[11], ((v.x * m[12] + v.y * m[13]) + v.z * m[14]) + v.w * m[15]);
+}
+// UNORM_INT8 conversions of OpenCL 1.2 section 8.3.1.1
+__device__ inline float chv_unorm8(uint8_t c) { return (float)c / 255.0f; }
+__device__ inline uint8_t chv_to_unorm8(float f) {
+    float v = rintf(f * 255.0f);
+    return (uint8_t)fminf(fmaxf(v, 0.0f), 255.0f);         // NaN -> 0
+}
+// read_imagef, nearest, unnormalized integer coordinates (zero outside the plane)
+__device__ inline float chv_read(const chv_dev_plane &p, int x, int y, int c) {
+    if (x < 0 || y < 0 || x >= p.width || y >= p.height) return 0.0f;
+    return chv_unorm8(p.ptr[(size_t)y * p.pitch + (size_t)x * p.components + c]);
+}
+// write_imagef of one component (dropped outside the plane)
+__device__ inline void chv_write(const chv_dev_plane &p, int x, int y, int c, float f) {
+    if (x < 0 || y < 0 || x >= p.width || y >= p.height) return;
+    p.ptr[(size_t)y * p.pitch + (size_t)x * p.components + c] = chv_to_unorm8(f);
+}
+// read_imagef, LINEAR | CLAMP_TO_EDGE | NORMALIZED (OpenCL 1.2 section 8.2), component c
+__device__ inline float chv_sample(const chv_dev_plane &p, float u, float v, int c) {
+    float um = u * (float)p.width - 0.5f, vm = v * (float)p.height - 0.5f;
+    float fu = floorf(um), fv = floorf(vm);
+    float a = um - fu, b = vm - fv;
+    int i0 = min(max((int)fu, 0), p.width - 1), i1 = min(max((int)fu + 1, 0), p.width - 1);
+    int j0 = min(max((int)fv, 0), p.height - 1), j1 = min(max((int)fv + 1, 0), p.height - 1);
+    const uint8_t *r0 = p.ptr + (size_t)j0 * p.pitch + c, *r1 = p.ptr + (size_t)j1 * p.pitch + c;
+    float t00 = chv_unorm8(r0[i0 * p.components]), t10 = chv_unorm8(r0[i1 * p.components]);
+    float t01 = chv_unorm8(r1[i0 * p.components]), t11 = chv_unorm8(r1[i1 * p.components]);
+    return (((1.0f - a) * (1.0f - b) * t00 + a * (1.0f - b) * t10) + (1.0f - a) * b * t01) + a * b * t11;
+}
+// ---- end of prelude ----
+#line 1 "custom_kernel"
+)CHV";
+
+extern "C" const char *chv_custom_prelude(void) { return kCustomPrelude; }
+
+extern "C" int chv_kernel_build(chv_context *c, const char *name, const char *source) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!name || !*name || !source) return fail(CHV_ERR_INVALID_VALUE, "null kernel name or source");
+    (void)hipSetDevice(c->device);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    std::string text = std::string(kCustomPrelude) + source;
+    hiprtcProgram prog = nullptr;
+    if (hiprtcCreateProgram(&prog, text.c_str(), name, 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail(CHV_ERR_UNKNOWN, "hiprtcCreateProgram failed");
+    std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+    const char *opts[] = { arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17" };
+    hiprtcResult cr = hiprtcCompileProgram(prog, 4, opts);
+    if (cr != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        std::string log;
+        if (hiprtcGetProgramLogSize(prog, &n) == HIPRTC_SUCCESS && n > 1) { log.resize(n); (void)hiprtcGetProgramLog(prog, &log[0]); }
+        (void)hiprtcDestroyProgram(&prog);
+        if (log.size() > 3000) log.resize(3000);
+        return fail(CHV_ERR_BAD_INPUT, "Unable to create kernel named %s (%s)\nBuild log:\n%s", name, hiprtcGetErrorString(cr), log.c_str());
+    }
+    size_t code_size = 0;
+    std::vector<char> code;
+    if (hiprtcGetCodeSize(prog, &code_size) != HIPRTC_SUCCESS || code_size == 0) { (void)hiprtcDestroyProgram(&prog); return fail(CHV_ERR_UNKNOWN, "hiprtcGetCodeSize failed"); }
+    code.resize(code_size);
+    hiprtcResult gr = hiprtcGetCode(prog, code.data());
+    (void)hiprtcDestroyProgram(&prog);
+    if (gr != HIPRTC_SUCCESS) return fail(CHV_ERR_UNKNOWN, "hiprtcGetCode failed");
+    auto k = std::make_shared<CustomKernel>();
+    k->device = c->device;
+    hipError_t e = hipModuleLoadData(&k->module, code.data());
+    if (e != hipSuccess) return hip_fail(e, "hipModuleLoadData");
+    e = hipModuleGetFunction(&k->fn, k->module, name);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CHV_ERR_BAD_INPUT, "Unable to create kernel named %s: the source defines no extern \"C\" __global__ function of that name", name);
+    }
+    c->library[name] = std::move(k);     // merging { $1 }: the new kernel replaces an older one (compute.cl.swift:190-194)
+    return CHV_OK;
+}
+
+static int image_to_device_any(const chv_image *img, int device, chv_dev_image *out, int err, const char *what) {
+    memset(out, 0, sizeof *out);
+    if (!img) return fail(err, "null %s image", what);
+    if (img->n_planes < 1 || img->n_planes > 3) return fail(err, "%s image has %d planes", what, img->n_planes);
+    for (int i = 0; i < img->n_planes; i++) {
+        const chv_plane &p = img->planes[i];
+        if (p.components != 1 && p.components != 2 && p.components != 4) return fail(err, "%s plane %d: %d components", what, i, p.components);
+        DPlane d;
+        int rc = plane_to_device(p, p.components, device, &d, err, what, i);
+        if (rc) return rc;
+        out->planes[i].ptr = d.ptr; out->planes[i].width = d.w; out->planes[i].height = d.h;
+        out->planes[i].pitch = d.pitch; out->planes[i].components = d.comps;
+    }
+    out->n_planes = img->n_planes;
+    out->format = img->format;
+    return CHV_OK;
+}
+
+extern "C" int chv_run_custom(chv_context *c, const char *name, const chv_image *target,
+                              const chv_image *inputs, int n_inputs,
+                              const void *uniforms, size_t uniforms_size, int blends) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!name) return fail(CHV_ERR_INVALID_VALUE, "null kernel name");
+    auto it = c->library.find(name);
+    if (it == c->library.end()) return fail(CHV_ERR_KERNEL_NOT_FOUND, "no custom kernel named %s in this context's library", name);
+    if (n_inputs < 0 || n_inputs > CHV_CUSTOM_MAX_INPUTS) return fail(CHV_ERR_BAD_INPUT, "%d input images (max %d)", n_inputs, CHV_CUSTOM_MAX_INPUTS);
+    if (n_inputs > 0 && !inputs) return fail(CHV_ERR_BAD_INPUT, "null inputs");
+    if (uniforms_size > CHV_CUSTOM_MAX_UNIFORMS || (uniforms_size && !uniforms))
+        return fail(CHV_ERR_INVALID_VALUE, "%zu uniform bytes (max %d)", uniforms_size, CHV_CUSTOM_MAX_UNIFORMS);
+    (void)hipSetDevice(c->device);
+    chv_custom_args a;
+    memset(&a, 0, sizeof a);
+    DepScope deps;
+    int rc = image_to_device_any(target, c->device, &a.target, CHV_ERR_BAD_TARGET, "target");
+    if (rc) return rc;
+    if (blends) a.current = a.target;
+    for (int i = 0; i < n_inputs; i++) {
+        rc = image_to_device_any(&inputs[i], c->device, &a.inputs[i], CHV_ERR_BAD_INPUT, "input");
+        if (rc) return rc;
+    }
+    a.n_inputs = n_inputs;
+    a.uniforms_size = (int32_t)uniforms_size;
+    if (uniforms_size) memcpy(a.uniforms, uniforms, uniforms_size);
+    auto dp = deps.pairs();
+    rc = wait_for_uploads(c->stream, dp);
+    if (rc) return rc;
+    size_t size = sizeof a;
+    void *config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END };
+    const unsigned gx = (unsigned)(a.target.planes[0].width + 15) / 16, gy = (unsigned)(a.target.planes[0].height + 15) / 16;
+    HIP_TRY(hipModuleLaunchKernel(it->second->fn, gx, gy, 1, 16, 16, 1, 0, c->stream, nullptr, config));
+    return CHV_OK;
+}
+
 static double sinc_pi(double t) {
     if (t == 0.0) return 1.0;
     double pt = 3.14159265358979323846 * t;
@@ -954,6 +1130,7 @@ extern "C" int chv_scale_lanczos(chv_context *c, const chv_image *dst, const chv
     if (rc) return rc;
     rc = lanczos_table(c, s.h, d.h, &ty);
     if (rc) return rc;
+    (void)hipGetLastError();
     hipError_t e = launch_lanczos(d, s, tx.first, tx.weights, tx.taps, ty.first, ty.weights, ty.taps, c->stream);
     if (e != hipSuccess) return hip_fail(e, "lanczos launch");
     return CHV_OK;

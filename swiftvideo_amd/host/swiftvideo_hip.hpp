@@ -337,6 +337,29 @@ inline ComputeContext runComputeKernel(ComputeContext ctx, const std::vector<Pic
     return ctx;
 }
 
+// ---- ComputeKernel.custom(name:) (compute.swift:72-73) + buildComputeKernel (compute.cl.swift:153-195) ----
+struct CustomKernel { std::string name; };
+
+// `source` is HIP C++ (hipRTC), prefixed with chv_custom_prelude(); it defines
+// extern "C" __global__ void <name>(chv_custom_args a).  Failure: ComputeError.badInputData with the build log.
+inline ComputeContext buildComputeKernel(ComputeContext ctx, const std::string &name, const std::string &source) {
+    check(chv_kernel_build(ctx.get(), name.c_str(), source.c_str()));
+    return ctx;
+}
+
+// runComputeKernel<T> with a kernel from the context's library; `uniforms` may be any trivially copyable value
+template <typename T = ImageUniforms>
+inline ComputeContext runComputeKernel(ComputeContext ctx, const std::vector<PictureSample> &images, const PictureSample &target,
+                                       const CustomKernel &kernel, int maxPlanes = 3, const T *uniforms = nullptr, bool blends = false) {
+    chv_image t;
+    if (!describe(target, &t)) throw ComputeError(CHV_ERR_BAD_TARGET, "target has no GPU image buffer");
+    std::vector<chv_image> in(images.size());
+    for (size_t i = 0; i < images.size(); i++)
+        if (!describe(images[i], &in[i], maxPlanes)) throw ComputeError(CHV_ERR_BAD_INPUT, "Bad input image");
+    check(chv_run_custom(ctx.get(), kernel.name.c_str(), &t, in.data(), (int)in.size(), uniforms, uniforms ? sizeof(T) : 0, blends ? 1 : 0));
+    return ctx;
+}
+
 inline ImageUniforms imageUniformsFor(const PictureSample &image, const PictureSample &target) {   // compute.swift:147-161
     ImageUniforms u;
     std::memset(&u, 0, sizeof u);

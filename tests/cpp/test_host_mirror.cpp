@@ -261,6 +261,42 @@ static void gpuTests() {
         auto o3 = bad(src);
         EXPECT(o3.kind == o3.error && o3.err.source == "filter.pict");
     }
+    // .custom kernels through hipRTC: swap B and R of a picture, scaled by a float uniform
+    {
+        const char *src_text =
+            "extern \"C\" __global__ void swap_br(chv_custom_args a) {\n"
+            "    const chv_dev_plane &d = a.target.planes[0]; CHV_GUARD(d);\n"
+            "    const chv_dev_plane &s = a.inputs[0].planes[0];\n"
+            "    float gain = *(const float *)a.uniforms;\n"
+            "    int x = CHV_GID_X, y = CHV_GID_Y;\n"
+            "    chv_write(d, x, y, 0, chv_read(s, x, y, 2) * gain); chv_write(d, x, y, 1, chv_read(s, x, y, 1) * gain);\n"
+            "    chv_write(d, x, y, 2, chv_read(s, x, y, 0) * gain); chv_write(d, x, y, 3, 1.0f);\n"
+            "}\n";
+        sv::PictureSample pic = randomPicture(sv::PixelFormat::BGRA, 50, 20, 41);
+        auto gsrc = sv::uploadComputePicture(ctx, pic);
+        auto gdst = sv::uploadComputePicture(ctx, sv::createPictureSample({ 50, 20 }, sv::PixelFormat::BGRA));
+        sv::CustomKernel k{ "swap_br" };
+        try { sv::runComputeKernel<float>(ctx, { gsrc }, gdst, k); EXPECT(false); }
+        catch (const sv::ComputeError &e) { EXPECT(e.caseName == "computeKernelNotFound"); }
+        try { sv::buildComputeKernel(ctx, "bad", "extern \"C\" __global__ void bad(chv_custom_args a) { oops }"); EXPECT(false); }
+        catch (const sv::ComputeError &e) { EXPECT(e.caseName == "badInputData"); }
+        ctx = sv::buildComputeKernel(ctx, "swap_br", src_text);
+        float gain = 0.5f;
+        ctx = sv::usingContext(ctx, [&](sv::ComputeContext c) { return sv::runComputeKernel<float>(c, { gsrc }, gdst, k, 3, &gain); });
+        auto got = sv::downloadComputePicture(ctx, gdst, true);
+        const uint8_t *in = pic.img->buffers[0]->data(), *out = got.img->buffers[0]->data();
+        int stride_in = pic.img->planes[0].stride, stride_out = got.img->planes[0].stride;
+        bool ok = true;
+        for (int y = 0; y < 20 && ok; y++) for (int x = 0; x < 50 && ok; x++) {
+            const uint8_t *p = in + y * stride_in + x * 4, *q = out + y * stride_out + x * 4;
+            for (int c = 0; c < 3; c++) {
+                float f = ((float)p[2 - c] / 255.0f) * 0.5f;
+                ok = ok && q[c] == orc_store_unorm8(f);
+            }
+            ok = ok && q[3] == 255;
+        }
+        EXPECT(ok);
+    }
     sv::destroyComputeContext(ctx);
 }
 

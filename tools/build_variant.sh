@@ -10,5 +10,5 @@ for f in chipvideo.cpp kernels_general.hip.cpp kernels_fast.hip.cpp kernels_fast
   /opt/rocm/bin/hipcc $FLAGS "$@" -x hip -c $f -o ../../variants/obj_$NAME/${f%.cpp}.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/$NAME.so ../../variants/obj_$NAME/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/$NAME.so ../../variants/obj_$NAME/*.o -lhiprtc
 rm -rf ../../variants/obj_$NAME
