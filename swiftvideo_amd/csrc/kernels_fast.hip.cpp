@@ -156,18 +156,18 @@ CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, const DPlane
     int x0 = min(max(ix, 0), SY.w - 1), x1 = min(max(ix + 1, 0), SY.w - 1);
     int y0 = min(max(iy, 0), SY.h - 1), y1 = min(max(iy + 1, 0), SY.h - 1);
     const uint8_t *p0 = SY.ptr + (size_t)y0 * SY.pitch, *p1 = SY.ptr + (size_t)y1 * SY.pitch;
-    fy = cs_mix(w00, w10, w01, w11, (float)p0[x0], (float)p0[x1], (float)p1[x0], (float)p1[x1]);
+    fy = cs_mix(w00, w10, w01, w11, (float)gld<uint8_t>(p0 + x0), (float)gld<uint8_t>(p0 + x1), (float)gld<uint8_t>(p1 + x0), (float)gld<uint8_t>(p1 + x1));
     int u0 = min(max(cx, 0), SC.w - 1), u1 = min(max(cx + 1, 0), SC.w - 1);
     int v0 = min(max(cy, 0), SC.h - 1), v1 = min(max(cy + 1, 0), SC.h - 1);
     const uint8_t *q0 = SC.ptr + (size_t)v0 * SC.pitch, *q1 = SC.ptr + (size_t)v1 * SC.pitch;
     uint32_t a00, a10, a01, a11;
     if (SV) {
         const uint8_t *z0 = SV->ptr + (size_t)v0 * SV->pitch, *z1 = SV->ptr + (size_t)v1 * SV->pitch;
-        a00 = q0[u0] | (z0[u0] << 8); a10 = q0[u1] | (z0[u1] << 8);
-        a01 = q1[u0] | (z1[u0] << 8); a11 = q1[u1] | (z1[u1] << 8);
+        a00 = gld<uint8_t>(q0 + u0) | (gld<uint8_t>(z0 + u0) << 8); a10 = gld<uint8_t>(q0 + u1) | (gld<uint8_t>(z0 + u1) << 8);
+        a01 = gld<uint8_t>(q1 + u0) | (gld<uint8_t>(z1 + u0) << 8); a11 = gld<uint8_t>(q1 + u1) | (gld<uint8_t>(z1 + u1) << 8);
     } else {
-        a00 = *(const uint16_t *)(q0 + u0 * 2); a10 = *(const uint16_t *)(q0 + u1 * 2);
-        a01 = *(const uint16_t *)(q1 + u0 * 2); a11 = *(const uint16_t *)(q1 + u1 * 2);
+        a00 = gld<uint16_t>(q0 + u0 * 2); a10 = gld<uint16_t>(q0 + u1 * 2);
+        a01 = gld<uint16_t>(q1 + u0 * 2); a11 = gld<uint16_t>(q1 + u1 * 2);
     }
     fu = cs_mix(c00, c10, c01, c11, (float)(a00 & 255), (float)(a10 & 255), (float)(a01 & 255), (float)(a11 & 255));
     fv = cs_mix(c00, c10, c01, c11, (float)(a00 >> 8), (float)(a10 >> 8), (float)(a01 >> 8), (float)(a11 >> 8));
@@ -187,8 +187,10 @@ CHV_DEV void stage_store_uv_planar(const uint4 (&uregs)[N], const uint4 (&vregs)
             uint4 uu = uregs[n], vw = vregs[n];
             if (g.edge) {
                 int row = min(max(g.r_lo + r, 0), PU.h - 1);
-                uu = patch_edges<1>(uu, PU, row, g.b0 + v * 16);
-                vw = patch_edges<1>(vw, PV, row, g.b0 + v * 16);
+                int off = g.b0 + v * 16;
+                if (off >= 0 && off < PU.w && !vec_loadable(PU, row, off)) { uu = load_tail_vec(PU, row, off); vw = load_tail_vec(PV, row, off); }
+                uu = patch_edges<1>(uu, PU, row, off);
+                vw = patch_edges<1>(vw, PV, row, off);
             }
             float4 *d = (float4 *)(lds + r * lds_pitch + 128 + v * 128);
             const uint32_t us[4] = { uu.x, uu.y, uu.z, uu.w }, vs[4] = { vw.x, vw.y, vw.z, vw.w };
@@ -326,6 +328,14 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     const CscFolded cscb = csc_fold_biased(kCsc[L.csc & 3]);
     const bool opaque = (L.flags & LF_OPAQUE) != 0;
 
+    // gfx950 counts loads and stores in ONE vmcnt, and the compiler's wait insertion is conservative across the
+    // loop: left alone it puts `s_waitcnt vmcnt(0)` in front of every prefetch load of the next iteration (the
+    // destination registers "may still be pending"), which serialises the loads and waits for the tile's stores
+    // to drain.  An explicit wait at the end of the compute phase — where the prefetched vectors have long landed
+    // and no store is outstanding — tells it that nothing but stores is pending from there on.
+    auto wait_prefetch_landed = []() { vmem_wait_all(); };
+
+    wait_prefetch_landed();      // tile 0's vectors (issued before the column setup above)
     for (int j = 0; j < ntiles; j++) {
         // ---- phase 1: the prefetched rectangle of tile j goes to LDS ------------------------
         if (staged) {
@@ -364,17 +374,21 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
             }
         };
         auto store_row = [&](uint8_t *drow, const uint32_t (&outw)[PXT]) {
-            if (PXT == 4) *(uint4 *)(drow + (size_t)xq * 4) = make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]);
-            else if (PXT == 2) *(uint2 *)(drow + (size_t)xq * 4) = make_uint2(outw[0], outw[PXT - 1]);
-            else *(uint32_t *)(drow + (size_t)xq * 4) = outw[0];
+            if (PXT == 4) gst<uint4>(drow + (size_t)xq * 4, make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]));
+            else if (PXT == 2) gst<uint2>(drow + (size_t)xq * 4, make_uint2(outw[0], outw[PXT - 1]));
+            else gst<uint32_t>(drow + (size_t)xq * 4, outw[0]);
         };
         const bool fast_tile = uniform_inside && opaque;
-        if (fast_tile && full4 && ys0 + (j + 1) * TH <= T.H) {
+        const bool whole_tile = fast_tile && full4 && ys0 + (j + 1) * TH <= T.H;
+        uint32_t outw[RPT][PXT];
+        if (whole_tile) {
             // whole tile on the common path: one straight-line block for all RPT rows, so the
             // LDS reads of a later row are in flight while an earlier row is computed
-            uint32_t outw[RPT][PXT];
 #pragma unroll
             for (int rr = 0; rr < RPT; rr++) fast_row(j * TH + tyi + rr * TYT, outw[rr]);
+        }
+        wait_prefetch_landed();        // on every path, before any store of this tile
+        if (whole_tile) {
 #pragma unroll
             for (int rr = 0; rr < RPT; rr++) store_row(D.ptr + (size_t)(ys0 + j * TH + tyi + rr * TYT) * D.pitch, outw[rr]);
         } else if (xq < T.W) {
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
                 if (fast_tile) {
                     fast_row(ly, outw);
                     if (full4) store_row(drow, outw);
-                    else for (int k = 0; k < PXT; k++) if (xq + k < T.W) *(uint32_t *)(drow + (size_t)(xq + k) * 4) = outw[k];
+                    else for (int k = 0; k < PXT; k++) if (xq + k < T.W) gst<uint32_t>(drow + (size_t)(xq + k) * 4, outw[k]);
                     continue;
                 }
                 // tiles on a picture/border edge, translucent layers, unstaged tiles: one pixel at a
@@ -401,8 +415,8 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
                     if (xq + k >= T.W) break;
                     const int c = txi * PXT + k;
                     const int fl = tb.cfl[c] & rfl;
-                    uint32_t *dp = (uint32_t *)(drow + (size_t)(xq + k) * 4);
-                    uint32_t cpx = CLEAR ? 0xFF000000u : *dp;
+                    uint8_t *dp = drow + (size_t)(xq + k) * 4;
+                    uint32_t cpx = CLEAR ? 0xFF000000u : gld<uint32_t>(dp);
                     if (fl & AX_BORDER) {
                         const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
                         uint32_t w = 0;
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
                         }
                         cpx = blend_bgra_general(cpx, U, in_pic, w);
                     }
-                    *dp = cpx;
+                    gst<uint32_t>(dp, cpx);
                 }
             }
         }
@@ -458,7 +472,8 @@ static TileDims tile_dims(const DTick &T, const DLayer &L) {
     return d;
 }
 
-static bool aligned16(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0; }
+// what the staged loads need: 16-byte aligned base and pitch, rows of at least one 16-byte vector
+static bool aligned16(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0 && p.w * p.comps >= 16; }
 
 const char *fast_path_name(int path) {
     switch (path) {

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
         const DLayer &Ly = L[l];
         const DPlane &S = Ly.src.pl[0];
         const RgbLayerTable &t = tabs[l];
+        vmem_wait_all();                  // the prefetched vectors (stage_load's loads are not tracked by the compiler)
         if (staged) stage_store<4, false>(regs, smem + tbase, tpitch, S, g, tid);
         __syncthreads();
         const int ln = next_hit(l + 1);
@@ -316,7 +317,7 @@ static bool finite16r(const float *m) {
     for (int i = 0; i < 16; i++) if (!(m[i] - m[i] == 0.f)) return false;
     return true;
 }
-static bool aligned16r(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0; }
+static bool aligned16r(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0 && p.w * p.comps >= 16; }
 
 static void rgb_tile_dims(const DTick &T, const DLayer &L, int *pitch, int *rows) {
     const float *U = L.u;

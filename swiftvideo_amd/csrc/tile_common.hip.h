@@ -54,17 +54,19 @@ CHV_DEV void codes16(const uint4 &v, float4 &f0, float4 &f1, float4 &f2, float4 
     f0 = codes4(v.x); f1 = codes4(v.y); f2 = codes4(v.z); f3 = codes4(v.w);
 }
 
-// 16 bytes at byte offset `off` of row `row` of a plane whose base and pitch are 16-byte
-// aligned (host-checked).  A vector that would run past the end of the LAST row is read
-// bytewise; bytes past the row's payload are don't-care.
-CHV_DEV uint4 load_row_vec(const DPlane &P, int row, int off) {
+// Does the 16-byte vector at byte offset `off` of row `row` lie inside the plane's allocation as one
+// aligned load?  Not when it starts outside the row, and not when it would run past the end of the LAST
+// row (planes on the tiled paths have base and pitch 16-byte aligned and rows of >= 16 bytes, host-checked).
+CHV_DEV bool vec_loadable(const DPlane &P, int row, int off) {
     const int row_bytes = P.w * P.comps;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (off < 0 || off >= row_bytes) return val;
+    return off >= 0 && off < row_bytes && (row < P.h - 1 || off + 16 <= row_bytes);
+}
+// the last row's tail vector, read bytewise (bytes past the row's payload are don't-care)
+CHV_DEV uint4 load_tail_vec(const DPlane &P, int row, int off) {
+    const int row_bytes = P.w * P.comps;
     const uint8_t *s = P.ptr + (size_t)row * P.pitch + off;
-    if (row < P.h - 1 || off + 16 <= row_bytes) return *(const uint4 *)s;
     uint32_t w[4] = { 0, 0, 0, 0 };
-    for (int k = 0; k < 16 && off + k < row_bytes; k++) w[k >> 2] |= (uint32_t)s[k] << ((k & 3) * 8);
+    for (int k = 0; k < 16 && off + k < row_bytes; k++) w[k >> 2] |= (uint32_t)gld<uint8_t>(s + k) << ((k & 3) * 8);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -79,12 +81,12 @@ CHV_DEV uint4 patch_edges(uint4 val, const DPlane &P, int row, int off) {
     uint32_t w[4] = { val.x, val.y, val.z, val.w };
     if (off < 0) {
         // padding vector in front of texel 0: only its last texel slot is ever addressed
-        uint32_t e = BPT == 1 ? (uint32_t)s[0] << 24 : BPT == 2 ? (uint32_t)(*(const uint16_t *)s) << 16 : *(const uint32_t *)s;
+        uint32_t e = BPT == 1 ? (uint32_t)gld<uint8_t>(s) << 24 : BPT == 2 ? (uint32_t)gld<uint16_t>(s) << 16 : gld<uint32_t>(s);
         w[3] = (w[3] & (BPT == 1 ? 0x00FFFFFFu : BPT == 2 ? 0x0000FFFFu : 0u)) | e;
     } else {
-        uint32_t e = BPT == 1 ? (uint32_t)s[row_bytes - 1] * 0x01010101u
-                   : BPT == 2 ? (uint32_t)(*(const uint16_t *)(s + row_bytes - 2)) * 0x00010001u
-                              : *(const uint32_t *)(s + row_bytes - 4);
+        uint32_t e = BPT == 1 ? (uint32_t)gld<uint8_t>(s + row_bytes - 1) * 0x01010101u
+                   : BPT == 2 ? (uint32_t)gld<uint16_t>(s + row_bytes - 2) * 0x00010001u
+                              : gld<uint32_t>(s + row_bytes - 4);
         int nvalid = max(row_bytes - off, 0);     // bytes of this vector inside the row
 #pragma unroll
         for (int d = 0; d < 4; d++) {
@@ -123,15 +125,21 @@ CHV_DEV void stage_slot(const StageGeom &g, int i, int &r, int &vv) {
 
 template <int N>
 CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, int tid) {
+    // Exactly one global_load_dwordx4 per slot, straight into its final register and invisible to the
+    // compiler's wait insertion (gld16_untracked): any control flow that merges differently-produced values
+    // here makes the compiler copy — and therefore wait for — the loaded registers on the spot, and the
+    // prefetch would hide nothing.  Callers place vmem_wait_all() before the matching stage_store.  Vectors that are
+    // not loadable as such (outside the row: their texels are replaced by patch_edges anyway; the last
+    // row's tail: re-read bytewise in stage_store) load the row's first vector instead.
 #pragma unroll
     for (int n = 0; n < N; n++) {
         int i = tid + n * NTHREADS, r, vv;
         stage_slot(g, i, r, vv);
-        regs[n] = make_uint4(0, 0, 0, 0);
         if (i < 1024 && r < g.rows) {
             int row = min(max(g.r_lo + r, 0), P.h - 1);
             int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
-            regs[n] = g.edge ? load_row_vec(P, row, off) : *(const uint4 *)(P.ptr + (size_t)row * P.pitch + off);
+            if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
+            gld16_untracked(regs[n], P.ptr + (size_t)row * P.pitch + off);
         }
     }
 }
@@ -152,7 +160,9 @@ CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, co
             uint4 val = regs[n];
             if (g.edge) {
                 int row = min(max(g.r_lo + r, 0), P.h - 1);
-                val = patch_edges<BPT>(val, P, row, g.b0 + v * 16);
+                int off = g.b0 + v * 16;
+                if (off >= 0 && off < P.w * BPT && !vec_loadable(P, row, off)) val = load_tail_vec(P, row, off);
+                val = patch_edges<BPT>(val, P, row, off);
             }
             if (!TO_FLOAT) {
                 *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
