@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
             const uint8_t *drow = D.ptr + (size_t)(yq + 16 * r) * D.pitch;
 #pragma unroll
             for (int k = 0; k < RCOLS; k++) {
-                uint32_t cur = (xq + 16 * k < T.W) ? *(const uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) : 0;
+                uint32_t cur = (xq + 16 * k < T.W) ? gld<uint32_t>(drow + (size_t)(xq + 16 * k) * 4) : 0;
                 cb[r][k] = (float)(cur & 255); cg[r][k] = (float)((cur >> 8) & 255); cr[r][k] = (float)((cur >> 16) & 255);
                 orig_a[r] |= (cur >> 24) << (8 * k);
             }
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
                             } else {
                                 int xa = min(max(t.cp[c], 0), S.w - 1), xb = min(max(t.cp[c] + 1, 0), S.w - 1);
                                 int ya = min(max(t.rp[lr], 0), S.h - 1), yb = min(max(t.rp[lr] + 1, 0), S.h - 1);
-                                auto ld = [&](int xx, int yy) { return *(const uint32_t *)(S.ptr + (size_t)yy * S.pitch + (size_t)xx * 4); };
+                                auto ld = [&](int xx, int yy) { return gld<uint32_t>(S.ptr + (size_t)yy * S.pitch + (size_t)xx * 4); };
                                 u00 = ld(xa, ya); u10 = ld(xb, ya); u01 = ld(xa, yb); u11 = ld(xb, yb);
                             }
                             const float4 t00 = codes4(u00), t10 = codes4(u10), t01 = codes4(u01), t11 = codes4(u11);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
             for (int k = 0; k < RCOLS; k++) {
                 const uint32_t a8 = ((touched >> (r * 4 + k)) & 1u) ? 0xFF000000u : (((orig_a[r] >> (8 * k)) & 255u) << 24);
                 const uint32_t w = (uint32_t)cb[r][k] | ((uint32_t)cg[r][k] << 8) | ((uint32_t)cr[r][k] << 16) | a8;
-                if (xq + 16 * k < T.W) *(uint32_t *)(drow + (size_t)(xq + 16 * k) * 4) = w;
+                if (xq + 16 * k < T.W) gst<uint32_t>(drow + (size_t)(xq + 16 * k) * 4, w);
             }
         }
     }

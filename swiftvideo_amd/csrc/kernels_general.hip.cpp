@@ -29,7 +29,7 @@ CHV_DEV uint32_t apply_layer_bgra(const DLayer &L, int x, int y, float sx, float
         float ry = U[U_INSIZE + 1] / U[U_OUTSIZE + 1];
         int ix = min(max((int)((float)x * rx), 0), L.src.pl[0].w - 1);
         int iy = min(max((int)((float)y * ry), 0), L.src.pl[0].h - 1);
-        uint32_t s = *(const uint32_t *)(L.src.pl[0].ptr + (size_t)iy * L.src.pl[0].pitch + (size_t)ix * 4);
+        uint32_t s = gld<uint32_t>(L.src.pl[0].ptr + (size_t)iy * L.src.pl[0].pitch + (size_t)ix * 4);
         float a = unorm8(s >> 24);
         float ia = 1.0f - a;
         uint32_t o0 = to_code(unorm8(s & 255) * a + unorm8(cur & 255) * ia);
@@ -51,8 +51,8 @@ CHV_DEV uint32_t apply_layer_bgra(const DLayer &L, int x, int y, float sx, float
         if (L.kind == LK_BGRA_FROM_RGB) {
             const DPlane &P = L.src.pl[0];
             Lin2 l = lin_setup(P, g.u, g.v);
-            uint32_t t00 = *(const uint32_t *)(P.ptr + l.o00), t10 = *(const uint32_t *)(P.ptr + l.o10);
-            uint32_t t01 = *(const uint32_t *)(P.ptr + l.o01), t11 = *(const uint32_t *)(P.ptr + l.o11);
+            uint32_t t00 = gld<uint32_t>(P.ptr + l.o00), t10 = gld<uint32_t>(P.ptr + l.o10);
+            uint32_t t01 = gld<uint32_t>(P.ptr + l.o01), t11 = gld<uint32_t>(P.ptr + l.o11);
             float q0 = cs_mix(l, (float)(t00 & 255), (float)(t10 & 255), (float)(t01 & 255), (float)(t11 & 255));
             float q1 = cs_mix(l, (float)((t00 >> 8) & 255), (float)((t10 >> 8) & 255),
                               (float)((t01 >> 8) & 255), (float)((t11 >> 8) & 255));
@@ -93,9 +93,9 @@ __global__ __launch_bounds__(256) void tick_general_bgra(const DTick *__restrict
     if (x >= T.W || y >= T.H) return;
     const DPlane &D = T.dst.pl[0];
     if (x >= D.w || y >= D.h) return;
-    uint32_t *dp = (uint32_t *)(D.ptr + (size_t)y * D.pitch + (size_t)x * 4);
+    uint8_t *dp = D.ptr + (size_t)y * D.pitch + (size_t)x * 4;
     // img_clear_bgra: (0,0,0,1), kernels.cl.swift:257-265
-    uint32_t cur = T.clear_first ? 0xFF000000u : *dp;
+    uint32_t cur = T.clear_first ? 0xFF000000u : gld<uint32_t>(dp);
     float sx = (float)T.W, sy = (float)T.H;
     const DLayer *L = layers + T.first_layer;
     for (int l = 0; l < T.n_layers; l++) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void tick_general_bgra(const DTick *__restrict
         if (x < Ly.bbox[0] || x >= Ly.bbox[2] || y < Ly.bbox[1] || y >= Ly.bbox[3]) continue;   // fails the border test for sure
         cur = apply_layer_bgra(Ly, x, y, sx, sy, cur);
     }
-    *dp = cur;
+    gst<uint32_t>(dp, cur);
 }
 
 // ---------------------------------------------------------------------------
@@ -167,8 +167,8 @@ CHV_DEV void apply_yuv_from_rgb(const DLayer &L, int x, int y, float sx, float s
     if (g.in_uv) {
         const DPlane &P = L.src.pl[0];
         Lin2 l = lin_setup(P, g.u, g.v);
-        uint32_t t00 = *(const uint32_t *)(P.ptr + l.o00), t10 = *(const uint32_t *)(P.ptr + l.o10);
-        uint32_t t01 = *(const uint32_t *)(P.ptr + l.o01), t11 = *(const uint32_t *)(P.ptr + l.o11);
+        uint32_t t00 = gld<uint32_t>(P.ptr + l.o00), t10 = gld<uint32_t>(P.ptr + l.o10);
+        uint32_t t01 = gld<uint32_t>(P.ptr + l.o01), t11 = gld<uint32_t>(P.ptr + l.o11);
         float q0 = lin_mix(l, unorm8(t00 & 255), unorm8(t10 & 255), unorm8(t01 & 255), unorm8(t11 & 255));
         float q1 = lin_mix(l, unorm8((t00 >> 8) & 255), unorm8((t10 >> 8) & 255),
                            unorm8((t01 >> 8) & 255), unorm8((t11 >> 8) & 255));
@@ -215,12 +215,12 @@ __global__ __launch_bounds__(256) void tick_general_yuv(const DTick *__restrict_
         s.y[0] = s.y[1] = s.y[2] = s.y[3] = 0;
         s.u = s.v = cvalid ? 128u : 0u;
     } else {
-        s.y[0] = py0[0];
-        s.y[1] = hx ? py0[1] : 0;
-        s.y[2] = hy ? py1[0] : 0;
-        s.y[3] = (hx && hy) ? py1[1] : 0;
-        s.u = cvalid ? *pu : 0;
-        s.v = cvalid ? *pv : 0;
+        s.y[0] = gld<uint8_t>(py0);
+        s.y[1] = hx ? gld<uint8_t>(py0 + 1) : 0;
+        s.y[2] = hy ? gld<uint8_t>(py1) : 0;
+        s.y[3] = (hx && hy) ? gld<uint8_t>(py1 + 1) : 0;
+        s.u = cvalid ? gld<uint8_t>(pu) : 0;
+        s.v = cvalid ? gld<uint8_t>(pv) : 0;
     }
     float sx = (float)T.W, sy = (float)T.H;
     const DLayer *L = layers + T.first_layer;
@@ -240,11 +240,11 @@ __global__ __launch_bounds__(256) void tick_general_yuv(const DTick *__restrict_
                 apply_yuv_from_yuv(Ly, x0 + i, y0 + j, sx, sy, owner, s.y[k], owner ? s.u : du, owner ? s.v : dv);
         }
     }
-    py0[0] = (uint8_t)s.y[0];
-    if (hx) py0[1] = (uint8_t)s.y[1];
-    if (hy) py1[0] = (uint8_t)s.y[2];
-    if (hx && hy) py1[1] = (uint8_t)s.y[3];
-    if (cvalid) { *pu = (uint8_t)s.u; *pv = (uint8_t)s.v; }
+    gst<uint8_t>(py0, (uint8_t)s.y[0]);
+    if (hx) gst<uint8_t>(py0 + 1, (uint8_t)s.y[1]);
+    if (hy) gst<uint8_t>(py1, (uint8_t)s.y[2]);
+    if (hx && hy) gst<uint8_t>(py1 + 1, (uint8_t)s.y[3]);
+    if (cvalid) { gst<uint8_t>(pu, (uint8_t)s.u); gst<uint8_t>(pv, (uint8_t)s.v); }
 }
 
 // ---------------------------------------------------------------------------

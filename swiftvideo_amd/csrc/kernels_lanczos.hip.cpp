@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
     for (int idx = tid; idx < nrows * ncols; idx += 256) {
         int r = idx / ncols, c = idx - r * ncols;
         int sy = min(max(row0 + r, 0), src.h - 1), sx = min(max(col0 + c, 0), src.w - 1);
-        stile[r * max_cols + c] = *(const uint32_t *)(src.ptr + (size_t)sy * src.pitch + (size_t)sx * 4);
+        stile[r * max_cols + c] = gld<uint32_t>(src.ptr + (size_t)sy * src.pitch + (size_t)sx * 4);
     }
     __syncthreads();
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
             acc.w = __builtin_fmaf(wk, h.w, acc.w);
         }
         uint32_t o = to_code_raw(acc.x) | (to_code_raw(acc.y) << 8) | (to_code_raw(acc.z) << 16) | (to_code_raw(acc.w) << 24);
-        *(uint32_t *)(dst.ptr + (size_t)oy * dst.pitch + (size_t)ox * 4) = o;
+        gst<uint32_t>(dst.ptr + (size_t)oy * dst.pitch + (size_t)ox * 4, o);
     }
 }
 

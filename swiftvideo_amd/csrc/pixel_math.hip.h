@@ -169,7 +169,7 @@ CHV_DEV float lin_mix(const Lin2 &l, float t00, float t10, float t01, float t11)
 }
 CHV_DEV float lin_fetch(const DPlane &p, const Lin2 &l, int c) {
     const uint8_t *b = p.ptr + c;
-    return lin_mix(l, unorm8(b[l.o00]), unorm8(b[l.o10]), unorm8(b[l.o01]), unorm8(b[l.o11]));
+    return lin_mix(l, unorm8(gld<uint8_t>(b + l.o00)), unorm8(gld<uint8_t>(b + l.o10)), unorm8(gld<uint8_t>(b + l.o01)), unorm8(gld<uint8_t>(b + l.o11)));
 }
 
 // ---- code-scale arithmetic of the BGRA-target family (spec owned by this repo) ----
@@ -185,7 +185,7 @@ CHV_DEV float cs_mix(const Lin2 &l, float t00, float t10, float t01, float t11) 
 }
 CHV_DEV float cs_fetch(const DPlane &p, const Lin2 &l, int c) {
     const uint8_t *b = p.ptr + c;
-    return cs_mix(l, (float)b[l.o00], (float)b[l.o10], (float)b[l.o01], (float)b[l.o11]);
+    return cs_mix(l, (float)gld<uint8_t>(b + l.o00), (float)gld<uint8_t>(b + l.o10), (float)gld<uint8_t>(b + l.o01), (float)gld<uint8_t>(b + l.o11));
 }
 // RTE of a code-scale value known to lie in [0, 255 + a few ulp] and not NaN (a convex combination
 // of codes), through the float adder: returns the raw bits 0x4B400000 + rint(v)
