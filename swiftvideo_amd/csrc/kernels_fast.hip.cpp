@@ -374,9 +374,9 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
             }
         };
         auto store_row = [&](uint8_t *drow, const uint32_t (&outw)[PXT]) {
-            if (PXT == 4) gst<uint4>(drow + (size_t)xq * 4, make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]));
-            else if (PXT == 2) gst<uint2>(drow + (size_t)xq * 4, make_uint2(outw[0], outw[PXT - 1]));
-            else gst<uint32_t>(drow + (size_t)xq * 4, outw[0]);
+            if (PXT == 4) gst<uint4>(drow + (uint32_t)(xq * 4), make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]));
+            else if (PXT == 2) gst<uint2>(drow + (uint32_t)(xq * 4), make_uint2(outw[0], outw[PXT - 1]));
+            else gst<uint32_t>(drow + (uint32_t)(xq * 4), outw[0]);
         };
         const bool fast_tile = uniform_inside && opaque;
         const bool whole_tile = fast_tile && full4 && ys0 + (j + 1) * TH <= T.H;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
                 if (fast_tile) {
                     fast_row(ly, outw);
                     if (full4) store_row(drow, outw);
-                    else for (int k = 0; k < PXT; k++) if (xq + k < T.W) gst<uint32_t>(drow + (size_t)(xq + k) * 4, outw[k]);
+                    else for (int k = 0; k < PXT; k++) if (xq + k < T.W) gst<uint32_t>(drow + (uint32_t)((xq + k) * 4), outw[k]);
                     continue;
                 }
                 // tiles on a picture/border edge, translucent layers, unstaged tiles: one pixel at a
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
                     if (xq + k >= T.W) break;
                     const int c = txi * PXT + k;
                     const int fl = tb.cfl[c] & rfl;
-                    uint8_t *dp = drow + (size_t)(xq + k) * 4;
+                    uint8_t *dp = drow + (uint32_t)((xq + k) * 4);
                     uint32_t cpx = CLEAR ? 0xFF000000u : gld<uint32_t>(dp);
                     if (fl & AX_BORDER) {
                         const bool in_pic = (fl & (AX_TX | AX_UV)) == (AX_TX | AX_UV);
