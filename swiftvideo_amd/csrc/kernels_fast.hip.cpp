@@ -328,16 +328,10 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     const CscFolded cscb = csc_fold_biased(kCsc[L.csc & 3]);
     const bool opaque = (L.flags & LF_OPAQUE) != 0;
 
-    // gfx950 counts loads and stores in ONE vmcnt, and the compiler's wait insertion is conservative across the
-    // loop: left alone it puts `s_waitcnt vmcnt(0)` in front of every prefetch load of the next iteration (the
-    // destination registers "may still be pending"), which serialises the loads and waits for the tile's stores
-    // to drain.  An explicit wait at the end of the compute phase — where the prefetched vectors have long landed
-    // and no store is outstanding — tells it that nothing but stores is pending from there on.
-    auto wait_prefetch_landed = []() { vmem_wait_all(); };
-
-    wait_prefetch_landed();      // tile 0's vectors (issued before the column setup above)
     for (int j = 0; j < ntiles; j++) {
         // ---- phase 1: the prefetched rectangle of tile j goes to LDS ------------------------
+        touch_regs(yregs); touch_regs(cregs);          // the wait for the prefetch, on every path (see touch_regs)
+        if (PLANAR) touch_regs(vregs);
         if (staged) {
             stage_store<1, false>(yregs, smem + ybase, ypitch, SY, gy, tid);
             if constexpr (PLANAR) stage_store_uv_planar(cregs, vregs, smem + cbase, cpitch, SC, SV, gc, tid);
@@ -387,7 +381,6 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
 #pragma unroll
             for (int rr = 0; rr < RPT; rr++) fast_row(j * TH + tyi + rr * TYT, outw[rr]);
         }
-        wait_prefetch_landed();        // on every path, before any store of this tile
         if (whole_tile) {
 #pragma unroll
             for (int rr = 0; rr < RPT; rr++) store_row(D.ptr + (size_t)(ys0 + j * TH + tyi + rr * TYT) * D.pitch, outw[rr]);

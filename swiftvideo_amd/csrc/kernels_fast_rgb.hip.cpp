@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
         const DLayer &Ly = L[l];
         const DPlane &S = Ly.src.pl[0];
         const RgbLayerTable &t = tabs[l];
-        vmem_wait_all();                  // the prefetched vectors (stage_load's loads are not tracked by the compiler)
+        touch_regs(regs);                 // the wait for the prefetch, on every path (see touch_regs)
         if (staged) stage_store<4, false>(regs, smem + tbase, tpitch, S, g, tid);
         __syncthreads();
         const int ln = next_hit(l + 1);

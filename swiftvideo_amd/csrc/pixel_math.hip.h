@@ -37,28 +37,6 @@ template <typename T> CHV_DEV T gld(const void *p) { return *(const CHV_GLOBAL T
 template <> CHV_DEV uint2 gld<uint2>(const void *p) { chv_u32x2 v = *(const CHV_GLOBAL chv_u32x2 *)(uintptr_t)p; return make_uint2(v.x, v.y); }
 template <> CHV_DEV uint4 gld<uint4>(const void *p) { chv_u32x4 v = *(const CHV_GLOBAL chv_u32x4 *)(uintptr_t)p; return make_uint4(v.x, v.y, v.z, v.w); }
 template <typename T> CHV_DEV void gst(void *p, T v) { *(CHV_GLOBAL T *)(uintptr_t)p = v; }
-// A 16-byte global load the compiler does not track: no s_waitcnt is inserted for it anywhere.  hipcc's wait
-// insertion is path-insensitive, and for a register prefetch that is consumed under a condition it ends up
-// waiting vmcnt(0) in front of every NEXT prefetch load ("the destination may still be pending") — which
-// serialises the loads and drains the tile's stores.  The caller owns the ordering: vmem_wait_all() before
-// the first use of `dst`.
-CHV_DEV void gld16_untracked(uint4 &dst, const void *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    chv_u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    dst = make_uint4(v.x, v.y, v.z, v.w);
-#else
-    (void)dst; (void)p;
-#endif
-}
-CHV_DEV void vmem_wait_all() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0); expcnt and lgkmcnt at their maxima = not waited for
-#endif
-}
-template <> CHV_DEV void gst<uint2>(void *p, uint2 v) { chv_u32x2 w = { v.x, v.y }; *(CHV_GLOBAL chv_u32x2 *)(uintptr_t)p = w; }
-template <> CHV_DEV void gst<uint4>(void *p, uint4 v) { chv_u32x4 w = { v.x, v.y, v.z, v.w }; *(CHV_GLOBAL chv_u32x4 *)(uintptr_t)p = w; }
-
 // c / 255.0f, correctly rounded, without a divide: with r_hi = RN(1/255) and
 // r_lo = RN(1/255 - r_hi), RN(c*r_hi + RN(c*r_lo)) equals RN(c/255) for all 256 codes
 // (checked in exact rational arithmetic by tests/test_host_logic.py and on device by

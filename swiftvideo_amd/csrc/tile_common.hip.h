@@ -123,14 +123,27 @@ CHV_DEV void stage_slot(const StageGeom &g, int i, int &r, int &vv) {
     vv = i - r * g.nslot;
 }
 
+// An unconditional (empty) use of prefetched registers.  hipcc places its s_waitcnt for a load in front of the
+// first use it sees on a path and merges paths pessimistically: with the prefetch consumed only under conditions
+// (staged? lane owns a slot?) the registers stay "maybe pending" on the paths that skip the use, and every load
+// of the NEXT prefetch then gets `s_waitcnt vmcnt(0)` in front of it, which serialises the loads.  A use on
+// every path, right where the wait belongs anyway, settles it.
+template <int N>
+CHV_DEV void touch_regs(const uint4 (&regs)[N]) {
+#pragma unroll
+    for (int n = 0; n < N; n++) asm volatile("" :: "v"(regs[n].x), "v"(regs[n].y), "v"(regs[n].z), "v"(regs[n].w));
+}
+
 template <int N>
 CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, int tid) {
-    // Exactly one global_load_dwordx4 per slot, straight into its final register and invisible to the
-    // compiler's wait insertion (gld16_untracked): any control flow that merges differently-produced values
-    // here makes the compiler copy — and therefore wait for — the loaded registers on the spot, and the
-    // prefetch would hide nothing.  Callers place vmem_wait_all() before the matching stage_store.  Vectors that are
-    // not loadable as such (outside the row: their texels are replaced by patch_edges anyway; the last
-    // row's tail: re-read bytewise in stage_store) load the row's first vector instead.
+    // Exactly one global_load_dwordx4 per slot, straight into its final register: control flow that merges
+    // differently-produced values here makes the compiler copy — and therefore wait for — the loaded
+    // registers on the spot.  Vectors that are not loadable as such (outside the row: their texels are
+    // replaced by patch_edges anyway; the last row's tail: re-read bytewise in stage_store) load the row's
+    // first vector instead.
+    // (Issuing these loads from inline asm — untracked, with hand-placed waits — measured 4 % faster on cfg2, and a
+    // static check of the generated code then found the register allocator copying half of a destination vector
+    // while its load was still in flight.  The loads stay tracked; callers use touch_regs() to place the wait.)
 #pragma unroll
     for (int n = 0; n < N; n++) {
         int i = tid + n * NTHREADS, r, vv;
@@ -139,7 +152,7 @@ CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, i
             int row = min(max(g.r_lo + r, 0), P.h - 1);
             int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
             if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
-            gld16_untracked(regs[n], P.ptr + (size_t)row * P.pitch + off);
+            regs[n] = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
         }
     }
 }
