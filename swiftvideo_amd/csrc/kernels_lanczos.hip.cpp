@@ -36,11 +36,28 @@ __global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
     const int ncols = min(fx[ox_last] + tx - col0, max_cols);
     const int tid = threadIdx.x;
 
-    // phase A: source rectangle -> LDS (CLAMP_TO_EDGE applied to the load address)
-    for (int idx = tid; idx < nrows * ncols; idx += 256) {
-        int r = idx / ncols, c = idx - r * ncols;
-        int sy = min(max(row0 + r, 0), src.h - 1), sx = min(max(col0 + c, 0), src.w - 1);
-        stile[r * max_cols + c] = gld<uint32_t>(src.ptr + (size_t)sy * src.pitch + (size_t)sx * 4);
+    // phase A: source rectangle -> LDS (CLAMP_TO_EDGE applied to the load address).  32 lanes walk a row in
+    // 16-byte vectors (4 texels; texels are 4-byte aligned, which is all global_load_dwordx4 needs), 8 rows at a
+    // time; only vectors that stick out of the picture fall back to per-texel clamped loads.
+    {
+        const int v = tid & 31, rg = tid >> 5;
+        const int nvec = (ncols + 3) >> 2;                       // max_cols is a multiple of 4: the tail vector fits
+        for (int r = rg; r < nrows; r += 8) {
+            const int sy = min(max(row0 + r, 0), src.h - 1);
+            const uint8_t *srow = src.ptr + (size_t)sy * src.pitch;
+            for (int vv = v; vv < nvec; vv += 32) {
+                const int c = col0 + 4 * vv;
+                uint4 t;
+                if (c >= 0 && c + 4 <= src.w) t = gld<uint4>(srow + (size_t)c * 4);
+                else {
+                    t.x = gld<uint32_t>(srow + (size_t)min(max(c, 0), src.w - 1) * 4);
+                    t.y = gld<uint32_t>(srow + (size_t)min(max(c + 1, 0), src.w - 1) * 4);
+                    t.z = gld<uint32_t>(srow + (size_t)min(max(c + 2, 0), src.w - 1) * 4);
+                    t.w = gld<uint32_t>(srow + (size_t)min(max(c + 3, 0), src.w - 1) * 4);
+                }
+                *(uint4 *)(stile + r * max_cols + 4 * vv) = t;
+            }
+        }
     }
     __syncthreads();
 
