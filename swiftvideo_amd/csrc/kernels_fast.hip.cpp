@@ -222,7 +222,7 @@ CHV_DEV void stage_store_uv_planar(const uint4 (&uregs)[N], const uint4 (&vregs)
 template <bool CLEAR, bool PLANAR, int NYV, int NCV>
 __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const DTick *__restrict__ ticks,
                                                                   const DLayer *__restrict__ layers,
-                                                                  int n_ticks, int tiles_x, int strips_y,
+                                                                  int n_ticks, int tiles_x, int strips_y, int kt,
                                                                   int ypitch, int yrows, int cpitch, int crows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     TileTables &tb = *(TileTables *)smem;
@@ -240,9 +240,9 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     const int tick = index / strips;
     const int strip = index - tick * strips;
     const DTick &T = ticks[tick];
-    const int x0 = (strip % tiles_x) * TW, ys0 = (strip / tiles_x) * (KT * TH);
+    const int x0 = (strip % tiles_x) * TW, ys0 = (strip / tiles_x) * (kt * TH);   // kt <= KT tiles per strip (host's choice)
     if (x0 >= T.W || ys0 >= T.H) return;
-    const int ntiles = min(KT, (T.H - ys0 + TH - 1) / TH);
+    const int ntiles = min(kt, (T.H - ys0 + TH - 1) / TH);
     const DLayer &L = layers[T.first_layer];
     const float *U = L.u;
     const DPlane &SY = L.src.pl[0];
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
         group_summary(tb.csum[tid >> 6], 6, x < T.W, fl, iy, ic);   // TW / 64 column waves
         if (x >= T.W) fl = AX_ALL;   // past the canvas edge: never stored; copy of the last column
         tb.cy[tid] = iy; tb.cya[tid] = ay; tb.cc[tid] = ic; tb.cca[tid] = ac; tb.cfl[tid] = fl;
-    } else if (tid < TW + KT * TH) {
+    } else if (tid < TW + kt * TH) {
         int j = tid - TW, y = ys0 + j;
         int iy, ic, fl; float ay, ac;
         axis_entry_y(U, min(y, T.H - 1), sx, sy, SY.h, SC.h, iy, ay, ic, ac, fl);
@@ -520,11 +520,15 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
         m.crows = std::max(1, (int)((LDS_BUDGET - sizeof(TileTables)) / 2 / m.cpitch));
         lds = sizeof(TileTables) + (size_t)m.ypitch * m.yrows + (size_t)m.cpitch * m.crows;
     }
-    int tiles_x = (maxW + TW - 1) / TW, tiles_y = (maxH + KT * TH - 1) / (KT * TH);   // strips of KT tiles
+    // strips of kt tiles: KT amortises the column tables best, but a small launch (one mixer tick = 120 strips of 4)
+    // would leave most CUs idle — shorter strips until there are a few blocks per CU
+    int tiles_x = (maxW + TW - 1) / TW, kt = KT;
+    while (kt > 1 && (long)n_ticks * tiles_x * ((maxH + kt * TH - 1) / (kt * TH)) < 1024) kt >>= 1;
+    int tiles_y = (maxH + kt * TH - 1) / (kt * TH);
     int per_xcd = (n_ticks * tiles_x * tiles_y + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8));
 #define CHV_LAUNCH(C, P, NY, NC) hipLaunchKernelGGL((tick_yuv_bgra_tiled<C, P, NY, NC>), grid, dim3(NTHREADS), lds, stream, ticks, layers, \
-                                                    n_ticks, tiles_x, tiles_y, m.ypitch, m.yrows, m.cpitch, m.crows)
+                                                    n_ticks, tiles_x, tiles_y, kt, m.ypitch, m.yrows, m.cpitch, m.crows)
 #define CHV_LAUNCH_N(C, P) do { if (small) CHV_LAUNCH(C, P, 2, 1); else CHV_LAUNCH(C, P, 3, 2); } while (0)
     const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;
     // upper bounds of the staging slots a tile can need (rows x vectors per row incl. the two edge vectors)
