@@ -265,7 +265,9 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
         int j = tid - TW, y = ys0 + j;
         int iy, ic, fl; float ay, ac;
         axis_entry_y(U, min(y, T.H - 1), sx, sy, SY.h, SC.h, iy, ay, ic, ac, fl);
-        group_summary(tb.rsum[j >> 4], 4, y < T.H, fl, iy, ic);
+        constexpr int TH_SHIFT = TH == 8 ? 3 : TH == 16 ? 4 : 5;
+        static_assert((1 << TH_SHIFT) == TH, "tile height: 8, 16 or 32 rows");
+        group_summary(tb.rsum[j >> TH_SHIFT], TH_SHIFT, y < T.H, fl, iy, ic);
         if (y >= T.H) fl = AX_ALL;
         tb.ry[j] = iy; tb.rya[j] = ay; tb.rc[j] = ic; tb.rca[j] = ac; tb.rfl[j] = fl;
     }
