@@ -16,11 +16,13 @@
 
 namespace chv {
 
-constexpr int LZ_TW = 32;
-constexpr int LZ_TH = 16;
+// Output tile per block: 32 x 16 normally; 8 x 4 for large reduction factors, whose source rectangle
+// (tile * scale + taps in each direction) would not fit the LDS otherwise.
 constexpr int LZ_MAXT = 24;      // taps held in registers (scale <= 4); more taps use the slow loop
+constexpr int LZ_KS = 4;         // tiles per block, side by side: tile t+1's source rectangle is prefetched into
+constexpr int LZ_NPRE = 6;       // registers (one 16-byte vector per row rg + 8n, n < LZ_NPRE) while tile t is filtered
 
-template <int TAPS_IN_REGS>
+template <int TAPS_IN_REGS, bool PREFETCH, int LZ_TW, int LZ_TH>
 __global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
                                                      const int32_t *__restrict__ fx, const float *__restrict__ wx, int tx,
                                                      const int32_t *__restrict__ fy, const float *__restrict__ wy, int ty,
@@ -28,51 +30,92 @@ __global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *hrow = (float4 *)smem;                                   // [max_rows][LZ_TW]
     uint32_t *stile = (uint32_t *)(smem + (size_t)max_rows * LZ_TW * sizeof(float4));   // [max_rows][max_cols]
-    const int ox0 = blockIdx.x * LZ_TW, oy0 = blockIdx.y * LZ_TH;
-    const int ox_last = min(ox0 + LZ_TW, dst.w) - 1, oy_last = min(oy0 + LZ_TH, dst.h) - 1;
+    const int oy0 = blockIdx.y * LZ_TH;
+    const int oy_last = min(oy0 + LZ_TH, dst.h) - 1;
     const int row0 = fy[oy0];
     const int nrows = min(fy[oy_last] + ty - row0, max_rows);
-    const int col0 = fx[ox0];
-    const int ncols = min(fx[ox_last] + tx - col0, max_cols);
     const int tid = threadIdx.x;
+    const int v = tid & 31, rg = tid >> 5;                           // staging: 32 lanes walk a row in 16-byte vectors, 8 rows at a time
 
-    // phase A: source rectangle -> LDS (CLAMP_TO_EDGE applied to the load address).  32 lanes walk a row in
-    // 16-byte vectors (4 texels; texels are 4-byte aligned, which is all global_load_dwordx4 needs), 8 rows at a
-    // time; only vectors that stick out of the picture fall back to per-texel clamped loads.
-    {
-        const int v = tid & 31, rg = tid >> 5;
-        const int nvec = (ncols + 3) >> 2;                       // max_cols is a multiple of 4: the tail vector fits
-        for (int r = rg; r < nrows; r += 8) {
-            const int sy = min(max(row0 + r, 0), src.h - 1);
-            const uint8_t *srow = src.ptr + (size_t)sy * src.pitch;
+    // source rectangle of a tile: first column, width in 16-byte vectors (4 texels; max_cols is a multiple of 4)
+    auto tile_geom = [&](int ox0, int &col0, int &nvec) {
+        const int ox_last = min(ox0 + LZ_TW, dst.w) - 1;
+        col0 = fx[ox0];
+        nvec = (min(fx[ox_last] + tx - col0, max_cols) + 3) >> 2;
+    };
+    // One vector (4 texels from column c) of source row r with CLAMP_TO_EDGE applied at staging time, so the taps
+    // below never clamp.  Split in two so that the load is a single instruction on every path (a prefetch that merges
+    // differently-produced values makes the compiler wait for it on the spot): load_vec reads the aligned-in-range
+    // vector at clamp(c, 0, w-4) (texels are 4-byte aligned, all global_load_dwordx4 needs; src.w >= 4 host-checked),
+    // fix_vec re-orders its texels for the vectors that stick out of the picture.
+    auto load_vec = [&](int r, int c) {
+        const int sy = min(max(row0 + r, 0), src.h - 1);
+        return gld<uint4>(src.ptr + (size_t)sy * src.pitch + (size_t)min(max(c, 0), src.w - 4) * 4);
+    };
+    auto fix_vec = [&](uint4 L, int c) {
+        const int cc = min(max(c, 0), src.w - 4);
+        if (c == cc) return L;
+        auto pick = [&](int k) {
+            const int idx = min(max(c + k, 0), src.w - 1) - cc;
+            return idx == 0 ? L.x : idx == 1 ? L.y : idx == 2 ? L.z : L.w;
+        };
+        return make_uint4(pick(0), pick(1), pick(2), pick(3));
+    };
+
+    uint4 pre[LZ_NPRE];
+    int col0 = 0, nvec = 0;
+    const int first_ox0 = blockIdx.x * (LZ_KS * LZ_TW);
+    if (PREFETCH && first_ox0 < dst.w) {
+        tile_geom(first_ox0, col0, nvec);
+#pragma unroll
+        for (int n = 0; n < LZ_NPRE; n++) if (rg + 8 * n < nrows && v < nvec) pre[n] = load_vec(rg + 8 * n, col0 + 4 * v);
+    }
+
+    for (int t = 0; t < LZ_KS; t++) {
+    const int ox0 = first_ox0 + t * LZ_TW;
+    if (ox0 >= dst.w) break;
+
+    // phase A: source rectangle -> LDS
+    if (PREFETCH) {
+        touch_regs(pre);                 // the wait for the prefetch, on every path (see touch_regs)
+#pragma unroll
+        for (int n = 0; n < LZ_NPRE; n++) if (rg + 8 * n < nrows && v < nvec) *(uint4 *)(stile + (rg + 8 * n) * max_cols + 4 * v) = fix_vec(pre[n], col0 + 4 * v);
+    } else {
+        tile_geom(ox0, col0, nvec);
+        for (int r = rg; r < nrows; r += 8)
             for (int vv = v; vv < nvec; vv += 32) {
+                // no prefetch (large scale factors, or pictures narrower than one vector): gather texel by texel
                 const int c = col0 + 4 * vv;
-                uint4 t;
-                if (c >= 0 && c + 4 <= src.w) t = gld<uint4>(srow + (size_t)c * 4);
-                else {
-                    t.x = gld<uint32_t>(srow + (size_t)min(max(c, 0), src.w - 1) * 4);
-                    t.y = gld<uint32_t>(srow + (size_t)min(max(c + 1, 0), src.w - 1) * 4);
-                    t.z = gld<uint32_t>(srow + (size_t)min(max(c + 2, 0), src.w - 1) * 4);
-                    t.w = gld<uint32_t>(srow + (size_t)min(max(c + 3, 0), src.w - 1) * 4);
-                }
-                *(uint4 *)(stile + r * max_cols + 4 * vv) = t;
+                const uint8_t *srow = src.ptr + (size_t)min(max(row0 + r, 0), src.h - 1) * src.pitch;
+                uint4 t4;
+                t4.x = gld<uint32_t>(srow + (size_t)min(max(c, 0), src.w - 1) * 4);
+                t4.y = gld<uint32_t>(srow + (size_t)min(max(c + 1, 0), src.w - 1) * 4);
+                t4.z = gld<uint32_t>(srow + (size_t)min(max(c + 2, 0), src.w - 1) * 4);
+                t4.w = gld<uint32_t>(srow + (size_t)min(max(c + 3, 0), src.w - 1) * 4);
+                *(uint4 *)(stile + r * max_cols + 4 * vv) = t4;
             }
-        }
     }
     __syncthreads();
+    const int cur_col0 = col0;
+    if (PREFETCH && t + 1 < LZ_KS && ox0 + LZ_TW < dst.w) {
+        tile_geom(ox0 + LZ_TW, col0, nvec);
+#pragma unroll
+        for (int n = 0; n < LZ_NPRE; n++) if (rg + 8 * n < nrows && v < nvec) pre[n] = load_vec(rg + 8 * n, col0 + 4 * v);
+    }
 
     // phase B: horizontal pass, one output column per thread
     {
-        const int i = tid & (LZ_TW - 1), rg = tid >> 5;     // 8 row groups
+        constexpr int RGS = 256 / LZ_TW;                   // row groups: 8 for 32-wide tiles, 32 for 8-wide ones
+        const int i = tid & (LZ_TW - 1), rg = tid / LZ_TW;
         const int ox = min(ox0 + i, dst.w - 1);
-        const int cbase = fx[ox] - col0;
+        const int cbase = fx[ox] - cur_col0;
         const float *w = wx + (size_t)ox * tx;
         float wr[TAPS_IN_REGS > 0 ? TAPS_IN_REGS : 1];
         if (TAPS_IN_REGS > 0) {
 #pragma unroll
             for (int k = 0; k < TAPS_IN_REGS; k++) wr[k] = k < tx ? w[k] : 0.f;
         }
-        for (int r = rg; r < nrows; r += 8) {
+        for (int r = rg; r < nrows; r += RGS) {
             const uint32_t *row = stile + r * max_cols + cbase;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TAPS_IN_REGS > 0) {
@@ -120,18 +163,29 @@ __global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
         uint32_t o = to_code_raw(acc.x) | (to_code_raw(acc.y) << 8) | (to_code_raw(acc.z) << 16) | (to_code_raw(acc.w) << 24);
         gst<uint32_t>(dst.ptr + (size_t)oy * dst.pitch + (size_t)ox * 4, o);
     }
+    // the next tile's phase A writes `stile` only (every wave is past phase B) and is followed by a barrier before its
+    // phase B overwrites `hrow`, which slower waves may still be reading here
+    }   // tiles of the strip
 }
 
 hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *fx, const float *wx,
                           int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream) {
     // rows / columns of source one tile can need: first[] advances by at most ceil(scale) per output
-    double sy = (double)src.h / (double)dst.h, sxs = (double)src.w / (double)dst.w;
-    int max_rows = (int)((LZ_TH - 1) * sy + 2) + ty;
-    int max_cols = (int)((LZ_TW - 1) * sxs + 2) + tx;
-    max_cols = (max_cols + 3) & ~3;
-    size_t lds = (size_t)max_rows * LZ_TW * sizeof(float4) + (size_t)max_rows * max_cols * sizeof(uint32_t);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    dim3 grid((dst.w + LZ_TW - 1) / LZ_TW, (dst.h + LZ_TH - 1) / LZ_TH);
+    const double sy = (double)src.h / (double)dst.h, sxs = (double)src.w / (double)dst.w;
+    auto dims = [&](int tw, int th, int *max_rows, int *max_cols) -> size_t {
+        *max_rows = (int)((th - 1) * sy + 2) + ty;
+        *max_cols = ((int)((tw - 1) * sxs + 2) + tx + 3) & ~3;
+        return (size_t)*max_rows * tw * sizeof(float4) + (size_t)*max_rows * *max_cols * sizeof(uint32_t);
+    };
+    int max_rows, max_cols;
+    size_t lds = dims(32, 16, &max_rows, &max_cols);
+    const bool small_tiles = lds > 64 * 1024;                 // reduction factors beyond about 4
+    if (small_tiles) lds = dims(8, 4, &max_rows, &max_cols);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;        // beyond about 24:1
+    const int tw = small_tiles ? 8 : 32, th = small_tiles ? 4 : 16;
+    dim3 grid((dst.w + LZ_KS * tw - 1) / (LZ_KS * tw), (dst.h + th - 1) / th);
+    // register prefetch of the next tile's rectangle: one vector per thread and 8-row group
+    const bool prefetch = !small_tiles && max_rows <= 8 * LZ_NPRE && max_cols / 4 <= 32 && src.w >= 4;
     auto launch = [&](auto kernel) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -140,9 +194,10 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
         hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, dst, src, fx, wx, tx, fy, wy, ty, max_rows, max_cols);
         return hipGetLastError();
     };
-    if (tx <= 12) return launch(lanczos3_bgra<12>);
-    if (tx <= LZ_MAXT) return launch(lanczos3_bgra<LZ_MAXT>);
-    return launch(lanczos3_bgra<0>);
+    if (small_tiles) return tx <= LZ_MAXT ? launch(lanczos3_bgra<LZ_MAXT, false, 8, 4>) : launch(lanczos3_bgra<0, false, 8, 4>);
+    if (tx <= 12) return prefetch ? launch(lanczos3_bgra<12, true, 32, 16>) : launch(lanczos3_bgra<12, false, 32, 16>);
+    if (tx <= LZ_MAXT) return prefetch ? launch(lanczos3_bgra<LZ_MAXT, true, 32, 16>) : launch(lanczos3_bgra<LZ_MAXT, false, 32, 16>);
+    return launch(lanczos3_bgra<0, false, 32, 16>);
 }
 
 }  // namespace chv

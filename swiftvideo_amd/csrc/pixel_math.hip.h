@@ -37,6 +37,17 @@ template <typename T> CHV_DEV T gld(const void *p) { return *(const CHV_GLOBAL T
 template <> CHV_DEV uint2 gld<uint2>(const void *p) { chv_u32x2 v = *(const CHV_GLOBAL chv_u32x2 *)(uintptr_t)p; return make_uint2(v.x, v.y); }
 template <> CHV_DEV uint4 gld<uint4>(const void *p) { chv_u32x4 v = *(const CHV_GLOBAL chv_u32x4 *)(uintptr_t)p; return make_uint4(v.x, v.y, v.z, v.w); }
 template <typename T> CHV_DEV void gst(void *p, T v) { *(CHV_GLOBAL T *)(uintptr_t)p = v; }
+// An unconditional (empty) use of prefetched registers.  hipcc places its s_waitcnt for a load in front of the
+// first use it sees on a path and merges paths pessimistically: with the prefetch consumed only under conditions
+// (staged? lane owns a slot?) the registers stay "maybe pending" on the paths that skip the use, and every load
+// of the NEXT prefetch then gets `s_waitcnt vmcnt(0)` in front of it, which serialises the loads.  A use on
+// every path, right where the wait belongs anyway, settles it.
+template <int N>
+CHV_DEV void touch_regs(const uint4 (&regs)[N]) {
+#pragma unroll
+    for (int n = 0; n < N; n++) asm volatile("" :: "v"(regs[n].x), "v"(regs[n].y), "v"(regs[n].z), "v"(regs[n].w));
+}
+
 // c / 255.0f, correctly rounded, without a divide: with r_hi = RN(1/255) and
 // r_lo = RN(1/255 - r_hi), RN(c*r_hi + RN(c*r_lo)) equals RN(c/255) for all 256 codes
 // (checked in exact rational arithmetic by tests/test_host_logic.py and on device by

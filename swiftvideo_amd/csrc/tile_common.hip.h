@@ -123,17 +123,6 @@ CHV_DEV void stage_slot(const StageGeom &g, int i, int &r, int &vv) {
     vv = i - r * g.nslot;
 }
 
-// An unconditional (empty) use of prefetched registers.  hipcc places its s_waitcnt for a load in front of the
-// first use it sees on a path and merges paths pessimistically: with the prefetch consumed only under conditions
-// (staged? lane owns a slot?) the registers stay "maybe pending" on the paths that skip the use, and every load
-// of the NEXT prefetch then gets `s_waitcnt vmcnt(0)` in front of it, which serialises the loads.  A use on
-// every path, right where the wait belongs anyway, settles it.
-template <int N>
-CHV_DEV void touch_regs(const uint4 (&regs)[N]) {
-#pragma unroll
-    for (int n = 0; n < N; n++) asm volatile("" :: "v"(regs[n].x), "v"(regs[n].y), "v"(regs[n].z), "v"(regs[n].w));
-}
-
 template <int N>
 CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, int tid) {
     // Exactly one global_load_dwordx4 per slot, straight into its final register: control flow that merges

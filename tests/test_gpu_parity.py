@@ -291,3 +291,18 @@ def test_wrapped_decoder_surface_with_plane_offsets(ctx):
     cv.check(lib.chv_download(ctx.handle, back.ctypes.data, 16, owner, 0, 16, 16, 1))
     assert np.array_equal(back, frame[:16])
     cv.check(lib.chv_buffer_free(owner))
+
+
+@pytest.mark.parametrize("iw,ih,ow,oh", [(3, 5, 7, 9),          # narrower than one 16-byte vector: texel-by-texel staging
+                                         (200, 120, 20, 12),    # 10:1, 60 taps: weights from memory, no register prefetch
+                                         (130, 70, 40, 22),     # 3.25:1, 20 taps in registers, rectangle too tall to prefetch
+                                         (257, 131, 129, 66),   # ~2:1 with odd sizes: prefetch path, edge vectors re-ordered
+                                         (16, 16, 16, 16)])     # identity size
+def test_lanczos_paths_match_oracle(ctx, iw, ih, ow, oh):
+    src = util.alloc_image("bgra", iw, ih, seed=iw * 7 + oh)
+    exp = util.alloc_image("bgra", ow, oh)
+    assert O.lanczos_bgra(exp[0], src[0]) == 0
+    gs = G.to_gpu(ctx, "bgra", iw, ih, src)
+    gd = G.to_gpu(ctx, "bgra", ow, oh, util.alloc_image("bgra", ow, oh))
+    sv.usingContext(ctx, lambda c: sv.scaleLanczos(c, gd, gs))
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"lanczos {iw}x{ih} -> {ow}x{oh}")
