@@ -1,0 +1,76 @@
+"""Asynchronous uploads from caller-pinned memory (chv_host_alloc + chv_upload(async=2)) on a side context, ordered
+against kernels of another context by the per-buffer upload events and against reuse of the pinned frame by
+chv_event_wait — the hipMemcpyAsync-on-a-side-stream arrangement of north_star / SURVEY section 8d (cfg4 end-to-end),
+and the stream timers (chv_event_*)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gpuutil as G
+import util
+from oracle import oracle as O
+from swiftvideo_amd import chipvideo as cv
+from swiftvideo_amd import compute as sv
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pinned_uploads_overlap_with_kernels_and_stay_ordered(ctx):
+    lib = cv.load()
+    up = sv.createComputeContext(sharing=ctx)            # GPUBarrierUpload's own context (compute.swift:177)
+    (W, H), (w, h) = (320, 180), (160, 90)
+    ysz, csz = W * H, W * H // 2
+    n_frames, ring = 12, 3                               # more frames than pinned slots: slots are recycled
+    pinned = C.c_void_p()
+    cv.check(lib.chv_host_alloc(up.handle, ring * (ysz + csz), C.byref(pinned)))
+    host = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_uint8)), shape=(ring * (ysz + csz),))
+    # one device picture per pinned slot; uploads overwrite them, kernels read them
+    dev = [G.to_gpu(ctx, "nv12", W, H, util.alloc_image("nv12", W, H)) for _ in range(ring)]
+    outs = [G.to_gpu(ctx, "bgra", w, h, util.alloc_image("bgra", w, h)) for _ in range(n_frames)]
+    u = util.full_canvas_uniforms((w, h), (W, H))
+    done = [C.c_void_p() for _ in range(ring)]           # "the kernel that read slot k has run"
+    for e in done:
+        cv.check(lib.chv_event_create(ctx.handle, C.byref(e)))
+        cv.check(lib.chv_event_record(ctx.handle, e))
+    t0, t1 = C.c_void_p(), C.c_void_p()
+    cv.check(lib.chv_event_create(ctx.handle, C.byref(t0)))
+    cv.check(lib.chv_event_create(ctx.handle, C.byref(t1)))
+    cv.check(lib.chv_event_record(ctx.handle, t0))
+    expected = []
+    for f in range(n_frames):
+        k = f % ring
+        src = util.alloc_image("nv12", W, H, seed=300 + f)
+        exp = util.alloc_image("bgra", w, h)
+        assert O.run_kernel("img_clear_bgra", exp) == 0 and O.run_kernel("img_nv12_bgra", exp, src, u) == 0
+        expected.append(exp)
+        # the pinned slot may only be rewritten once the previous upload from it has been passed by `up`'s stream,
+        # and the device picture only once the kernel that read it has run
+        cv.check(lib.chv_event_wait(up.handle, done[k]))
+        sv.endComputePass(up, True)
+        base = k * (ysz + csz)
+        host[base:base + ysz] = src[0].reshape(-1)
+        host[base + ysz:base + ysz + csz] = src[1].reshape(-1)
+        tex = dev[k].imageBuffer().computeTextures
+        cv.check(lib.chv_upload(up.handle, tex[0]._h, 0, tex[0].pitch, host[base:].ctypes.data, W, W, H, 2))
+        cv.check(lib.chv_upload(up.handle, tex[1]._h, 0, tex[1].pitch, host[base + ysz:].ctypes.data, W, W, H // 2, 2))
+        # no host-side wait: the kernel's stream waits for the two uploads through the buffers' events
+        layer = (sv.ComputeKernel.img_nv12_bgra, dev[k], u, 0)
+        sv.compositeTick(ctx, outs[f], [layer], clearFirst=True)
+        cv.check(lib.chv_event_record(ctx.handle, done[k]))
+    cv.check(lib.chv_event_record(ctx.handle, t1))
+    cv.check(lib.chv_event_synchronize(t1))
+    ms = C.c_float(-1)
+    cv.check(lib.chv_event_elapsed_ms(t0, t1, C.byref(ms)))
+    assert 0.0 < ms.value < 5000.0
+    sv.endComputePass(ctx, True)
+    sv.endComputePass(up, True)
+    for f in range(n_frames):
+        G.assert_same(G.from_gpu(ctx, outs[f], "bgra", w, h), expected[f], f"frame {f}")
+    for e in done + [t0, t1]:
+        cv.check(lib.chv_event_destroy(e))
+    cv.check(lib.chv_host_free(up.handle, pinned))
+    sv.destroyComputeContext(up)
+    # argument checks
+    assert lib.chv_event_elapsed_ms(None, None, C.byref(ms)) != 0
+    assert lib.chv_host_alloc(ctx.handle, 0, C.byref(pinned)) != 0
