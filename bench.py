@@ -269,8 +269,10 @@ def run_with_upload(args, sv, cv, lib, ctx, wl, rank, n_gpus, dist):
         for f in range(args.frames):
             src = keep[2 * f].imageBuffer()
             base = pinned.value + (f % distinct) * (ysz + csz)
-            cv.check(lib.chv_upload(up.handle, src.computeTextures[0]._h, 0, src.gpuPitches[0], base, sw, sw, sh, 2))
-            cv.check(lib.chv_upload(up.handle, src.computeTextures[1]._h, 0, src.gpuPitches[1], base + ysz, sw, sw, sh // 2, 2))
+            # luma + interleaved chroma are adjacent with equal pitch on both sides: one pitched copy per frame
+            # (3.1 MB copies reach ~48 GB/s on this link, separate 2 MB + 1 MB copies ~37 GB/s; tools/h2d_probe.py)
+            assert src.gpuPitches[0] == src.gpuPitches[1] and src.gpuOffsets[1] == src.gpuPitches[0] * sh
+            cv.check(lib.chv_upload(up.handle, src.computeTextures[0]._h, src.gpuOffsets[0], src.gpuPitches[0], base, sw, sw, sh + sh // 2, 2))
 
     def convert_set(k):
         cv.check(lib.chv_batch_run(ctx.handle, sets[k]["batch"]))  # waits for the set's upload events on its stream

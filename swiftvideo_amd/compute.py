@@ -208,7 +208,8 @@ def planesForFormat(fmt, size):
 class ImageBuffer:
     """sample.pict.linux.swift:23-72"""
 
-    def __init__(self, pixelFormat, bufferType, size, computeTextures=(), buffers=(), planes=(), gpuPitches=()):
+    def __init__(self, pixelFormat, bufferType, size, computeTextures=(), buffers=(), planes=(), gpuPitches=(),
+                 gpuOffsets=()):
         if not computeTextures and not buffers:
             raise ComputeError(5, "Must provide either compute textures or buffers")
         self.pixelFormat = pixelFormat
@@ -218,11 +219,15 @@ class ImageBuffer:
         self.buffers = list(buffers)          # one uint8 ndarray (rows, stride) per plane
         self.planes = list(planes)
         self.gpuPitches = list(gpuPitches)
+        # HIP backend: the planes of one picture live in ONE device allocation (computeTextures holds the same
+        # ComputeBuffer for each plane) at these byte offsets, so that a picture whose host planes are contiguous
+        # (sample.pict.linux.swift:296-311) goes up in one copy instead of one per plane
+        self.gpuOffsets = list(gpuOffsets) if gpuOffsets else [0] * len(self.computeTextures)
 
     def withChanges(self, **kw):
         d = dict(pixelFormat=self.pixelFormat, bufferType=self.bufferType, size=self.size,
                  computeTextures=self.computeTextures, buffers=self.buffers, planes=self.planes,
-                 gpuPitches=self.gpuPitches)
+                 gpuPitches=self.gpuPitches, gpuOffsets=self.gpuOffsets)
         d.update(kw)
         return ImageBuffer(**d)
 
@@ -295,26 +300,48 @@ def pictureFromArrays(fmt, size, arrays, **kw):
 
 
 # ---- transfers ----------------------------------------------------------------------
+def _plane_comps(plane):
+    comps = len(plane.components)
+    return 4 if comps >= 3 else comps
+
+
 def _createTexture(ctx, image, maxPlanes=3):
-    """compute.cl.swift:532-581: one device plane per image plane (R8 / RG8 / RGBA8)."""
+    """compute.cl.swift:532-581 creates one device image per plane (R8 / RG8 / RGBA8); here the planes of a picture are
+    linear pitched regions of ONE allocation (128-byte aligned pitches, each plane starting where the previous one ends)."""
     if image.bufferType != "cpu":
-        return image.computeTextures, image.gpuPitches
+        return image.computeTextures, image.gpuPitches, image.gpuOffsets
     n = len(image.planes)
     if not (0 < n <= 3):
         raise ComputeError(5, "Input image must have 1, 2, or 3 planes")
     if n != len(image.buffers):
         raise ComputeError(5, f"Input image must have the same number of buffers as planes: {len(image.buffers)} vs. {n}")
-    lib = cv.load()
-    texs, pitches = [], []
+    pitches, offsets, total = [], [], 0
     for p in image.planes[: min(n, maxPlanes)]:
-        comps = len(p.components)
-        comps = 4 if comps >= 3 else comps
-        h = C.c_void_p()
-        pitch = C.c_size_t()
-        cv.check(lib.chv_plane_alloc(ctx.handle, p.size[0], p.size[1], comps, C.byref(h), C.byref(pitch)))
-        texs.append(ComputeBuffer(h.value, pitch.value * p.size[1], pitch.value))
-        pitches.append(pitch.value)
-    return texs, pitches
+        if p.size[0] <= 0 or p.size[1] <= 0:
+            raise ComputeError(10, f"plane of size {p.size[0]}x{p.size[1]}")
+        pitch = (p.size[0] * _plane_comps(p) + 127) // 128 * 128
+        pitches.append(pitch)
+        offsets.append(total)
+        total += pitch * p.size[1]
+    h = C.c_void_p()
+    cv.check(cv.load().chv_buffer_alloc(ctx.handle, total, C.byref(h)))
+    tex = ComputeBuffer(h.value, total)
+    return [tex] * len(pitches), pitches, offsets
+
+
+def _upload_regions(image, pitches, offsets):
+    """(dst_offset, dst_pitch, src_address, src_pitch, width_bytes, rows) per copy: planes that are adjacent with equal
+    pitches and widths on both sides (Y + interleaved chroma of NV12; the two chroma planes of y420p) travel as one."""
+    regions = []
+    for off, pitch, buf, plane in zip(offsets, pitches, image.buffers, image.planes):
+        wb, rows, src = plane.size[0] * _plane_comps(plane), plane.size[1], buf.ctypes.data
+        if regions:
+            o, p, s0, sp, w, r = regions[-1]
+            if p == pitch and sp == plane.stride and w == wb and o + p * r == off and s0 + sp * r == src:
+                regions[-1] = (o, p, s0, sp, w, r + rows)
+                continue
+        regions.append((off, pitch, src, plane.stride, wb, rows))
+    return regions
 
 
 def uploadComputePicture(ctx, pict, maxPlanes=3, retainCpuBuffer=True, asynchronous=False):
@@ -324,18 +351,15 @@ def uploadComputePicture(ctx, pict, maxPlanes=3, retainCpuBuffer=True, asynchron
     image = pict.imageBuffer()
     if image is None:
         raise ComputeError(5, "Missing image buffer")
-    texs, pitches = _createTexture(ctx, image, maxPlanes)
+    texs, pitches, offsets = _createTexture(ctx, image, maxPlanes)
     lib = cv.load()
     beginComputePass(ctx)
-    for tex, pitch, buf, plane in zip(texs, pitches, image.buffers, image.planes):
-        comps = len(plane.components)
-        comps = 4 if comps >= 3 else comps
-        cv.check(lib.chv_upload(ctx.handle, tex._h, 0, pitch, buf.ctypes.data, plane.stride,
-                                plane.size[0] * comps, plane.size[1], 1 if asynchronous else 0))
+    for off, pitch, src, src_pitch, wb, rows in _upload_regions(image, pitches, offsets):
+        cv.check(lib.chv_upload(ctx.handle, texs[0]._h, off, pitch, src, src_pitch, wb, rows, 1 if asynchronous else 0))
     # asynchronous: the bytes are already staged in pinned memory and the copies are ordered on this
     # context's stream; kernels on other contexts wait on the planes' upload events, so no host stall
     endComputePass(ctx, not asynchronous)
-    img = image.withChanges(computeTextures=texs, gpuPitches=pitches,
+    img = image.withChanges(computeTextures=texs, gpuPitches=pitches, gpuOffsets=offsets,
                             buffers=image.buffers if retainCpuBuffer else [], bufferType="gpu")
     return pict.derive(img=img)
 
@@ -355,12 +379,13 @@ def downloadComputePicture(ctx, pict, retainGpuBuffer=False):
         comps = len(plane.components)
         comps = 4 if comps >= 3 else comps
         buf = image.buffers[idx] if idx < len(image.buffers) else np.zeros((max(plane.size[1], 1), plane.stride), dtype=np.uint8)
-        cv.check(lib.chv_download(ctx.handle, buf.ctypes.data, plane.stride, tex._h, 0, image.gpuPitches[idx],
+        cv.check(lib.chv_download(ctx.handle, buf.ctypes.data, plane.stride, tex._h, image.gpuOffsets[idx], image.gpuPitches[idx],
                                   plane.size[0] * comps, plane.size[1]))
         bufs.append(buf)
     endComputePass(ctx, True)
     img = image.withChanges(computeTextures=image.computeTextures if retainGpuBuffer else [],
-                            gpuPitches=image.gpuPitches if retainGpuBuffer else [], buffers=bufs, bufferType="cpu")
+                            gpuPitches=image.gpuPitches if retainGpuBuffer else [],
+                            gpuOffsets=image.gpuOffsets if retainGpuBuffer else [], buffers=bufs, bufferType="cpu")
     return pict.derive(img=img)
 
 
@@ -422,7 +447,7 @@ def _image_desc(sample, maxPlanes=3):
         p = image.planes[i]
         comps = len(p.components)
         comps = 4 if comps >= 3 else comps
-        d.planes[i] = cv.Plane(image.computeTextures[i]._h, 0, p.size[0], p.size[1], image.gpuPitches[i], comps)
+        d.planes[i] = cv.Plane(image.computeTextures[i]._h, image.gpuOffsets[i], p.size[0], p.size[1], image.gpuPitches[i], comps)
     return d
 
 

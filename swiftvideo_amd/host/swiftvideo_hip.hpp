@@ -214,6 +214,10 @@ struct ImageBuffer {
     std::vector<ComputeBufferRef> computeTextures;
     std::vector<std::shared_ptr<Data>> buffers;     // one per plane, stride * rows bytes
     std::vector<Plane> planes;
+    // HIP backend: the planes of one picture are regions of ONE device allocation (computeTextures holds the same
+    // buffer for every plane) at these byte offsets / pitches, so that a picture whose host planes are contiguous
+    // (sample.pict.linux.swift:296-311) is uploaded with one copy instead of one per plane
+    std::vector<size_t> gpuOffsets, gpuPitches;
 };
 
 // sample.pict.linux.swift:275-294
@@ -263,17 +267,37 @@ inline PictureSample uploadComputePicture(const ComputeContext &ctx, const Pictu
     if (!(n > 0 && n <= 3)) throw ComputeError(CHV_ERR_BAD_INPUT, "Input image must have 1, 2, or 3 planes");
     if (n != image.buffers.size()) throw ComputeError(CHV_ERR_BAD_INPUT, "Input image must have the same number of buffers as planes");
     auto out = std::make_shared<ImageBuffer>(image);
-    out->computeTextures.clear();
-    beginComputePass(ctx);
-    for (size_t i = 0; i < std::min(n, (size_t)maxPlanes); i++) {
+    out->computeTextures.clear(); out->gpuOffsets.clear(); out->gpuPitches.clear();
+    const size_t np = std::min(n, (size_t)maxPlanes);
+    size_t total = 0;
+    for (size_t i = 0; i < np; i++) {                  // 128-byte aligned pitches, planes back to back
         const Plane &p = image.planes[i];
-        int comps = planeComponents(p);
-        chv_buffer *h = nullptr; size_t pitch = 0;
-        check(chv_plane_alloc(ctx.get(), (int)p.size.x, (int)p.size.y, comps, &h, &pitch));
-        auto tex = std::make_shared<ComputeBuffer>(h, pitch * (size_t)p.size.y, pitch);
-        out->computeTextures.push_back(tex);
-        check(chv_upload(ctx.get(), h, 0, pitch, image.buffers[i]->data(), (size_t)p.stride, (size_t)p.size.x * comps,
-                         (size_t)p.size.y, asynchronous ? 1 : 0));
+        if (p.size.x <= 0 || p.size.y <= 0) throw ComputeError(CHV_ERR_INVALID_OPERATION, "empty plane");
+        size_t pitch = ((size_t)p.size.x * planeComponents(p) + 127) / 128 * 128;
+        out->gpuPitches.push_back(pitch); out->gpuOffsets.push_back(total);
+        total += pitch * (size_t)p.size.y;
+    }
+    chv_buffer *h = nullptr;
+    check(chv_buffer_alloc(ctx.get(), total, &h));
+    auto tex = std::make_shared<ComputeBuffer>(h, total, 0);
+    for (size_t i = 0; i < np; i++) out->computeTextures.push_back(tex);
+    beginComputePass(ctx);
+    // planes that are adjacent with equal pitch and width on both sides (NV12's luma + chroma, y420p's two chroma
+    // planes) travel as one pitched copy
+    for (size_t i = 0; i < np;) {
+        const Plane &p = image.planes[i];
+        const size_t wb = (size_t)p.size.x * planeComponents(p);
+        size_t rows = (size_t)p.size.y, j = i + 1;
+        const uint8_t *src = image.buffers[i]->data();
+        while (j < np) {
+            const Plane &q = image.planes[j];
+            if (out->gpuPitches[j] != out->gpuPitches[i] || q.stride != p.stride || (size_t)q.size.x * planeComponents(q) != wb ||
+                out->gpuOffsets[j] != out->gpuOffsets[i] + out->gpuPitches[i] * rows || image.buffers[j]->data() != src + (size_t)p.stride * rows)
+                break;
+            rows += (size_t)q.size.y; j++;
+        }
+        check(chv_upload(ctx.get(), h, out->gpuOffsets[i], out->gpuPitches[i], src, (size_t)p.stride, wb, rows, asynchronous ? 1 : 0));
+        i = j;
     }
     endComputePass(ctx, true);
     out->bufferType = BufferType::gpu;
@@ -294,13 +318,13 @@ inline PictureSample downloadComputePicture(const ComputeContext &ctx, const Pic
         const Plane &p = image.planes[i];
         int comps = planeComponents(p);
         auto buf = i < image.buffers.size() ? image.buffers[i] : std::make_shared<Data>((size_t)p.stride * (size_t)p.size.y, 0);
-        check(chv_download(ctx.get(), buf->data(), (size_t)p.stride, image.computeTextures[i]->handle, 0,
-                           image.computeTextures[i]->pitch, (size_t)p.size.x * comps, (size_t)p.size.y));
+        check(chv_download(ctx.get(), buf->data(), (size_t)p.stride, image.computeTextures[i]->handle, image.gpuOffsets[i],
+                           image.gpuPitches[i], (size_t)p.size.x * comps, (size_t)p.size.y));
         out->buffers.push_back(buf);
     }
     endComputePass(ctx, true);
     out->bufferType = BufferType::cpu;
-    if (!retainGpuBuffer) out->computeTextures.clear();
+    if (!retainGpuBuffer) { out->computeTextures.clear(); out->gpuOffsets.clear(); out->gpuPitches.clear(); }
     PictureSample r = pict;
     r.img = out;
     return r;
@@ -317,8 +341,8 @@ inline bool describe(const PictureSample &s, chv_image *d, int maxPlanes = 3) {
     d->n_planes = n;
     for (int i = 0; i < n; i++) {
         const Plane &p = s.img->planes[i];
-        d->planes[i] = chv_plane{ s.img->computeTextures[i]->handle, 0, (int)p.size.x, (int)p.size.y,
-                                  (int)s.img->computeTextures[i]->pitch, planeComponents(p) };
+        d->planes[i] = chv_plane{ s.img->computeTextures[i]->handle, s.img->gpuOffsets[i], (int)p.size.x, (int)p.size.y,
+                                  (int)s.img->gpuPitches[i], planeComponents(p) };
     }
     return true;
 }

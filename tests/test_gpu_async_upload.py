@@ -51,9 +51,14 @@ def test_pinned_uploads_overlap_with_kernels_and_stay_ordered(ctx):
         base = k * (ysz + csz)
         host[base:base + ysz] = src[0].reshape(-1)
         host[base + ysz:base + ysz + csz] = src[1].reshape(-1)
-        tex = dev[k].imageBuffer().computeTextures
-        cv.check(lib.chv_upload(up.handle, tex[0]._h, 0, tex[0].pitch, host[base:].ctypes.data, W, W, H, 2))
-        cv.check(lib.chv_upload(up.handle, tex[1]._h, 0, tex[1].pitch, host[base + ysz:].ctypes.data, W, W, H // 2, 2))
+        img = dev[k].imageBuffer()
+        tex, pitch, off = img.computeTextures, img.gpuPitches, img.gpuOffsets
+        if f & 1:      # plane by plane ...
+            cv.check(lib.chv_upload(up.handle, tex[0]._h, off[0], pitch[0], host[base:].ctypes.data, W, W, H, 2))
+            cv.check(lib.chv_upload(up.handle, tex[1]._h, off[1], pitch[1], host[base + ysz:].ctypes.data, W, W, H // 2, 2))
+        else:          # ... or the whole NV12 picture as one pitched region (the planes are adjacent on both sides)
+            assert tex[0] is tex[1] and pitch[0] == pitch[1] and off[1] == off[0] + pitch[0] * H
+            cv.check(lib.chv_upload(up.handle, tex[0]._h, off[0], pitch[0], host[base:].ctypes.data, W, W, H + H // 2, 2))
         # no host-side wait: the kernel's stream waits for the two uploads through the buffers' events
         layer = (sv.ComputeKernel.img_nv12_bgra, dev[k], u, 0)
         sv.compositeTick(ctx, outs[f], [layer], clearFirst=True)
