@@ -621,6 +621,11 @@ static int32_t layer_flags(const float *u) {
     bool fill_finite = finite255(u[U_FILL]) && finite255(u[U_FILL + 1]) && finite255(u[U_FILL + 2]);
     if (u[U_OPACITY] * u[U_FILL + 3] == 0.f && fill_finite) f |= LF_NO_FILL;
     if (u[U_OPACITY] == 1.f) f |= LF_OPAQUE;
+    // bounded matrices: with |entry| < 2^60 and |nx|, |ny| <= 3 no product of the geometry prologue overflows, so the
+    // zero entries of an axis-aligned layer contribute exact zeros (geometry_axis, pixel_math.hip.h)
+    bool bounded = true;
+    for (int i = 0; i < 48; i++) bounded = bounded && std::fabs(u[i]) < 0x1p60f;      // false for NaN as well
+    if (bounded) f |= LF_BOUNDED;
     return f;
 }
 

@@ -48,7 +48,8 @@ struct DLayer {
 enum LayerFlags : int32_t {
     LF_AXIS_ALIGNED = 1,  // no rotation/shear: tx.x/uv.x depend on x only, tx.y/uv.y on y only
     LF_NO_FILL = 2,       // opacity * fillColor.w == 0 exactly
-    LF_OPAQUE = 4         // opacity == 1 exactly
+    LF_OPAQUE = 4,        // opacity == 1 exactly
+    LF_BOUNDED = 8        // all 48 matrix entries finite and < 2^60 in magnitude: no product in the prologue overflows
 };
 
 enum TargetFormat : int32_t { TF_NV12 = 0, TF_Y420P = 1, TF_BGRA = 2 };

@@ -38,7 +38,7 @@ CHV_DEV uint32_t apply_layer_bgra(const DLayer &L, int x, int y, float sx, float
         return o0 | (o1 << 8) | (o2 << 16) | 0xFF000000u;
     }
     // BGRA-target family: code-scale arithmetic (pixel_math.hip.h)
-    Geo g = geometry(U, x, y, sx, sy);
+    Geo g = geometry_for(L, x, y, sx, sy);
     if (!g.in_border) return cur;
     // fill colour under the picture / on the border, straight alpha
     float af = U[U_OPACITY] * U[U_FILL + 3];
@@ -118,7 +118,7 @@ struct QuadState {
 CHV_DEV void apply_yuv_from_yuv(const DLayer &L, int x, int y, float sx, float sy, bool owner,
                                 uint32_t &cy, uint32_t &cu, uint32_t &cv) {
     const float *U = L.u;
-    Geo g = geometry(U, x, y, sx, sy);
+    Geo g = geometry_for(L, x, y, sx, sy);
     if (!g.in_border) return;
     float curY = unorm8(cy);
     if (g.in_tx && g.in_uv) {
@@ -156,7 +156,7 @@ CHV_DEV void apply_yuv_from_yuv(const DLayer &L, int x, int y, float sx, float s
 CHV_DEV void apply_yuv_from_rgb(const DLayer &L, int x, int y, float sx, float sy, bool owner,
                                 uint32_t &cy, uint32_t &cu, uint32_t &cv) {
     const float *U = L.u;
-    Geo g = geometry(U, x, y, sx, sy);
+    Geo g = geometry_for(L, x, y, sx, sy);
     if (!g.in_border || !g.in_tx) return;
     float alpha = U[U_OPACITY] * U[U_FILL + 3];
     float fy, fu, fv;
