@@ -77,3 +77,35 @@ def test_no_device_is_an_error_not_a_fallback(built):
     with pytest.raises(sv.ComputeError) as e:
         sv.makeComputeContext(forType="GPU")
     assert e.value.case == "deviceNotAvailable"
+
+
+def test_header_is_plain_c_and_layouts_match_the_binding(tmp_path):
+    """include/chipvideo.h is what a Swift module map (or cgo, JNI, ...) consumes: it must compile as C99 with no
+    C++-isms, and the structs the ctypes binding declares must have the C compiler's sizes and offsets."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "layout.c"
+    src.write_text('''
+#include <stddef.h>
+#include <stdio.h>
+#include "chipvideo.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(chv_plane), sizeof(chv_image), sizeof(chv_uniforms), sizeof(chv_kernel_opts),
+           sizeof(chv_layer), sizeof(chv_tick), sizeof(chv_device_info), sizeof(chv_custom_args));
+    printf("%zu %zu %zu %zu %zu\\n", offsetof(chv_plane, pitch), offsetof(chv_image, planes), offsetof(chv_layer, uniforms),
+           offsetof(chv_layer, opts), offsetof(chv_tick, layers));
+    return 0;
+}
+''')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)])
+    sizes, offsets = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    sizes = [int(x) for x in sizes.split()]
+    offsets = [int(x) for x in offsets.split()]
+    assert sizes[:7] == [C.sizeof(cv.Plane), C.sizeof(cv.Image), C.sizeof(cv.Uniforms), C.sizeof(cv.KernelOpts), C.sizeof(cv.Layer),
+                         C.sizeof(cv.Tick), C.sizeof(cv.DeviceInfo)]
+    assert sizes[7] == 6 * 80 + 8 + 256                      # chv_custom_args: 6 images, two counts, 256 uniform bytes
+    assert offsets == [cv.Plane.pitch.offset, cv.Image.planes.offset, cv.Layer.uniforms.offset, cv.Layer.opts.offset,
+                       cv.Tick.layers.offset]
