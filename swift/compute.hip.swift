@@ -132,7 +132,7 @@ func destroyComputeContext( _ context: ComputeContext) throws {
 func buildComputeKernel(_ context: ComputeContext, name: String, source: String) throws -> ComputeContext {
     context.logger.info("buildComputeKernel")
     let status = chv_kernel_build(context.handle, name, source)
-    if status != CHV_OK.rawValue, let detail = chv_last_error_detail() {
+    if status != 0, let detail = chv_last_error_detail() {
         context.logger.info("Build log:\n\(String(cString: detail))")
     }
     try check(status)
@@ -143,7 +143,7 @@ func buildComputeKernel(_ context: ComputeContext, name: String, source: String)
 private func userKernelName(_ kernel: ComputeKernel) -> String? {
     guard case .custom(let name) = kernel else { return nil }
     var id: Int32 = -1
-    return chv_kernel_from_string(name, &id) == CHV_OK.rawValue ? nil : name
+    return chv_kernel_from_string(name, &id) == 0 ? nil : name
 }
 
 // MARK: - Passes and kernels (compute.cl.swift:234-359)
