@@ -29,7 +29,7 @@ __all__ = [
     "destroyComputeContext", "beginComputePass", "endComputePass", "usingContext", "runComputeKernel",
     "applyComputeImage", "uploadComputePicture", "downloadComputePicture", "uploadComputeBuffer",
     "downloadComputeBuffer", "createPictureSample", "GPUBarrierUpload", "GPUBarrierDownload", "VideoMixer",
-    "compositeTick", "scaleLanczos", "PictureFilter", "CustomKernel", "buildComputeKernel",
+    "compositeTick", "scaleLanczos", "PictureFilter", "CustomKernel", "buildComputeKernel", "TickBatch", "VideoMixerGroup",
 ]
 
 
@@ -548,6 +548,51 @@ def compositeTick(ctx, target, layers, clearFirst=True):
     return ctx
 
 
+class TickBatch:
+    """Many independent mixer ticks issued as ONE launch (chv_batch_*): what a host with several mixers / streams on a
+    device (composer.swift:203-224) uses instead of one chv_composite per tick.  Byte-identical to running the ticks
+    one by one.  ticks: [(target PictureSample, clearFirst, [(kernel, PictureSample, uniforms, colorspace)])].
+    The batch keeps the descriptors on the device; the pictures it refers to must stay alive until it is destroyed."""
+
+    def __init__(self, ctx, ticks):
+        lib = cv.load()
+        arr = (cv.Tick * max(1, len(ticks)))()
+        self._keep = [arr]
+        for i, (target, clear, layers) in enumerate(ticks):
+            tdesc = _image_desc(target)
+            if tdesc is None:
+                raise ComputeError(4, "target has no GPU image buffer")
+            la = _layer_array(layers)
+            self._keep += [la, target, [l[1] for l in layers]]
+            arr[i].target = tdesc
+            arr[i].clear_first = 1 if clear else 0
+            arr[i].n_layers = len(layers)
+            arr[i].layers = la
+        self._h = C.c_void_p()
+        cv.check(lib.chv_batch_create(ctx.handle, arr, len(ticks), C.byref(self._h)))
+        name = C.create_string_buffer(128)
+        launches = C.c_int(0)
+        cv.check(lib.chv_batch_describe(self._h, name, 128, C.byref(launches)))
+        self.kernelName, self.launches, self.count = name.value.decode(), launches.value, len(ticks)
+
+    def run(self, ctx):
+        """Enqueue the batch on ctx's stream (inside a compute pass, like runComputeKernel)."""
+        cv.check(cv.load().chv_batch_run(ctx.handle, self._h))
+        return ctx
+
+    def destroy(self):
+        if self._h:
+            cv.check(cv.load().chv_batch_destroy(self._h))
+            self._h = C.c_void_p()
+            self._keep = []
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 def scaleLanczos(ctx, dst, src):
     d, s = _image_desc(dst), _image_desc(src)
     if d is None:
@@ -660,6 +705,56 @@ class PictureFilter:
                                        revision=sample.revision()))
         except ComputeError as e:
             return ("error", ("filter.pict", -2, f"Compute error {e}", sample.assetId()))
+
+
+class VideoMixerGroup:
+    """Several VideoMixers of one device ticked together: their canvases are composed by one launch per canvas format
+    (TickBatch) and one host wait, instead of one launch and one host wait per mixer (mix.video.swift:116-124 per mixer).  Each mixer keeps its own samples,
+    backing ring and z-order; the result of `mix(at)` is the list of what every mixer's own `mix(at)` would return."""
+
+    def __init__(self, mixers):
+        if not mixers:
+            raise ComputeError(0, "empty mixer group")
+        self.mixers = list(mixers)
+        self.context = self.mixers[0].clContext
+
+    def mix(self, at=0.0):
+        ticks, backings = [], []
+        try:
+            for m in self.mixers:
+                backing = m.getBacking()
+                merged = dict(m.samples[1])
+                merged.update(m.samples[0])
+                images = sorted(merged.values(), key=lambda s: s.zIndex())
+                ticks.append((backing, True, [(m.findKernel(im, backing), im, imageUniformsFor(im, backing), m.colorspace)
+                                              for im in images]))
+                backings.append(backing)
+            # a batch is one kernel family: one batch per canvas format, all enqueued in one pass
+            by_format = {}
+            for tick in ticks:
+                by_format.setdefault(int(tick[0].pixelFormat()), []).append(tick)
+            batches = [TickBatch(self.context, group) for group in by_format.values()]
+            try:
+                def body(c):
+                    for batch in batches:
+                        c = batch.run(c)
+                    return c
+                usingContext(self.context, body)
+            finally:
+                for batch in batches:
+                    batch.destroy()
+            out = [b.derive(pts=at, time=at, assetId=m.assetId()) for b, m in zip(backings, self.mixers)]
+            for m in self.mixers:
+                m.result = ("nothing", None)
+            return out
+        except ComputeError as e:
+            for m in self.mixers:
+                m.result = ("error", ("mix.video", -2, f"Compute error {e}", at, m.idAsset))
+            return None
+        finally:
+            for m in self.mixers:
+                m.samples[1] = m.samples[0]
+                m.samples[0] = dict()
 
 
 def _unit_quad_to_ndc():

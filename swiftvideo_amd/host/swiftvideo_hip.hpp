@@ -431,6 +431,45 @@ inline ComputeContext scaleLanczos(ComputeContext ctx, const PictureSample &dst,
     return ctx;
 }
 
+// Many independent ticks as ONE launch (chv_batch_*): what a host with several mixers / streams on a device
+// (composer.swift:203-224) uses instead of one chv_composite per tick; byte-identical to running them one by one.
+struct Tick { PictureSample target; bool clearFirst = true; std::vector<TickLayer> layers; };
+class TickBatch {
+public:
+    TickBatch(const ComputeContext &ctx, const std::vector<Tick> &ticks) : keep_(ticks) {
+        std::vector<chv_tick> ts(ticks.size());
+        layers_.resize(ticks.size());
+        for (size_t i = 0; i < ticks.size(); i++) {
+            std::memset(&ts[i], 0, sizeof ts[i]);
+            if (!describe(ticks[i].target, &ts[i].target)) throw ComputeError(CHV_ERR_BAD_TARGET, "target has no GPU image buffer");
+            layers_[i].resize(ticks[i].layers.size());
+            for (size_t l = 0; l < ticks[i].layers.size(); l++) {
+                chv_layer &d = layers_[i][l];
+                std::memset(&d, 0, sizeof d);
+                d.kernel = (int)ticks[i].layers[l].kernel;
+                if (!describe(ticks[i].layers[l].image, &d.image)) throw ComputeError(CHV_ERR_BAD_INPUT, "Bad input image");
+                d.uniforms = ticks[i].layers[l].uniforms;
+                d.opts.colorspace = ticks[i].layers[l].colorspace;
+            }
+            ts[i].clear_first = ticks[i].clearFirst ? 1 : 0;
+            ts[i].n_layers = (int)layers_[i].size();
+            ts[i].layers = layers_[i].data();
+        }
+        check(chv_batch_create(ctx.get(), ts.data(), (int)ts.size(), &batch_));
+        char name[128] = { 0 };
+        check(chv_batch_describe(batch_, name, sizeof name, nullptr));
+        kernelName = name;
+    }
+    TickBatch(const TickBatch &) = delete;
+    ~TickBatch() { if (batch_) chv_batch_destroy(batch_); }
+    ComputeContext run(ComputeContext ctx) const { check(chv_batch_run(ctx.get(), batch_)); return ctx; }   // inside a compute pass
+    std::string kernelName;
+private:
+    chv_batch *batch_ = nullptr;
+    std::vector<Tick> keep_;                       // the pictures stay alive as long as the device descriptors do
+    std::vector<std::vector<chv_layer>> layers_;
+};
+
 // ---- pipeline operators (compute.swift:175-255) -------------------------------------------------------
 struct EventError { std::string source; int code = 0; std::string description; std::string assetId; };
 template <typename T> struct EventBox {          // event.swift:63-95: .just / .nothing / .error / .gone
@@ -497,15 +536,23 @@ public:
         return defaultComputeKernelFromString(name);
     }
 
+    const ComputeContext &context() const { return clContext_; }
+
+    // the tick of this mixer as data (next backing image, z-sorted layers): for VideoMixerGroup
+    Tick prepareTick() {
+        Tick t;
+        t.target = getBacking();
+        t.clearFirst = true;
+        for (auto &im : sortedImages()) t.layers.push_back(TickLayer{ findKernel(&im, t.target), im, imageUniformsFor(im, t.target) });
+        return t;
+    }
+    void finishTick() { samples_[1] = samples_[0]; samples_[0].clear(); }   // mix.video.swift:104-107
+
     EventBox<PictureSample> mix(double at) {
         EventBox<PictureSample> out;
         try {
             PictureSample backing = getBacking();
-            std::map<std::string, PictureSample> merged = samples_[1];
-            for (auto &kv : samples_[0]) merged[kv.first] = kv.second;       // lhs wins, mix.video.swift:114
-            std::vector<PictureSample> images;
-            for (auto &kv : merged) images.push_back(kv.second);
-            std::stable_sort(images.begin(), images.end(), [](const PictureSample &a, const PictureSample &b) { return a.zIndex < b.zIndex; });
+            std::vector<PictureSample> images = sortedImages();
             if (fused_) {
                 std::vector<TickLayer> layers;
                 for (auto &im : images) layers.push_back(TickLayer{ findKernel(&im, backing), im, imageUniformsFor(im, backing) });
@@ -521,12 +568,19 @@ public:
         } catch (const ComputeError &e) {
             out.kind = out.error; out.err = EventError{ "mix.video", -2, std::string("Compute error ") + e.what(), idAsset_ };
         }
-        samples_[1] = samples_[0];
-        samples_[0].clear();
+        finishTick();
         return out;
     }
 
 private:
+    std::vector<PictureSample> sortedImages() const {
+        std::map<std::string, PictureSample> merged = samples_[1];
+        for (auto &kv : samples_[0]) merged[kv.first] = kv.second;       // lhs wins, mix.video.swift:114
+        std::vector<PictureSample> images;
+        for (auto &kv : merged) images.push_back(kv.second);
+        std::stable_sort(images.begin(), images.end(), [](const PictureSample &a, const PictureSample &b) { return a.zIndex < b.zIndex; });
+        return images;
+    }
     PictureSample getBacking() {                      // mix.video.swift:148-165
         if ((int)backing_.size() < numberBackingImages) {
             PictureSample image = createPictureSample(backingSize_, backingFormat_, idAsset_, idWorkspace_);
@@ -546,6 +600,41 @@ private:
     std::map<std::string, PictureSample> samples_[2];
 };
 
+
+// Several VideoMixers of one device ticked together: one launch per canvas format and one host wait instead of one
+// launch and one wait per mixer; each element of the result is what that mixer's own mix(at) returns.
+class VideoMixerGroup {
+public:
+    explicit VideoMixerGroup(std::vector<VideoMixer *> mixers) : mixers_(std::move(mixers)) {}
+    std::vector<EventBox<PictureSample>> mix(double at) {
+        std::vector<EventBox<PictureSample>> out(mixers_.size());
+        try {
+            std::map<int, std::vector<Tick>> byFormat;
+            std::vector<PictureSample> backings;
+            for (VideoMixer *m : mixers_) {
+                Tick t = m->prepareTick();
+                backings.push_back(t.target);
+                byFormat[(int)t.target.pixelFormat()].push_back(std::move(t));
+            }
+            std::vector<std::unique_ptr<TickBatch>> batches;
+            for (auto &kv : byFormat) batches.emplace_back(new TickBatch(mixers_[0]->context(), kv.second));
+            usingContext(mixers_[0]->context(), [&](ComputeContext c) { for (auto &b : batches) c = b->run(c); return c; });
+            for (size_t i = 0; i < mixers_.size(); i++) {
+                out[i].kind = out[i].just; out[i].value = backings[i];
+                out[i].value.pts = at; out[i].value.time = at; out[i].value.assetId = mixers_[i]->assetId();
+            }
+        } catch (const ComputeError &e) {
+            for (size_t i = 0; i < mixers_.size(); i++) {
+                out[i].kind = out[i].error;
+                out[i].err = EventError{ "mix.video", -2, std::string("Compute error ") + e.what(), mixers_[i]->assetId() };
+            }
+        }
+        for (VideoMixer *m : mixers_) m->finishTick();
+        return out;
+    }
+private:
+    std::vector<VideoMixer *> mixers_;
+};
 
 // ---- PictureFilter: the Tx<PictureSample, PictureSample> the reference sketches and leaves commented out
 //      (filter.pict.swift:20-47).  Converts a picture to outputFormat at outputSize on the device: one

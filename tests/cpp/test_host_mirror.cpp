@@ -261,6 +261,30 @@ static void gpuTests() {
         auto o3 = bad(src);
         EXPECT(o3.kind == o3.error && o3.err.source == "filter.pict");
     }
+    // VideoMixerGroup / TickBatch: three mixers ticked by one launch per canvas format == each mixer's own mix()
+    {
+        std::vector<std::unique_ptr<sv::VideoMixer>> grouped, solo;
+        sv::PixelFormat fmts[3] = { sv::PixelFormat::nv12, sv::PixelFormat::BGRA, sv::PixelFormat::BGRA };
+        for (int k = 0; k < 3; k++) for (auto *dest : { &grouped, &solo }) {
+            dest->emplace_back(new sv::VideoMixer("ws", { 80, 44 }, fmts[k], ctx, "mixer" + std::to_string(k)));
+            sv::PictureSample s = randomPicture(sv::PixelFormat::nv12, 48, 30, 60 + k);
+            s.matrix = sv::Matrix4::ortho(80, 44) * sv::Matrix4::scale(80, 44); s.borderMatrix = s.matrix; s.revision = "cam";
+            dest->back()->push(sv::uploadComputePicture(ctx, s));
+            sv::PictureSample o = randomPicture(sv::PixelFormat::BGRA, 20, 16, 70 + k);
+            o.matrix = sv::Matrix4::ortho(80, 44) * sv::Matrix4::translation(8, 6) * sv::Matrix4::scale(30, 20); o.borderMatrix = o.matrix;
+            o.opacity = 0.7f; o.zIndex = 1; o.revision = "logo";
+            dest->back()->push(sv::uploadComputePicture(ctx, o));
+        }
+        sv::VideoMixerGroup group({ grouped[0].get(), grouped[1].get(), grouped[2].get() });
+        auto outs = group.mix(1.0);
+        EXPECT(outs.size() == 3);
+        for (int k = 0; k < 3; k++) {
+            auto ref = solo[k]->mix(1.0);
+            EXPECT(outs[k].kind == outs[k].just && ref.kind == ref.just && outs[k].value.assetId == "mixer" + std::to_string(k));
+            if (outs[k].kind == outs[k].just && ref.kind == ref.just)
+                EXPECT(samePlanes(sv::downloadComputePicture(ctx, outs[k].value, true), sv::downloadComputePicture(ctx, ref.value, true)));
+        }
+    }
     // .custom kernels through hipRTC: swap B and R of a picture, scaled by a float uniform
     {
         const char *src_text =

@@ -111,3 +111,31 @@ def test_picture_filter_lanczos_and_errors(ctx):
     assert tag == "error"
     with pytest.raises(sv.ComputeError):
         sv.PictureFilter((w, h), scaler="bicubic")
+
+
+def test_mixer_group_ticks_many_mixers_in_one_launch(ctx):
+    """VideoMixerGroup / TickBatch: N mixers of a device composed by one launch give the bytes each mixer's own
+    mix() gives (chv_batch_* vs chv_composite)."""
+    specs = [("nv12", (96, 54)), ("y420p", (64, 36)), ("bgra", (80, 44)), ("bgra", (80, 44))]
+    group_mixers, solo_mixers = [], []
+    for k, (fmt, canvas) in enumerate(specs):
+        for dest in (group_mixers, solo_mixers):
+            m = sv.VideoMixer("ws", 1 / 30, canvas, outputFormat=G.FMT[fmt], computeContext=ctx, assetId=f"mixer{k}")
+            src_fmt = "nv12" if fmt != "y420p" else "y420p"
+            m.push(_layer(ctx, src_fmt, 48, 30, 40 + k, canvas, (0, 0) + canvas, 0))
+            m.push(_layer(ctx, "bgra", 20, 16, 50 + k, canvas, (8, 6, 30, 20), 1, opacity=0.7, asset="logo"))
+            dest.append(m)
+    group = sv.VideoMixerGroup(group_mixers)
+    outs = group.mix(at=1.0)
+    assert outs is not None and len(outs) == len(specs), [m.result for m in group_mixers]
+    for k, ((fmt, canvas), out, solo) in enumerate(zip(specs, outs, solo_mixers)):
+        ref = solo.mix(at=1.0)
+        assert out.assetId() == f"mixer{k}" and out.time() == 1.0
+        G.assert_same(G.from_gpu(ctx, out, fmt, *canvas), G.from_gpu(ctx, ref, fmt, *canvas), f"mixer {k} ({fmt})")
+    # a TickBatch on its own: two clears of same-format canvases in one launch; mixed formats are refused
+    with pytest.raises(sv.ComputeError):
+        sv.TickBatch(ctx, [(outs[0], True, []), (outs[2], True, [])])
+    b = sv.TickBatch(ctx, [(outs[2], True, []), (outs[3], True, [])])
+    assert b.count == 2 and b.launches >= 1 and b.kernelName
+    sv.usingContext(ctx, b.run)
+    b.destroy()
