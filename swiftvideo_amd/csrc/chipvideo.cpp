@@ -1108,9 +1108,17 @@ static int lanczos_table(chv_context *c, int in_size, int out_size, LanczosTable
     int rc = lanczos_host_table(in_size, out_size, &t.taps, &first, &weights);
     if (rc) return rc;
     HIP_TRY(hipMalloc((void **)&t.first, first.size() * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void **)&t.weights, weights.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(t.first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t.weights, weights.data(), weights.size() * sizeof(float), hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc((void **)&t.weights, weights.size() * sizeof(float));
+    if (e != hipSuccess) t.weights = nullptr;
+    if (e == hipSuccess)
+        e = hipMemcpy(t.first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(t.weights, weights.data(), weights.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(t.first);
+        if (t.weights) (void)hipFree(t.weights);
+        return hip_fail(e, "lanczos table upload");
+    }
     c->shared->lanczos[key] = t;
     *out = t;
     return CHV_OK;
