@@ -22,8 +22,10 @@ constexpr int LZ_MAXT = 24;      // taps held in registers (scale <= 4); more ta
 constexpr int LZ_KS = 4;         // tiles per block, side by side: tile t+1's source rectangle is prefetched into
 constexpr int LZ_NPRE = 6;       // registers (one 16-byte vector per row rg + 8n, n < LZ_NPRE) while tile t is filtered
 
-template <int TAPS_IN_REGS, bool PREFETCH, int LZ_TW, int LZ_TH>
-__global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
+// EXACT: tx == ty == TAPS_IN_REGS, the tap loops are straight-line code.  Otherwise taps beyond the table's count
+// re-read the last tap with weight 0 (fma(0, finite, acc) == acc): still no branch per tap, at one address add each.
+template <int TAPS_IN_REGS, bool EXACT, bool PREFETCH, int LZ_TW, int LZ_TH>
+__global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void lanczos3_bgra(DPlane dst, DPlane src,
                                                      const int32_t *__restrict__ fx, const float *__restrict__ wx, int tx,
                                                      const int32_t *__restrict__ fy, const float *__restrict__ wy, int ty,
                                                      int max_rows, int max_cols) {
@@ -61,6 +63,29 @@ __global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
         };
         return make_uint4(pick(0), pick(1), pick(2), pick(3));
     };
+
+    // Vertical pass, per thread: output column tid % LZ_TW of every tile, rows cj + n * CRG.  Row positions and
+    // row weights do not depend on the tile, so they are fetched once per block (a load per tap inside the tap
+    // loop made the vertical pass a chain of dependent memory latencies: 2/3 of the kernel's time).
+    constexpr int CT = TAPS_IN_REGS > 0 ? TAPS_IN_REGS : 1;
+    constexpr int CRG = 256 / LZ_TW;                      // row groups of the vertical pass
+    constexpr int CNR = (LZ_TH + CRG - 1) / CRG;          // rows per thread: 2 (32 x 16 tiles) or 1 (8 x 4)
+    const int ci = tid & (LZ_TW - 1), cj = tid / LZ_TW;
+    const bool rows_in_regs = EXACT ? true : (TAPS_IN_REGS > 0 && ty <= TAPS_IN_REGS);
+    float wrow[CNR][CT];
+    int rbase_c[CNR];
+#pragma unroll
+    for (int n = 0; n < CNR; n++) {
+        const int oy = min(oy0 + cj + n * CRG, dst.h - 1);
+        rbase_c[n] = fy[oy] - row0;
+        if (rows_in_regs) {
+#pragma unroll
+            for (int k = 0; k < CT; k++) {
+                const float wk = wy[(size_t)oy * ty + (EXACT ? k : min(k, ty - 1))];
+                wrow[n][k] = (EXACT || k < ty) ? wk : 0.f;
+            }
+        }
+    }
 
     uint4 pre[LZ_NPRE];
     int col0 = 0, nvec = 0;
@@ -113,23 +138,42 @@ __global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
         float wr[TAPS_IN_REGS > 0 ? TAPS_IN_REGS : 1];
         if (TAPS_IN_REGS > 0) {
 #pragma unroll
-            for (int k = 0; k < TAPS_IN_REGS; k++) wr[k] = k < tx ? w[k] : 0.f;
+            for (int k = 0; k < TAPS_IN_REGS; k++) {
+                const float wk = w[EXACT ? k : min(k, tx - 1)];
+                wr[k] = (EXACT || k < tx) ? wk : 0.f;
+            }
         }
-        for (int r = rg; r < nrows; r += RGS) {
-            const uint32_t *row = stile + r * max_cols + cbase;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (TAPS_IN_REGS > 0) {
+        if (TAPS_IN_REGS > 0) {
+            // the taps of row r + RGS are read from LDS while row r is filtered: left to itself the compiler issues
+            // one LDS read per tap pair and waits for it on the spot (6 exposed LDS latencies per row)
+            constexpr int T = TAPS_IN_REGS > 0 ? TAPS_IN_REGS : 1;
+            uint32_t p[T], q[T];
+            auto load_row = [&](int r, uint32_t (&d)[T]) {
+                const uint32_t *row = stile + r * max_cols + cbase;
 #pragma unroll
-                for (int k = 0; k < TAPS_IN_REGS; k++) {
-                    if (k < tx) {
-                        uint32_t p = row[k];
-                        acc.x = __builtin_fmaf(wr[k], (float)(p & 255), acc.x);
-                        acc.y = __builtin_fmaf(wr[k], (float)((p >> 8) & 255), acc.y);
-                        acc.z = __builtin_fmaf(wr[k], (float)((p >> 16) & 255), acc.z);
-                        acc.w = __builtin_fmaf(wr[k], (float)(p >> 24), acc.w);
-                    }
+                for (int k = 0; k < T; k++) d[k] = row[EXACT ? k : min(k, tx - 1)];
+            };
+            int r = rg;
+            if (r < nrows) load_row(r, p);
+            for (; r < nrows; r += RGS) {
+                if (r + RGS < nrows) load_row(r + RGS, q);
+                __builtin_amdgcn_sched_barrier(0);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < T; k++) {
+                    acc.x = __builtin_fmaf(wr[k], (float)(p[k] & 255), acc.x);
+                    acc.y = __builtin_fmaf(wr[k], (float)((p[k] >> 8) & 255), acc.y);
+                    acc.z = __builtin_fmaf(wr[k], (float)((p[k] >> 16) & 255), acc.z);
+                    acc.w = __builtin_fmaf(wr[k], (float)(p[k] >> 24), acc.w);
                 }
-            } else {
+                hrow[r * LZ_TW + i] = acc;
+#pragma unroll
+                for (int k = 0; k < T; k++) p[k] = q[k];
+            }
+        } else {
+            for (int r = rg; r < nrows; r += RGS) {
+                const uint32_t *row = stile + r * max_cols + cbase;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int k = 0; k < tx; k++) {
                     uint32_t p = row[k];
                     float wk = w[k];
@@ -138,30 +182,51 @@ __global__ __launch_bounds__(256) void lanczos3_bgra(DPlane dst, DPlane src,
                     acc.z = __builtin_fmaf(wk, (float)((p >> 16) & 255), acc.z);
                     acc.w = __builtin_fmaf(wk, (float)(p >> 24), acc.w);
                 }
+                hrow[r * LZ_TW + i] = acc;
             }
-            hrow[r * LZ_TW + i] = acc;
         }
     }
     __syncthreads();
 
     // phase C: vertical pass out of LDS
-    for (int idx = tid; idx < LZ_TW * LZ_TH; idx += 256) {
-        int j = idx / LZ_TW, i = idx % LZ_TW;
-        int ox = ox0 + i, oy = oy0 + j;
-        if (ox >= dst.w || oy >= dst.h) continue;
-        int rbase = fy[oy] - row0;
-        const float *w = wy + (size_t)oy * ty;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < ty; k++) {
-            float4 h = hrow[(rbase + k) * LZ_TW + i];
-            float wk = w[k];
-            acc.x = __builtin_fmaf(wk, h.x, acc.x);
-            acc.y = __builtin_fmaf(wk, h.y, acc.y);
-            acc.z = __builtin_fmaf(wk, h.z, acc.z);
-            acc.w = __builtin_fmaf(wk, h.w, acc.w);
+    if (rows_in_regs) {
+#pragma unroll
+        for (int n = 0; n < CNR; n++) {
+            const int j = cj + n * CRG, ox = ox0 + ci, oy = oy0 + j;
+            if (j >= LZ_TH || ox >= dst.w || oy >= dst.h) continue;
+            const float4 *col = hrow + rbase_c[n] * LZ_TW + ci;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < CT; k++) {
+                const float4 h = col[(EXACT ? k : min(k, ty - 1)) * LZ_TW];
+                const float wk = wrow[n][k];
+                acc.x = __builtin_fmaf(wk, h.x, acc.x);
+                acc.y = __builtin_fmaf(wk, h.y, acc.y);
+                acc.z = __builtin_fmaf(wk, h.z, acc.z);
+                acc.w = __builtin_fmaf(wk, h.w, acc.w);
+            }
+            uint32_t o = to_code_raw(acc.x) | (to_code_raw(acc.y) << 8) | (to_code_raw(acc.z) << 16) | (to_code_raw(acc.w) << 24);
+            gst<uint32_t>(dst.ptr + (size_t)oy * dst.pitch + (size_t)ox * 4, o);
         }
-        uint32_t o = to_code_raw(acc.x) | (to_code_raw(acc.y) << 8) | (to_code_raw(acc.z) << 16) | (to_code_raw(acc.w) << 24);
-        gst<uint32_t>(dst.ptr + (size_t)oy * dst.pitch + (size_t)ox * 4, o);
+    } else {
+        for (int idx = tid; idx < LZ_TW * LZ_TH; idx += 256) {
+            int j = idx / LZ_TW, i = idx % LZ_TW;
+            int ox = ox0 + i, oy = oy0 + j;
+            if (ox >= dst.w || oy >= dst.h) continue;
+            int rbase = fy[oy] - row0;
+            const float *w = wy + (size_t)oy * ty;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < ty; k++) {
+                float4 h = hrow[(rbase + k) * LZ_TW + i];
+                float wk = w[k];
+                acc.x = __builtin_fmaf(wk, h.x, acc.x);
+                acc.y = __builtin_fmaf(wk, h.y, acc.y);
+                acc.z = __builtin_fmaf(wk, h.z, acc.z);
+                acc.w = __builtin_fmaf(wk, h.w, acc.w);
+            }
+            uint32_t o = to_code_raw(acc.x) | (to_code_raw(acc.y) << 8) | (to_code_raw(acc.z) << 16) | (to_code_raw(acc.w) << 24);
+            gst<uint32_t>(dst.ptr + (size_t)oy * dst.pitch + (size_t)ox * 4, o);
+        }
     }
     // the next tile's phase A writes `stile` only (every wave is past phase B) and is followed by a barrier before its
     // phase B overwrites `hrow`, which slower waves may still be reading here
@@ -194,10 +259,14 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
         hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, dst, src, fx, wx, tx, fy, wy, ty, max_rows, max_cols);
         return hipGetLastError();
     };
-    if (small_tiles) return tx <= LZ_MAXT ? launch(lanczos3_bgra<LZ_MAXT, false, 8, 4>) : launch(lanczos3_bgra<0, false, 8, 4>);
-    if (tx <= 12) return prefetch ? launch(lanczos3_bgra<12, true, 32, 16>) : launch(lanczos3_bgra<12, false, 32, 16>);
-    if (tx <= LZ_MAXT) return prefetch ? launch(lanczos3_bgra<LZ_MAXT, true, 32, 16>) : launch(lanczos3_bgra<LZ_MAXT, false, 32, 16>);
-    return launch(lanczos3_bgra<0, false, 32, 16>);
+    if (small_tiles) return tx <= LZ_MAXT ? launch(lanczos3_bgra<LZ_MAXT, false, false, 8, 4>) : launch(lanczos3_bgra<0, false, false, 8, 4>);
+    if (tx == 12 && ty == 12)      // 2:1 (2160p -> 1080p) and its neighbourhood
+        return prefetch ? launch(lanczos3_bgra<12, true, true, 32, 16>) : launch(lanczos3_bgra<12, true, false, 32, 16>);
+    if (tx == 6 && ty == 6)        // enlargements
+        return prefetch ? launch(lanczos3_bgra<6, true, true, 32, 16>) : launch(lanczos3_bgra<6, true, false, 32, 16>);
+    if (tx <= 12) return prefetch ? launch(lanczos3_bgra<12, false, true, 32, 16>) : launch(lanczos3_bgra<12, false, false, 32, 16>);
+    if (tx <= LZ_MAXT) return prefetch ? launch(lanczos3_bgra<LZ_MAXT, false, true, 32, 16>) : launch(lanczos3_bgra<LZ_MAXT, false, false, 32, 16>);
+    return launch(lanczos3_bgra<0, false, false, 32, 16>);
 }
 
 }  // namespace chv
