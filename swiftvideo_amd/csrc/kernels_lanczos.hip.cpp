@@ -100,13 +100,33 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
     const int ox0 = first_ox0 + t * LZ_TW;
     if (ox0 >= dst.w) break;
 
+    // this thread's output column in the horizontal pass: tap position and weights, fetched before the staging
+    // so that their latency hides behind it
+    if (!PREFETCH) tile_geom(ox0, col0, nvec);
+    const int bx = min(ox0 + (tid & (LZ_TW - 1)), dst.w - 1);
+    const int cbase = fx[bx] - col0;
+    const float *w = wx + (size_t)bx * tx;
+    float wr[TAPS_IN_REGS > 0 ? TAPS_IN_REGS : 1];
+    if (TAPS_IN_REGS > 0) {
+#pragma unroll
+        for (int k = 0; k < TAPS_IN_REGS; k++) {
+            const float wk = w[EXACT ? k : min(k, tx - 1)];
+            wr[k] = (EXACT || k < tx) ? wk : 0.f;
+        }
+    }
+
     // phase A: source rectangle -> LDS
     if (PREFETCH) {
         touch_regs(pre);                 // the wait for the prefetch, on every path (see touch_regs)
+        // block-uniform test: a rectangle inside the picture's columns needs no texel re-ordering
+        if (col0 >= 0 && col0 + 4 * nvec <= src.w) {
 #pragma unroll
-        for (int n = 0; n < LZ_NPRE; n++) if (rg + 8 * n < nrows && v < nvec) *(uint4 *)(stile + (rg + 8 * n) * max_cols + 4 * v) = fix_vec(pre[n], col0 + 4 * v);
+            for (int n = 0; n < LZ_NPRE; n++) if (rg + 8 * n < nrows && v < nvec) *(uint4 *)(stile + (rg + 8 * n) * max_cols + 4 * v) = pre[n];
+        } else {
+#pragma unroll
+            for (int n = 0; n < LZ_NPRE; n++) if (rg + 8 * n < nrows && v < nvec) *(uint4 *)(stile + (rg + 8 * n) * max_cols + 4 * v) = fix_vec(pre[n], col0 + 4 * v);
+        }
     } else {
-        tile_geom(ox0, col0, nvec);
         for (int r = rg; r < nrows; r += 8)
             for (int vv = v; vv < nvec; vv += 32) {
                 // no prefetch (large scale factors, or pictures narrower than one vector): gather texel by texel
@@ -121,7 +141,6 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
             }
     }
     __syncthreads();
-    const int cur_col0 = col0;
     if (PREFETCH && t + 1 < LZ_KS && ox0 + LZ_TW < dst.w) {
         tile_geom(ox0 + LZ_TW, col0, nvec);
 #pragma unroll
@@ -132,17 +151,6 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
     {
         constexpr int RGS = 256 / LZ_TW;                   // row groups: 8 for 32-wide tiles, 32 for 8-wide ones
         const int i = tid & (LZ_TW - 1), rg = tid / LZ_TW;
-        const int ox = min(ox0 + i, dst.w - 1);
-        const int cbase = fx[ox] - cur_col0;
-        const float *w = wx + (size_t)ox * tx;
-        float wr[TAPS_IN_REGS > 0 ? TAPS_IN_REGS : 1];
-        if (TAPS_IN_REGS > 0) {
-#pragma unroll
-            for (int k = 0; k < TAPS_IN_REGS; k++) {
-                const float wk = w[EXACT ? k : min(k, tx - 1)];
-                wr[k] = (EXACT || k < tx) ? wk : 0.f;
-            }
-        }
         if (TAPS_IN_REGS > 0) {
             // the taps of row r + RGS are read from LDS while row r is filtered: left to itself the compiler issues
             // one LDS read per tap pair and waits for it on the spot (6 exposed LDS latencies per row)
