@@ -12,6 +12,8 @@
 // 0.0f — the same chain the oracle evaluates with fmaf().
 #include "pixel_math.hip.h"
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace chv {
@@ -19,7 +21,7 @@ namespace chv {
 // Output tile per block: 32 x 16 normally; 8 x 4 for large reduction factors, whose source rectangle
 // (tile * scale + taps in each direction) would not fit the LDS otherwise.
 constexpr int LZ_MAXT = 24;      // taps held in registers (scale <= 4); more taps use the slow loop
-constexpr int LZ_KS = 4;         // tiles per block, side by side: tile t+1's source rectangle is prefetched into
+// `ks` tiles per block, side by side (the host's choice, see launch_lanczos): tile t+1's source rectangle is prefetched into
 constexpr int LZ_NPRE = 6;       // registers (one 16-byte vector per row rg + 8n, n < LZ_NPRE) while tile t is filtered
 
 // EXACT: tx == ty == TAPS_IN_REGS, the tap loops are straight-line code.  Otherwise taps beyond the table's count
@@ -28,7 +30,7 @@ template <int TAPS_IN_REGS, bool EXACT, bool PREFETCH, int LZ_TW, int LZ_TH>
 __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void lanczos3_bgra(DPlane dst, DPlane src,
                                                      const int32_t *__restrict__ fx, const float *__restrict__ wx, int tx,
                                                      const int32_t *__restrict__ fy, const float *__restrict__ wy, int ty,
-                                                     int max_rows, int max_cols) {
+                                                     int max_rows, int max_cols, int ks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *hrow = (float4 *)smem;                                   // [max_rows][LZ_TW]
     uint32_t *stile = (uint32_t *)(smem + (size_t)max_rows * LZ_TW * sizeof(float4));   // [max_rows][max_cols]
@@ -89,14 +91,14 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
 
     uint4 pre[LZ_NPRE];
     int col0 = 0, nvec = 0;
-    const int first_ox0 = blockIdx.x * (LZ_KS * LZ_TW);
+    const int first_ox0 = blockIdx.x * (ks * LZ_TW);
     if (PREFETCH && first_ox0 < dst.w) {
         tile_geom(first_ox0, col0, nvec);
 #pragma unroll
         for (int n = 0; n < LZ_NPRE; n++) if (rg + 8 * n < nrows && v < nvec) pre[n] = load_vec(rg + 8 * n, col0 + 4 * v);
     }
 
-    for (int t = 0; t < LZ_KS; t++) {
+    for (int t = 0; t < ks; t++) {
     const int ox0 = first_ox0 + t * LZ_TW;
     if (ox0 >= dst.w) break;
 
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
             }
     }
     __syncthreads();
-    if (PREFETCH && t + 1 < LZ_KS && ox0 + LZ_TW < dst.w) {
+    if (PREFETCH && t + 1 < ks && ox0 + LZ_TW < dst.w) {
         tile_geom(ox0 + LZ_TW, col0, nvec);
 #pragma unroll
         for (int n = 0; n < LZ_NPRE; n++) if (rg + 8 * n < nrows && v < nvec) pre[n] = load_vec(rg + 8 * n, col0 + 4 * v);
@@ -256,7 +258,18 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
     if (small_tiles) lds = dims(8, 4, &max_rows, &max_cols);
     if (lds > 160 * 1024) return hipErrorInvalidValue;        // beyond about 24:1
     const int tw = small_tiles ? 8 : 32, th = small_tiles ? 4 : 16;
-    dim3 grid((dst.w + LZ_KS * tw - 1) / (LZ_KS * tw), (dst.h + th - 1) / th);
+    // Tiles per block: a block lives for `ks` tile times and the chip holds 256 CUs x floor(160 KB / lds) blocks at once,
+    // so the launch takes about ceil(blocks / resident) * ks tile times; pick the ks in 2..8 that minimises it (ties: the
+    // longer strip, fewer cold starts of the prefetch).  2160p -> 1080p: 4 (1020 blocks on 1024 slots).
+    const int tiles_x = (dst.w + tw - 1) / tw, tiles_y = (dst.h + th - 1) / th;
+    const long resident = 256L * std::max<long>(1, (long)(160 * 1024 / lds));
+    int ks = 2; long best = -1;
+    for (int k = 2; k <= 8; k++) {
+        const long blocks = (long)((tiles_x + k - 1) / k) * tiles_y;
+        const long cost = ((blocks + resident - 1) / resident) * k;
+        if (best < 0 || cost <= best) { best = cost; ks = k; }
+    }
+    dim3 grid((tiles_x + ks - 1) / ks, tiles_y);
     // register prefetch of the next tile's rectangle: one vector per thread and 8-row group
     const bool prefetch = !small_tiles && max_rows <= 8 * LZ_NPRE && max_cols / 4 <= 32 && src.w >= 4;
     auto launch = [&](auto kernel) -> hipError_t {
@@ -264,7 +277,7 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
             hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, dst, src, fx, wx, tx, fy, wy, ty, max_rows, max_cols);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, dst, src, fx, wx, tx, fy, wy, ty, max_rows, max_cols, ks);
         return hipGetLastError();
     };
     if (small_tiles) return tx <= LZ_MAXT ? launch(lanczos3_bgra<LZ_MAXT, false, false, 8, 4>) : launch(lanczos3_bgra<0, false, false, 8, 4>);

@@ -39,6 +39,9 @@ __global__ void bench(uint64_t *out, int iters, float seed) {
         if (OP == 19) { REP64(asm volatile("v_max_i32 %0, %0, %2\n v_min_i32 %1, %1, %2" : "+v"(i0), "+v"(i1) : "v"(i2));) }
         if (OP == 20) { REP64(asm volatile("v_med3_i32 %0, %0, %2, %3\n v_med3_i32 %1, %1, %2, %3" : "+v"(i0), "+v"(i1) : "v"(i2), "v"(i3));) }
         if (OP == 21) { REP64(asm volatile("v_ashrrev_i32 %0, 16, %0\n v_lshrrev_b32 %1, 8, %1" : "+v"(i0), "+v"(i1));) }
+        if (OP == 22) { REP64(asm volatile("v_fma_mix_f32 %0, %2, %3, %0 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %1, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(a0), "+v"(a1) : "v"(b0), "v"(i2));) }
+        if (OP == 23) { REP64(asm volatile("v_cvt_f16_u16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n v_cvt_f16_u16_sdwa %1, %3 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(i0), "+v"(i1) : "v"(i2), "v"(i3));) }
+        if (OP == 24) { REP64(asm volatile("v_cvt_f16_u16 %0, %2\n v_cvt_f16_u16 %1, %3" : "=v"(i0), "=v"(i1) : "v"(i2), "v"(i3));) }
     }
     uint64_t s1 = __builtin_amdgcn_s_memtime();
     (void)t0;
@@ -75,6 +78,7 @@ void run(const char *name, uint64_t *d_out, int waves_per_simd) {
 int main() {
     uint64_t *d_out; hipMalloc(&d_out, 256 * 8);
     for (int w : {4, 8}) {
+        run<22>("v_fma_mix_f32", d_out, w); run<23>("v_cvt_f16_u16_sdwa", d_out, w); run<24>("v_cvt_f16_u16", d_out, w);
         run<0>("v_mul_f32", d_out, w); run<1>("v_fma_f32", d_out, w); run<16>("v_add/sub_f32", d_out, w);
         run<9>("v_pk_mul_f32", d_out, w); run<17>("v_pk_fma_f32", d_out, w);
         run<2>("v_cvt_f32_ubyteN", d_out, w); run<18>("v_cvt_f32_u32", d_out, w); run<3>("v_rndne_f32", d_out, w);
