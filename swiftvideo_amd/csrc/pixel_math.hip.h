@@ -37,6 +37,10 @@ template <typename T> CHV_DEV T gld(const void *p) { return *(const CHV_GLOBAL T
 template <> CHV_DEV uint2 gld<uint2>(const void *p) { chv_u32x2 v = *(const CHV_GLOBAL chv_u32x2 *)(uintptr_t)p; return make_uint2(v.x, v.y); }
 template <> CHV_DEV uint4 gld<uint4>(const void *p) { chv_u32x4 v = *(const CHV_GLOBAL chv_u32x4 *)(uintptr_t)p; return make_uint4(v.x, v.y, v.z, v.w); }
 template <typename T> CHV_DEV void gst(void *p, T v) { *(CHV_GLOBAL T *)(uintptr_t)p = v; }
+// streaming stores (nt): for data written once per launch and not read back by it
+CHV_DEV void gst_stream(void *p, uint2 v) { chv_u32x2 t = { v.x, v.y }; __builtin_nontemporal_store(t, (CHV_GLOBAL chv_u32x2 *)(uintptr_t)p); }
+CHV_DEV void gst_stream(void *p, uint4 v) { chv_u32x4 t = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(t, (CHV_GLOBAL chv_u32x4 *)(uintptr_t)p); }
+CHV_DEV void gst_stream(void *p, uint32_t v) { __builtin_nontemporal_store(v, (CHV_GLOBAL uint32_t *)(uintptr_t)p); }
 // An unconditional (empty) use of prefetched registers.  hipcc places its s_waitcnt for a load in front of the
 // first use it sees on a path and merges paths pessimistically: with the prefetch consumed only under conditions
 // (staged? lane owns a slot?) the registers stay "maybe pending" on the paths that skip the use, and every load
