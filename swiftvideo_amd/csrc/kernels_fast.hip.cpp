@@ -124,7 +124,7 @@ CHV_DEV uint32_t blend_bgra_general(uint32_t c, const float *__restrict__ U, boo
         r1 = __builtin_fmaf((float)((w >> 8) & 255), a, r1 * ia);
         r2 = __builtin_fmaf((float)((w >> 16) & 255), a, r2 * ia);
     }
-    return to_code_raw(r0) | (to_code_raw(r1) << 8) | (to_code_raw(r2) << 16) | 0xFF000000u;
+    return pack_codes(r0, r1, r2, 0xFF000000u);
 }
 
 // NV12 sample at one pixel from the staged tile, on the code scale: luma bytes, chroma float

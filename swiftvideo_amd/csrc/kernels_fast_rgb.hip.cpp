@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
 #pragma unroll
             for (int k = 0; k < RCOLS; k++) {
                 const uint32_t a8 = ((touched >> (r * 4 + k)) & 1u) ? 0xFF000000u : (((orig_a[r] >> (8 * k)) & 255u) << 24);
-                const uint32_t w = (uint32_t)cb[r][k] | ((uint32_t)cg[r][k] << 8) | ((uint32_t)cr[r][k] << 16) | a8;
+                const uint32_t w = pack_codes(cb[r][k], cg[r][k], cr[r][k], a8);     // codes are integral floats in [0, 255] here
                 if (xq + 16 * k < T.W) gst<uint32_t>(drow + (size_t)(xq + 16 * k) * 4, w);
             }
         }

@@ -82,7 +82,7 @@ CHV_DEV uint32_t apply_layer_bgra(const DLayer &L, int x, int y, float sx, float
         r1 = __builtin_fmaf(p1, a, r1 * ia);
         r2 = __builtin_fmaf(p2, a, r2 * ia);
     }
-    return to_code_raw(r0) | (to_code_raw(r1) << 8) | (to_code_raw(r2) << 16) | 0xFF000000u;
+    return pack_codes(r0, r1, r2, 0xFF000000u);
 }
 
 __global__ __launch_bounds__(256) void tick_general_bgra(const DTick *__restrict__ ticks,

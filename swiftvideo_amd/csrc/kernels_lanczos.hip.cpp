@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
                 acc.z = __builtin_fmaf(wk, h.z, acc.z);
                 acc.w = __builtin_fmaf(wk, h.w, acc.w);
             }
-            uint32_t o = to_code_raw(acc.x) | (to_code_raw(acc.y) << 8) | (to_code_raw(acc.z) << 16) | (to_code_raw(acc.w) << 24);
+            uint32_t o = pack_codes(acc.x, acc.y, acc.z, acc.w);
             gst<uint32_t>(dst.ptr + (size_t)oy * dst.pitch + (size_t)ox * 4, o);
         }
     } else {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
                 acc.z = __builtin_fmaf(wk, h.z, acc.z);
                 acc.w = __builtin_fmaf(wk, h.w, acc.w);
             }
-            uint32_t o = to_code_raw(acc.x) | (to_code_raw(acc.y) << 8) | (to_code_raw(acc.z) << 16) | (to_code_raw(acc.w) << 24);
+            uint32_t o = pack_codes(acc.x, acc.y, acc.z, acc.w);
             gst<uint32_t>(dst.ptr + (size_t)oy * dst.pitch + (size_t)ox * 4, o);
         }
     }

@@ -76,6 +76,21 @@ CHV_DEV uint32_t to_code_raw(float v) {
     return (uint32_t)v;
 }
 
+// Four (three) code-scale values -> one packed word, byte k = to_code_raw(ck): gfx950's v_cvt_pk_u8_f32 clamps to
+// [0, 255], rounds to nearest even, turns NaN into 0 and leaves the other bytes of its destination alone
+// (tools/probe_cvt_pk_u8.cpp, profiles/r01_probe_cvt_pk_u8.txt) — to_code_raw plus the packing in one instruction per byte.
+CHV_DEV uint32_t pack_codes(float c0, float c1, float c2, uint32_t w) {
+    asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(w) : "v"(c0));
+    asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(w) : "v"(c1));
+    asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(w) : "v"(c2));
+    return w;
+}
+CHV_DEV uint32_t pack_codes(float c0, float c1, float c2, float c3) {
+    uint32_t w = pack_codes(c0, c1, c2, 0u);
+    asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(w) : "v"(c3));
+    return w;
+}
+
 // to_code for a value known to lie in [0, 1 + a few ulp] and not NaN (a convex
 // combination of unorm8 samples): the saturation cannot trigger, so it is dropped.
 CHV_DEV uint32_t to_code_unit(float f) {
