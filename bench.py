@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--alias", default="none", choices=("none", "src", "dst", "both"),
+                    help="DIAGNOSTIC (cfg2 only): every tick reads frame 0's source and/or writes frame 0's canvas, so that "
+                         "side of the traffic stays in cache; the line is marked and is not a benchmark result")
     ap.add_argument("--device", type=int, default=None,
                     help="device index for every rank (default: LOCAL_RANK); lets the N>1 path be exercised on a 1-GPU box")
     ap.add_argument("--with-upload", action="store_true",
@@ -95,7 +98,7 @@ def stream_to_device(stream_id, n_gpus):
     return stream_id % n_gpus
 
 
-def build_workload(sv, ctx, wl, frames, seed_base):
+def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
     """Device-resident source frames, canvases and the batch descriptor."""
     import util
     from swiftvideo_amd import chipvideo as cv
@@ -140,6 +143,10 @@ def build_workload(sv, ctx, wl, frames, seed_base):
                                           retainCpuBuffer=False)
             dst = sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False)
             keep += [src, dst]
+            if f > 0 and alias in ("src", "both"):
+                src = keep[0]
+            if f > 0 and alias in ("dst", "both"):
+                dst = keep[1]
             arr = sv._layer_array([(sv.ComputeKernel.img_nv12_bgra, src, u, cv.CSC_BT601_LIMITED)])
             layer_arrays.append(arr)
             ticks[f].target = sv._image_desc(dst)
@@ -324,7 +331,7 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    w = build_workload(sv, ctx, wl, args.frames, seed_base=0x5EED0000 + 16 * 2 + rank)
+    w = build_workload(sv, ctx, wl, args.frames, seed_base=0x5EED0000 + 16 * 2 + rank, alias=args.alias)
 
     def step():
         cv.check(lib.chv_batch_run(ctx.handle, w["batch"]))
@@ -404,6 +411,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": w["kernel"], "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        if args.alias != "none":
+            out["data"] = f"DIAGNOSTIC --alias {args.alias}: ticks share frame 0's buffers, cache-resident traffic; not a benchmark result"
+            out["roofline"]["frac"] = None
         if n_gpus == 1 and not args.no_cpu_baseline and w["verify"] is not None:
             out["cpu_baseline"] = cpu_baseline(wl, w, args.cpu_seconds)
         print(json.dumps(out), flush=True)

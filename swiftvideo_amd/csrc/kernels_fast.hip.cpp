@@ -7,15 +7,18 @@
 //      once per tile row (same instruction sequence as the general kernel, so the
 //      bits are identical) and parks tap offsets + weights in LDS tables,
 //   1. stages the source rectangle the tile's taps touch into LDS with 16-byte
-//      coalesced global loads (each source byte leaves HBM once) and normalises it
-//      to float there — c/255 is paid once per source texel, not once per tap,
-//   2. lets every thread produce 4 horizontally adjacent pixels x 2 rows from LDS
-//      and store them as one 16-byte BGRA write per row.
+//      coalesced global loads (each source byte leaves HBM once); luma and interleaved
+//      chroma stay bytes there (code-scale arithmetic: a tap is one v_cvt_f32_ubyte),
+//      planar chroma is interleaved into (u, v) float pairs,
+//   2. lets every thread produce PXT horizontally adjacent pixels x RPT rows from LDS
+//      and store them as one 8- or 16-byte BGRA write per row.
 // Blocks are numbered so that all tiles of one frame run on one XCD (block b runs
 // on XCD b % 8): tile halos are shared through that XCD's L2.
 //
-// The kernels are VALU-bound, not HBM-bound, on gfx950 (profiles/): the inner loop
-// is kept to single-rate f32 ops (no v_pk_*, see tools/ubench_valu.cpp).
+// Where the time goes on gfx950 (profiles/r01_notes.md): neither the VALU (~70 % busy) nor
+// HBM is saturated; arithmetic, LDS traffic and the read / write phases overlap only partly
+// across the 6 resident blocks of a CU.  The inner loop avoids v_pk_* (slower than two
+// scalar ops, tools/ubench_valu.cpp).
 //
 // Every path here produces exactly the bytes of kernels_general.hip.cpp; the host
 // picks a path per batch (select_fast_path) and falls back to the general kernel.
@@ -127,7 +130,7 @@ CHV_DEV uint32_t blend_bgra_general(uint32_t c, const float *__restrict__ U, boo
     return pack_codes(r0, r1, r2, 0xFF000000u);
 }
 
-// NV12 sample at one pixel from the staged tile, on the code scale: luma bytes, chroma float
+// Sample at one pixel from the staged tile, on the code scale, planar sources: luma bytes, chroma float
 // pairs; tap 1 is the next texel, the next row is one LDS pitch further.
 CHV_DEV void sample_nv12_lds(const uint8_t *smem, int ya, int ypitch, int ca, int cpitch,
                              float w00, float w10, float w01, float w11,
@@ -145,6 +148,19 @@ CHV_DEV void sample_nv12_lds(const uint8_t *smem, int ya, int ypitch, int ca, in
     const float2 q01 = *(const float2 *)(smem + ca + cpitch), q11 = *(const float2 *)(smem + ca1 + 8);
     fu = cs_mix(c00, c10, c01, c11, q00.x, q10.x, q01.x, q11.x);
     fv = cs_mix(c00, c10, c01, c11, q00.y, q10.y, q01.y, q11.y);
+}
+
+// the same with interleaved chroma kept as bytes in LDS (u | v << 8 per texel)
+CHV_DEV void sample_nv12_lds_bytes(const uint8_t *smem, int ya, int ypitch, int ca, int cpitch,
+                                   float w00, float w10, float w01, float w11,
+                                   float c00, float c10, float c01, float c11,
+                                   float &fy, float &fu, float &fv) {
+    const uint8_t *py = smem + ya;
+    fy = cs_mix(w00, w10, w01, w11, (float)py[0], (float)py[1], (float)py[ypitch], (float)py[ypitch + 1]);
+    const uint32_t q00 = *(const uint16_t *)(smem + ca), q10 = *(const uint16_t *)(smem + ca + 2);
+    const uint32_t q01 = *(const uint16_t *)(smem + ca + cpitch), q11 = *(const uint16_t *)(smem + ca + cpitch + 2);
+    fu = cs_mix(c00, c10, c01, c11, (float)(q00 & 255), (float)(q10 & 255), (float)(q01 & 255), (float)(q11 & 255));
+    fv = cs_mix(c00, c10, c01, c11, (float)(q00 >> 8), (float)(q10 >> 8), (float)(q01 >> 8), (float)(q11 >> 8));
 }
 
 // the same sample straight from the source planes (tile did not fit the LDS budget);
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     TileTables &tb = *(TileTables *)smem;
     const int ybase = (int)sizeof(TileTables);          // [yrows][ypitch] luma bytes
-    const int cbase = ybase + yrows * ypitch;           // [crows][cpitch] chroma float pairs
+    const int cbase = ybase + yrows * ypitch;           // [crows][cpitch] chroma: byte pairs (NV12) or float pairs (planar)
 
     // XCD-aware numbering: consecutive blocks go to consecutive XCDs, so give each
     // XCD whole frames: block -> (xcd, slot) -> (tick = group*8 + xcd, strip)
@@ -249,6 +265,11 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     const DPlane &SC = L.src.pl[1];
     const DPlane &SV = L.src.pl[PLANAR ? 2 : 1];
     constexpr int CVEC = PLANAR ? 16 : 8;           // chroma texels per 16-byte source vector
+    // Interleaved (NV12) chroma stays bytes in LDS and is converted per tap (8 more v_cvt_f32_ubyte per pixel, but 4x less
+    // LDS traffic for the chroma taps and no conversion at staging time: -2 % on cfg2, whose VALU has slack and whose LDS
+    // pipe does not); planar chroma is interleaved into float pairs at staging time.
+    constexpr bool CB = !PLANAR;
+    constexpr int CTB = CB ? 2 : 8;                 // LDS bytes per chroma texel
     const DPlane &D = T.dst.pl[0];
     const int tid = threadIdx.x;
     const float sx = (float)T.W, sy = (float)T.H;
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     const int ccol0 = max(clo, 0) & ~(CVEC - 1);               // chroma: CVEC texels per 16-byte vector
     const int ynv = (min(yhi, SY.w - 1) - ycol0) / 16 + 1;
     const int cnv = (min(chi, SC.w - 1) - ccol0) / CVEC + 1;
-    const bool cols_fit = (ynv + 2) * 16 <= ypitch && (cnv + 2) * CVEC * 8 <= cpitch;
+    const bool cols_fit = (ynv + 2) * 16 <= ypitch && (cnv + 2) * CVEC * CTB <= cpitch;
 
     // per-tile staging geometry from the tile's row summary
     auto tile_geom = [&](int j, StageGeom &gy, StageGeom &gc) -> bool {
@@ -324,7 +345,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
         int c = txi * PXT + k;
         cya[k] = tb.cya[c]; icya[k] = 1.0f - cya[k];
         cca[k] = tb.cca[c]; icca[k] = 1.0f - cca[k];
-        cyo[k] = tb.cy[c] - ycol0 + 16; cco[k] = (tb.cc[c] - ccol0 + CVEC) * 8;
+        cyo[k] = tb.cy[c] - ycol0 + 16; cco[k] = (tb.cc[c] - ccol0 + CVEC) * CTB;
     }
     const CscFolded csc = csc_fold(kCsc[L.csc & 3]);
     const CscFolded cscb = csc_fold_biased(kCsc[L.csc & 3]);
@@ -337,6 +358,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
         if (staged) {
             stage_store<1, false>(yregs, smem + ybase, ypitch, SY, gy, tid);
             if constexpr (PLANAR) stage_store_uv_planar(cregs, vregs, smem + cbase, cpitch, SC, SV, gc, tid);
+            else if constexpr (CB) stage_store<2, false>(cregs, smem + cbase, cpitch, SC, gc, tid);
             else stage_store<2, true>(cregs, smem + cbase, cpitch, SC, gc, tid);
         }
         __syncthreads();
@@ -363,9 +385,14 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
 #pragma unroll
             for (int k = 0; k < PXT; k++) {
                 float fy, fu, fv;
-                sample_nv12_lds(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
-                                icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
-                                icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                if constexpr (CB)
+                    sample_nv12_lds_bytes(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
+                                          icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                          icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                else
+                    sample_nv12_lds(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
+                                    icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                    icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
                 outw[k] = yuv_to_bgra_word(cscb, (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv));
             }
         };
@@ -420,7 +447,10 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
                             const int pyx = tb.cy[c], pcx = tb.cc[c];
                             const float ya = tb.cya[c], iya = 1.0f - ya, ca = tb.cca[c], ica = 1.0f - ca;
                             float fy, fu, fv;
-                            if (staged)
+                            if (staged && CB)
+                                sample_nv12_lds_bytes(smem, yrow + (pyx - ycol0 + 16), ypitch, crow + (pcx - ccol0 + CVEC) * CTB, cpitch,
+                                                      iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
+                            else if (staged)
                                 sample_nv12_lds(smem, yrow + (pyx - ycol0 + 16), ypitch, crow + (pcx - ccol0 + CVEC) * 8, cpitch,
                                                 iya * iyb, ya * iyb, iya * yb, ya * yb, ica * icb, ca * icb, ica * cb, ca * cb, fy, fu, fv);
                             else
@@ -460,7 +490,7 @@ static TileDims tile_dims(const DTick &T, const DLayer &L) {
     int cspan = (int)std::ceil(TW * sxr * L.src.pl[1].w) + 4;
     d.ypitch = ((yspan + 15) / 16 + 3) * 16;                    // luma bytes: vectors + alignment + 2 pad vectors
     const bool planar = L.kind == LK_BGRA_FROM_Y420P;
-    d.cpitch = planar ? ((cspan + 15) / 16 + 3) * 128 : ((cspan + 7) / 8 + 3) * 64;   // chroma float pairs
+    d.cpitch = planar ? ((cspan + 15) / 16 + 3) * 128 : ((cspan + 7) / 8 + 3) * 16;   // chroma: float pairs (planar sources) / byte pairs (NV12)
     // rows a tile's taps span: <= ceil((TH-1)*scale) + 2 (tap 1 of the last row) <= ceil(TH*scale) + 2
     d.yrows = (int)std::ceil(TH * syr * L.src.pl[0].h) + 3;
     d.crows = (int)std::ceil(TH * syr * L.src.pl[1].h) + 3;
@@ -535,7 +565,7 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
 #define CHV_LAUNCH_N(C, P) do { if (small) CHV_LAUNCH(C, P, 2, 1); else CHV_LAUNCH(C, P, 3, 2); } while (0)
     const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;
     // upper bounds of the staging slots a tile can need (rows x vectors per row incl. the two edge vectors)
-    const bool small = m.yrows * (m.ypitch / 16) <= 2 * NTHREADS && m.crows * (m.cpitch / (planar ? 128 : 64)) <= NTHREADS;
+    const bool small = m.yrows * (m.ypitch / 16) <= 2 * NTHREADS && m.crows * (m.cpitch / (planar ? 128 : 16)) <= NTHREADS;
     if (clear && planar) CHV_LAUNCH_N(true, true);
     else if (clear) CHV_LAUNCH_N(true, false);
     else if (planar) CHV_LAUNCH_N(false, true);
