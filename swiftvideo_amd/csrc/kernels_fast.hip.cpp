@@ -49,11 +49,10 @@ constexpr int TW = CHV_TW;       // tile width  (output pixels), a multiple of 6
 constexpr int PXT = CHV_PXT;     // horizontally adjacent pixels per thread (4: one 16-byte store, 2: one 8-byte store)
 constexpr int TXT = TW / PXT;    // threads across a tile row
 constexpr int TYT = NTHREADS / TXT;   // tile rows covered per pass
-#ifndef CHV_TH
-#define CHV_TH 16
-#endif
-constexpr int TH = CHV_TH;       // tile height (output rows)
-constexpr int RPT = TH / TYT;    // rows per thread
+// Tile height (output rows) is a kernel template parameter THV: 32 rows for launches that fill the chip anyway (more pixels
+// per barrier interval: -6 % on cfg2), 16 rows for small launches such as a single mixer tick (twice the blocks: 9.6 instead
+// of 12.3 us for one 720p tick).  RPT = THV / TYT rows per thread.
+constexpr int TH_SMALL = 16, TH_LARGE = 32;
 // NTHREADS = 256: 32 x 8 threads, each 4 px x 2 rows per tile
 
 #ifndef CHV_KT
@@ -65,7 +64,8 @@ constexpr int KT = CHV_KT;             // tiles per block: a vertical strip of K
 // Tap positions are the UNCLAMPED i0 = floor(u - 0.5) of the linear filter (tap 1 is
 // i0 + 1): the staged tile replicates the edge texels, so CLAMP_TO_EDGE costs nothing
 // in the inner loop and tap 1 always sits right next to tap 0.
-struct TileTables {
+template <int TH>
+struct TileTablesT {
     int cy[TW]; float cya[TW];     // luma column:   tap-0 position, weight of tap 1
     int cc[TW]; float cca[TW];     // chroma column
     int cfl[TW];
@@ -233,14 +233,16 @@ CHV_DEV void stage_store_uv_planar(const uint4 (&uregs)[N], const uint4 (&vregs)
 // (tools/ubench_issue.cpp), so the small-prefetch NV12 variant is held to 80 VGPRs = 6 waves per SIMD
 // (it fits without spilling); the others stay at 96 VGPRs = 5 waves.
 #ifndef CHV_MINW
-#define CHV_MINW ((NYV == 2 && !PLANAR) ? 6 : (NYV == 3 && PLANAR) ? 4 : 5)
+#define CHV_MINW ((!PLANAR && (NYV == 2 || THV == 32)) ? 6 : (NYV == 3 && PLANAR) ? 4 : 5)
 #endif
-template <bool CLEAR, bool PLANAR, int NYV, int NCV>
+template <bool CLEAR, bool PLANAR, int NYV, int NCV, int THV>
 __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const DTick *__restrict__ ticks,
                                                                   const DLayer *__restrict__ layers,
                                                                   int n_ticks, int tiles_x, int strips_y, int kt,
                                                                   int ypitch, int yrows, int cpitch, int crows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int TH = THV, RPT = TH / TYT;
+    using TileTables = TileTablesT<THV>;
     TileTables &tb = *(TileTables *)smem;
     const int ybase = (int)sizeof(TileTables);          // [yrows][ypitch] luma bytes
     const int cbase = ybase + yrows * ypitch;           // [crows][cpitch] chroma: byte pairs (NV12) or float pairs (planar)
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
         stage_slots_init(gy);
         stage_slots_init(gc);
         return cols_fit && gy.rows <= yrows && gc.rows <= crows &&
-               stage_slots(gy) <= NYV * NTHREADS && stage_slots(gc) <= NCV * NTHREADS;
+               // byte tiles take what the prefetch registers cannot hold through stage_tail (slot numbers < 1024)
+               stage_slots(gy) <= 1024 && stage_slots(gc) <= (CB ? 1024 : NCV * NTHREADS);
     };
 
     uint4 yregs[NYV], cregs[NCV], vregs[PLANAR ? NCV : 1];
@@ -360,6 +363,8 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
             if constexpr (PLANAR) stage_store_uv_planar(cregs, vregs, smem + cbase, cpitch, SC, SV, gc, tid);
             else if constexpr (CB) stage_store<2, false>(cregs, smem + cbase, cpitch, SC, gc, tid);
             else stage_store<2, true>(cregs, smem + cbase, cpitch, SC, gc, tid);
+            if (stage_slots(gy) > NYV * NTHREADS) stage_tail<1>(smem + ybase, ypitch, SY, gy, tid, NYV * NTHREADS);
+            if constexpr (CB) { if (stage_slots(gc) > NCV * NTHREADS) stage_tail<2>(smem + cbase, cpitch, SC, gc, tid, NCV * NTHREADS); }
         }
         __syncthreads();
         // ---- prefetch tile j+1 while tile j is computed ---------------------------------------
@@ -473,6 +478,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
 // host side: path selection and launch geometry
 // ---------------------------------------------------------------------------
 struct TileDims { int ypitch, yrows, cpitch, crows; size_t lds; };
+static size_t tables_bytes(int th) { return th == TH_LARGE ? sizeof(TileTablesT<TH_LARGE>) : sizeof(TileTablesT<TH_SMALL>); }
 
 static bool finite16(const float *m) {
     for (int i = 0; i < 16; i++) if (!(m[i] - m[i] == 0.f)) return false;
@@ -480,7 +486,7 @@ static bool finite16(const float *m) {
 }
 
 // LDS rectangle one tile of this layer can touch, from the layer's scale factors.
-static TileDims tile_dims(const DTick &T, const DLayer &L) {
+static TileDims tile_dims(const DTick &T, const DLayer &L, int TH) {
     const float *U = L.u;
     // |d(uv)/d(pixel)| as a fraction of the source per output pixel
     double sxr = std::fabs((double)U[U_TEXTURE + 0] * (double)U[U_TRANSFORM + 0] * 2.0 / (double)T.W);
@@ -494,7 +500,7 @@ static TileDims tile_dims(const DTick &T, const DLayer &L) {
     // rows a tile's taps span: <= ceil((TH-1)*scale) + 2 (tap 1 of the last row) <= ceil(TH*scale) + 2
     d.yrows = (int)std::ceil(TH * syr * L.src.pl[0].h) + 3;
     d.crows = (int)std::ceil(TH * syr * L.src.pl[1].h) + 3;
-    d.lds = sizeof(TileTables) + (size_t)d.ypitch * d.yrows + (size_t)d.cpitch * d.crows;
+    d.lds = tables_bytes(TH) + (size_t)d.ypitch * d.yrows + (size_t)d.cpitch * d.crows;
     return d;
 }
 
@@ -529,7 +535,7 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
         if (L.kind == LK_BGRA_FROM_Y420P && !aligned16(L.src.pl[2])) return FP_NONE;
         if (!finite16(L.u + U_TRANSFORM) || !finite16(L.u + U_TEXTURE) || !finite16(L.u + U_BORDER)) return FP_NONE;
         if (!aligned16(T.dst.pl[0]) || !aligned16(L.src.pl[0]) || !aligned16(L.src.pl[1])) return FP_NONE;
-        if (tile_dims(T, L).lds > (size_t)LDS_BUDGET) return FP_NONE;
+        if (tile_dims(T, L, TH_SMALL).lds > (size_t)LDS_BUDGET) return FP_NONE;
     }
     return layers[ticks[0].first_layer].kind == LK_BGRA_FROM_Y420P ? FP_Y420P_BGRA_TILED : FP_NV12_BGRA_TILED;
 }
@@ -539,33 +545,54 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
                             int maxW, int maxH, hipStream_t stream) {
     if (path == FP_RGB_LAYERS_TILED) return launch_rgb_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path != FP_NV12_BGRA_TILED && path != FP_Y420P_BGRA_TILED) return hipErrorNotSupported;
-    TileDims m = { 0, 0, 0, 0, 0 };
-    for (int i = 0; i < n_ticks; i++) {
-        TileDims d = tile_dims(ticks_host[i], layers_host[ticks_host[i].first_layer]);
-        m.ypitch = std::max(m.ypitch, d.ypitch); m.yrows = std::max(m.yrows, d.yrows);
-        m.cpitch = std::max(m.cpitch, d.cpitch); m.crows = std::max(m.crows, d.crows);
+    const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;
+    const int tiles_x = (maxW + TW - 1) / TW;
+    // tile height: 32 rows when that still gives every CU a few blocks and the rectangles fit the LDS budget, else 16
+    auto dims_for = [&](int th, TileDims &m) -> size_t {
+        m = TileDims{ 0, 0, 0, 0, 0 };
+        for (int i = 0; i < n_ticks; i++) {
+            TileDims d = tile_dims(ticks_host[i], layers_host[ticks_host[i].first_layer], th);
+            m.ypitch = std::max(m.ypitch, d.ypitch); m.yrows = std::max(m.yrows, d.yrows);
+            m.cpitch = std::max(m.cpitch, d.cpitch); m.crows = std::max(m.crows, d.crows);
+        }
+        return tables_bytes(th) + (size_t)m.ypitch * m.yrows + (size_t)m.cpitch * m.crows;
+    };
+    // staging slots a tile can need: rows x vectors per row; `pad` = 2 counts the padding vectors of rectangles at a
+    // picture edge (the worst case), 0 the interior tiles
+    auto slots_fit = [&](const TileDims &m, int ny, int nc, int pad) {
+        return m.yrows * (m.ypitch / 16 - 2 + pad) <= ny * NTHREADS && m.crows * (m.cpitch / (planar ? 128 : 16) - 2 + pad) <= nc * NTHREADS;
+    };
+    TileDims m;
+    int th = TH_LARGE;
+    size_t lds = dims_for(th, m);
+    long blocks_large = (long)n_ticks * tiles_x * ((maxH + TH_LARGE - 1) / TH_LARGE);
+    // A/B and test switch: CHV_TILE_ROWS=32 takes the 32-row kernels whatever the launch size (if they fit), =16 never
+    if (const char *e = getenv("CHV_TILE_ROWS")) blocks_large = atoi(e) == TH_LARGE ? 1024 : 0;
+    // 32-row tiles: interior rectangles must fit the prefetch registers; edge rectangles may spill into stage_tail
+    // (byte tiles only: planar chroma has no tail) as long as slot numbers stay below 1024
+    if (blocks_large < 1024 || lds > (size_t)LDS_BUDGET || !slots_fit(m, 3, 2, planar ? 2 : 0) || !slots_fit(m, 4, 4, 2)) {
+        th = TH_SMALL;
+        lds = dims_for(th, m);
     }
-    size_t lds = sizeof(TileTables) + (size_t)m.ypitch * m.yrows + (size_t)m.cpitch * m.crows;
     if (lds > (size_t)LDS_BUDGET) {
         // per-tick maxima combined exceed the budget: shrink to it; tiles that do not fit
         // fall back to unstaged taps inside the kernel
-        m.yrows = std::max(1, (int)((LDS_BUDGET - sizeof(TileTables)) / 2 / m.ypitch));
-        m.crows = std::max(1, (int)((LDS_BUDGET - sizeof(TileTables)) / 2 / m.cpitch));
-        lds = sizeof(TileTables) + (size_t)m.ypitch * m.yrows + (size_t)m.cpitch * m.crows;
+        m.yrows = std::max(1, (int)((LDS_BUDGET - tables_bytes(th)) / 2 / m.ypitch));
+        m.crows = std::max(1, (int)((LDS_BUDGET - tables_bytes(th)) / 2 / m.cpitch));
+        lds = tables_bytes(th) + (size_t)m.ypitch * m.yrows + (size_t)m.cpitch * m.crows;
     }
     // strips of kt tiles: KT amortises the column tables best, but a small launch (one mixer tick = 120 strips of 4)
     // would leave most CUs idle — shorter strips until there are a few blocks per CU
-    int tiles_x = (maxW + TW - 1) / TW, kt = KT;
-    while (kt > 1 && (long)n_ticks * tiles_x * ((maxH + kt * TH - 1) / (kt * TH)) < 1024) kt >>= 1;
-    int tiles_y = (maxH + kt * TH - 1) / (kt * TH);
+    int kt = KT;
+    while (kt > 1 && (long)n_ticks * tiles_x * ((maxH + kt * th - 1) / (kt * th)) < 1024) kt >>= 1;
+    int tiles_y = (maxH + kt * th - 1) / (kt * th);
     int per_xcd = (n_ticks * tiles_x * tiles_y + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8));
-#define CHV_LAUNCH(C, P, NY, NC) hipLaunchKernelGGL((tick_yuv_bgra_tiled<C, P, NY, NC>), grid, dim3(NTHREADS), lds, stream, ticks, layers, \
-                                                    n_ticks, tiles_x, tiles_y, kt, m.ypitch, m.yrows, m.cpitch, m.crows)
-#define CHV_LAUNCH_N(C, P) do { if (small) CHV_LAUNCH(C, P, 2, 1); else CHV_LAUNCH(C, P, 3, 2); } while (0)
-    const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;
-    // upper bounds of the staging slots a tile can need (rows x vectors per row incl. the two edge vectors)
-    const bool small = m.yrows * (m.ypitch / 16) <= 2 * NTHREADS && m.crows * (m.cpitch / (planar ? 128 : 16)) <= NTHREADS;
+#define CHV_LAUNCH(C, P, NY, NC, H) hipLaunchKernelGGL((tick_yuv_bgra_tiled<C, P, NY, NC, H>), grid, dim3(NTHREADS), lds, stream, ticks, layers, \
+                                                       n_ticks, tiles_x, tiles_y, kt, m.ypitch, m.yrows, m.cpitch, m.crows)
+#define CHV_LAUNCH_N(C, P) do { if (th == TH_LARGE) { if (small) CHV_LAUNCH(C, P, 2, 1, TH_LARGE); else CHV_LAUNCH(C, P, 3, 2, TH_LARGE); } \
+                                else { if (small) CHV_LAUNCH(C, P, 2, 1, TH_SMALL); else CHV_LAUNCH(C, P, 3, 2, TH_SMALL); } } while (0)
+    const bool small = slots_fit(m, 2, 1, 2);
     if (clear && planar) CHV_LAUNCH_N(true, true);
     else if (clear) CHV_LAUNCH_N(true, false);
     else if (planar) CHV_LAUNCH_N(false, true);

@@ -124,7 +124,7 @@ CHV_DEV void stage_slot(const StageGeom &g, int i, int &r, int &vv) {
 }
 
 template <int N>
-CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, int tid) {
+CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, int tid, int base = 0) {
     // Exactly one global_load_dwordx4 per slot, straight into its final register: control flow that merges
     // differently-produced values here makes the compiler copy — and therefore wait for — the loaded
     // registers on the spot.  Vectors that are not loadable as such (outside the row: their texels are
@@ -135,7 +135,7 @@ CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, i
     // while its load was still in flight.  The loads stay tracked; callers use touch_regs() to place the wait.)
 #pragma unroll
     for (int n = 0; n < N; n++) {
-        int i = tid + n * NTHREADS, r, vv;
+        int i = base + tid + n * NTHREADS, r, vv;
         stage_slot(g, i, r, vv);
         if (i < 1024 && r < g.rows) {
             int row = min(max(g.r_lo + r, 0), P.h - 1);
@@ -152,10 +152,10 @@ CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, i
 //                   (BPT = 2: float pairs, LDS texel slot 8 + k = source texel b0/2 + k;
 //                    BPT = 4: float4 texels, LDS texel slot 4 + k = source texel b0/4 + k)
 template <int BPT, bool TO_FLOAT, int N>
-CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid) {
+CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid, int base = 0) {
 #pragma unroll
     for (int n = 0; n < N; n++) {
-        int i = tid + n * NTHREADS, r, vv;
+        int i = base + tid + n * NTHREADS, r, vv;
         stage_slot(g, i, r, vv);
         if (i < 1024 && r < g.rows) {
             int v = g.edge ? vv - 1 : vv;
@@ -178,5 +178,15 @@ CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, co
     }
 }
 
+// Slots beyond the prefetch registers' capacity (rectangles at a picture edge carry two padding vectors per row):
+// loaded and written on the spot, latency exposed — rare, and still one HBM read per source byte.
+template <int BPT>
+CHV_DEV void stage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid, int first) {
+    for (int base = first; base < stage_slots(g); base += NTHREADS) {
+        uint4 t[1] = { make_uint4(0, 0, 0, 0) };
+        stage_load(t, P, g, tid, base);
+        stage_store<BPT, false>(t, lds, lds_pitch, P, g, tid, base);
+    }
+}
 
 }  // namespace chv

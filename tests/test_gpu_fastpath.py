@@ -50,6 +50,36 @@ def test_nv12_bgra_tiled_matches_oracle(ctx, case, csc):
     G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"{case}/csc{csc} via {name}")
 
 
+# 32-row tiles (chosen for launches of >= 1024 blocks; CHV_TILE_ROWS=32 forces them here): same bytes, including
+# rectangles at a picture edge that overflow the prefetch registers and finish through stage_tail
+TILE32_CASES = {
+    "cfg2_small":   (320, 180, 480, 270, dict()),
+    "edge_tail":    (256, 96, 400, 152, dict()),          # 1.56 x 1.58: edge rectangles are 15 vectors x >= 52 rows > 768 luma slots
+    "partial_rows": (300, 75, 300, 75, dict(opacity=0.6)),
+    "rect_border":  (260, 100, 96, 54, dict(rect=(33, 9, 180, 70), border=(5, 3, 7, 2), fill=(0.9, 0.2, 0.1, 0.6), opacity=0.8)),
+    "upscale":      (384, 128, 128, 48, dict()),
+}
+
+
+@pytest.mark.parametrize("case", list(TILE32_CASES))
+@pytest.mark.parametrize("fmt", ["nv12", "y420p"])
+def test_yuv_bgra_32_row_tiles_match_oracle(ctx, monkeypatch, case, fmt):
+    monkeypatch.setenv("CHV_TILE_ROWS", "32")
+    cw, ch, sw, sh, kw = TILE32_CASES[case]
+    u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+    src = util.alloc_image(fmt, sw, sh, seed=31)
+    exp = util.alloc_image("bgra", cw, ch)
+    kname = f"img_{fmt}_bgra"
+    assert O.run_kernel("img_clear_bgra", exp) == 0
+    assert O.run_kernel(kname, exp, src, u, threads=4) == 0
+    gd = G.to_gpu(ctx, "bgra", cw, ch, util.alloc_image("bgra", cw, ch, seed=32))
+    h, name, keep = G.make_batch(ctx, [(gd, True, [(sv.defaultComputeKernelFromString(kname), G.to_gpu(ctx, fmt, sw, sh, src), u, 0)])])
+    assert name == f"tick_{fmt}_bgra_tiled"
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"{case}/{fmt} with 32-row tiles")
+
+
 def test_rotated_layer_falls_back_to_general(ctx):
     u = util.make_uniforms((64, 36), rect=(10, 5, 40, 20), rotation=0.2, in_size=(32, 18))
     gs = G.to_gpu(ctx, "nv12", 32, 18, util.alloc_image("nv12", 32, 18, seed=1))
