@@ -565,12 +565,16 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
     TileDims m;
     int th = TH_LARGE;
     size_t lds = dims_for(th, m);
-    long blocks_large = (long)n_ticks * tiles_x * ((maxH + TH_LARGE - 1) / TH_LARGE);
-    // A/B and test switch: CHV_TILE_ROWS=32 takes the 32-row kernels whatever the launch size (if they fit), =16 never
-    if (const char *e = getenv("CHV_TILE_ROWS")) blocks_large = atoi(e) == TH_LARGE ? 1024 : 0;
-    // 32-row tiles: interior rectangles must fit the prefetch registers; edge rectangles may spill into stage_tail
-    // (byte tiles only: planar chroma has no tail) as long as slot numbers stay below 1024
-    if (blocks_large < 1024 || lds > (size_t)LDS_BUDGET || !slots_fit(m, 3, 2, planar ? 2 : 0) || !slots_fit(m, 4, 4, 2)) {
+    const long blocks_large = (long)n_ticks * tiles_x * ((maxH + TH_LARGE - 1) / TH_LARGE);
+    // 32-row tiles when the launch is large and interior rectangles fit the prefetch registers; edge rectangles may spill
+    // into stage_tail as long as slot numbers stay below 1024 (luma and NV12 chroma: planar chroma has no tail).
+    // CHV_TILE_ROWS (A/B and test switch): 16 = never; 32 = whatever the launch size, and even when interior rectangles
+    // overflow the prefetch registers (everything beyond them then goes through stage_tail).
+    const char *rows_env = getenv("CHV_TILE_ROWS");
+    const int rows_forced = rows_env ? atoi(rows_env) : 0;
+    const bool tail_ok = slots_fit(m, 4, planar ? 2 : 4, 2);
+    const bool large_wanted = rows_forced == TH_LARGE || (rows_forced != TH_SMALL && blocks_large >= 1024 && slots_fit(m, 3, 2, planar ? 2 : 0));
+    if (!(large_wanted && tail_ok && lds <= (size_t)LDS_BUDGET)) {
         th = TH_SMALL;
         lds = dims_for(th, m);
     }

@@ -54,7 +54,7 @@ def test_nv12_bgra_tiled_matches_oracle(ctx, case, csc):
 # rectangles at a picture edge that overflow the prefetch registers and finish through stage_tail
 TILE32_CASES = {
     "cfg2_small":   (320, 180, 480, 270, dict()),
-    "edge_tail":    (256, 96, 400, 152, dict()),          # 1.56 x 1.58: edge rectangles are 15 vectors x >= 52 rows > 768 luma slots
+    "tail":         (256, 96, 432, 164, dict()),          # 1.69 x 1.71: 58 rows x 14-16 vectors > 768 luma slots: the rest goes through stage_tail
     "partial_rows": (300, 75, 300, 75, dict(opacity=0.6)),
     "rect_border":  (260, 100, 96, 54, dict(rect=(33, 9, 180, 70), border=(5, 3, 7, 2), fill=(0.9, 0.2, 0.1, 0.6), opacity=0.8)),
     "upscale":      (384, 128, 128, 48, dict()),
