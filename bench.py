@@ -34,6 +34,8 @@ WORKLOADS = {
     # name: (src fmt, src w, h, dst w, h, n_layers, algorithmic bytes per tick)
     "cfg2": dict(desc="1920x1080 NV12 -> BGRA (BT.601 int) + bilinear downscale to 1280x720",
                  sw=1920, sh=1080, dw=1280, dh=720, layers=1, bytes=3110400 + 3686400),
+    "cfg2_y420p": dict(desc="cfg2 with a planar source: 1920x1080 y420p -> BGRA (BT.601 int) + bilinear downscale to 1280x720",
+                 sw=1920, sh=1080, dw=1280, dh=720, layers=1, bytes=3110400 + 3686400, src="y420p"),
     "cfg3": dict(desc="4 x 1080p BGRA layers (opacity 1/.75/.5/.25) alpha-composited onto a 1080p BGRA canvas",
                  sw=1920, sh=1080, dw=1920, dh=1080, layers=4, bytes=4 * 8294400 + 8294400),
     "mixer_y420p": dict(desc="reference-default canvas: 1080p y420p canvas <- full-canvas 1080p y420p layer + two 640x360 BGRA overlays (opacity .8/.6)",
@@ -135,11 +137,14 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
             ticks[f].layers = arr
         verify = None
     elif wl["layers"] == 1:
+        sfmt = wl.get("src", "nv12")
+        spf = sv.PixelFormat.y420p if sfmt == "y420p" else sv.PixelFormat.nv12
+        skernel = sv.ComputeKernel.img_y420p_bgra if sfmt == "y420p" else sv.ComputeKernel.img_nv12_bgra
         for i in range(distinct):
-            host_src.append(util.alloc_image("nv12", sw, sh, seed=seed_base + i))
+            host_src.append(util.alloc_image(sfmt, sw, sh, seed=seed_base + i))
         u = util.full_canvas_uniforms((dw, dh), (sw, sh))
         for f in range(frames):
-            src = sv.uploadComputePicture(ctx, sv.pictureFromArrays(sv.PixelFormat.nv12, (sw, sh), host_src[f % distinct]),
+            src = sv.uploadComputePicture(ctx, sv.pictureFromArrays(spf, (sw, sh), host_src[f % distinct]),
                                           retainCpuBuffer=False)
             dst = sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False)
             keep += [src, dst]
@@ -147,13 +152,13 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
                 src = keep[0]
             if f > 0 and alias in ("dst", "both"):
                 dst = keep[1]
-            arr = sv._layer_array([(sv.ComputeKernel.img_nv12_bgra, src, u, cv.CSC_BT601_LIMITED)])
+            arr = sv._layer_array([(skernel, src, u, cv.CSC_BT601_LIMITED)])
             layer_arrays.append(arr)
             ticks[f].target = sv._image_desc(dst)
             ticks[f].clear_first = 1
             ticks[f].n_layers = 1
             ticks[f].layers = arr
-        verify = ("img_nv12_bgra", host_src, [u])
+        verify = (f"img_{sfmt}_bgra", host_src, [u])
     else:
         nl = wl["layers"]
         for i in range(distinct):

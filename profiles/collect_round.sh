@@ -11,6 +11,7 @@ python bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
 python bench.py --workload cfg3 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python bench.py --workload cfg5 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
 python bench.py --workload mixer_y420p --no-cpu-baseline > $OUT/bench_mixer_y420p.json 2> $OUT/bench_mixer.err
+python bench.py --workload cfg2_y420p --no-cpu-baseline > $OUT/bench_cfg2_y420p.json 2> $OUT/bench_cfg2_y420p.err
 CHV_FORCE_GENERAL=1 python bench.py --no-cpu-baseline > $OUT/bench_cfg2_general_kernel.json 2>/dev/null
 CHV_FORCE_GENERAL=1 python bench.py --workload cfg3 --no-cpu-baseline > $OUT/bench_cfg3_general_kernel.json 2>/dev/null
 bash profiles/run_profile.sh ${R}_cfg2 > /dev/null 2>&1
