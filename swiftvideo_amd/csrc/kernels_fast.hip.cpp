@@ -366,10 +366,19 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
             }
         };
         auto store_row = [&](uint8_t *drow, const uint32_t (&outw)[PXT]) {
-            // streaming (nt) stores: the canvas is written once per tick and not read again by this launch (-1.5 % on cfg2)
-            if (PXT == 4) gst_stream(drow + (uint32_t)(xq * 4), make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]));
-            else if (PXT == 2) gst_stream(drow + (uint32_t)(xq * 4), make_uint2(outw[0], outw[PXT - 1]));
-            else gst_stream(drow + (uint32_t)(xq * 4), outw[0]);
+            // Large launches (the 32-row instantiation: >= 1024 blocks, the canvases together exceed every cache) use streaming
+            // (nt) stores — each canvas is written once and not read back by the launch: -1.5 % on cfg2.  Small launches (a
+            // mixer tick, whose canvas the next kernel or a download reads right away) use plain stores.
+            constexpr bool STREAM = THV == TH_LARGE;
+            if (PXT == 4) {
+                const uint4 v = make_uint4(outw[0], outw[1 % PXT], outw[2 % PXT], outw[PXT - 1]);
+                if (STREAM) gst_stream(drow + (uint32_t)(xq * 4), v); else gst<uint4>(drow + (uint32_t)(xq * 4), v);
+            } else if (PXT == 2) {
+                const uint2 v = make_uint2(outw[0], outw[PXT - 1]);
+                if (STREAM) gst_stream(drow + (uint32_t)(xq * 4), v); else gst<uint2>(drow + (uint32_t)(xq * 4), v);
+            } else {
+                if (STREAM) gst_stream(drow + (uint32_t)(xq * 4), outw[0]); else gst<uint32_t>(drow + (uint32_t)(xq * 4), outw[0]);
+            }
         };
         const bool fast_tile = uniform_inside && opaque;
         const bool whole_tile = fast_tile && full4 && ys0 + (j + 1) * TH <= T.H;
