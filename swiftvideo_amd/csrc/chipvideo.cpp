@@ -28,6 +28,7 @@ hipError_t launch_tick_general(int target_format, const DTick *ticks, const DLay
 hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
                            const float *den, float *out_q, int n, hipStream_t stream);
 hipError_t launch_selftest_pack(const int *b, const int *g, const int *r, uint32_t *out, int n, hipStream_t stream);
+hipError_t launch_selftest_pack_codes(const float *in, uint32_t *out, int n, hipStream_t stream);
 // kernels_fast.hip.cpp
 const char *fast_path_name(int path);
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
@@ -1256,4 +1257,19 @@ extern "C" int chv_selftest_pack(chv_context *c, const int *b, const int *g, con
     HIP_TRY(hipMemcpy(out, d_o, n * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d_b); (void)hipFree(d_g); (void)hipFree(d_r); (void)hipFree(d_o);
     return CHV_OK;
+}
+
+extern "C" int chv_selftest_pack_codes(chv_context *c, const float *in /*4n*/, uint32_t *out /*2n*/, int n) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (n <= 0 || !in || !out) return fail(CHV_ERR_INVALID_VALUE, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    float *d_in = nullptr; uint32_t *d_o = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_in, (size_t)n * 16));
+    hipError_t e = hipMalloc((void **)&d_o, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, (size_t)n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_selftest_pack_codes(d_in, d_o, n, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in); if (d_o) (void)hipFree(d_o);
+    return e == hipSuccess ? CHV_OK : hip_fail(e, "selftest pack_codes");
 }

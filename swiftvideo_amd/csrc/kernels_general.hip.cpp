@@ -287,6 +287,19 @@ __global__ void selftest_pack_kernel(const int *b, const int *g, const int *r, u
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { out[2 * i] = pack_bgra_fixed(b[i], g[i], r[i]); out[2 * i + 1] = pack_bgra_fixed_pk(b[i], g[i], r[i]); }
 }
+// out[i] = {to_code_raw x 4 packed with shifts, pack_codes(c0, c1, c2, c3)} for code-scale floats in[4i .. 4i+3]
+__global__ void selftest_pack_codes_kernel(const float *in, uint32_t *out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float c0 = in[4 * i], c1 = in[4 * i + 1], c2 = in[4 * i + 2], c3 = in[4 * i + 3];
+        out[2 * i] = to_code_raw(c0) | (to_code_raw(c1) << 8) | (to_code_raw(c2) << 16) | (to_code_raw(c3) << 24);
+        out[2 * i + 1] = pack_codes(c0, c1, c2, c3);
+    }
+}
+hipError_t launch_selftest_pack_codes(const float *in, uint32_t *out, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(selftest_pack_codes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n);
+    return hipGetLastError();
+}
 hipError_t launch_selftest_pack(const int *b, const int *g, const int *r, uint32_t *out, int n, hipStream_t stream) {
     hipLaunchKernelGGL(selftest_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, b, g, r, out, n);
     return hipGetLastError();

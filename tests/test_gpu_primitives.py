@@ -68,3 +68,28 @@ def test_packed_saturating_shift_matches_plain_packing(ctx):
     assert np.array_equal(out[0::2], exp), "pack_bgra_fixed"
     bad = np.nonzero(out[1::2] != exp)[0]
     assert bad.size == 0, f"pack_bgra_fixed_pk differs at {bad[:5]}: {[hex(v) for v in out[1::2][bad[:5]]]} vs {[hex(v) for v in exp[bad[:5]]]}"
+
+
+def test_pack_codes_matches_round_clamp_pack(ctx):
+    """pack_codes (v_cvt_pk_u8_f32 per byte) == clamp(rint(x), 0, 255) per channel with NaN -> 0, packed: ties, values around
+    both clamps, huge magnitudes, infinities, NaN, denormals."""
+    lib = cv.load()
+    fn = lib.chv_selftest_pack_codes
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(5)
+    k = np.arange(-3, 260, dtype=np.float64)
+    edge = np.concatenate([k + 0.5 + d for d in (-1e-3, -2e-5, 0.0, 2e-5, 1e-3)] + [k])
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-45, -1e-45, 1e30, -1e30, 255.49998, 255.5, 255.50002, 0.49999997, 0.5], dtype=np.float64)
+    vals = np.concatenate([edge, special, rng.uniform(-40, 300, 40000)]).astype(np.float32)
+    vals = np.resize(vals, (vals.size + 3) // 4 * 4)
+    rng.shuffle(vals)
+    n = vals.size // 4
+    out = np.zeros(2 * n, dtype=np.uint32)
+    cv.check(fn(ctx.handle, vals.ctypes.data, out.ctypes.data, n))
+    with np.errstate(invalid="ignore"):
+        code = np.where(np.isnan(vals), 0.0, np.clip(np.rint(vals.astype(np.float64)), 0, 255)).astype(np.uint32).reshape(n, 4)
+    exp = code[:, 0] | (code[:, 1] << 8) | (code[:, 2] << 16) | (code[:, 3] << 24)
+    assert np.array_equal(out[0::2], exp), "to_code_raw"
+    bad = np.nonzero(out[1::2] != exp)[0]
+    assert bad.size == 0, f"pack_codes differs for {vals.reshape(n, 4)[bad[:3]]}: {[hex(v) for v in out[1::2][bad[:3]]]} vs {[hex(v) for v in exp[bad[:3]]]}"
