@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
         const DPlane &S = Ly.src.pl[0];
         const RgbLayerTable &t = tabs[l];
         touch_regs(regs);                 // the wait for the prefetch, on every path (see touch_regs)
-        if (staged) stage_store<4, false>(regs, smem + tbase, tpitch, S, g, tid);
+        if (staged) stage_store<4, false>(regs, smem + tbase, tpitch, S, g, tid, 0, Ly.swizzle != 0);   // RGBA -> BGRA on the way
         __syncthreads();
         const int ln = next_hit(l + 1);
         bool nstaged = false;
@@ -234,10 +234,9 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
                         const float q2 = cs_mix(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z);
                         const float q3 = cs_mix(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w);
                         const float al = q3 * ka, ial = 1.f - al;
-                        const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
-                        cb[r][k] = code_rintf(__builtin_fmaf(pb, al, cb[r][k] * ial));
+                        cb[r][k] = code_rintf(__builtin_fmaf(q0, al, cb[r][k] * ial));     // staged texels are BGRA whatever the source order
                         cg[r][k] = code_rintf(__builtin_fmaf(q1, al, cg[r][k] * ial));
-                        cr[r][k] = code_rintf(__builtin_fmaf(pr, al, cr[r][k] * ial));
+                        cr[r][k] = code_rintf(__builtin_fmaf(q2, al, cr[r][k] * ial));
                     }
                 }
                 touched = ~0u;
@@ -280,7 +279,8 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
                             const float q1 = cs_mix(w00, w10, w01, w11, t00.y, t10.y, t01.y, t11.y);
                             const float q2 = cs_mix(w00, w10, w01, w11, t00.z, t10.z, t01.z, t11.z);
                             const float q3 = cs_mix(w00, w10, w01, w11, t00.w, t10.w, t01.w, t11.w);
-                            const float pb = Ly.swizzle ? q2 : q0, pr = Ly.swizzle ? q0 : q2;
+                            const bool swz = !staged && Ly.swizzle;       // taps gathered from global memory keep the source order
+                            const float pb = swz ? q2 : q0, pr = swz ? q0 : q2;
                             const float al = q3 * ka, ial = 1.f - al;
                             r0 = __builtin_fmaf(pb, al, r0 * ial);
                             r1 = __builtin_fmaf(q1, al, r1 * ial);

@@ -148,11 +148,13 @@ CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, i
 
 // BPT = bytes per source texel (1, 2, 4; selects the edge patching).
 // TO_FLOAT = false: the 16 source bytes are kept as bytes (LDS byte 16 + k of a row = source byte b0 + k)
+// swap02 (BPT = 4): bytes 0 and 2 of every texel are exchanged on the way (RGBA sources staged as BGRA)
 // TO_FLOAT = true : bytes become floats on the code scale, 64 LDS bytes per vector
 //                   (BPT = 2: float pairs, LDS texel slot 8 + k = source texel b0/2 + k;
 //                    BPT = 4: float4 texels, LDS texel slot 4 + k = source texel b0/4 + k)
 template <int BPT, bool TO_FLOAT, int N>
-CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid, int base = 0) {
+CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid, int base = 0,
+                         bool swap02 = false) {
 #pragma unroll
     for (int n = 0; n < N; n++) {
         int i = base + tid + n * NTHREADS, r, vv;
@@ -165,6 +167,10 @@ CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, co
                 int off = g.b0 + v * 16;
                 if (off >= 0 && off < P.w * BPT && !vec_loadable(P, row, off)) val = load_tail_vec(P, row, off);
                 val = patch_edges<BPT>(val, P, row, off);
+            }
+            if (BPT == 4 && swap02) {     // RGBA texels become BGRA in LDS (block-uniform): the tap loops need no channel select
+                val.x = __builtin_amdgcn_perm(val.x, val.x, 0x03000102u); val.y = __builtin_amdgcn_perm(val.y, val.y, 0x03000102u);
+                val.z = __builtin_amdgcn_perm(val.z, val.z, 0x03000102u); val.w = __builtin_amdgcn_perm(val.w, val.w, 0x03000102u);
             }
             if (!TO_FLOAT) {
                 *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
