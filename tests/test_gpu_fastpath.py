@@ -80,6 +80,50 @@ def test_yuv_bgra_32_row_tiles_match_oracle(ctx, monkeypatch, case, fmt):
     G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"{case}/{fmt} with 32-row tiles")
 
 
+@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("rows", ["16", "32"])
+def test_random_axis_aligned_yuv_bgra_ticks(ctx, monkeypatch, seed, rows):
+    """Seeded random axis-aligned geometry (placement, crop, flips, borders, fill, opacity, up- and downscales), three ticks of
+    different sizes per launch, both tile heights: tiled kernels == oracle."""
+    monkeypatch.setenv("CHV_TILE_ROWS", rows)
+    rng = np.random.default_rng(7000 + seed)
+    fmt = "nv12" if seed % 2 == 0 else "y420p"
+    kname = f"img_{fmt}_bgra"
+    clear = bool(rng.integers(0, 2))
+    ticks, exps, gds = [], [], []
+    for t in range(3):
+        cw, ch = int(rng.integers(3, 330)), int(rng.integers(2, 140))
+        sw, sh = int(rng.integers(8, 260)) * 2, int(rng.integers(2, 110)) * 2     # rows of >= 16 bytes for the staged loads
+        kw = {}
+        if rng.random() < 0.7:
+            kw["rect"] = (float(rng.uniform(-0.3, 0.6) * cw), float(rng.uniform(-0.3, 0.6) * ch),
+                          float(rng.uniform(0.2, 1.5) * cw), float(rng.uniform(0.2, 1.5) * ch))
+        if rng.random() < 0.4:
+            kw["border"] = tuple(float(v) for v in rng.uniform(0, 10, 4))
+        if rng.random() < 0.4:
+            kw["fill"] = tuple(float(v) for v in rng.uniform(0, 1, 4))
+        if rng.random() < 0.5:
+            kw["tex"] = (float(rng.uniform(0.0, 0.4)), float(rng.uniform(0.0, 0.4)),
+                         float(rng.uniform(0.3, 1.0)) * (1 if rng.random() < 0.8 else -1), float(rng.uniform(0.3, 1.0)))
+        kw["opacity"] = float(rng.choice([1.0, 1.0, rng.uniform(0, 1)]))
+        u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+        src = util.alloc_image(fmt, sw, sh, seed=int(rng.integers(1, 1 << 20)))
+        canvas0 = util.alloc_image("bgra", cw, ch, seed=int(rng.integers(1, 1 << 20)))
+        exp = util.copy_image(canvas0)
+        if clear:
+            assert O.run_kernel("img_clear_bgra", exp) == 0
+        assert O.run_kernel(kname, exp, src, u, csc=seed % 4, threads=4) == 0
+        gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+        ticks.append((gd, clear, [(sv.defaultComputeKernelFromString(kname), G.to_gpu(ctx, fmt, sw, sh, src), u, seed % 4)]))
+        exps.append(exp)
+        gds.append((gd, cw, ch))
+    h, name, keep = G.make_batch(ctx, ticks)
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    for i, ((gd, cw, ch), exp) in enumerate(zip(gds, exps)):
+        G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed} rows {rows} tick {i} via {name}")
+
+
 def test_rotated_layer_falls_back_to_general(ctx):
     u = util.make_uniforms((64, 36), rect=(10, 5, 40, 20), rotation=0.2, in_size=(32, 18))
     gs = G.to_gpu(ctx, "nv12", 32, 18, util.alloc_image("nv12", 32, 18, seed=1))
