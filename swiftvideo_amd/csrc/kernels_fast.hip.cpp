@@ -321,9 +321,9 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
         touch_regs(yregs); touch_regs(cregs);          // the wait for the prefetch, on every path (see touch_regs)
         if (PLANAR) touch_regs(vregs);
         if (staged) {
-            stage_store<1, false>(yregs, smem + ybase, ypitch, SY, gy, tid);
-            stage_store<(PLANAR ? 1 : 2), false>(cregs, smem + cbase, cpitch, SC, gc, tid);
-            if constexpr (PLANAR) stage_store<1, false>(vregs, smem + cbase + voff, cpitch, SV, gc, tid);
+            stage_store<1>(yregs, smem + ybase, ypitch, SY, gy, tid);
+            stage_store<(PLANAR ? 1 : 2)>(cregs, smem + cbase, cpitch, SC, gc, tid);
+            if constexpr (PLANAR) stage_store<1>(vregs, smem + cbase + voff, cpitch, SV, gc, tid);
             if (stage_slots(gy) > NYV * NTHREADS) stage_tail<1>(smem + ybase, ypitch, SY, gy, tid, NYV * NTHREADS);
             if (stage_slots(gc) > NCV * NTHREADS) {
                 stage_tail<(PLANAR ? 1 : 2)>(smem + cbase, cpitch, SC, gc, tid, NCV * NTHREADS);

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_RGB_MINW) void tick_rgb_layers_tiled(
         const DPlane &S = Ly.src.pl[0];
         const RgbLayerTable &t = tabs[l];
         touch_regs(regs);                 // the wait for the prefetch, on every path (see touch_regs)
-        if (staged) stage_store<4, false>(regs, smem + tbase, tpitch, S, g, tid, 0, Ly.swizzle != 0);   // RGBA -> BGRA on the way
+        if (staged) stage_store<4>(regs, smem + tbase, tpitch, S, g, tid, 0, Ly.swizzle != 0);   // RGBA -> BGRA on the way
         __syncthreads();
         const int ln = next_hit(l + 1);
         bool nstaged = false;

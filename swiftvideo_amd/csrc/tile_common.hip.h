@@ -45,13 +45,10 @@ CHV_DEV void lin_axis_raw(float s, int w, int &i0, float &a) {
     i0 = (int)fl;
 }
 
-// 16 source bytes -> 16 floats on the code scale (0..255, exact): the BGRA-target family samples
-// code values (pixel_math.hip.h), so staging is a plain v_cvt_f32_ubyteN per byte
+// the four bytes of a texel as floats on the code scale (0..255, exact): the BGRA-target family samples code
+// values (pixel_math.hip.h), so a tap is a plain v_cvt_f32_ubyteN per byte
 CHV_DEV float4 codes4(uint32_t w) {
     return make_float4((float)(w & 255), (float)((w >> 8) & 255), (float)((w >> 16) & 255), (float)(w >> 24));
-}
-CHV_DEV void codes16(const uint4 &v, float4 &f0, float4 &f1, float4 &f2, float4 &f3) {
-    f0 = codes4(v.x); f1 = codes4(v.y); f2 = codes4(v.z); f3 = codes4(v.w);
 }
 
 // Does the 16-byte vector at byte offset `off` of row `row` lie inside the plane's allocation as one
@@ -101,7 +98,7 @@ CHV_DEV uint4 patch_edges(uint4 val, const DPlane &P, int row, int off) {
 // Staging of one plane's source rectangle, split in two so that the global loads of the
 // NEXT tile are in flight while the current tile is being computed:
 //   stage_load : raw 16-byte vectors -> registers (no dependent instruction)
-//   stage_store: CLAMP_TO_EDGE patching, byte -> float code value (chroma, RGB texels), LDS write
+//   stage_store: CLAMP_TO_EDGE patching, LDS write
 // Slot i = tid + n * NTHREADS maps to row i / nslot, vector i % nslot of that row; LDS row r
 // holds source row clamp(r_lo + r).  With `edge` (block-uniform: the rectangle touches a
 // picture edge) vectors -1 .. nvec are staged, with the outside texels replicated.
@@ -146,13 +143,10 @@ CHV_DEV void stage_load(uint4 (&regs)[N], const DPlane &P, const StageGeom &g, i
     }
 }
 
-// BPT = bytes per source texel (1, 2, 4; selects the edge patching).
-// TO_FLOAT = false: the 16 source bytes are kept as bytes (LDS byte 16 + k of a row = source byte b0 + k)
+// BPT = bytes per source texel (1, 2, 4; selects the edge patching).  The 16 source bytes stay bytes: LDS byte 16 + k of
+// a row = source byte b0 + k (float tiles were measured and dropped for every format, profiles/r01_notes.md).
 // swap02 (BPT = 4): bytes 0 and 2 of every texel are exchanged on the way (RGBA sources staged as BGRA)
-// TO_FLOAT = true : bytes become floats on the code scale, 64 LDS bytes per vector
-//                   (BPT = 2: float pairs, LDS texel slot 8 + k = source texel b0/2 + k;
-//                    BPT = 4: float4 texels, LDS texel slot 4 + k = source texel b0/4 + k)
-template <int BPT, bool TO_FLOAT, int N>
+template <int BPT, int N>
 CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int tid, int base = 0,
                          bool swap02 = false) {
 #pragma unroll
@@ -172,14 +166,7 @@ CHV_DEV void stage_store(const uint4 (&regs)[N], uint8_t *lds, int lds_pitch, co
                 val.x = __builtin_amdgcn_perm(val.x, val.x, 0x03000102u); val.y = __builtin_amdgcn_perm(val.y, val.y, 0x03000102u);
                 val.z = __builtin_amdgcn_perm(val.z, val.z, 0x03000102u); val.w = __builtin_amdgcn_perm(val.w, val.w, 0x03000102u);
             }
-            if (!TO_FLOAT) {
-                *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
-            } else {
-                float4 f0, f1, f2, f3;
-                codes16(val, f0, f1, f2, f3);
-                float4 *d = (float4 *)(lds + r * lds_pitch + 64 + v * 64);
-                d[0] = f0; d[1] = f1; d[2] = f2; d[3] = f3;
-            }
+            *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
         }
     }
 }
@@ -191,7 +178,7 @@ CHV_DEV void stage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const Stag
     for (int base = first; base < stage_slots(g); base += NTHREADS) {
         uint4 t[1] = { make_uint4(0, 0, 0, 0) };
         stage_load(t, P, g, tid, base);
-        stage_store<BPT, false>(t, lds, lds_pitch, P, g, tid, base);
+        stage_store<BPT>(t, lds, lds_pitch, P, g, tid, base);
     }
 }
 
