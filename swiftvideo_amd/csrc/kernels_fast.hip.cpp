@@ -188,12 +188,12 @@ CHV_DEV void sample_y420p_lds_bytes(const uint8_t *smem, int ya, int ypitch, int
 // the next tile's global loads | compute + store | barrier].
 // CLEAR: canvas starts as img_clear_bgra's value instead of being read.
 // ---------------------------------------------------------------------------
-// NYV / NCV: prefetch registers (16-byte vectors) per thread for the luma / chroma rectangle of the next
-// tile.  The host picks the smallest pair the layer geometry needs: (2, 1) covers scale factors up to
-// about 1.7 (cfg2), (3, 2) the rest up to the LDS budget.
-// Occupancy: the kernel is VALU-issue bound and the SIMD's issue rate keeps rising with resident waves
-// (tools/ubench_issue.cpp), so the small-prefetch NV12 variant is held to 80 VGPRs = 6 waves per SIMD
-// (it fits without spilling); the others stay at 96 VGPRs = 5 waves.
+// NYV / NCV: prefetch registers (16-byte vectors) per thread for the luma / chroma rectangle of the next tile (planar
+// sources: NCV each for the U and the V plane).  The host picks (2, 1) when the worst-case rectangle fits, else (3, 2);
+// slots beyond the registers' capacity go through stage_tail.  THV: tile height, 16 or 32 rows (launch_tick_fast).
+// Occupancy: the SIMD's issue rate keeps rising with resident waves (tools/ubench_issue.cpp), so the NV12 variants that
+// matter (small prefetch, and the 32-row bench kernel) are held to 80 VGPRs = 6 waves per SIMD; planar sources need
+// more registers (three planes in flight) and run 5 or 4 waves — an 80-VGPR cap there spills and is 65 % slower.
 #ifndef CHV_MINW
 #define CHV_MINW ((!PLANAR && (NYV == 2 || THV == 32)) ? 6 : (NYV == 3 && PLANAR) ? 4 : 5)
 #endif
