@@ -1,23 +1,40 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the picture hot path on MI355X.
 
-Workload at every N (weak scaling, one process per GPU, no collective on the data
-path): BASELINE.json configs[1] — 1920x1080 NV12 -> BGRA (integer BT.601) with
-bilinear downscale to 1280x720 — over a batch of `--frames` distinct device-resident
-frames per GPU (the per-device PictureSample buses of configs[3]); one step = one
-pass of the path over the batch = one chv_batch_run launch.
+Headline workload ("pipeline", the literal metric of BASELINE.json: NV12 -> BGRA + scale + 4-layer composite):
+one mixer tick = four distinct 1920x1080 NV12 streams, converted (integer BT.601), bilinearly scaled to 1280x720
+and alpha-composited (opacities 1 / .75 / .5 / .25, z order 0..3) onto one cleared 720p BGRA canvas
+(mix.video.swift:114-124 with findKernel -> img_nv12_bgra).  `--frames` such ticks — each with its own four
+device-resident source frames and its own canvas, i.e. the ticks of `--frames` independent PictureSample buses —
+form one batch = one chv_batch_run launch.
 
-Prints ONE JSON line on rank 0 (see the contract in the task description):
-  value     = target pixels written per second, whole job, inputs resident in HBM
-  roofline  = algorithmic bytes per launch / mean launch duration (HIP events on the
-              context's stream) against the 8 TB/s HBM peak
-  cpu_baseline = the oracle (CPU restatement of the same kernels, "port") timed on the
-              host cores of this box on a bounded sample of the same workload (N=1 only)
+One step = `launches_per_step` passes of the path over the batch.  The count is calibrated after warm-up so that the
+timed region lasts >= --min-seconds whatever --steps is (a 256-tick launch is ~1 ms); the K steps are timed exactly as
+the contract says (barrier + device sync on both sides, max over ranks).
+
+The other BASELINE configs (cfg2 convert+scale, cfg3 4 x BGRA composite, cfg5 4K 8-layer + Lanczos, the reference's
+own 4:2:0 mixer canvas, and cfg2 end-to-end with H2D uploads on a side stream) are timed the same way right after
+and reported under "workloads" in the same JSON line.
+
+Multi-GPU: weak scaling, one process per GPU, no collective on the data path (stream s -> device s mod N).  When
+started without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the script spawns its N
+ranks itself; under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  The control plane (barrier,
+max over ranks) is gloo on the host.
+
+Prints ONE JSON line on rank 0:
+  value        = target pixels written per second, whole job, inputs resident in HBM
+  roofline     = algorithmic bytes per launch / mean launch duration (HIP events on the context's stream) against the
+                 8 TB/s HBM peak (frac) and the 6.29 TB/s measured copy ceiling (frac_of_copy_ceiling)
+  cpu_baseline = the oracle (CPU restatement of the same kernels, "port") timed on the host cores of this box on a
+                 bounded sample of the same workload (N=1 only)
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -28,45 +45,107 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0      # same guide: what a float4 copy kernel reaches
+METRIC = "Gpix/s + achieved HBM GB/s, 1080p NV12→BGRA+scale+4-layer composite, 1/2/4/8 GPU"
+
+NV12_1080 = 3110400
+BGRA_720, BGRA_1080, BGRA_2160 = 3686400, 8294400, 33177600
 
 WORKLOADS = {
-    # name: (src fmt, src w, h, dst w, h, n_layers, algorithmic bytes per tick)
+    # algorithmic bytes per tick = every distinct input byte once + every output byte once
+    "pipeline": dict(desc="4 x 1920x1080 NV12 streams -> BGRA (BT.601 int) + bilinear downscale to 1280x720 + 4-layer "
+                          "alpha composite (opacity 1/.75/.5/.25) onto one 720p BGRA canvas, one launch per batch of ticks",
+                     kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=4, frames=256,
+                     bytes=4 * NV12_1080 + BGRA_720),
     "cfg2": dict(desc="1920x1080 NV12 -> BGRA (BT.601 int) + bilinear downscale to 1280x720",
-                 sw=1920, sh=1080, dw=1280, dh=720, layers=1, bytes=3110400 + 3686400),
+                 kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=1, frames=256,
+                 bytes=NV12_1080 + BGRA_720),
     "cfg2_y420p": dict(desc="cfg2 with a planar source: 1920x1080 y420p -> BGRA (BT.601 int) + bilinear downscale to 1280x720",
-                 sw=1920, sh=1080, dw=1280, dh=720, layers=1, bytes=3110400 + 3686400, src="y420p"),
+                       kind="yuv_layers", src="y420p", sw=1920, sh=1080, dw=1280, dh=720, layers=1, frames=256,
+                       bytes=NV12_1080 + BGRA_720),
     "cfg3": dict(desc="4 x 1080p BGRA layers (opacity 1/.75/.5/.25) alpha-composited onto a 1080p BGRA canvas",
-                 sw=1920, sh=1080, dw=1920, dh=1080, layers=4, bytes=4 * 8294400 + 8294400),
-    "mixer_y420p": dict(desc="reference-default canvas: 1080p y420p canvas <- full-canvas 1080p y420p layer + two 640x360 BGRA overlays (opacity .8/.6)",
-                 sw=1920, sh=1080, dw=1920, dh=1080, layers=3, bytes=3110400 + 3110400 + 2 * 921600, mixer="y420p"),
+                 kind="rgb_layers", sw=1920, sh=1080, dw=1920, dh=1080, layers=4, frames=128,
+                 bytes=4 * BGRA_1080 + BGRA_1080),
+    "mixer_y420p": dict(desc="reference-default canvas: 1080p y420p canvas <- full-canvas 1080p y420p layer + two 640x360 BGRA "
+                             "overlays (opacity .8/.6)",
+                        kind="mixer420", mixer="y420p", sw=1920, sh=1080, dw=1920, dh=1080, layers=3, frames=128,
+                        bytes=NV12_1080 + NV12_1080 + 2 * 921600),
+    "mixer_nv12": dict(desc="1080p NV12 canvas <- full-canvas 1080p NV12 layer + two 640x360 BGRA overlays (opacity .8/.6)",
+                       kind="mixer420", mixer="nv12", sw=1920, sh=1080, dw=1920, dh=1080, layers=3, frames=128,
+                       bytes=NV12_1080 + NV12_1080 + 2 * 921600),
     "cfg5": dict(desc="8 x 3840x2160 BGRA layers composited onto a 2160p canvas, then Lanczos-3 down to 1920x1080",
-                 sw=3840, sh=2160, dw=3840, dh=2160, layers=8, bytes=8 * 33177600 + 8294400, lanczos=(1920, 1080)),
+                 kind="rgb_layers", sw=3840, sh=2160, dw=3840, dh=2160, layers=8, frames=24,
+                 bytes=8 * BGRA_2160 + BGRA_1080, lanczos=(1920, 1080)),
+    "mixed": dict(desc="1080p NV12 video + 1080p y420p video (opacity .5) + two 640x360 BGRA/RGBA overlays -> 720p BGRA canvas",
+                  kind="mixed", sw=1920, sh=1080, dw=1280, dh=720, layers=4, frames=128,
+                  bytes=2 * NV12_1080 + 2 * 921600 + BGRA_720),
 }
+HEADLINE = "pipeline"
+DEFAULT_SET = ["pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p"]
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=256, help="distinct frames (ticks) per launch per GPU")
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=None, help="ticks per launch per GPU (default: per workload, 256 for the headline)")
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS),
+                    help="the workload `value` / `roofline` are reported on")
+    ap.add_argument("--also", default=None,
+                    help="comma-separated workloads timed after the headline and reported under \"workloads\" "
+                         "(default: the BASELINE set when --workload is the default, none otherwise); 'none' for none")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="minimum duration of the headline's timed region")
+    ap.add_argument("--min-seconds-other", type=float, default=0.6, help="minimum timed region of each other workload")
+    ap.add_argument("--launches-per-step", type=int, default=0, help="fixed instead of calibrated (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-upload-leg", action="store_true", help="skip the end-to-end (H2D-inclusive) cfg2 measurement")
     ap.add_argument("--alias", default="none", choices=("none", "src", "dst", "both"),
-                    help="DIAGNOSTIC (cfg2 only): every tick reads frame 0's source and/or writes frame 0's canvas, so that "
-                         "side of the traffic stays in cache; the line is marked and is not a benchmark result")
+                    help="DIAGNOSTIC (single-layer YUV workloads): every tick reads frame 0's source and/or writes frame 0's "
+                         "canvas, so that side of the traffic stays in cache; the line is marked and is not a benchmark result")
     ap.add_argument("--device", type=int, default=None,
                     help="device index for every rank (default: LOCAL_RANK); lets the N>1 path be exercised on a 1-GPU box")
     ap.add_argument("--with-upload", action="store_true",
-                    help="end-to-end mode: every step also uploads its source frames from pinned host memory on a side "
+                    help="end-to-end mode only: every step also uploads its source frames from pinned host memory on a side "
                          "stream (PCIe-inclusive rate; reported for DESIGN.md, never the headline value)")
-    return ap.parse_args()
+    ap.add_argument("--pmc-json", default=None,
+                    help="a profiles/pmc_*.json produced by profiles/run_profile.sh for THIS command: its HBM bytes per launch "
+                         "are copied into roofline.traffic with roofline.traffic_source naming the file")
+    return ap.parse_args(argv)
 
 
-def dist_setup(n_gpus):
+# ---------------------------------------------------------------------------------------------------------------
+# launcher / control plane
+# ---------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rank r -> device r
+    unless --device pins them), pass rank 0's stdout through, fail if any rank fails."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CHV_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+def dist_setup():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,6 +154,7 @@ def dist_setup(n_gpus):
         import torch.distributed as dist_mod
         # control plane only (barrier, max over ranks): gloo on the host; the pixel path has no collective
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)
         dist = dist_mod
     return rank, local, world, dist
@@ -90,6 +170,17 @@ def reduce_max(dist, value):
     return float(t[0])
 
 
+def gather_floats(dist, value, world):
+    """every rank's value, on every rank"""
+    if dist is None:
+        return [float(value)]
+    import torch
+    t = torch.zeros(world, dtype=torch.float64)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t]
+
+
 def whole_job_gpix(n_gpus, px_per_step_per_gpu, steps, elapsed_max):
     """Weak scaling: every rank processes the same per-GPU batch; value = all pixels / slowest rank's time."""
     return n_gpus * px_per_step_per_gpu * steps / elapsed_max / 1e9
@@ -100,6 +191,19 @@ def stream_to_device(stream_id, n_gpus):
     return stream_id % n_gpus
 
 
+def pick_device(args, local, n_visible):
+    """rank -> device: --device pins every rank to one device (1-GPU boxes); otherwise LOCAL_RANK, which must exist."""
+    if args.device is not None:
+        return args.device
+    if local >= n_visible:
+        raise SystemExit(f"rank with LOCAL_RANK={local} has no device: {n_visible} visible "
+                         f"(use --device D to run several ranks on one device)")
+    return local
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------
 def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
     """Device-resident source frames, canvases and the batch descriptor."""
     import util
@@ -108,13 +212,26 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
     sw, sh, dw, dh = wl["sw"], wl["sh"], wl["dw"], wl["dh"]
     distinct = 4
     host_src = []
-    keep = []  # keep PictureSamples alive (they own the device memory)
+    keep = []      # keep PictureSamples alive (they own the device memory)
+    canvases = []
     ticks = (cv.Tick * frames)()
     layer_arrays = []
     lanczos_pairs = []
-    if "mixer" in wl:
+    verify = None
+    up = lambda pf, size, planes: sv.uploadComputePicture(ctx, sv.pictureFromArrays(pf, size, planes), retainCpuBuffer=False)   # noqa: E731
+    blank = lambda pf, size: sv.uploadComputePicture(ctx, sv.createPictureSample(size, pf), retainCpuBuffer=False)              # noqa: E731
+    PF = {"nv12": sv.PixelFormat.nv12, "y420p": sv.PixelFormat.y420p, "bgra": sv.PixelFormat.BGRA, "rgba": sv.PixelFormat.RGBA}
+
+    def finish_tick(f, dst, layers):
+        arr = sv._layer_array(layers)
+        layer_arrays.append(arr)
+        ticks[f].target = sv._image_desc(dst)
+        ticks[f].clear_first = 1
+        ticks[f].n_layers = len(layers)
+        ticks[f].layers = arr
+
+    if wl["kind"] == "mixer420":
         fmt = wl["mixer"]
-        pf = sv.PixelFormat.y420p if fmt == "y420p" else sv.PixelFormat.nv12
         for i in range(distinct):
             host_src.append(util.alloc_image(fmt, sw, sh, seed=seed_base + i))
         ov = [util.alloc_image("bgra", 640, 360, seed=seed_base + 100 + i) for i in range(2)]
@@ -123,43 +240,44 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
               util.make_uniforms((dw, dh), rect=(1200, 640, 640, 360), opacity=0.6, in_size=(640, 360))]
         k_main = sv.defaultComputeKernelFromString(f"img_{fmt}_{fmt}")
         k_ov = sv.defaultComputeKernelFromString(f"img_bgra_{fmt}")
-        govs = [sv.uploadComputePicture(ctx, sv.pictureFromArrays(sv.PixelFormat.BGRA, (640, 360), o), retainCpuBuffer=False) for o in ov]
+        govs = [up(sv.PixelFormat.BGRA, (640, 360), o) for o in ov]
         keep += govs
         for f in range(frames):
-            src = sv.uploadComputePicture(ctx, sv.pictureFromArrays(pf, (sw, sh), host_src[f % distinct]), retainCpuBuffer=False)
-            dst = sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), pf), retainCpuBuffer=False)
+            src = up(PF[fmt], (sw, sh), host_src[f % distinct])
+            dst = blank(PF[fmt], (dw, dh))
             keep += [src, dst]
-            arr = sv._layer_array([(k_main, src, us[0], 0), (k_ov, govs[0], us[1], 0), (k_ov, govs[1], us[2], 0)])
-            layer_arrays.append(arr)
-            ticks[f].target = sv._image_desc(dst)
-            ticks[f].clear_first = 1
-            ticks[f].n_layers = 3
-            ticks[f].layers = arr
-        verify = None
-    elif wl["layers"] == 1:
-        sfmt = wl.get("src", "nv12")
-        spf = sv.PixelFormat.y420p if sfmt == "y420p" else sv.PixelFormat.nv12
-        skernel = sv.ComputeKernel.img_y420p_bgra if sfmt == "y420p" else sv.ComputeKernel.img_nv12_bgra
+            canvases.append(dst)
+            finish_tick(f, dst, [(k_main, src, us[0], 0), (k_ov, govs[0], us[1], 0), (k_ov, govs[1], us[2], 0)])
+        verify = dict(target=fmt, layers=lambda f: [(f"img_{fmt}_{fmt}", host_src[f % distinct], us[0]),
+                                                    (f"img_bgra_{fmt}", ov[0], us[1]), (f"img_bgra_{fmt}", ov[1], us[2])])
+    elif wl["kind"] == "yuv_layers":
+        sfmt, nl = wl["src"], wl["layers"]
+        skernel = sv.defaultComputeKernelFromString(f"img_{sfmt}_bgra")
         for i in range(distinct):
             host_src.append(util.alloc_image(sfmt, sw, sh, seed=seed_base + i))
-        u = util.full_canvas_uniforms((dw, dh), (sw, sh))
+        ops = (1.0, 0.75, 0.5, 0.25)
+        us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=ops[l]) for l in range(nl)]
+        first_src = first_dst = None
         for f in range(frames):
-            src = sv.uploadComputePicture(ctx, sv.pictureFromArrays(spf, (sw, sh), host_src[f % distinct]),
-                                          retainCpuBuffer=False)
-            dst = sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False)
-            keep += [src, dst]
-            if f > 0 and alias in ("src", "both"):
-                src = keep[0]
+            layers = []
+            for l in range(nl):
+                src = up(PF[sfmt], (sw, sh), host_src[(f + l) % distinct])
+                keep.append(src)
+                if first_src is None:
+                    first_src = src
+                if f > 0 and alias in ("src", "both"):
+                    src = first_src
+                layers.append((skernel, src, us[l], cv.CSC_BT601_LIMITED))
+            dst = blank(sv.PixelFormat.BGRA, (dw, dh))
+            keep.append(dst)
+            if first_dst is None:
+                first_dst = dst
             if f > 0 and alias in ("dst", "both"):
-                dst = keep[1]
-            arr = sv._layer_array([(skernel, src, u, cv.CSC_BT601_LIMITED)])
-            layer_arrays.append(arr)
-            ticks[f].target = sv._image_desc(dst)
-            ticks[f].clear_first = 1
-            ticks[f].n_layers = 1
-            ticks[f].layers = arr
-        verify = (f"img_{sfmt}_bgra", host_src, [u])
-    else:
+                dst = first_dst
+            canvases.append(dst)
+            finish_tick(f, dst, layers)
+        verify = dict(target="bgra", layers=lambda f: [(f"img_{sfmt}_bgra", host_src[(f + l) % distinct], us[l]) for l in range(nl)])
+    elif wl["kind"] == "rgb_layers":
         nl = wl["layers"]
         for i in range(distinct):
             host_src.append(util.alloc_image("bgra", sw, sh, seed=seed_base + i))
@@ -168,46 +286,73 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
         for f in range(frames):
             layers = []
             for l in range(nl):
-                src = sv.uploadComputePicture(ctx, sv.pictureFromArrays(sv.PixelFormat.BGRA, (sw, sh), host_src[(f + l) % distinct]),
-                                              retainCpuBuffer=False)
+                src = up(sv.PixelFormat.BGRA, (sw, sh), host_src[(f + l) % distinct])
                 keep.append(src)
                 layers.append((sv.ComputeKernel.img_bgra_bgra_tx, src, us[l], 0))
-            dst = sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False)
+            dst = blank(sv.PixelFormat.BGRA, (dw, dh))
             keep.append(dst)
+            canvases.append(dst)
             if "lanczos" in wl:
-                small = sv.uploadComputePicture(ctx, sv.createPictureSample(wl["lanczos"], sv.PixelFormat.BGRA), retainCpuBuffer=False)
+                small = blank(sv.PixelFormat.BGRA, wl["lanczos"])
                 lanczos_pairs.append((small, dst))
-            arr = sv._layer_array(layers)
-            layer_arrays.append(arr)
-            ticks[f].target = sv._image_desc(dst)
-            ticks[f].clear_first = 1
-            ticks[f].n_layers = nl
-            ticks[f].layers = arr
-        verify = ("img_bgra_bgra_tx", host_src, us)
+            finish_tick(f, dst, layers)
+        verify = dict(target="bgra", layers=lambda f: [("img_bgra_bgra_tx", host_src[(f + l) % distinct], us[l]) for l in range(nl)])
+    elif wl["kind"] == "mixed":
+        nv = [util.alloc_image("nv12", sw, sh, seed=seed_base + i) for i in range(distinct)]
+        yp = [util.alloc_image("y420p", sw, sh, seed=seed_base + 50 + i) for i in range(distinct)]
+        ov = [util.alloc_image("bgra", 640, 360, seed=seed_base + 100), util.alloc_image("rgba", 640, 360, seed=seed_base + 101)]
+        us = [util.full_canvas_uniforms((dw, dh), (sw, sh)), util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=0.5),
+              util.make_uniforms((dw, dh), rect=(48, 40, 426, 240), opacity=0.8, in_size=(640, 360)),
+              util.make_uniforms((dw, dh), rect=(800, 430, 426, 240), opacity=0.6, in_size=(640, 360))]
+        govs = [up(sv.PixelFormat.BGRA, (640, 360), ov[0]), up(sv.PixelFormat.RGBA, (640, 360), ov[1])]
+        keep += govs
+        K = sv.ComputeKernel
+        for f in range(frames):
+            a, b = up(sv.PixelFormat.nv12, (sw, sh), nv[f % distinct]), up(sv.PixelFormat.y420p, (sw, sh), yp[f % distinct])
+            dst = blank(sv.PixelFormat.BGRA, (dw, dh))
+            keep += [a, b, dst]
+            canvases.append(dst)
+            finish_tick(f, dst, [(K.img_nv12_bgra, a, us[0], 0), (K.img_y420p_bgra, b, us[1], 0),
+                                 (K.img_bgra_bgra_tx, govs[0], us[2], 0), (K.img_rgba_bgra_tx, govs[1], us[3], 0)])
+        verify = dict(target="bgra", layers=lambda f: [("img_nv12_bgra", nv[f % distinct], us[0]), ("img_y420p_bgra", yp[f % distinct], us[1]),
+                                                       ("img_bgra_bgra_tx", ov[0], us[2]), ("img_rgba_bgra_tx", ov[1], us[3])])
+    else:
+        raise ValueError(wl["kind"])
     batch = C.c_void_p()
     cv.check(lib.chv_batch_create(ctx.handle, ticks, frames, C.byref(batch)))
     name = C.create_string_buffer(128)
     cv.check(lib.chv_batch_describe(batch, name, 128, None))
     return dict(batch=batch, keep=keep, layer_arrays=layer_arrays, ticks=ticks, kernel=name.value.decode(), verify=verify,
-                lanczos=lanczos_pairs)
+                lanczos=lanczos_pairs, canvases=canvases)
+
+
+def free_workload(w):
+    from swiftvideo_amd import chipvideo as cv
+    cv.check(cv.load().chv_batch_destroy(w["batch"]))
+    w["keep"].clear(); w["canvases"].clear(); w["lanczos"].clear(); w["layer_arrays"].clear()
+    import gc
+    gc.collect()
 
 
 def verify_frame(sv, ctx, wl, w, frame=0):
-    """Frame `frame` of the batch output == oracle (outside any timed region)."""
+    """Canvas of tick `frame` == oracle: clear + the tick's layer kernels in z order (outside any timed region)."""
     import util
     from oracle import oracle as O
-    kernel, host_src, us = w["verify"]
+    v = w["verify"]
     dw, dh = wl["dw"], wl["dh"]
-    exp = util.alloc_image("bgra", dw, dh)
-    assert O.run_kernel("img_clear_bgra", exp, threads=os.cpu_count()) == 0
-    distinct = len(host_src)
-    for l, u in enumerate(us):
-        src = host_src[(frame + l) % distinct] if len(us) > 1 else host_src[frame % distinct]
-        assert O.run_kernel(kernel, exp, src, u, threads=os.cpu_count()) == 0
-    per_frame = 1 + len(us) if len(us) > 1 else 2
-    dst = w["keep"][frame * per_frame + per_frame - 1]
-    got = sv.downloadComputePicture(ctx, dst, retainGpuBuffer=True).imageBuffer().buffers[0]
-    return bool(np.array_equal(got[:, : dw * 4].reshape(dh, dw, 4), exp[0]))
+    fmt = v["target"]
+    exp = util.alloc_image(fmt, dw, dh)
+    threads = os.cpu_count() or 1
+    assert O.run_kernel(f"img_clear_{fmt}", exp, threads=threads) == 0
+    for kernel, src, u in v["layers"](frame):
+        assert O.run_kernel(kernel, exp, src, u, threads=threads) == 0
+    got = sv.downloadComputePicture(ctx, w["canvases"][frame], retainGpuBuffer=True).imageBuffer().buffers
+    for g, e in zip(got, exp):
+        comps = 1 if e.ndim == 2 else e.shape[2]
+        view = g[: e.shape[0], : e.shape[1] * comps].reshape(e.shape)
+        if not np.array_equal(view, e):
+            return False
+    return True
 
 
 def cpu_baseline(wl, w, budget_s):
@@ -217,20 +362,22 @@ def cpu_baseline(wl, w, budget_s):
     import threading
     import util
     from oracle import oracle as O
-    kernel, host_src, us = w["verify"]
+    v = w["verify"]
     dw, dh = wl["dw"], wl["dh"]
     cores = os.cpu_count() or 1
     O.lib()
     counts = [0] * cores
     t_end = [0.0]
+    fmt = v["target"]
+    n_kernels = len(v["layers"](0))
 
     def worker(i):
-        canvas = util.alloc_image("bgra", dw, dh)
+        canvas = util.alloc_image(fmt, dw, dh)
         n = 0
         while time.perf_counter() < t_end[0]:
-            O.run_kernel("img_clear_bgra", canvas, threads=1)
-            for l, u in enumerate(us):
-                O.run_kernel(kernel, canvas, host_src[(n + l) % len(host_src)], u, threads=1)
+            O.run_kernel(f"img_clear_{fmt}", canvas, threads=1)
+            for kernel, src, u in v["layers"](n):
+                O.run_kernel(kernel, canvas, src, u, threads=1)
             n += 1
         counts[i] = n
 
@@ -246,16 +393,125 @@ def cpu_baseline(wl, w, budget_s):
     gpix = n * dw * dh / el / 1e9
     return {"value": gpix, "unit": "Gpix/s", "cores": cores, "kind": "port",
             "sample": f"{n} ticks of the same workload in {el:.1f} s: oracle/ref_kernels.c, {cores} threads each "
-                      f"compositing whole ticks (clear + {len(us)} layer kernel(s) per tick, as the reference issues them)"}
+                      f"compositing whole ticks (clear + {n_kernels} layer kernel(s) per tick, as the reference issues them)"}
 
 
-def run_with_upload(args, sv, cv, lib, ctx, wl, rank, n_gpus, dist):
+class Timer:
+    """K steps of R launches each, bracketed as the contract says; per-step HIP events on the context's stream."""
+
+    def __init__(self, cv, lib, ctx, dist):
+        self.cv, self.lib, self.ctx, self.dist = cv, lib, ctx, dist
+
+    def sync(self):
+        self.cv.check(self.lib.chv_device_synchronize(self.ctx.handle))
+        try:
+            import torch
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def event(self):
+        e = C.c_void_p()
+        self.cv.check(self.lib.chv_event_create(self.ctx.handle, C.byref(e)))
+        return e
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self.cv.check(self.lib.chv_event_elapsed_ms(a, b, C.byref(ms)))
+        return ms.value
+
+    def calibrate(self, launch, steps, min_seconds, fixed):
+        """launches per step so that `steps` steps last >= min_seconds; the same number on every rank"""
+        if fixed > 0:
+            return fixed
+        a, b = self.event(), self.event()
+        self.cv.check(self.lib.chv_event_record(self.ctx.handle, a))
+        for _ in range(3):
+            launch()
+        self.cv.check(self.lib.chv_event_record(self.ctx.handle, b))
+        self.sync()
+        ms = max(self.elapsed_ms(a, b) / 3.0, 1e-3)
+        for e in (a, b):
+            self.cv.check(self.lib.chv_event_destroy(e))
+        r = max(1, math.ceil(min_seconds * 1e3 / (steps * ms)))
+        return int(reduce_max(self.dist, r))
+
+    def run(self, launch, steps, per_step):
+        evs = [self.event() for _ in range(steps + 1)]
+        self.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        self.cv.check(self.lib.chv_event_record(self.ctx.handle, evs[0]))
+        for k in range(steps):
+            for _ in range(per_step):
+                launch()
+            self.cv.check(self.lib.chv_event_record(self.ctx.handle, evs[k + 1]))
+        self.sync()
+        self.barrier()
+        t1 = time.perf_counter()
+        local = t1 - t0
+        elapsed = reduce_max(self.dist, local)
+        step_ms = [self.elapsed_ms(evs[k], evs[k + 1]) for k in range(steps)]
+        for e in evs:
+            self.cv.check(self.lib.chv_event_destroy(e))
+        return elapsed, local, float(np.mean(step_ms)) / per_step
+
+
+def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
+    """Build, warm up, verify, time and free one workload; returns its report (complete on rank 0)."""
+    wl = WORKLOADS[name]
+    frames = args.frames if (args.frames and headline) else wl["frames"]
+    w = build_workload(sv, ctx, wl, frames, seed_base=0x5EED0000 + 16 * 2 + rank, alias=args.alias if headline else "none")
+
+    def launch():
+        cv.check(lib.chv_batch_run(ctx.handle, w["batch"]))
+        for small, big in w["lanczos"]:
+            sv.scaleLanczos(ctx, small, big)
+
+    for _ in range(max(args.warmup, 1)):
+        launch()
+    tm.sync()
+    verified = None
+    if not args.no_verify and rank == 0 and w["verify"] is not None and (not headline or args.alias == "none"):
+        verified = verify_frame(sv, ctx, wl, w, 0) and verify_frame(sv, ctx, wl, w, frames - 1)
+    per_step = tm.calibrate(launch, args.steps, args.min_seconds if headline else args.min_seconds_other, args.launches_per_step)
+    elapsed, local, launch_ms = tm.run(launch, args.steps, per_step)
+    locals_ = gather_floats(tm.dist, local, n_gpus)
+    px_per_launch = frames * wl["dw"] * wl["dh"] if "lanczos" not in wl else frames * wl["lanczos"][0] * wl["lanczos"][1]
+    bytes_per_launch = frames * wl["bytes"]
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    rep = {
+        "workload": f"{name}: {wl['desc']}",
+        "value": whole_job_gpix(n_gpus, px_per_launch * per_step, args.steps, elapsed), "unit": "Gpix/s",
+        "ms_per_step": elapsed / args.steps * 1e3, "launches_per_step": per_step, "timed_seconds": elapsed,
+        "frames_per_launch_per_gpu": frames, "kernel": w["kernel"], "verified_vs_oracle": verified,
+        "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "frac_of_copy_ceiling": achieved / HBM_COPY_GBS},
+        "per_gpu_gpix": [px_per_launch * per_step * args.steps / t / 1e9 for t in locals_],
+        # a tick belongs to one PictureSample bus: `frames` streams per GPU advance by one tick per launch
+        "per_stream_ticks_per_s": 1e3 / launch_ms,
+        "source_mpix_per_launch_per_gpu": frames * wl["sw"] * wl["sh"] * (wl["layers"] if wl["kind"] != "mixer420" else 1) / 1e6,
+    }
+    cpu = None
+    if headline and rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and w["verify"] is not None:
+        cpu = cpu_baseline(wl, w, args.cpu_seconds)
+    free_workload(w)
+    return rep, cpu
+
+
+def run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=64):
     """PCIe-inclusive pipeline for cfg2: two frame sets; while set A is converted on the compute
     context's stream, set B's NV12 planes are uploaded (hipMemcpy2DAsync from pinned memory) on a
     sharing context's stream.  Ordering: per-buffer upload events (kernel waits for its inputs) and a
     per-set 'batch done' event (the next upload into the set waits for the kernel that read it)."""
     import util
-    assert wl["layers"] == 1, "--with-upload is implemented for the convert+scale workload"
+    wl = WORKLOADS["cfg2"]
     up = sv.createComputeContext(sharing=ctx)
     sw, sh = wl["sw"], wl["sh"]
     ysz, csz = sw * sh, sw * sh // 2
@@ -267,7 +523,7 @@ def run_with_upload(args, sv, cv, lib, ctx, wl, rank, n_gpus, dist):
         img = util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 32 + i)
         host[i * (ysz + csz): i * (ysz + csz) + ysz] = img[0].reshape(-1)
         host[i * (ysz + csz) + ysz: (i + 1) * (ysz + csz)] = img[1].reshape(-1)
-    sets = [build_workload(sv, ctx, wl, args.frames, seed_base=0x5EED0000 + 32) for _ in range(2)]
+    sets = [build_workload(sv, ctx, wl, frames, seed_base=0x5EED0000 + 32) for _ in range(2)]
     done = []
     for _ in sets:
         e = C.c_void_p()
@@ -278,7 +534,7 @@ def run_with_upload(args, sv, cv, lib, ctx, wl, rank, n_gpus, dist):
     def upload_set(k):
         cv.check(lib.chv_event_wait(up.handle, done[k]))          # the kernel that last read this set is finished
         keep = sets[k]["keep"]
-        for f in range(args.frames):
+        for f in range(frames):
             src = keep[2 * f].imageBuffer()
             base = pinned.value + (f % distinct) * (ysz + csz)
             # luma + interleaved chroma are adjacent with equal pitch on both sides: one pitched copy per frame
@@ -290,139 +546,117 @@ def run_with_upload(args, sv, cv, lib, ctx, wl, rank, n_gpus, dist):
         cv.check(lib.chv_batch_run(ctx.handle, sets[k]["batch"]))  # waits for the set's upload events on its stream
         cv.check(lib.chv_event_record(ctx.handle, done[k]))
 
-    def sync():
-        cv.check(lib.chv_device_synchronize(ctx.handle))
+    state = [0]
 
-    for w in range(args.warmup):
-        upload_set(w % 2); convert_set(w % 2)
-    sync()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        upload_set(k % 2); convert_set(k % 2)
-    sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = reduce_max(dist, time.perf_counter() - t0)
-    if rank == 0:
-        px = args.frames * wl["dw"] * wl["dh"]
-        h2d = args.frames * (ysz + csz) * args.steps / elapsed / 1e9
-        print(json.dumps({
-            "metric": "Gpix/s + achieved HBM GB/s, 1080p NV12→BGRA+scale+4-layer composite, 1/2/4/8 GPU",
-            "value": whole_job_gpix(n_gpus, px, args.steps, elapsed), "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['desc']}", "mode": "END-TO-END incl. H2D upload of every source frame "
-                       "from pinned host memory on a side stream (not the headline mode)", "frames_per_step_per_gpu": args.frames,
-                       "h2d_GBps_per_gpu": h2d, "kernel": sets[0]["kernel"]}}), flush=True)
+    def launch():
+        k = state[0] & 1
+        state[0] += 1
+        upload_set(k)
+        convert_set(k)
+
+    for _ in range(max(args.warmup, 2)):
+        launch()
+    tm.sync()
+    per_step = tm.calibrate(launch, args.steps, args.min_seconds_other, args.launches_per_step)
+    elapsed, local, launch_ms = tm.run(launch, args.steps, per_step)
+    px = frames * wl["dw"] * wl["dh"]
+    rep = {
+        "workload": "cfg2_upload: cfg2 END-TO-END incl. H2D upload of every 1080p NV12 source frame from pinned host memory on a "
+                    "side stream (PCIe-bound; never the headline value)",
+        "value": whole_job_gpix(n_gpus, px * per_step, args.steps, elapsed), "unit": "Gpix/s",
+        "ms_per_step": elapsed / args.steps * 1e3, "launches_per_step": per_step, "timed_seconds": elapsed,
+        "frames_per_launch_per_gpu": frames, "kernel": sets[0]["kernel"],
+        "h2d_GBps_per_gpu": frames * (ysz + csz) * per_step * args.steps / local / 1e9,
+        "per_stream_ticks_per_s": 1e3 / launch_ms,
+    }
+    for e in done:
+        cv.check(lib.chv_event_destroy(e))
+    for s in sets:
+        free_workload(s)
     cv.check(lib.chv_host_free(up.handle, pinned))
+    sv.destroyComputeContext(up)
+    return rep
 
 
-def main():
-    args = parse_args()
-    rank, local, world, dist = dist_setup(args.gpus)
-    if world != args.gpus and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    rank, local, world, dist = dist_setup()
+    if world != args.gpus:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     n_gpus = max(world, 1)
 
     from swiftvideo_amd import chipvideo as cv
     from swiftvideo_amd import compute as sv
     lib = cv.load()
-    ctx = sv.makeComputeContext(forType="GPU", index=local if args.device is None else args.device)
-    wl = WORKLOADS[args.workload]
+    dev = pick_device(args, local, cv.device_count())
+    ctx = sv.makeComputeContext(forType="GPU", index=dev)
+    tm = Timer(cv, lib, ctx, dist)
+
     if args.with_upload:
-        run_with_upload(args, sv, cv, lib, ctx, wl, rank, n_gpus, dist)
+        rep = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": rep["value"], "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": rep["workload"], "mode": "END-TO-END (not the headline mode)",
+                                         "launches_per_step": rep["launches_per_step"], "h2d_GBps_per_gpu": rep["h2d_GBps_per_gpu"],
+                                         "frames_per_step_per_gpu": rep["frames_per_launch_per_gpu"] * rep["launches_per_step"],
+                                         "kernel": rep["kernel"]}}), flush=True)
+        tm.barrier()
         if dist is not None:
             dist.destroy_process_group()
         return
-    w = build_workload(sv, ctx, wl, args.frames, seed_base=0x5EED0000 + 16 * 2 + rank, alias=args.alias)
 
-    def step():
-        cv.check(lib.chv_batch_run(ctx.handle, w["batch"]))
-        for small, big in w["lanczos"]:
-            sv.scaleLanczos(ctx, small, big)
-
-    def sync():
-        cv.check(lib.chv_device_synchronize(ctx.handle))
-        try:
-            import torch
-            if torch.cuda.is_available() and torch.cuda.is_initialized():
-                torch.cuda.synchronize()
-        except Exception:
-            pass
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    verified = None
-    if not args.no_verify and rank == 0 and w["verify"] is not None:
-        verified = verify_frame(sv, ctx, wl, w, frame=0) and verify_frame(sv, ctx, wl, w, frame=args.frames - 1)
-
-    # per-launch HIP events on the stream the kernels run on
-    evs = []
-    for _ in range(args.steps + 1):
-        e = C.c_void_p()
-        cv.check(lib.chv_event_create(ctx.handle, C.byref(e)))
-        evs.append(e)
-
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    cv.check(lib.chv_event_record(ctx.handle, evs[0]))
-    for k in range(args.steps):
-        step()
-        cv.check(lib.chv_event_record(ctx.handle, evs[k + 1]))
-    sync()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = reduce_max(dist, t1 - t0)
-
-    durs = []
-    for k in range(args.steps):
-        ms = C.c_float()
-        cv.check(lib.chv_event_elapsed_ms(evs[k], evs[k + 1], C.byref(ms)))
-        durs.append(ms.value)
-    launch_ms = float(np.mean(durs))
+    head, cpu = measure(args.workload, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline=True)
+    if args.also is None:
+        others = [n for n in DEFAULT_SET if n != args.workload] if args.workload == HEADLINE else []
+    else:
+        others = [n for n in args.also.split(",") if n and n != "none"]
+    reports = {args.workload: head}
+    for name in others:
+        reports[name], _ = measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline=False)
+    if others and not args.no_upload_leg:
+        reports["cfg2_upload"] = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus)
 
     if rank == 0:
-        px_per_step = args.frames * wl["dw"] * wl["dh"]
-        value = whole_job_gpix(n_gpus, px_per_step, args.steps, elapsed)
-        bytes_per_launch = args.frames * wl["bytes"]
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = ROOT / "profiles" / "pmc_latest.json"
-        if pmc.exists():
+        wl = WORKLOADS[args.workload]
+        roof = dict(head["roofline"])
+        roof.update({"traffic": None, "traffic_source": None, "kernel": head["kernel"], "launch_ms": head["launch_ms"],
+                     "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"]})
+        if args.pmc_json:
             try:
-                j = json.loads(pmc.read_text())
-                if j.get("workload") == args.workload and j.get("frames") == args.frames:
-                    traffic = j.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                j = json.loads(Path(args.pmc_json).read_text())
+                if j.get("workload") == args.workload and j.get("frames") == head["frames_per_launch_per_gpu"]:
+                    roof["traffic"] = j.get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = f"{args.pmc_json}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of a separate run of this command"
+            except Exception as e:    # noqa: BLE001
+                roof["traffic_source"] = f"unreadable {args.pmc_json}: {e}"
         out = {
-            "metric": "Gpix/s + achieved HBM GB/s, 1080p NV12→BGRA+scale+4-layer composite, 1/2/4/8 GPU",
-            "value": value, "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC, "value": head["value"], "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['desc']}", "frames_per_step_per_gpu": args.frames,
-                       "gpix_counts": "target pixels written", "source_mpix_per_step_per_gpu": args.frames * wl["sw"] * wl["sh"] * wl["layers"] / 1e6,
-                       "parallelism": f"{n_gpus} independent per-device picture buses, no collective",
-                       "kernel": w["kernel"], "verified_vs_oracle": verified},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": w["kernel"], "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+            "config": {"workload": head["workload"], "launches_per_step": head["launches_per_step"],
+                       "frames_per_launch_per_gpu": head["frames_per_launch_per_gpu"],
+                       "frames_per_step_per_gpu": head["frames_per_launch_per_gpu"] * head["launches_per_step"],
+                       "timed_seconds": head["timed_seconds"], "gpix_counts": "target pixels written",
+                       "source_mpix_per_launch_per_gpu": head["source_mpix_per_launch_per_gpu"],
+                       "parallelism": f"{n_gpus} process(es), one per GPU; {head['frames_per_launch_per_gpu']} independent picture "
+                                      f"buses per device, bus s -> device s mod {n_gpus}; no collective",
+                       "per_gpu_gpix": head["per_gpu_gpix"], "per_stream_ticks_per_s": head["per_stream_ticks_per_s"],
+                       "kernel": head["kernel"], "verified_vs_oracle": head["verified_vs_oracle"]},
+            "roofline": roof,
+            "workloads": {k: {kk: vv for kk, vv in v.items() if kk not in ("source_mpix_per_launch_per_gpu",)} for k, v in reports.items()},
         }
         if args.alias != "none":
             out["data"] = f"DIAGNOSTIC --alias {args.alias}: ticks share frame 0's buffers, cache-resident traffic; not a benchmark result"
             out["roofline"]["frac"] = None
-        if n_gpus == 1 and not args.no_cpu_baseline and w["verify"] is not None:
-            out["cpu_baseline"] = cpu_baseline(wl, w, args.cpu_seconds)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    barrier()
+    tm.barrier()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -132,11 +132,13 @@ def load():
     """Load libchipvideo.so (built in-tree by swiftvideo_amd/build.py). Raises if absent."""
     global _lib
     if _lib is None:
-        if not LIB_PATH.exists():
+        # CHV_LIB: another build of the same library (A/B measurements, tools/build_variant.sh)
+        path = Path(os.environ["CHV_LIB"]).resolve() if os.environ.get("CHV_LIB") else LIB_PATH
+        if not path.exists():
             raise ImportError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the picture kernels)")
-        lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+        lib = C.CDLL(str(path), mode=getattr(os, "RTLD_NOW", 2))
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch
             fn.restype = res

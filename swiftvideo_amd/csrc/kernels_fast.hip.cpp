@@ -32,11 +32,15 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_MIX_LAYERS_TILED = 3, FP_COUNT };
 
 // kernels_fast_rgb.hip.cpp
 bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
 hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
+                             int n_ticks, int maxW, int maxH, hipStream_t stream);
+// kernels_fast_mix.hip.cpp
+bool mix_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
+hipError_t launch_mix_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                              int n_ticks, int maxW, int maxH, hipStream_t stream);
 
 #ifndef CHV_TW
@@ -78,108 +82,8 @@ struct TileTablesT {
     int rsum[KT][8];               // per tile of the strip
 };
 
-// x-dependent half of `geometry` + the sampler's x axis, evaluated at row 0 (under axis
-// alignment the x components do not depend on y; signs of zero apart, which no later
-// operation observes)
-CHV_DEV void axis_entry_x(const float *__restrict__ U, int x, float sx, float sy, int wy, int wc,
-                          int &iy, float &ay, int &ic, float &ac, int &flags) {
-    float ou = (float)x / sx, ov = 0.0f / sy;
-    float nx = ou * 2.f - 1.f, ny = ov * 2.f - 1.f;
-    float t0 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 0);
-    float t1 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 4);
-    float t2 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 8);
-    float t3 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 12);
-    float b0 = dot4(nx, ny, 0.f, 1.f, U + U_BORDER + 0);
-    float u = dot4(t0, t1, t2, t3, U + U_TEXTURE + 0);
-    flags = ((b0 >= 0.f && b0 <= 1.f) ? AX_BORDER : 0) | ((t0 >= 0.f && t0 <= 1.f) ? AX_TX : 0) |
-            ((u >= 0.f && u <= 1.f) ? AX_UV : 0);
-    lin_axis_raw(u, wy, iy, ay);
-    lin_axis_raw(u, wc, ic, ac);
-}
-CHV_DEV void axis_entry_y(const float *__restrict__ U, int y, float sx, float sy, int hy, int hc,
-                          int &iy, float &ay, int &ic, float &ac, int &flags) {
-    float ou = 0.0f / sx, ov = (float)y / sy;
-    float nx = ou * 2.f - 1.f, ny = ov * 2.f - 1.f;
-    float t0 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 0);
-    float t1 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 4);
-    float t2 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 8);
-    float t3 = dot4(nx, ny, 0.f, 1.f, U + U_TRANSFORM + 12);
-    float b1 = dot4(nx, ny, 0.f, 1.f, U + U_BORDER + 4);
-    float v = dot4(t0, t1, t2, t3, U + U_TEXTURE + 4);
-    flags = ((b1 >= 0.f && b1 <= 1.f) ? AX_BORDER : 0) | ((t1 >= 0.f && t1 <= 1.f) ? AX_TX : 0) |
-            ((v >= 0.f && v <= 1.f) ? AX_UV : 0);
-    lin_axis_raw(v, hy, iy, ay);
-    lin_axis_raw(v, hc, ic, ac);
-}
-
-// One pixel of the BGRA-target family from already-sampled, quantised YUV (code-scale
-// arithmetic, pixel_math.hip.h): fill under the picture, then the picture itself.
-CHV_DEV uint32_t blend_bgra_general(uint32_t c, const float *__restrict__ U, bool in_pic, uint32_t w) {
-    const float opacity = U[U_OPACITY];
-    const float af = opacity * U[U_FILL + 3];
-    const float iaf = 1.f - af;
-    float r0 = clampf(__builtin_fmaf(U[U_FILL + 2] * 255.0f, af, (float)(c & 255) * iaf), 0.f, 255.f);
-    float r1 = clampf(__builtin_fmaf(U[U_FILL + 1] * 255.0f, af, (float)((c >> 8) & 255) * iaf), 0.f, 255.f);
-    float r2 = clampf(__builtin_fmaf(U[U_FILL + 0] * 255.0f, af, (float)((c >> 16) & 255) * iaf), 0.f, 255.f);
-    if (in_pic) {
-        const float a = 1.0f * opacity, ia = 1.f - a;
-        r0 = __builtin_fmaf((float)(w & 255), a, r0 * ia);
-        r1 = __builtin_fmaf((float)((w >> 8) & 255), a, r1 * ia);
-        r2 = __builtin_fmaf((float)((w >> 16) & 255), a, r2 * ia);
-    }
-    return pack_codes(r0, r1, r2, 0xFF000000u);
-}
-
-// NV12 sample at one pixel from the staged byte tiles, on the code scale: luma bytes, interleaved chroma (u | v << 8
-// per texel); tap 1 is the next texel, the next row is one LDS pitch further.
-CHV_DEV void sample_nv12_lds_bytes(const uint8_t *smem, int ya, int ypitch, int ca, int cpitch,
-                                   float w00, float w10, float w01, float w11,
-                                   float c00, float c10, float c01, float c11,
-                                   float &fy, float &fu, float &fv) {
-    const uint8_t *py = smem + ya;
-    fy = cs_mix(w00, w10, w01, w11, (float)py[0], (float)py[1], (float)py[ypitch], (float)py[ypitch + 1]);
-    const uint32_t q00 = *(const uint16_t *)(smem + ca), q10 = *(const uint16_t *)(smem + ca + 2);
-    const uint32_t q01 = *(const uint16_t *)(smem + ca + cpitch), q11 = *(const uint16_t *)(smem + ca + cpitch + 2);
-    fu = cs_mix(c00, c10, c01, c11, (float)(q00 & 255), (float)(q10 & 255), (float)(q01 & 255), (float)(q11 & 255));
-    fv = cs_mix(c00, c10, c01, c11, (float)(q00 >> 8), (float)(q10 >> 8), (float)(q01 >> 8), (float)(q11 >> 8));
-}
-
-// the same sample straight from the source planes (tile did not fit the LDS budget);
-// SV != nullptr: planar chroma (y420p: U from SC, V from SV), else interleaved (NV12)
-CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, const DPlane *SV, int ix, int iy, int cx, int cy,
-                                float w00, float w10, float w01, float w11,
-                                float c00, float c10, float c01, float c11,
-                                float &fy, float &fu, float &fv) {
-    int x0 = min(max(ix, 0), SY.w - 1), x1 = min(max(ix + 1, 0), SY.w - 1);
-    int y0 = min(max(iy, 0), SY.h - 1), y1 = min(max(iy + 1, 0), SY.h - 1);
-    const uint8_t *p0 = SY.ptr + (size_t)y0 * SY.pitch, *p1 = SY.ptr + (size_t)y1 * SY.pitch;
-    fy = cs_mix(w00, w10, w01, w11, (float)gld<uint8_t>(p0 + x0), (float)gld<uint8_t>(p0 + x1), (float)gld<uint8_t>(p1 + x0), (float)gld<uint8_t>(p1 + x1));
-    int u0 = min(max(cx, 0), SC.w - 1), u1 = min(max(cx + 1, 0), SC.w - 1);
-    int v0 = min(max(cy, 0), SC.h - 1), v1 = min(max(cy + 1, 0), SC.h - 1);
-    const uint8_t *q0 = SC.ptr + (size_t)v0 * SC.pitch, *q1 = SC.ptr + (size_t)v1 * SC.pitch;
-    uint32_t a00, a10, a01, a11;
-    if (SV) {
-        const uint8_t *z0 = SV->ptr + (size_t)v0 * SV->pitch, *z1 = SV->ptr + (size_t)v1 * SV->pitch;
-        a00 = gld<uint8_t>(q0 + u0) | (gld<uint8_t>(z0 + u0) << 8); a10 = gld<uint8_t>(q0 + u1) | (gld<uint8_t>(z0 + u1) << 8);
-        a01 = gld<uint8_t>(q1 + u0) | (gld<uint8_t>(z1 + u0) << 8); a11 = gld<uint8_t>(q1 + u1) | (gld<uint8_t>(z1 + u1) << 8);
-    } else {
-        a00 = gld<uint16_t>(q0 + u0 * 2); a10 = gld<uint16_t>(q0 + u1 * 2);
-        a01 = gld<uint16_t>(q1 + u0 * 2); a11 = gld<uint16_t>(q1 + u1 * 2);
-    }
-    fu = cs_mix(c00, c10, c01, c11, (float)(a00 & 255), (float)(a10 & 255), (float)(a01 & 255), (float)(a11 & 255));
-    fv = cs_mix(c00, c10, c01, c11, (float)(a00 >> 8), (float)(a10 >> 8), (float)(a01 >> 8), (float)(a11 >> 8));
-}
-
-// the same for planar chroma (y420p): U tile at `ca`, V tile `voff` bytes further, one byte per texel
-CHV_DEV void sample_y420p_lds_bytes(const uint8_t *smem, int ya, int ypitch, int ca, int voff, int cpitch,
-                                    float w00, float w10, float w01, float w11,
-                                    float c00, float c10, float c01, float c11,
-                                    float &fy, float &fu, float &fv) {
-    const uint8_t *py = smem + ya, *pu = smem + ca, *pv = smem + ca + voff;
-    fy = cs_mix(w00, w10, w01, w11, (float)py[0], (float)py[1], (float)py[ypitch], (float)py[ypitch + 1]);
-    fu = cs_mix(c00, c10, c01, c11, (float)pu[0], (float)pu[1], (float)pu[cpitch], (float)pu[cpitch + 1]);
-    fv = cs_mix(c00, c10, c01, c11, (float)pv[0], (float)pv[1], (float)pv[cpitch], (float)pv[cpitch + 1]);
-}
+// axis_entry_x / axis_entry_y, blend_bgra_general and the LDS / global YUV samplers live in tile_common.hip.h
+// (shared with kernels_fast_mix.hip.cpp)
 
 // ---------------------------------------------------------------------------
 // FP_NV12_BGRA_TILED / FP_Y420P_BGRA_TILED: one LK_BGRA_FROM_{NV12,Y420P} layer per tick, axis aligned.
@@ -485,18 +389,13 @@ const char *fast_path_name(int path) {
     case FP_NV12_BGRA_TILED: return "tick_nv12_bgra_tiled";
     case FP_RGB_LAYERS_TILED: return "tick_rgb_layers_tiled";
     case FP_Y420P_BGRA_TILED: return "tick_y420p_bgra_tiled";
+    case FP_MIX_LAYERS_TILED: return "tick_mix_layers_tiled";
     default: return "none";
     }
 }
 
-int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
-    if (n_ticks <= 0) return FP_NONE;
-    // A/B switch for measurements: CHV_FORCE_GENERAL=1 routes everything through the general kernels
-    static const bool force_general = [] { const char *e = getenv("CHV_FORCE_GENERAL"); return e && e[0] == '1'; }();
-    if (force_general) return FP_NONE;
-    // 4:2:0 canvases: the general quad kernel with per-layer bounding-box skipping measured faster than an
-    // LDS-tiled variant (profiles/r01_notes.md), so there is no tiled path for them yet
-    if (target_format != TF_BGRA) return FP_NONE;
+// the single-purpose kernels: exactly one YUV layer per tick (cfg2 / cfg4), or RGB layers only (cfg3 / cfg5)
+static int select_single_purpose(const DTick *ticks, const DLayer *layers, int n_ticks) {
     if (ticks[0].n_layers >= 1 && layers[ticks[0].first_layer].kind == LK_BGRA_FROM_RGB)
         return rgb_layers_eligible(ticks, layers, n_ticks) ? FP_RGB_LAYERS_TILED : FP_NONE;
     for (int i = 0; i < n_ticks; i++) {
@@ -513,10 +412,27 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     return layers[ticks[0].first_layer].kind == LK_BGRA_FROM_Y420P ? FP_Y420P_BGRA_TILED : FP_NV12_BGRA_TILED;
 }
 
+int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
+    if (n_ticks <= 0) return FP_NONE;
+    // A/B switches for measurements and tests: CHV_FORCE_GENERAL=1 routes everything through the general kernels,
+    // CHV_FORCE_MIXED=1 every eligible BGRA-canvas batch through the mixed-layer kernel (read per call: tests flip them)
+    const char *fg = getenv("CHV_FORCE_GENERAL"), *fm = getenv("CHV_FORCE_MIXED");
+    if (fg && fg[0] == '1') return FP_NONE;
+    // 4:2:0 canvases: kernels_fast_yuv.hip.cpp decides
+    if (target_format != TF_BGRA) return FP_NONE;
+    if (!(fm && fm[0] == '1')) {
+        int p = select_single_purpose(ticks, layers, n_ticks);
+        if (p != FP_NONE) return p;
+    }
+    // any mix of NV12 / y420p / BGRA / RGBA layers, 1..8 per tick
+    return mix_layers_eligible(ticks, layers, n_ticks) ? FP_MIX_LAYERS_TILED : FP_NONE;
+}
+
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
     if (path == FP_RGB_LAYERS_TILED) return launch_rgb_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
+    if (path == FP_MIX_LAYERS_TILED) return launch_mix_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path != FP_NV12_BGRA_TILED && path != FP_Y420P_BGRA_TILED) return hipErrorNotSupported;
     const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;
     const int tiles_x = (maxW + TW - 1) / TW;

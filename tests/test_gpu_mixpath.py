@@ -1,0 +1,191 @@
+"""tick_mix_layers_tiled — N layers of ANY mix of NV12 / y420p / BGRA / RGBA onto a BGRA canvas in one LDS-tiled launch
+(the literal "NV12 -> BGRA + scale + 4-layer composite" tick of VideoMixer.mix, mix.video.swift:114-124) — gives exactly
+the bytes of the oracle's clear + per-layer kernel calls: tile edges, scale factors, partial cover, borders, fill,
+opacity, flips, odd sizes, covered-tile culling, un-cleared canvases, the staging tail and the unstaged fallback."""
+import numpy as np
+import pytest
+
+import gpuutil as G
+import util
+from oracle import oracle as O
+from swiftvideo_amd import compute as sv
+from test_gpu_fastpath import NV12_BGRA_CASES, RGB_CASES
+
+pytestmark = pytest.mark.gpu
+
+MIX = "tick_mix_layers_tiled"
+
+
+def run_tick_case(ctx, cw, ch, clear, specs, seed=61, expect=MIX, csc=0):
+    """specs: [(kernel name, src w, h, make_uniforms kwargs)] -> asserts HIP == oracle, returns the dispatched kernel name"""
+    canvas0 = util.alloc_image("bgra", cw, ch, seed=seed)
+    exp = util.copy_image(canvas0)
+    if clear:
+        assert O.run_kernel("img_clear_bgra", exp) == 0
+    layers = []
+    for i, (k, sw, sh, kw) in enumerate(specs):
+        u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+        s = k.split("_")[1]
+        src = util.alloc_image(s, sw, sh, seed=seed + 9 + i)
+        assert O.run_kernel(k, exp, src, u, csc=csc, threads=4) == 0
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, csc))
+    gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+    h, name, keep = G.make_batch(ctx, [(gd, clear, layers)])
+    if expect is not None:
+        assert name == expect, f"dispatched to {name}"
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"via {name}")
+    return name
+
+
+MIXED_CASES = {
+    # name: (canvas w, h, clear_first, [(kernel, src w, h, make_uniforms kwargs)])
+    "pipeline_small": (320, 180, True, [("img_nv12_bgra", 480, 270, dict(opacity=o)) for o in (1.0, 0.75, 0.5, 0.25)]),
+    "pipeline_y420p": (320, 180, True, [("img_y420p_bgra", 480, 270, dict(opacity=o)) for o in (1.0, 0.75, 0.5, 0.25)]),
+    "video_overlays": (320, 180, True, [("img_nv12_bgra", 480, 270, dict()),
+                                         ("img_bgra_bgra_tx", 96, 54, dict(rect=(12, 10, 96, 54), opacity=0.8)),
+                                         ("img_rgba_bgra_tx", 64, 36, dict(rect=(200, 100, 100, 60), opacity=0.6, border=(3, 3, 3, 3), fill=(0.1, 0.9, 0.2, 0.7)))]),
+    "all_four_kinds": (260, 70, True, [("img_y420p_bgra", 96, 54, dict(rect=(0, 0, 130, 70))),
+                                        ("img_nv12_bgra", 96, 54, dict(rect=(130, 0, 130, 70), opacity=0.9)),
+                                        ("img_rgba_bgra_tx", 50, 40, dict(rect=(-20, -10, 120, 60), fill=(0.1, 0.5, 0.9, 1.0), opacity=0.35)),
+                                        ("img_bgra_bgra_tx", 33, 17, dict(rect=(150, 5, 90, 60), tex=(0.25, 0.0, 0.5, 1.0), fill=(1, 1, 0, 1)))]),
+    "grid_2x2":       (256, 128, True, [("img_nv12_bgra", 192, 108, dict(rect=(0, 0, 128, 64))), ("img_y420p_bgra", 192, 108, dict(rect=(128, 0, 128, 64))),
+                                         ("img_nv12_bgra", 96, 54, dict(rect=(0, 64, 128, 64))), ("img_bgra_bgra_tx", 192, 108, dict(rect=(128, 64, 128, 64)))]),
+    "covered_top":    (200, 70, True, [("img_bgra_bgra_tx", 200, 70, dict(opacity=0.7)), ("img_nv12_bgra", 64, 36, dict(rect=(5, 5, 60, 30), opacity=0.5)),
+                                        ("img_y420p_bgra", 300, 106, dict())]),     # opaque full-canvas picture on top: everything beneath is culled
+    "covered_noclear": (200, 70, False, [("img_rgba_bgra_tx", 200, 70, dict(opacity=0.7)), ("img_nv12_bgra", 300, 106, dict()),
+                                          ("img_bgra_bgra_tx", 40, 20, dict(rect=(150, 40, 40, 20), opacity=0.5))]),
+    "covered_partial": (200, 70, False, [("img_rgba_bgra_tx", 200, 70, dict(opacity=0.7)),
+                                          ("img_nv12_bgra", 96, 54, dict(rect=(30, 0, 140, 70)))]),    # covers the middle tiles only
+    "covered_fill":   (200, 70, False, [("img_nv12_bgra", 96, 54, dict(opacity=0.4)), ("img_nv12_bgra", 300, 106, dict(fill=(0.3, 0.2, 0.9, 1.0)))]),
+    "noclear_blend":  (260, 70, False, [("img_nv12_bgra", 96, 54, dict(rect=(-20, -10, 200, 100), opacity=0.35, fill=(0.1, 0.5, 0.9, 1.0), border=(40, 40, 40, 40))),
+                                         ("img_y420p_bgra", 64, 64, dict(rect=(150, 5, 90, 60), opacity=0.8))]),
+    "flips":          (192, 40, True, [("img_nv12_bgra", 96, 54, dict(tex=(1.0, 0.0, -1.0, 1.0))), ("img_y420p_bgra", 96, 54, dict(tex=(0.2, 1.0, 0.5, -0.7), opacity=0.5))]),
+    "eight_layers":   (128, 48, True, [(("img_nv12_bgra", "img_rgba_bgra_tx", "img_y420p_bgra", "img_bgra_bgra_tx")[i % 4], 128, 48, dict(opacity=1.0 - 0.1 * i)) for i in range(8)]),
+    "opacity_gt_1":   (100, 30, True, [("img_nv12_bgra", 100, 30, dict(opacity=1.7)), ("img_y420p_bgra", 100, 30, dict(opacity=-0.3))]),
+    "upscale_3x":     (300, 90, True, [("img_nv12_bgra", 100, 30, dict(opacity=0.5)), ("img_y420p_bgra", 100, 30, dict(opacity=0.5))]),
+    "odd_width":      (131, 19, True, [("img_nv12_bgra", 98, 42, dict()), ("img_bgra_bgra_tx", 97, 41, dict(opacity=0.5))]),
+    "down_2x_tail":   (160, 64, True, [("img_nv12_bgra", 320, 128, dict()), ("img_y420p_bgra", 352, 140, dict(opacity=0.5))]),   # luma rectangles > 512 slots: staging tail
+    "down_4x":        (96, 40, True, [("img_nv12_bgra", 384, 160, dict(opacity=0.6)), ("img_bgra_bgra_tx", 384, 160, dict(opacity=0.5))]),
+}
+
+
+@pytest.mark.parametrize("case", list(MIXED_CASES))
+@pytest.mark.parametrize("csc", [0, 1])
+def test_mixed_layers_match_oracle(ctx, case, csc):
+    cw, ch, clear, specs = MIXED_CASES[case]
+    # down_4x: the rectangles of a 64x32 tile exceed the LDS budget -> general kernel
+    run_tick_case(ctx, cw, ch, clear, specs, csc=csc, expect=None if case == "down_4x" else MIX)
+
+
+@pytest.mark.parametrize("case", [c for c in NV12_BGRA_CASES if c not in ("huge_downscale", "tiny")])
+@pytest.mark.parametrize("fmt", ["nv12", "y420p"])
+def test_single_yuv_layer_through_the_mixed_kernel(ctx, monkeypatch, case, fmt):
+    """the cases of the single-purpose NV12 -> BGRA kernel, routed through the mixed kernel (CHV_FORCE_MIXED)"""
+    monkeypatch.setenv("CHV_FORCE_MIXED", "1")
+    cw, ch, sw, sh, kw, clear = NV12_BGRA_CASES[case]
+    run_tick_case(ctx, cw, ch, clear, [(f"img_{fmt}_bgra", sw, sh, kw)], seed=21, csc=3)
+
+
+@pytest.mark.parametrize("case", [c for c in RGB_CASES if c != "odd_tiny"])
+def test_rgb_cases_through_the_mixed_kernel(ctx, monkeypatch, case):
+    monkeypatch.setenv("CHV_FORCE_MIXED", "1")
+    cw, ch, clear, specs = RGB_CASES[case]
+    run_tick_case(ctx, cw, ch, clear, specs)
+
+
+def test_mixed_fallbacks(ctx):
+    """nine layers, a rotated layer, or a Metal-semantics img_bgra_bgra layer in the tick -> general kernel, same bytes"""
+    nine = [("img_nv12_bgra" if i % 2 else "img_bgra_bgra_tx", 48, 28, dict(opacity=0.9)) for i in range(9)]
+    assert run_tick_case(ctx, 96, 54, True, nine, expect=None) == "tick_general_bgra"
+    rot = [("img_nv12_bgra", 48, 28, dict()), ("img_bgra_bgra_tx", 48, 28, dict(rect=(10, 5, 40, 20), rotation=0.3))]
+    assert run_tick_case(ctx, 96, 54, True, rot, expect=None) == "tick_general_bgra"
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_mixed_ticks(ctx, seed):
+    """Seeded random ticks: 1..8 layers of random kinds with random axis-aligned geometry (placement, crop, flips, borders,
+    fill, opacity, up- and downscales), three ticks of different sizes per launch."""
+    rng = np.random.default_rng(9000 + seed)
+    clear = bool(rng.integers(0, 2))
+    kinds = ["img_nv12_bgra", "img_y420p_bgra", "img_bgra_bgra_tx", "img_rgba_bgra_tx"]
+    ticks, exps, gds = [], [], []
+    for t in range(3):
+        cw, ch = int(rng.integers(8, 330)), int(rng.integers(4, 140))
+        canvas0 = util.alloc_image("bgra", cw, ch, seed=int(rng.integers(1, 1 << 20)))
+        exp = util.copy_image(canvas0)
+        if clear:
+            assert O.run_kernel("img_clear_bgra", exp) == 0
+        layers = []
+        for l in range(int(rng.integers(1, 9))):
+            k = kinds[int(rng.integers(0, 4))]
+            s = k.split("_")[1]
+            sw, sh = int(rng.integers(8, 200)) * 2, int(rng.integers(2, 90)) * 2      # rows of >= 16 bytes in every plane
+            kw = {}
+            if rng.random() < 0.7:
+                kw["rect"] = (float(rng.uniform(-0.3, 0.6) * cw), float(rng.uniform(-0.3, 0.6) * ch),
+                              float(rng.uniform(0.2, 1.5) * cw), float(rng.uniform(0.2, 1.5) * ch))
+            if rng.random() < 0.3:
+                kw["border"] = tuple(float(v) for v in rng.uniform(0, 10, 4))
+            if rng.random() < 0.3:
+                kw["fill"] = tuple(float(v) for v in rng.uniform(0, 1, 4))
+            if rng.random() < 0.4:
+                kw["tex"] = (float(rng.uniform(0.0, 0.4)), float(rng.uniform(0.0, 0.4)),
+                             float(rng.uniform(0.3, 1.0)) * (1 if rng.random() < 0.8 else -1), float(rng.uniform(0.3, 1.0)))
+            kw["opacity"] = float(rng.choice([1.0, 1.0, rng.uniform(0, 1)]))
+            u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+            src = util.alloc_image(s, sw, sh, seed=int(rng.integers(1, 1 << 20)))
+            csc = int(rng.integers(0, 4))
+            assert O.run_kernel(k, exp, src, u, csc=csc, threads=4) == 0
+            layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, csc))
+        gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+        ticks.append((gd, clear, layers))
+        exps.append(exp)
+        gds.append((gd, cw, ch))
+    h, name, keep = G.make_batch(ctx, ticks)
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    for i, ((gd, cw, ch), exp) in enumerate(zip(gds, exps)):
+        G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed} tick {i} ({len(ticks[i][2])} layers) via {name}")
+
+
+def test_pipeline_full_size(ctx):
+    """The headline tick at full size: 4 x 1080p NV12 -> 720p BGRA canvas, opacities 1/.75/.5/.25 == oracle's clear + 4 kernel calls;
+    fused == the sequence of chv_run_kernel launches the reference would issue; replay is idempotent."""
+    sw, sh, dw, dh = 1920, 1080, 1280, 720
+    srcs = [util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 48 + i) for i in range(4)]
+    us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in (1.0, 0.75, 0.5, 0.25)]
+    exp = util.alloc_image("bgra", dw, dh)
+    assert O.run_kernel("img_clear_bgra", exp, threads=16) == 0
+    for s, u in zip(srcs, us):
+        assert O.run_kernel("img_nv12_bgra", exp, s, u, threads=16) == 0
+    gs = [G.to_gpu(ctx, "nv12", sw, sh, s) for s in srcs]
+    gd = G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=5))
+    layers = [(sv.ComputeKernel.img_nv12_bgra, g, u, 0) for g, u in zip(gs, us)]
+    h, name, keep = G.make_batch(ctx, [(gd, True, layers)])
+    assert name == MIX
+    G.run_batch(ctx, h)
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", dw, dh), exp, "pipeline, fused")
+    # the reference's own launch sequence: clear, then one runComputeKernel(blends: true) per layer
+    gd2 = G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=6))
+
+    def seq(c):
+        sv.runComputeKernel(c, images=[], target=gd2, kernel=sv.ComputeKernel.img_clear_bgra)
+        for g, u in zip(gs, us):
+            sv.runComputeKernel(c, images=[g], target=gd2, kernel=sv.ComputeKernel.img_nv12_bgra, uniforms=u, blends=True)
+        return c
+    sv.usingContext(ctx, seq)
+    G.assert_same(G.from_gpu(ctx, gd2, "bgra", dw, dh), exp, "pipeline, sequential")
+
+
+def test_mixed_full_size_1080p_canvas(ctx):
+    """1080p canvas, four kinds of sources at different scales, in one tick"""
+    cw, ch = 1920, 1080
+    specs = [("img_nv12_bgra", 1280, 720, dict()),
+             ("img_y420p_bgra", 1920, 1080, dict(rect=(960, 0, 960, 540), opacity=0.9)),
+             ("img_bgra_bgra_tx", 640, 360, dict(rect=(64, 64, 640, 360), opacity=0.8)),
+             ("img_rgba_bgra_tx", 640, 360, dict(rect=(1200, 640, 640, 360), opacity=0.6, border=(8, 8, 8, 8), fill=(0.9, 0.9, 0.9, 0.5)))]
+    run_tick_case(ctx, cw, ch, True, specs, seed=77)

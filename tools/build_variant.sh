@@ -1,14 +1,17 @@
 #!/bin/bash
-# tools/build_variant.sh <name> [-DFLAG ...] — build libchipvideo with extra defines into variants/<name>.so
-# (A/B experiments on the GPU box: cp variants/<name>.so swiftvideo_amd/libchipvideo.so; variants/ is git-ignored)
+# tools/build_variant.sh <name> <file.hip.cpp|all> [-DFLAG ...] — build a libchipvideo variant into variants/<name>.so:
+# <file> (or every source with `all`) is recompiled with the extra defines, the rest is taken from the in-tree objects
+# (make -C swiftvideo_amd/csrc first).  A/B on the GPU box: CHV_LIB=variants/<name>.so python bench.py ...  (variants/ is git-ignored)
 set -e
-NAME=$1; shift
+NAME=$1; FILE=$2; shift 2
 cd "$(dirname "$0")/../swiftvideo_amd/csrc"
-mkdir -p ../../variants/obj_$NAME
+OBJ=../../variants/obj_$NAME
+mkdir -p $OBJ
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -w"
-for f in chipvideo.cpp kernels_general.hip.cpp kernels_fast.hip.cpp kernels_fast_rgb.hip.cpp kernels_lanczos.hip.cpp; do
-  /opt/rocm/bin/hipcc $FLAGS "$@" -x hip -c $f -o ../../variants/obj_$NAME/${f%.cpp}.o &
+for f in chipvideo.cpp kernels_*.hip.cpp; do
+  if [ "$FILE" = all ] || [ "$FILE" = "$f" ]; then /opt/rocm/bin/hipcc $FLAGS "$@" -x hip -c $f -o $OBJ/${f%.cpp}.o &
+  else cp ${f%.cpp}.o $OBJ/; fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/$NAME.so ../../variants/obj_$NAME/*.o -lhiprtc
-rm -rf ../../variants/obj_$NAME
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/$NAME.so $OBJ/*.o -lhiprtc
+rm -rf $OBJ
