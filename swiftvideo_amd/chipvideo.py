@@ -133,7 +133,10 @@ def load():
     global _lib
     if _lib is None:
         # CHV_LIB: another build of the same library (A/B measurements, tools/build_variant.sh)
-        path = Path(os.environ["CHV_LIB"]).resolve() if os.environ.get("CHV_LIB") else LIB_PATH
+        path = LIB_PATH
+        if os.environ.get("CHV_LIB"):
+            path = Path(os.environ["CHV_LIB"])
+            path = path if path.is_absolute() else _HERE.parent / path      # relative to the repository root
         if not path.exists():
             raise ImportError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cmath>
@@ -155,7 +156,9 @@ struct LanczosTable {
     int taps = 0;
     int32_t *first = nullptr;  // device
     float *weights = nullptr;  // device
+    uint64_t last_use = 0;     // LRU stamp
 };
+static constexpr size_t kLanczosCacheEntries = 64;   // (in, out) size pairs kept per device; least recently used goes first
 
 // State shared by a context and everything created with chv_context_share
 // (the role of InternalContext, compute.cl.swift:60-74).
@@ -163,6 +166,7 @@ struct DeviceShared {
     int device = 0;
     std::mutex mu;
     std::map<std::pair<int, int>, LanczosTable> lanczos;  // (in, out) -> tables
+    uint64_t lanczos_clock = 0;
     ~DeviceShared() {
         (void)hipSetDevice(device);
         for (auto &kv : lanczos) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.weights); }
@@ -220,14 +224,28 @@ struct chv_buffer {
     // cross-context ordering: an asynchronous upload records `ready` on the uploading
     // context's stream; a kernel launched from another context's stream waits on it first
     // (the reference gets this ordering from blocking copies, compute.cl.swift:440-450)
+    // (guarded by `mu`: the uploading thread and the launching thread are different threads in the reference's
+    // pipeline — a Bus runner and the mixer's queue)
+    std::mutex mu;
     hipEvent_t ready = nullptr;
     hipStream_t ready_stream = nullptr;
     uint64_t ready_seq = 0;
 };
 
+// after an asynchronous copy into `b` was enqueued on `stream`: record the buffer's event
+static int mark_uploaded(chv_buffer *b, hipStream_t stream);
+// before `stream` reads or overwrites `b`: wait (on the stream, not on the host) for a pending upload from another stream
+static int wait_for_buffer(chv_buffer *b, hipStream_t stream);
+
 struct chv_event {
     hipEvent_t ev = nullptr;
     int device = 0;
+};
+
+struct BatchDep {
+    chv_buffer *buf;
+    hipStream_t stream;   // the stream that last waited for this buffer on behalf of the batch
+    uint64_t seq;         // ... and the upload it saw
 };
 
 struct chv_batch {
@@ -238,7 +256,7 @@ struct chv_batch {
     int fast_path = -1;
     DTick *d_ticks = nullptr;
     DLayer *d_layers = nullptr;
-    std::vector<std::pair<chv_buffer *, uint64_t>> deps;   // buffers the descriptors point into + last upload seen
+    std::vector<BatchDep> deps;    // distinct buffers the descriptors point into + the last upload waited for, per stream
     std::vector<DTick> h_ticks;    // host copies: launch geometry of the fast paths
     std::vector<DLayer> h_layers;
     std::string kernel_name;
@@ -415,7 +433,10 @@ static int check_span(const chv_buffer *b, size_t offset, size_t pitch, size_t w
     if (!buf_ok(b)) return fail(CHV_ERR_BAD_INPUT, "%s: bad buffer", what);
     if (rows == 0 || width_bytes == 0) return fail(CHV_ERR_INVALID_VALUE, "%s: empty region", what);
     if (pitch < width_bytes) return fail(CHV_ERR_BAD_INPUT, "%s: pitch %zu < row bytes %zu", what, pitch, width_bytes);
-    size_t end = offset + (rows - 1) * pitch + width_bytes;
+    size_t end = 0, total = 0;
+    if (__builtin_mul_overflow(rows - 1, pitch, &end) || __builtin_add_overflow(end, width_bytes, &end) ||
+        __builtin_add_overflow(end, offset, &end) || __builtin_mul_overflow(rows, width_bytes, &total))
+        return fail(CHV_ERR_BAD_INPUT, "%s: region size overflows", what);
     if (end > b->size) return fail(CHV_ERR_BAD_INPUT, "%s: region ends at %zu, buffer has %zu bytes", what, end, b->size);
     return CHV_OK;
 }
@@ -434,20 +455,21 @@ extern "C" int chv_upload(chv_context *c, chv_buffer *dst, size_t dst_offset, si
         if (dst_pitch == width_bytes && from_pitch == width_bytes) return hipMemcpyAsync(d, from, width_bytes * rows, hipMemcpyHostToDevice, c->stream);
         return hipMemcpy2DAsync(d, dst_pitch, from, from_pitch, width_bytes, rows, hipMemcpyHostToDevice, c->stream);
     };
+    // an earlier asynchronous upload into the same buffer from another context must land first (stream order
+    // only covers this context's own copies)
+    rc = wait_for_buffer(dst, c->stream);
+    if (rc) return rc;
     if (!async) {
         HIP_TRY(copy_h2d(src, src_pitch));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        std::lock_guard<std::mutex> lock(dst->mu);
         dst->ready_stream = nullptr;   // complete: nobody has to wait
         return CHV_OK;
     }
     if (async == 2) {
         // caller-owned pinned memory (chv_host_alloc): no staging copy
         HIP_TRY(copy_h2d(src, src_pitch));
-        if (!dst->ready) HIP_TRY(hipEventCreateWithFlags(&dst->ready, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(dst->ready, c->stream));
-        dst->ready_stream = c->stream;
-        dst->ready_seq++;
-        return CHV_OK;
+        return mark_uploaded(dst, c->stream);
     }
     // stage into pinned memory so the caller's bytes are only borrowed for this call
     StagingSlot &s = c->staging[c->next_staging];
@@ -456,7 +478,7 @@ extern "C" int chv_upload(chv_context *c, chv_buffer *dst, size_t dst_offset, si
     size_t need = width_bytes * rows;
     if (s.cap < need) {
         if (s.host) { HIP_TRY(hipHostFree(s.host)); s.host = nullptr; s.cap = 0; }
-        size_t cap = (need + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+        size_t cap = (need + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);   // need = rows * width_bytes, overflow-checked by check_span
         HIP_TRY(hipHostMalloc(&s.host, cap, hipHostMallocDefault));
         s.cap = cap;
     }
@@ -468,10 +490,24 @@ extern "C" int chv_upload(chv_context *c, chv_buffer *dst, size_t dst_offset, si
     HIP_TRY(copy_h2d(hp, width_bytes));
     HIP_TRY(hipEventRecord(s.done, c->stream));
     s.pending = true;
-    if (!dst->ready) HIP_TRY(hipEventCreateWithFlags(&dst->ready, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(dst->ready, c->stream));
-    dst->ready_stream = c->stream;
-    dst->ready_seq++;
+    return mark_uploaded(dst, c->stream);
+}
+
+static int mark_uploaded(chv_buffer *b, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(b->mu);
+    if (!b->ready) HIP_TRY(hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->ready, stream));
+    b->ready_stream = stream;
+    b->ready_seq++;
+    return CHV_OK;
+}
+
+static int wait_for_buffer(chv_buffer *b, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(b->mu);
+    if (!b->ready_stream) return CHV_OK;
+    if (hipEventQuery(b->ready) == hipSuccess) { b->ready_stream = nullptr; return CHV_OK; }   // landed: nobody has to wait any more
+    (void)hipGetLastError();                                                                    // hipErrorNotReady is not an error here
+    if (b->ready_stream != stream) HIP_TRY(hipStreamWaitEvent(stream, b->ready, 0));
     return CHV_OK;
 }
 
@@ -501,6 +537,10 @@ extern "C" int chv_download(chv_context *c, void *dst, size_t dst_pitch, chv_buf
     if (rc) return rc;
     if (dst_pitch < width_bytes) return fail(CHV_ERR_BAD_INPUT, "destination pitch %zu < row bytes %zu", dst_pitch, width_bytes);
     HIP_TRY(hipSetDevice(c->device));
+    // a picture uploaded asynchronously on another context (GPUBarrierUpload's) and read back through this one
+    // (GPUBarrierDownload's, compute.swift:175-255): order the read behind the upload
+    rc = wait_for_buffer(src, c->stream);
+    if (rc) return rc;
     HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, (const uint8_t *)src->ptr + src_offset, src_pitch, width_bytes, rows,
                              hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -556,20 +596,31 @@ struct DepScope {
     std::vector<chv_buffer *> bufs;
     DepScope() { g_deps = &bufs; }
     ~DepScope() { g_deps = nullptr; }
-    std::vector<std::pair<chv_buffer *, uint64_t>> pairs() const {
-        std::vector<std::pair<chv_buffer *, uint64_t>> out;
-        for (chv_buffer *b : bufs) out.emplace_back(b, (uint64_t)-1);
+    // distinct buffers (a picture's planes usually share one allocation)
+    std::vector<BatchDep> deps() const {
+        std::vector<BatchDep> out;
+        for (chv_buffer *b : bufs) {
+            bool seen = false;
+            for (const BatchDep &d : out) seen = seen || d.buf == b;
+            if (!seen) out.push_back(BatchDep{ b, nullptr, 0 });
+        }
         return out;
     }
 };
 
-static int wait_for_uploads(hipStream_t stream, std::vector<std::pair<chv_buffer *, uint64_t>> &deps) {
-    for (auto &d : deps) {
-        chv_buffer *b = d.first;
-        if (b->ready_stream && b->ready_stream != stream && b->ready_seq != d.second) {
-            HIP_TRY(hipStreamWaitEvent(stream, b->ready, 0));
-            d.second = b->ready_seq;
-        }
+// Make `stream` wait for pending asynchronous uploads into the buffers a launch reads.  A batch remembers, per buffer,
+// the (stream, upload) it last waited for, so replaying it on the same stream with no new upload costs nothing; a
+// different stream, or a newer upload, waits again.
+static int wait_for_uploads(hipStream_t stream, std::vector<BatchDep> &deps) {
+    for (BatchDep &d : deps) {
+        chv_buffer *b = d.buf;
+        std::lock_guard<std::mutex> lock(b->mu);
+        if (!b->ready_stream || b->ready_stream == stream) continue;
+        if (d.stream == stream && d.seq == b->ready_seq) continue;
+        if (hipEventQuery(b->ready) == hipSuccess) { b->ready_stream = nullptr; continue; }
+        (void)hipGetLastError();
+        HIP_TRY(hipStreamWaitEvent(stream, b->ready, 0));
+        d.stream = stream; d.seq = b->ready_seq;
     }
     return CHV_OK;
 }
@@ -579,8 +630,13 @@ static int plane_to_device(const chv_plane &p, int comps, int device, DPlane *ou
     if (p.buffer->device != device) return fail(err, "%s plane %d lives on device %d, context on %d", what, idx, p.buffer->device, device);
     if (p.width <= 0 || p.height <= 0) return fail(err, "%s plane %d: size %dx%d", what, idx, p.width, p.height);
     if (p.components != comps) return fail(err, "%s plane %d: %d components, kernel expects %d", what, idx, p.components, comps);
-    if (p.pitch < p.width * comps) return fail(err, "%s plane %d: pitch %d < %d", what, idx, p.pitch, p.width * comps);
-    size_t end = p.offset + (size_t)(p.height - 1) * p.pitch + (size_t)p.width * comps;
+    const int64_t row_bytes = (int64_t)p.width * comps;
+    if (row_bytes > 0x3fffffff || p.height > 0x3fffffff) return fail(err, "%s plane %d: size %dx%d is out of range", what, idx, p.width, p.height);
+    if ((int64_t)p.pitch < row_bytes) return fail(err, "%s plane %d: pitch %d < %lld", what, idx, p.pitch, (long long)row_bytes);
+    size_t end = 0;
+    if (__builtin_mul_overflow((size_t)(p.height - 1), (size_t)p.pitch, &end) || __builtin_add_overflow(end, (size_t)row_bytes, &end) ||
+        __builtin_add_overflow(end, p.offset, &end))
+        return fail(err, "%s plane %d: extent overflows", what, idx);
     if (end > p.buffer->size) return fail(err, "%s plane %d: extent %zu exceeds buffer size %zu", what, idx, end, p.buffer->size);
     if (comps == 4 && (((uintptr_t)p.buffer->ptr + p.offset) & 3 || (p.pitch & 3)))
         return fail(err, "%s plane %d: 4-component planes must be 4-byte aligned", what, idx);
@@ -682,8 +738,9 @@ static int layer_to_device(const chv_layer &l, int device, int *target_format, D
 
 static int tick_to_device(const chv_tick &t, int device, int forced_target_format, DTick *dt,
                           std::vector<DLayer> *layers, int *target_format_out) {
-    if (t.n_layers < 0 || t.n_layers > CHV_MAX_LAYERS)
-        return fail(CHV_ERR_INVALID_VALUE, "%d layers (max %d)", t.n_layers, CHV_MAX_LAYERS);
+    // (no upper bound here: a batch's descriptors live in device memory; chv_composite splits a tick into launches of
+    // at most CHV_MAX_LAYERS layers, the capacity of a slot of its descriptor ring)
+    if (t.n_layers < 0 || t.n_layers > 4096) return fail(CHV_ERR_INVALID_VALUE, "%d layers", t.n_layers);
     if (t.n_layers > 0 && !t.layers) return fail(CHV_ERR_BAD_INPUT, "null layers");
     int tf = forced_target_format;
     int first = (int)layers->size();
@@ -800,7 +857,7 @@ extern "C" int chv_run_kernel(chv_context *c, int kernel, const chv_image *targe
     DepScope deps;
     rc = tick_to_device(t, c->device, s.is_clear ? s.target_format : -1, &dt, &dl, &tf);
     if (rc) return rc;
-    auto dp = deps.pairs();
+    auto dp = deps.deps();
     rc = wait_for_uploads(c->stream, dp);
     if (rc) return rc;
     return launch_transient(c, dt, dl, tf);
@@ -810,22 +867,37 @@ extern "C" int chv_composite(chv_context *c, const chv_image *target, int clear_
                              const chv_layer *layers, int n_layers) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
     if (!target) return fail(CHV_ERR_BAD_TARGET, "null target");
-    chv_tick t;
-    memset(&t, 0, sizeof t);
-    t.target = *target;
-    t.clear_first = clear_first;
-    t.n_layers = n_layers;
-    t.layers = layers;
-    DTick dt;
-    std::vector<DLayer> dl;
+    if (n_layers < 0) return fail(CHV_ERR_INVALID_VALUE, "%d layers", n_layers);
+    if (n_layers > 0 && !layers) return fail(CHV_ERR_BAD_INPUT, "null layers");
+    // A mixer composes any number of layers (mix.video.swift:116-124).  One launch takes up to CHV_MAX_LAYERS of them;
+    // a deeper tick becomes several launches on the context's stream — the first clears, the others continue on the
+    // canvas.  Byte-identical to one pass: the canvas is re-quantised between layers either way.
+    // All chunks are validated before the first one is launched, so a bad layer leaves the canvas untouched.
+    const int n_chunks = n_layers <= CHV_MAX_LAYERS ? 1 : (n_layers + CHV_MAX_LAYERS - 1) / CHV_MAX_LAYERS;
+    std::vector<DTick> dts((size_t)n_chunks);
+    std::vector<std::vector<DLayer>> dls((size_t)n_chunks);
     int tf = -1;
     DepScope deps;
-    int rc = tick_to_device(t, c->device, -1, &dt, &dl, &tf);
+    for (int k = 0; k < n_chunks; k++) {
+        chv_tick t;
+        memset(&t, 0, sizeof t);
+        t.target = *target;
+        t.clear_first = k == 0 ? clear_first : 0;
+        t.n_layers = std::min(CHV_MAX_LAYERS, n_layers - k * CHV_MAX_LAYERS);
+        t.layers = layers ? layers + (size_t)k * CHV_MAX_LAYERS : nullptr;
+        int tfk = tf;
+        int rc = tick_to_device(t, c->device, tf, &dts[k], &dls[k], &tfk);
+        if (rc) return rc;
+        tf = tfk;
+    }
+    auto dp = deps.deps();
+    int rc = wait_for_uploads(c->stream, dp);
     if (rc) return rc;
-    auto dp = deps.pairs();
-    rc = wait_for_uploads(c->stream, dp);
-    if (rc) return rc;
-    return launch_transient(c, dt, dl, tf);
+    for (int k = 0; k < n_chunks; k++) {
+        rc = launch_transient(c, dts[k], dls[k], tf);
+        if (rc) return rc;
+    }
+    return CHV_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -864,7 +936,7 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
     b->fast_path = select_fast_path(tf0, dts.data(), dls.data(), n_ticks);
     b->h_ticks = dts;
     b->h_layers = dls;
-    b->deps = deps.pairs();
+    b->deps = deps.deps();
     if (b->fast_path >= 0) b->kernel_name = fast_path_name(b->fast_path);
     else b->kernel_name = tf0 == TF_BGRA ? "tick_general_bgra" : (tf0 == TF_NV12 ? "tick_general_yuv<nv12>" : "tick_general_yuv<y420p>");
     *out = b.release();
@@ -1055,7 +1127,7 @@ extern "C" int chv_run_custom(chv_context *c, const char *name, const chv_image 
     a.n_inputs = n_inputs;
     a.uniforms_size = (int32_t)uniforms_size;
     if (uniforms_size) memcpy(a.uniforms, uniforms, uniforms_size);
-    auto dp = deps.pairs();
+    auto dp = deps.deps();
     rc = wait_for_uploads(c->stream, dp);
     if (rc) return rc;
     size_t size = sizeof a;
@@ -1099,10 +1171,14 @@ static int lanczos_host_table(int in_size, int out_size, int *taps_out, std::vec
 }
 
 static int lanczos_table(chv_context *c, int in_size, int out_size, LanczosTable *out) {
-    std::lock_guard<std::mutex> lock(c->shared->mu);
+    DeviceShared &sh = *c->shared;
     auto key = std::make_pair(in_size, out_size);
-    auto it = c->shared->lanczos.find(key);
-    if (it != c->shared->lanczos.end()) { *out = it->second; return CHV_OK; }
+    {
+        std::lock_guard<std::mutex> lock(sh.mu);
+        auto it = sh.lanczos.find(key);
+        if (it != sh.lanczos.end()) { it->second.last_use = ++sh.lanczos_clock; *out = it->second; return CHV_OK; }
+    }
+    // build and upload outside the lock: other contexts of the device keep running meanwhile
     std::vector<int32_t> first;
     std::vector<float> weights;
     LanczosTable t;
@@ -1120,8 +1196,29 @@ static int lanczos_table(chv_context *c, int in_size, int out_size, LanczosTable
         if (t.weights) (void)hipFree(t.weights);
         return hip_fail(e, "lanczos table upload");
     }
-    c->shared->lanczos[key] = t;
-    *out = t;
+    LanczosTable evicted, duplicate;
+    {
+        std::lock_guard<std::mutex> lock(sh.mu);
+        auto it = sh.lanczos.find(key);
+        if (it != sh.lanczos.end()) {                       // another context built the same table meanwhile: keep theirs
+            duplicate = t;
+            it->second.last_use = ++sh.lanczos_clock;
+            *out = it->second;
+        } else {
+            if (sh.lanczos.size() >= kLanczosCacheEntries) {
+                auto lru = sh.lanczos.begin();
+                for (auto jt = sh.lanczos.begin(); jt != sh.lanczos.end(); ++jt) if (jt->second.last_use < lru->second.last_use) lru = jt;
+                evicted = lru->second;
+                sh.lanczos.erase(lru);
+            }
+            t.last_use = ++sh.lanczos_clock;
+            sh.lanczos[key] = t;
+            *out = t;
+        }
+    }
+    // hipFree waits for in-flight work that may still read an evicted table
+    if (evicted.first) { (void)hipFree(evicted.first); (void)hipFree(evicted.weights); }
+    if (duplicate.first) { (void)hipFree(duplicate.first); (void)hipFree(duplicate.weights); }
     return CHV_OK;
 }
 
@@ -1136,7 +1233,7 @@ extern "C" int chv_scale_lanczos(chv_context *c, const chv_image *dst, const chv
     rc = plane_to_device(src->planes[0], 4, c->device, &s, CHV_ERR_BAD_INPUT, "input", 0);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    auto dp = deps.pairs();
+    auto dp = deps.deps();
     rc = wait_for_uploads(c->stream, dp);
     if (rc) return rc;
     LanczosTable tx, ty;

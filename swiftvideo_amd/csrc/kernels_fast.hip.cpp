@@ -32,7 +32,7 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_MIX_LAYERS_TILED = 3, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_MIX_LAYERS_TILED = 3, FP_WAVE_LAYERS = 4, FP_COUNT };
 
 // kernels_fast_rgb.hip.cpp
 bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
@@ -42,6 +42,10 @@ hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host,
 bool mix_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
 hipError_t launch_mix_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                              int n_ticks, int maxW, int maxH, hipStream_t stream);
+// kernels_wave.hip.cpp
+bool wave_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
+hipError_t launch_wave_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
+                              int n_ticks, int maxW, int maxH, hipStream_t stream);
 
 #ifndef CHV_TW
 #define CHV_TW 128
@@ -390,6 +394,7 @@ const char *fast_path_name(int path) {
     case FP_RGB_LAYERS_TILED: return "tick_rgb_layers_tiled";
     case FP_Y420P_BGRA_TILED: return "tick_y420p_bgra_tiled";
     case FP_MIX_LAYERS_TILED: return "tick_mix_layers_tiled";
+    case FP_WAVE_LAYERS: return "tick_bgra_wave";
     default: return "none";
     }
 }
@@ -414,17 +419,21 @@ static int select_single_purpose(const DTick *ticks, const DLayer *layers, int n
 
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
     if (n_ticks <= 0) return FP_NONE;
-    // A/B switches for measurements and tests: CHV_FORCE_GENERAL=1 routes everything through the general kernels,
-    // CHV_FORCE_MIXED=1 every eligible BGRA-canvas batch through the mixed-layer kernel (read per call: tests flip them)
-    const char *fg = getenv("CHV_FORCE_GENERAL"), *fm = getenv("CHV_FORCE_MIXED");
+    // A/B switches for measurements and tests (read per call: tests flip them):
+    //   CHV_FORCE_GENERAL=1      everything through the general kernels
+    //   CHV_BGRA_PATH=wave|mix|single   BGRA canvases: only the wave-per-strip kernel / only the block-tiled mixed-layer
+    //                            kernel / the single-purpose kernels first (one YUV layer, RGB layers only), then the default
+    const char *fg = getenv("CHV_FORCE_GENERAL"), *bp = getenv("CHV_BGRA_PATH"), *fm = getenv("CHV_FORCE_MIXED");
     if (fg && fg[0] == '1') return FP_NONE;
     // 4:2:0 canvases: kernels_fast_yuv.hip.cpp decides
     if (target_format != TF_BGRA) return FP_NONE;
-    if (!(fm && fm[0] == '1')) {
-        int p = select_single_purpose(ticks, layers, n_ticks);
-        if (p != FP_NONE) return p;
-    }
-    // any mix of NV12 / y420p / BGRA / RGBA layers, 1..8 per tick
+    const char mode = (fm && fm[0] == '1') ? 'm' : (bp ? bp[0] : 0);
+    if (mode == 'w') return wave_layers_eligible(ticks, layers, n_ticks) ? FP_WAVE_LAYERS : FP_NONE;
+    if (mode == 'm') return mix_layers_eligible(ticks, layers, n_ticks) ? FP_MIX_LAYERS_TILED : FP_NONE;
+    int p = select_single_purpose(ticks, layers, n_ticks);
+    if (p != FP_NONE) return p;
+    // any mix of NV12 / y420p / BGRA / RGBA layers
+    if (wave_layers_eligible(ticks, layers, n_ticks)) return FP_WAVE_LAYERS;
     return mix_layers_eligible(ticks, layers, n_ticks) ? FP_MIX_LAYERS_TILED : FP_NONE;
 }
 
@@ -433,6 +442,7 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
                             int maxW, int maxH, hipStream_t stream) {
     if (path == FP_RGB_LAYERS_TILED) return launch_rgb_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_MIX_LAYERS_TILED) return launch_mix_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
+    if (path == FP_WAVE_LAYERS) return launch_wave_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path != FP_NV12_BGRA_TILED && path != FP_Y420P_BGRA_TILED) return hipErrorNotSupported;
     const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;
     const int tiles_x = (maxW + TW - 1) / TW;

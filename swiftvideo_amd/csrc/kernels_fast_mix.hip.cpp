@@ -126,12 +126,12 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
 }
 
 #ifndef CHV_MIX_MINW
-#define CHV_MIX_MINW 5
+#define CHV_MIX_MINW 4
 #endif
 // CHV_MIX_ROWFENCE: keep the scheduler from interleaving the rows of a thread's pixels in the branch-free loops (fewer
 // live temporaries; the 8 pixels of a thread otherwise want ~127 VGPRs)
 #ifndef CHV_MIX_ROWFENCE
-#define CHV_MIX_ROWFENCE 1
+#define CHV_MIX_ROWFENCE 0
 #endif
 #if CHV_MIX_ROWFENCE
 #define MIX_ROW_FENCE() __builtin_amdgcn_sched_barrier(0)

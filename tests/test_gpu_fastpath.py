@@ -202,7 +202,7 @@ def test_rgb_layers_tiled_matches_oracle(ctx, case):
 
 
 def test_rgb_layers_fallbacks(ctx):
-    """More than 8 layers, a rotated layer or a YUV layer in the mix -> general kernel, same bytes."""
+    """More than 8 layers: beyond tick_rgb_layers_tiled, taken by the wave-per-strip kernel; same bytes."""
     cw, ch = 96, 54
     src = util.alloc_image("bgra", 48, 27, seed=5)
     gs = G.to_gpu(ctx, "bgra", 48, 27, src)
@@ -214,7 +214,7 @@ def test_rgb_layers_fallbacks(ctx):
         assert O.run_kernel("img_bgra_bgra_tx", exp, src, u) == 0
     gd = G.to_gpu(ctx, "bgra", cw, ch, util.alloc_image("bgra", cw, ch, seed=1))
     h, name, keep = G.make_batch(ctx, [(gd, True, many)])
-    assert name == "tick_general_bgra"
+    assert name == "tick_bgra_wave"
     G.run_batch(ctx, h)
     G.destroy_batch(h)
     G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, "nine layers")

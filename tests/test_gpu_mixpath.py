@@ -1,4 +1,4 @@
-"""tick_mix_layers_tiled — N layers of ANY mix of NV12 / y420p / BGRA / RGBA onto a BGRA canvas in one LDS-tiled launch
+"""tick_bgra_wave (one wave per canvas strip, no block barriers) and tick_mix_layers_tiled (block-tiled) — N layers of ANY mix of NV12 / y420p / BGRA / RGBA onto a BGRA canvas in one LDS-tiled launch
 (the literal "NV12 -> BGRA + scale + 4-layer composite" tick of VideoMixer.mix, mix.video.swift:114-124) — gives exactly
 the bytes of the oracle's clear + per-layer kernel calls: tile edges, scale factors, partial cover, borders, fill,
 opacity, flips, odd sizes, covered-tile culling, un-cleared canvases, the staging tail and the unstaged fallback."""
@@ -14,6 +14,15 @@ from test_gpu_fastpath import NV12_BGRA_CASES, RGB_CASES
 pytestmark = pytest.mark.gpu
 
 MIX = "tick_mix_layers_tiled"
+WAVE = "tick_bgra_wave"
+PATHS = {"wave": WAVE, "mix": MIX}
+
+
+@pytest.fixture(params=["wave", "mix"])
+def path(request, monkeypatch):
+    """route every eligible BGRA-canvas batch through one of the two multi-layer kernels; yields the kernel name expected"""
+    monkeypatch.setenv("CHV_BGRA_PATH", request.param)
+    return PATHS[request.param]
 
 
 def run_tick_case(ctx, cw, ch, clear, specs, seed=61, expect=MIX, csc=0):
@@ -73,38 +82,51 @@ MIXED_CASES = {
 
 @pytest.mark.parametrize("case", list(MIXED_CASES))
 @pytest.mark.parametrize("csc", [0, 1])
-def test_mixed_layers_match_oracle(ctx, case, csc):
+def test_mixed_layers_match_oracle(ctx, path, case, csc):
     cw, ch, clear, specs = MIXED_CASES[case]
-    # down_4x: the rectangles of a 64x32 tile exceed the LDS budget -> general kernel
-    run_tick_case(ctx, cw, ch, clear, specs, csc=csc, expect=None if case == "down_4x" else MIX)
+    # down_4x: the rectangles of a 64x32 tile exceed the block-tiled kernel's LDS budget -> general kernel
+    run_tick_case(ctx, cw, ch, clear, specs, csc=csc, expect=None if case == "down_4x" else path)
+
+
+def test_default_route_of_a_mixed_tick(ctx):
+    """without any switch: several YUV layers / mixed kinds -> the wave kernel; one YUV layer, RGB layers only -> single-purpose kernels"""
+    cw, ch, clear, specs = MIXED_CASES["pipeline_small"]
+    assert run_tick_case(ctx, cw, ch, clear, specs, expect=None) == WAVE
+    cw, ch, clear, specs = MIXED_CASES["video_overlays"]
+    assert run_tick_case(ctx, cw, ch, clear, specs, expect=None) == WAVE
 
 
 @pytest.mark.parametrize("case", [c for c in NV12_BGRA_CASES if c not in ("huge_downscale", "tiny")])
 @pytest.mark.parametrize("fmt", ["nv12", "y420p"])
-def test_single_yuv_layer_through_the_mixed_kernel(ctx, monkeypatch, case, fmt):
-    """the cases of the single-purpose NV12 -> BGRA kernel, routed through the mixed kernel (CHV_FORCE_MIXED)"""
-    monkeypatch.setenv("CHV_FORCE_MIXED", "1")
+def test_single_yuv_layer_through_the_multi_layer_kernels(ctx, path, case, fmt):
+    """the cases of the single-purpose NV12 -> BGRA kernel, routed through the multi-layer kernels (CHV_BGRA_PATH)"""
     cw, ch, sw, sh, kw, clear = NV12_BGRA_CASES[case]
-    run_tick_case(ctx, cw, ch, clear, [(f"img_{fmt}_bgra", sw, sh, kw)], seed=21, csc=3)
+    run_tick_case(ctx, cw, ch, clear, [(f"img_{fmt}_bgra", sw, sh, kw)], seed=21, csc=3, expect=path)
 
 
 @pytest.mark.parametrize("case", [c for c in RGB_CASES if c != "odd_tiny"])
-def test_rgb_cases_through_the_mixed_kernel(ctx, monkeypatch, case):
-    monkeypatch.setenv("CHV_FORCE_MIXED", "1")
+def test_rgb_cases_through_the_multi_layer_kernels(ctx, path, case):
     cw, ch, clear, specs = RGB_CASES[case]
-    run_tick_case(ctx, cw, ch, clear, specs)
+    run_tick_case(ctx, cw, ch, clear, specs, expect=path)
 
 
-def test_mixed_fallbacks(ctx):
-    """nine layers, a rotated layer, or a Metal-semantics img_bgra_bgra layer in the tick -> general kernel, same bytes"""
+def test_mixed_fallbacks(ctx, monkeypatch):
+    """nine layers: beyond the block-tiled kernel (general kernel), fine for the wave kernel; a rotated layer in the tick ->
+    general kernel; same bytes everywhere"""
     nine = [("img_nv12_bgra" if i % 2 else "img_bgra_bgra_tx", 48, 28, dict(opacity=0.9)) for i in range(9)]
+    assert run_tick_case(ctx, 96, 54, True, nine, expect=None) == WAVE
+    monkeypatch.setenv("CHV_BGRA_PATH", "mix")
     assert run_tick_case(ctx, 96, 54, True, nine, expect=None) == "tick_general_bgra"
+    monkeypatch.delenv("CHV_BGRA_PATH")
+    twenty = [(("img_nv12_bgra", "img_rgba_bgra_tx", "img_y420p_bgra", "img_bgra_bgra_tx")[i % 4], 64, 36,
+               dict(rect=(3 * i, i, 64, 36), opacity=0.95 - 0.04 * i)) for i in range(20)]
+    assert run_tick_case(ctx, 140, 60, True, twenty, expect=None) == WAVE
     rot = [("img_nv12_bgra", 48, 28, dict()), ("img_bgra_bgra_tx", 48, 28, dict(rect=(10, 5, 40, 20), rotation=0.3))]
     assert run_tick_case(ctx, 96, 54, True, rot, expect=None) == "tick_general_bgra"
 
 
 @pytest.mark.parametrize("seed", range(32))
-def test_random_mixed_ticks(ctx, seed):
+def test_random_mixed_ticks(ctx, path, seed):
     """Seeded random ticks: 1..8 layers of random kinds with random axis-aligned geometry (placement, crop, flips, borders,
     fill, opacity, up- and downscales), three ticks of different sizes per launch."""
     rng = np.random.default_rng(9000 + seed)
@@ -164,7 +186,7 @@ def test_pipeline_full_size(ctx):
     gd = G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=5))
     layers = [(sv.ComputeKernel.img_nv12_bgra, g, u, 0) for g, u in zip(gs, us)]
     h, name, keep = G.make_batch(ctx, [(gd, True, layers)])
-    assert name == MIX
+    assert name == WAVE
     G.run_batch(ctx, h)
     G.run_batch(ctx, h)
     G.destroy_batch(h)
@@ -188,4 +210,25 @@ def test_mixed_full_size_1080p_canvas(ctx):
              ("img_y420p_bgra", 1920, 1080, dict(rect=(960, 0, 960, 540), opacity=0.9)),
              ("img_bgra_bgra_tx", 640, 360, dict(rect=(64, 64, 640, 360), opacity=0.8)),
              ("img_rgba_bgra_tx", 640, 360, dict(rect=(1200, 640, 640, 360), opacity=0.6, border=(8, 8, 8, 8), fill=(0.9, 0.9, 0.9, 0.5)))]
-    run_tick_case(ctx, cw, ch, True, specs, seed=77)
+    run_tick_case(ctx, cw, ch, True, specs, seed=77, expect=WAVE)
+
+
+@pytest.mark.parametrize("target", ["bgra", "nv12"])
+def test_composite_more_than_sixteen_layers(ctx, target):
+    """chv_composite splits a tick deeper than CHV_MAX_LAYERS into several launches; a mixer composes any number of layers
+    (mix.video.swift:116-124)"""
+    cw, ch = 160, 64
+    src_kinds = ["nv12", "bgra", "y420p", "rgba"] if target == "bgra" else ["nv12", "bgra", "y420p", "rgba"]
+    exp = util.alloc_image(target, cw, ch)
+    assert O.run_kernel(f"img_clear_{target}", exp) == 0
+    layers = []
+    for i in range(21):
+        s = src_kinds[i % 4]
+        k = f"img_{s}_{target}" + ("_tx" if (target == "bgra" and s in ("bgra", "rgba")) else "")
+        u = util.make_uniforms((cw, ch), rect=(5 * i, i, 64, 36), opacity=0.95 - 0.03 * i, in_size=(64, 36))
+        src = util.alloc_image(s, 64, 36, seed=300 + i)
+        assert O.run_kernel(k, exp, src, u) == 0
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, 64, 36, src), u, 0))
+    gd = G.to_gpu(ctx, target, cw, ch, util.alloc_image(target, cw, ch, seed=9))
+    sv.usingContext(ctx, lambda c: sv.compositeTick(c, gd, layers, True))
+    G.assert_same(G.from_gpu(ctx, gd, target, cw, ch), exp, f"21 layers onto {target}")

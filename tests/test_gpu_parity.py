@@ -239,11 +239,10 @@ def test_descriptor_validation_through_the_c_abi(ctx):
     host = np.zeros(64, dtype=np.uint8)
     assert lib.chv_upload(ctx.handle, buf._h, buf.size - 8, 64, host.ctypes.data, 64, 64, 1, 0) == 5
     assert lib.chv_download(ctx.handle, host.ctypes.data, 64, buf._h, 0, 16, 64, 1) == 5   # pitch < row bytes
-    # too many layers, mixed target formats in a batch
+    # mixed target formats in a batch (a tick deeper than CHV_MAX_LAYERS is fine: chv_composite splits it,
+    # tests/test_gpu_mixpath.py::test_composite_more_than_sixteen_layers)
     layer = (sv.ComputeKernel.img_bgra_nv12, bgra, u, 0)
-    with pytest.raises(sv.ComputeError) as e:
-        sv.compositeTick(ctx, nv12, [layer] * 17, True)
-    assert e.value.case == "invalidValue"
+    sv.compositeTick(ctx, nv12, [layer] * 17, True)
     with pytest.raises(sv.ComputeError) as e:
         G.make_batch(ctx, [(nv12, True, [layer]), (bgra, True, [])])
     assert e.value.case == "badTarget"
