@@ -430,15 +430,17 @@ class Timer:
         if fixed > 0:
             return fixed
         a, b = self.event(), self.event()
+        n = 8
         self.cv.check(self.lib.chv_event_record(self.ctx.handle, a))
-        for _ in range(3):
+        for _ in range(n):
             launch()
         self.cv.check(self.lib.chv_event_record(self.ctx.handle, b))
         self.sync()
-        ms = max(self.elapsed_ms(a, b) / 3.0, 1e-3)
+        ms = max(self.elapsed_ms(a, b) / n, 1e-3)
         for e in (a, b):
             self.cv.check(self.lib.chv_event_destroy(e))
-        r = max(1, math.ceil(min_seconds * 1e3 / (steps * ms)))
+        # 15 % on top: the calibration launches run at least as slow as the timed ones
+        r = max(1, math.ceil(1.15 * min_seconds * 1e3 / (steps * ms)))
         return int(reduce_max(self.dist, r))
 
     def run(self, launch, steps, per_step):

@@ -32,15 +32,11 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_MIX_LAYERS_TILED = 3, FP_WAVE_LAYERS = 4, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_WAVE_LAYERS = 3, FP_COUNT };
 
 // kernels_fast_rgb.hip.cpp
 bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
 hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
-                             int n_ticks, int maxW, int maxH, hipStream_t stream);
-// kernels_fast_mix.hip.cpp
-bool mix_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
-hipError_t launch_mix_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                              int n_ticks, int maxW, int maxH, hipStream_t stream);
 // kernels_wave.hip.cpp
 bool wave_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
@@ -393,7 +389,6 @@ const char *fast_path_name(int path) {
     case FP_NV12_BGRA_TILED: return "tick_nv12_bgra_tiled";
     case FP_RGB_LAYERS_TILED: return "tick_rgb_layers_tiled";
     case FP_Y420P_BGRA_TILED: return "tick_y420p_bgra_tiled";
-    case FP_MIX_LAYERS_TILED: return "tick_mix_layers_tiled";
     case FP_WAVE_LAYERS: return "tick_bgra_wave";
     default: return "none";
     }
@@ -420,28 +415,25 @@ static int select_single_purpose(const DTick *ticks, const DLayer *layers, int n
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
     if (n_ticks <= 0) return FP_NONE;
     // A/B switches for measurements and tests (read per call: tests flip them):
-    //   CHV_FORCE_GENERAL=1      everything through the general kernels
-    //   CHV_BGRA_PATH=wave|mix|single   BGRA canvases: only the wave-per-strip kernel / only the block-tiled mixed-layer
-    //                            kernel / the single-purpose kernels first (one YUV layer, RGB layers only), then the default
-    const char *fg = getenv("CHV_FORCE_GENERAL"), *bp = getenv("CHV_BGRA_PATH"), *fm = getenv("CHV_FORCE_MIXED");
+    //   CHV_FORCE_GENERAL=1   everything through the general kernels
+    //   CHV_BGRA_PATH=wave    BGRA canvases: the wave-per-strip kernel also where a single-purpose kernel (exactly one YUV
+    //                         layer per tick; RGB layers only) would be chosen
+    const char *fg = getenv("CHV_FORCE_GENERAL"), *bp = getenv("CHV_BGRA_PATH");
     if (fg && fg[0] == '1') return FP_NONE;
     // 4:2:0 canvases: kernels_fast_yuv.hip.cpp decides
     if (target_format != TF_BGRA) return FP_NONE;
-    const char mode = (fm && fm[0] == '1') ? 'm' : (bp ? bp[0] : 0);
-    if (mode == 'w') return wave_layers_eligible(ticks, layers, n_ticks) ? FP_WAVE_LAYERS : FP_NONE;
-    if (mode == 'm') return mix_layers_eligible(ticks, layers, n_ticks) ? FP_MIX_LAYERS_TILED : FP_NONE;
-    int p = select_single_purpose(ticks, layers, n_ticks);
-    if (p != FP_NONE) return p;
-    // any mix of NV12 / y420p / BGRA / RGBA layers
-    if (wave_layers_eligible(ticks, layers, n_ticks)) return FP_WAVE_LAYERS;
-    return mix_layers_eligible(ticks, layers, n_ticks) ? FP_MIX_LAYERS_TILED : FP_NONE;
+    if (!(bp && bp[0] == 'w')) {
+        int p = select_single_purpose(ticks, layers, n_ticks);
+        if (p != FP_NONE) return p;
+    }
+    // any mix of NV12 / y420p / BGRA / RGBA layers, any number of them
+    return wave_layers_eligible(ticks, layers, n_ticks) ? FP_WAVE_LAYERS : FP_NONE;
 }
 
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
     if (path == FP_RGB_LAYERS_TILED) return launch_rgb_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
-    if (path == FP_MIX_LAYERS_TILED) return launch_mix_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_LAYERS) return launch_wave_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path != FP_NV12_BGRA_TILED && path != FP_Y420P_BGRA_TILED) return hipErrorNotSupported;
     const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;

@@ -129,18 +129,29 @@ template <int BPT, int OFF, int N>
 CHV_DEV void wstage_store(const uint4 (&regs)[WNR], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int lane, bool swap02) {
 #pragma unroll
     for (int n = 0; n < N; n++) wstage_put<BPT>(regs[OFF + n], lane + n * 64, lds, lds_pitch, P, g, swap02);
-    // slots beyond the registers' capacity: loaded and written on the spot (latency exposed; strong downscales, rectangles at a picture edge)
-    for (int base = N * 64; base < stage_slots(g); base += 64) {
-        int i = base + lane, r, vv;
-        stage_slot(g, i, r, vv);
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (i < 1024 && r < g.rows) {
-            int row = min(max(g.r_lo + r, 0), P.h - 1);
-            int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
-            if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
-            val = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
+}
+// Slots beyond the registers' share of a plane (stronger downscales, rectangles at a picture edge): further rounds of
+// WTAIL loads in flight, one wait, WTAIL LDS writes (not unrolled beyond that: the edge patching is large code).
+constexpr int WTAIL = 2;
+template <int BPT, int N>
+CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int lane, bool swap02) {
+#pragma unroll 1
+    for (int base = N * 64; base < stage_slots(g); base += WTAIL * 64) {
+        uint4 t[WTAIL];
+#pragma unroll
+        for (int n = 0; n < WTAIL; n++) {
+            int i = base + n * 64 + lane, r, vv;
+            stage_slot(g, i, r, vv);
+            t[n] = make_uint4(0, 0, 0, 0);
+            if (i < 1024 && r < g.rows) {
+                int row = min(max(g.r_lo + r, 0), P.h - 1);
+                int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
+                if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
+                t[n] = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
+            }
         }
-        wstage_put<BPT>(val, i, lds, lds_pitch, P, g, swap02);
+#pragma unroll 1
+        for (int n = 0; n < WTAIL; n++) wstage_put<BPT>(n == 0 ? t[0] : t[WTAIL - 1], base + n * 64 + lane, lds, lds_pitch, P, g, swap02);
     }
 }
 
@@ -294,17 +305,23 @@ __global__ __launch_bounds__(NTHREADS, CHV_WAVE_MINW) void tick_bgra_wave(const 
             if (Ly.kind == LK_BGRA_FROM_Y420P) wstage_load<WN_Y + WN_C, WN_C>(regs, Ly.src.pl[2], w.g1, lane);
         }
     };
-    auto commit = [&](int l, const WLayer &w) {                    // registers -> this wave's LDS region
+    auto commit = [&](int l, const WLayer &w) {                    // registers -> this wave's LDS region; then the tails
         const DLayer &Ly = L[l];
         if (Ly.kind == LK_BGRA_FROM_RGB) {
             wstage_store<4, 0, WN_RGB>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);   // RGBA -> BGRA on the way
+            wstage_tail<4, WN_RGB>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
         } else if (Ly.kind == LK_BGRA_FROM_NV12) {
             wstage_store<1, 0, WN_Y>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
             wstage_store<2, WN_Y, WN_C>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
+            wstage_tail<1, WN_Y>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
+            wstage_tail<2, WN_C>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
         } else {
             wstage_store<1, 0, WN_Y>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
             wstage_store<1, WN_Y, WN_C>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
             wstage_store<1, WN_Y + WN_C, WN_C>(regs, smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
+            wstage_tail<1, WN_Y>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
+            wstage_tail<1, WN_C>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
+            wstage_tail<1, WN_C>(smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
         }
     };
 

@@ -12,7 +12,7 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "swiftvideo_amd" / "csrc"
 LLVM = Path("/opt/rocm/lib/llvm/bin")
-OBJECTS = ["kernels_general", "kernels_fast", "kernels_fast_rgb", "kernels_fast_mix", "kernels_lanczos"]
+OBJECTS = ["kernels_general", "kernels_fast", "kernels_fast_rgb", "kernels_wave", "kernels_lanczos"]
 
 
 def _code_object(tmp_path, stem):

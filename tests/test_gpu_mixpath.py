@@ -1,4 +1,4 @@
-"""tick_bgra_wave (one wave per canvas strip, no block barriers) and tick_mix_layers_tiled (block-tiled) — N layers of ANY mix of NV12 / y420p / BGRA / RGBA onto a BGRA canvas in one LDS-tiled launch
+"""tick_bgra_wave (one wave per canvas strip, no block barriers) — N layers of ANY mix of NV12 / y420p / BGRA / RGBA onto a BGRA canvas in one LDS-tiled launch
 (the literal "NV12 -> BGRA + scale + 4-layer composite" tick of VideoMixer.mix, mix.video.swift:114-124) — gives exactly
 the bytes of the oracle's clear + per-layer kernel calls: tile edges, scale factors, partial cover, borders, fill,
 opacity, flips, odd sizes, covered-tile culling, un-cleared canvases, the staging tail and the unstaged fallback."""
@@ -13,19 +13,18 @@ from test_gpu_fastpath import NV12_BGRA_CASES, RGB_CASES
 
 pytestmark = pytest.mark.gpu
 
-MIX = "tick_mix_layers_tiled"
 WAVE = "tick_bgra_wave"
-PATHS = {"wave": WAVE, "mix": MIX}
 
 
-@pytest.fixture(params=["wave", "mix"])
-def path(request, monkeypatch):
-    """route every eligible BGRA-canvas batch through one of the two multi-layer kernels; yields the kernel name expected"""
-    monkeypatch.setenv("CHV_BGRA_PATH", request.param)
-    return PATHS[request.param]
+@pytest.fixture
+def path(monkeypatch):
+    """route every eligible BGRA-canvas batch through the wave kernel (also where a single-purpose kernel would be chosen);
+    yields the kernel name expected"""
+    monkeypatch.setenv("CHV_BGRA_PATH", "wave")
+    return WAVE
 
 
-def run_tick_case(ctx, cw, ch, clear, specs, seed=61, expect=MIX, csc=0):
+def run_tick_case(ctx, cw, ch, clear, specs, seed=61, expect=WAVE, csc=0):
     """specs: [(kernel name, src w, h, make_uniforms kwargs)] -> asserts HIP == oracle, returns the dispatched kernel name"""
     canvas0 = util.alloc_image("bgra", cw, ch, seed=seed)
     exp = util.copy_image(canvas0)
@@ -84,7 +83,7 @@ MIXED_CASES = {
 @pytest.mark.parametrize("csc", [0, 1])
 def test_mixed_layers_match_oracle(ctx, path, case, csc):
     cw, ch, clear, specs = MIXED_CASES[case]
-    # down_4x: the rectangles of a 64x32 tile exceed the block-tiled kernel's LDS budget -> general kernel
+    # down_4x: the four waves' rectangles exceed the LDS budget -> general kernel
     run_tick_case(ctx, cw, ch, clear, specs, csc=csc, expect=None if case == "down_4x" else path)
 
 
@@ -111,13 +110,9 @@ def test_rgb_cases_through_the_multi_layer_kernels(ctx, path, case):
 
 
 def test_mixed_fallbacks(ctx, monkeypatch):
-    """nine layers: beyond the block-tiled kernel (general kernel), fine for the wave kernel; a rotated layer in the tick ->
-    general kernel; same bytes everywhere"""
+    """any number of layers per tick is fine for the wave kernel; a rotated layer in the tick -> general kernel; same bytes"""
     nine = [("img_nv12_bgra" if i % 2 else "img_bgra_bgra_tx", 48, 28, dict(opacity=0.9)) for i in range(9)]
     assert run_tick_case(ctx, 96, 54, True, nine, expect=None) == WAVE
-    monkeypatch.setenv("CHV_BGRA_PATH", "mix")
-    assert run_tick_case(ctx, 96, 54, True, nine, expect=None) == "tick_general_bgra"
-    monkeypatch.delenv("CHV_BGRA_PATH")
     twenty = [(("img_nv12_bgra", "img_rgba_bgra_tx", "img_y420p_bgra", "img_bgra_bgra_tx")[i % 4], 64, 36,
                dict(rect=(3 * i, i, 64, 36), opacity=0.95 - 0.04 * i)) for i in range(20)]
     assert run_tick_case(ctx, 140, 60, True, twenty, expect=None) == WAVE
