@@ -82,8 +82,11 @@ typedef enum chv_kernel {
     CHV_K_IMG_RGBA_BGRA_TX = 35
 } chv_kernel;
 
-/* defaultComputeKernelFromString, compute.swift:90-110 (plus the four names
- * above).  Unknown name -> CHV_ERR_INVALID_VALUE, as the reference throws. */
+/* defaultComputeKernelFromString, compute.swift:90-110, plus the entries of the
+ * compute.swift hunk in INTEGRATION.md section 1: the four names above and
+ * "img_rgba_bgra" (-> CHV_K_IMG_RGBA_BGRA_TX; what VideoMixer.findKernel,
+ * mix.video.swift:142-146, synthesises for an RGBA layer on a BGRA canvas).
+ * Unknown name -> CHV_ERR_INVALID_VALUE, as the reference throws. */
 int chv_kernel_from_string(const char *name, int *kernel);
 /* String(describing: ComputeKernel) — the round trip computeTests.swift:9-39 checks. */
 const char *chv_kernel_name(int kernel);
@@ -237,6 +240,9 @@ typedef struct chv_layer {
     chv_kernel_opts opts;
 } chv_layer;
 
+/* Layers per launch of chv_composite; a deeper tick is issued as several launches
+ * on the context's stream (same bytes: the canvas is 8-bit between layers anyway).
+ * Ticks of a batch (chv_batch_create) may have any number of layers. */
 #define CHV_MAX_LAYERS 16
 
 int chv_composite(chv_context *ctx, const chv_image *target, int clear_first,

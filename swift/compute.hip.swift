@@ -3,9 +3,9 @@
 
    Drop-in for Sources/SwiftVideo/compute.cl.swift: it defines the same types
    (ComputeDevice, ComputeBuffer, ComputeContext) and the same free functions, so
-   compute.swift, mix.video.swift and sample.pict.linux.swift compile unchanged when the
-   package is built with the GPGPU_HIP define (see INTEGRATION.md for the Package.swift
-   hunk).  All pixel work happens in libchipvideo.so; this file only marshals
+   mix.video.swift and sample.pict.linux.swift compile unchanged when the package is built
+   with the GPGPU_HIP define; compute.swift gets four enum cases and five kernelMap entries
+   (INTEGRATION.md section 1 has that hunk and the Package.swift one).  All pixel work happens in libchipvideo.so; this file only marshals
    PictureSample / ImageBuffer values into chv_image descriptors and maps status codes
    to ComputeError.
 
@@ -30,18 +30,35 @@ struct ComputeDevice {
     let supportsImages: Bool
 }
 
-public class ComputeBuffer {
-    fileprivate let handle: OpaquePointer
-    fileprivate let size: Int
-    fileprivate let pitch: Int
-    fileprivate init(_ handle: OpaquePointer, size: Int, pitch: Int = 0) {
-        self.handle = handle
-        self.size = size
-        self.pitch = pitch
-    }
+/// One device allocation (chv_buffer); freed when the last ComputeBuffer that views it goes away.
+private final class DeviceAllocation {
+    let handle: OpaquePointer
+    init(_ handle: OpaquePointer) { self.handle = handle }
     deinit {
         // callable from any thread: the library makes the owning device current
         _ = chv_buffer_free(handle)
+    }
+}
+
+/// ComputeBuffer, compute.cl.swift:46-58.  A picture's planes are views (offset, pitch) of ONE allocation, so that planes
+/// which are adjacent on both sides travel as one pitched copy (INTEGRATION.md section 3).
+public class ComputeBuffer {
+    private let allocation: DeviceAllocation
+    fileprivate var handle: OpaquePointer { return allocation.handle }
+    fileprivate let offset: Int
+    fileprivate let size: Int
+    fileprivate let pitch: Int
+    fileprivate init(_ handle: OpaquePointer, size: Int, pitch: Int = 0) {
+        self.allocation = DeviceAllocation(handle)
+        self.offset = 0
+        self.size = size
+        self.pitch = pitch
+    }
+    fileprivate init(viewOf other: ComputeBuffer, offset: Int, size: Int, pitch: Int) {
+        self.allocation = other.allocation
+        self.offset = offset
+        self.size = size
+        self.pitch = pitch
     }
 }
 
@@ -78,10 +95,13 @@ private func check(_ status: Int32, kernel: ComputeKernel? = nil) throws {
     }
 }
 
+/// ComputeKernel -> chv_kernel.  Every case's name is its own description ("img_nv12_bgra", ...), and the library's name
+/// table (chv_kernel_from_string) is defaultComputeKernelFromString's table plus the cases the compute.swift hunk adds, so
+/// one lookup serves the reference's thirteen cases and the four new ones.  A `.custom(name:)` whose name the table knows
+/// is accepted as well (hosts that cannot patch compute.swift can spell `.custom(name: "img_nv12_bgra")`).
 private func kernelId(_ kernel: ComputeKernel) throws -> Int32 {
     var id: Int32 = -1
     if case .custom(let name) = kernel {
-        // "img_nv12_bgra", "img_bgra_bgra_tx", ... resolve through the library's name table
         try check(chv_kernel_from_string(name, &id), kernel: kernel)
         return id
     }
@@ -171,7 +191,7 @@ private func describe(_ image: ImageBuffer, maxPlanes: Int) -> chv_image? {
             for idx in 0..<count {
                 let plane = image.planes[idx]
                 let comps = plane.components.count >= 3 ? 4 : plane.components.count
-                planes[idx] = chv_plane(buffer: image.computeTextures[idx].handle, offset: 0,
+                planes[idx] = chv_plane(buffer: image.computeTextures[idx].handle, offset: image.computeTextures[idx].offset,
                                         width: Int32(plane.size.x), height: Int32(plane.size.y),
                                         pitch: Int32(image.computeTextures[idx].pitch),
                                         components: Int32(comps))
@@ -268,7 +288,7 @@ func uploadComputeBuffer(_ ctx: ComputeContext, src: Data, dst: ComputeBuffer?) 
         throw ComputeError.badInputData(description: "Compute buffer needs to be >= to data.count")
     }
     try src.withUnsafeBytes {
-        try check(chv_upload(ctx.handle, buffer.handle, 0, src.count, $0.baseAddress, src.count, src.count, 1, 0))
+        try check(chv_upload(ctx.handle, buffer.handle, buffer.offset, src.count, $0.baseAddress, src.count, src.count, 1, 0))
     }
     return buffer
 }
@@ -279,7 +299,7 @@ func downloadComputeBuffer(_ ctx: ComputeContext, src: ComputeBuffer, dst: Data?
         throw ComputeError.badInputData(description: "Destination data buffer must be >= buffer.size")
     }
     try dst.withUnsafeMutableBytes {
-        try check(chv_download(ctx.handle, $0.baseAddress, src.size, src.handle, 0, src.size, src.size, 1))
+        try check(chv_download(ctx.handle, $0.baseAddress, src.size, src.handle, src.offset, src.size, src.size, 1))
     }
     return dst
 }
@@ -299,20 +319,53 @@ func uploadComputePicture(_ ctx: ComputeContext,
     guard planeCount == imageBuffer.buffers.count else {
         throw ComputeError.badInputData(description: "Input image must have the same number of buffers as planes")
     }
-    let textures = try (0..<min(planeCount, maxPlanes)).map { idx -> ComputeBuffer in
+    // One allocation for the whole picture: 128-byte aligned pitches, each plane starting where the previous one ends
+    // (the role of createTexture, compute.cl.swift:532-581, which makes one image per plane).
+    let count = min(planeCount, maxPlanes)
+    var pitches = [Int](), offsets = [Int](), total = 0
+    for idx in 0..<count {
+        let plane = imageBuffer.planes[idx]
+        guard plane.size.x > 0 && plane.size.y > 0 else { throw ComputeError.invalidOperation }
+        let comps = plane.components.count >= 3 ? 4 : plane.components.count
+        let pitch = (Int(plane.size.x) * comps + 127) / 128 * 128
+        pitches.append(pitch)
+        offsets.append(total)
+        total += pitch * Int(plane.size.y)
+    }
+    var out: OpaquePointer?
+    try check(chv_buffer_alloc(ctx.handle, total, &out))
+    let whole = ComputeBuffer(out!, size: total)
+    let textures = (0..<count).map { idx in
+        ComputeBuffer(viewOf: whole, offset: offsets[idx], size: pitches[idx] * Int(imageBuffer.planes[idx].size.y), pitch: pitches[idx])
+    }
+    // Planes that are adjacent with equal pitch and width on BOTH sides go as one pitched copy: luma + interleaved chroma
+    // of NV12, the two chroma planes of y420p (buffersForPlanes slices one contiguous Data, sample.pict.linux.swift:296-311).
+    // 3 MiB copies reach 48 GB/s on this link, separate 2 MiB + 1 MiB copies 37 GB/s.
+    var idx = 0
+    while idx < count {
         let plane = imageBuffer.planes[idx]
         let comps = plane.components.count >= 3 ? 4 : plane.components.count
-        var out: OpaquePointer?
-        var pitch = 0
-        try check(chv_plane_alloc(ctx.handle, Int32(plane.size.x), Int32(plane.size.y), Int32(comps), &out, &pitch))
-        let texture = ComputeBuffer(out!, size: pitch * Int(plane.size.y), pitch: pitch)
-        try imageBuffer.buffers[idx].withUnsafeBytes {
-            // async = 1: bytes are staged into pinned memory before the call returns, the copy
-            // is ordered on the context's stream in front of the kernels that read the plane
-            try check(chv_upload(ctx.handle, texture.handle, 0, pitch, $0.baseAddress, plane.stride,
-                                 Int(plane.size.x) * comps, Int(plane.size.y), 1))
+        let widthBytes = Int(plane.size.x) * comps
+        var rows = Int(plane.size.y)
+        var last = idx
+        try imageBuffer.buffers[idx].withUnsafeBytes { first in
+            while last + 1 < count {
+                let next = imageBuffer.planes[last + 1]
+                let nextComps = next.components.count >= 3 ? 4 : next.components.count
+                let contiguous = imageBuffer.buffers[last + 1].withUnsafeBytes {
+                    $0.baseAddress == first.baseAddress.map { $0 + rows * plane.stride }
+                }
+                guard pitches[last + 1] == pitches[idx], next.stride == plane.stride,
+                      Int(next.size.x) * nextComps == widthBytes, contiguous else { break }
+                rows += Int(next.size.y)
+                last += 1
+            }
+            // async = 1: the bytes are staged into pinned memory before the call returns; the copy is ordered on the
+            // context's stream, and kernels or downloads of ANY context of the device wait for it (per-buffer event)
+            try check(chv_upload(ctx.handle, whole.handle, offsets[idx], pitches[idx], first.baseAddress, plane.stride,
+                                 widthBytes, rows, 1))
         }
-        return texture
+        idx = last + 1
     }
     let image = ImageBuffer(imageBuffer, computeTextures: textures,
                             buffers: !retainCpuBuffer ? [] : nil, bufferType: .gpu)
@@ -332,7 +385,7 @@ func downloadComputePicture(_ ctx: ComputeContext,
         var buffer = imageBuffer.buffers[safe: idx] ?? Data(count: Int(plane.size.y) * plane.stride)
         let texture = imageBuffer.computeTextures[idx]
         try buffer.withUnsafeMutableBytes {
-            try check(chv_download(ctx.handle, $0.baseAddress, plane.stride, texture.handle, 0, texture.pitch,
+            try check(chv_download(ctx.handle, $0.baseAddress, plane.stride, texture.handle, texture.offset, texture.pitch,
                                    Int(plane.size.x) * comps, Int(plane.size.y)))
         }
         return buffer

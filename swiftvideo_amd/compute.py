@@ -774,7 +774,7 @@ class VideoMixer:
     numberBackingImages = 10  # mix.video.swift:167
 
     def __init__(self, workspaceId, frameDuration, outputSize, outputFormat=PixelFormat.nv12,
-                 computeContext=None, assetId=None, fused=True, bgraKernelFamily="tx",
+                 computeContext=None, assetId=None, fused=True, bgraKernelFamily="reference",
                  colorspace=cv.CSC_BT601_LIMITED):
         self.clContext = createComputeContext(sharing=computeContext) if computeContext is not None \
             else makeComputeContext(forType="GPU")
@@ -799,7 +799,11 @@ class VideoMixer:
         return ("just", pic)
 
     def findKernel(self, image, target):
-        """mix.video.swift:142-146"""
+        """mix.video.swift:142-146: "img_" + (input format | "clear") + "_" + target format, resolved through
+        defaultComputeKernelFromString.  bgraKernelFamily = "reference" (default) is the unchanged Swift VideoMixer: a
+        BGRA layer on a BGRA canvas resolves to img_bgra_bgra, the Metal kernel's semantics (kernels.metal:52-62: nearest,
+        no transform, no opacity); "tx" is the optional mix.video.swift hunk of INTEGRATION.md section 1: BGRA / RGBA
+        layers on a BGRA canvas take the transform- and opacity-aware img_*_bgra_tx kernels."""
         inp = str(image.pixelFormat().name).lower() if image is not None else "clear"
         outp = str(target.pixelFormat().name).lower()
         name = f"img_{inp}_{outp}"

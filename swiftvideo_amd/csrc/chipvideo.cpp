@@ -115,6 +115,9 @@ static const KernelName kNames[] = {
     // names findKernel can synthesise for BGRA canvases (mix.video.swift:142-146)
     { "img_nv12_bgra", CHV_K_IMG_NV12_BGRA },   { "img_y420p_bgra", CHV_K_IMG_Y420P_BGRA },
     { "img_bgra_bgra_tx", CHV_K_IMG_BGRA_BGRA_TX }, { "img_rgba_bgra_tx", CHV_K_IMG_RGBA_BGRA_TX },
+    // an RGBA layer on a BGRA canvas: no reference backend has a kernel of that name; it resolves to the transform-aware
+    // one (as "img_clear_rgba" resolves to img_clear_bgra, compute.swift:101)
+    { "img_rgba_bgra", CHV_K_IMG_RGBA_BGRA_TX },
 };
 
 extern "C" int chv_kernel_from_string(const char *name, int *kernel) {

@@ -515,7 +515,7 @@ class VideoMixer {
 public:
     static constexpr int numberBackingImages = 10;     // mix.video.swift:167
     VideoMixer(const std::string &workspaceId, Vector2 outputSize, PixelFormat outputFormat, const ComputeContext &computeContext,
-               const std::string &assetId = "mixer", bool fused = true, bool bgraTransformAware = true)
+               const std::string &assetId = "mixer", bool fused = true, bool bgraTransformAware = false)
         : clContext_(createComputeContext(computeContext)), backingSize_(outputSize), backingFormat_(outputFormat),
           idWorkspace_(workspaceId), idAsset_(assetId), fused_(fused), bgraTx_(bgraTransformAware) {}
 

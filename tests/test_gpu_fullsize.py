@@ -50,7 +50,8 @@ def test_cfg2_1080p_nv12_to_720p_bgra(ctx, csc):
 
 
 def test_cfg3_four_1080p_bgra_layers(ctx):
-    """configs[2]: VideoMixer with four 1080p BGRA layers (opacity 1, .75, .5, .25) onto a 1080p canvas."""
+    """configs[2]: VideoMixer with four 1080p BGRA layers (opacity 1, .75, .5, .25) onto a 1080p canvas, with the
+    transform- and opacity-aware kernel family (bgraKernelFamily="tx": the optional mix.video.swift hunk of INTEGRATION.md)."""
     w, h = 1920, 1080
     layers = [util.alloc_image("bgra", w, h, seed=0x5EED0000 + 48 + i) for i in range(4)]
     us = [util.full_canvas_uniforms((w, h), (w, h), opacity=o) for o in (1.0, 0.75, 0.5, 0.25)]
@@ -58,7 +59,7 @@ def test_cfg3_four_1080p_bgra_layers(ctx):
     assert O.run_kernel("img_clear_bgra", exp, threads=CORES) == 0
     for l, u in zip(layers, us):
         assert O.run_kernel("img_bgra_bgra_tx", exp, l, u, threads=CORES) == 0
-    mixer = sv.VideoMixer("ws", 1 / 30, (w, h), outputFormat=sv.PixelFormat.BGRA, computeContext=ctx, fused=True)
+    mixer = sv.VideoMixer("ws", 1 / 30, (w, h), outputFormat=sv.PixelFormat.BGRA, computeContext=ctx, fused=True, bgraKernelFamily="tx")
     up = sv.GPUBarrierUpload(ctx)
     M = util.ortho(w, h) @ util._mat_scale(w, h)
     for z, (l, o) in enumerate(zip(layers, (1.0, 0.75, 0.5, 0.25))):
@@ -69,7 +70,7 @@ def test_cfg3_four_1080p_bgra_layers(ctx):
     assert out is not None, mixer.result
     G.assert_same(G.from_gpu(ctx, out, "bgra", w, h), exp, "cfg3 fused mixer tick")
     # the reference's own call sequence (clear + 4 x applyComputeImage) gives the same bytes
-    mixer2 = sv.VideoMixer("ws", 1 / 30, (w, h), outputFormat=sv.PixelFormat.BGRA, computeContext=ctx, fused=False)
+    mixer2 = sv.VideoMixer("ws", 1 / 30, (w, h), outputFormat=sv.PixelFormat.BGRA, computeContext=ctx, fused=False, bgraKernelFamily="tx")
     for z, (l, o) in enumerate(zip(layers, (1.0, 0.75, 0.5, 0.25))):
         mixer2.push(up(sv.pictureFromArrays(sv.PixelFormat.BGRA, (w, h), l, matrix=M, opacity=o, zIndex=z, assetId=f"in{z}"))[1])
     out2 = mixer2.mix(at=0.0)

@@ -72,7 +72,8 @@ def test_find_kernel_names():
     assert str(m.findKernel(None, nv)) == "img_clear_nv12" and str(m.findKernel(None, bg)) == "img_clear_bgra"
     assert str(m.findKernel(bg, nv)) == "img_bgra_nv12" and str(m.findKernel(yp, yp)) == "img_y420p_y420p"
     assert str(m.findKernel(nv, bg)) == "img_nv12_bgra" and str(m.findKernel(bg, bg)) == "img_bgra_bgra_tx"
-    assert str(M("metal").findKernel(bg, bg)) == "img_bgra_bgra"
+    assert str(M("reference").findKernel(bg, bg)) == "img_bgra_bgra"       # the unchanged Swift VideoMixer: Metal semantics
+    assert sv.VideoMixer.__init__.__defaults__[sv.VideoMixer.__init__.__code__.co_varnames.index("bgraKernelFamily") - 4] == "reference"
     with pytest.raises(sv.ComputeError):
         m.findKernel(nv, yp)                                  # img_nv12_y420p: no such kernel in the reference either
 
