@@ -111,6 +111,10 @@ def parse_args(argv=None):
     ap.add_argument("--with-upload", action="store_true",
                     help="end-to-end mode only: every step also uploads its source frames from pinned host memory on a side "
                          "stream (PCIe-inclusive rate; reported for DESIGN.md, never the headline value)")
+    ap.add_argument("--stub-device", action="store_true",
+                    help="control-plane self-test without a GPU (tests only): every launch is a short sleep, nothing is loaded or "
+                         "computed; spawn, rendezvous, calibration, barriers, reductions and the report are the real ones; the line "
+                         "is marked and is not a benchmark result")
     ap.add_argument("--pmc-json", default=None,
                     help="a profiles/pmc_*.json produced by profiles/run_profile.sh for THIS command: its HBM bytes per launch "
                          "are copied into roofline.traffic with roofline.traffic_source naming the file")
@@ -396,11 +400,11 @@ def cpu_baseline(wl, w, budget_s):
                       f"compositing whole ticks (clear + {n_kernels} layer kernel(s) per tick, as the reference issues them)"}
 
 
-class Timer:
-    """K steps of R launches each, bracketed as the contract says; per-step HIP events on the context's stream."""
+class HipDevice:
+    """events and synchronisation on the context's stream, through the C ABI"""
 
-    def __init__(self, cv, lib, ctx, dist):
-        self.cv, self.lib, self.ctx, self.dist = cv, lib, ctx, dist
+    def __init__(self, cv, lib, ctx):
+        self.cv, self.lib, self.ctx = cv, lib, ctx
 
     def sync(self):
         self.cv.check(self.lib.chv_device_synchronize(self.ctx.handle))
@@ -411,57 +415,128 @@ class Timer:
         except Exception:
             pass
 
-    def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
-
     def event(self):
         e = C.c_void_p()
         self.cv.check(self.lib.chv_event_create(self.ctx.handle, C.byref(e)))
         return e
+
+    def record(self, e):
+        self.cv.check(self.lib.chv_event_record(self.ctx.handle, e))
 
     def elapsed_ms(self, a, b):
         ms = C.c_float()
         self.cv.check(self.lib.chv_event_elapsed_ms(a, b, C.byref(ms)))
         return ms.value
 
+    def destroy(self, e):
+        self.cv.check(self.lib.chv_event_destroy(e))
+
+
+class StubDevice:
+    """--stub-device: host clock instead of stream events, nothing to synchronise"""
+
+    def sync(self):
+        pass
+
+    def event(self):
+        return [0.0]
+
+    def record(self, e):
+        e[0] = time.perf_counter()
+
+    def elapsed_ms(self, a, b):
+        return (b[0] - a[0]) * 1e3
+
+    def destroy(self, e):
+        pass
+
+
+class Timer:
+    """K steps of R launches each, bracketed as the contract says; per-step events on the stream the kernels run on."""
+
+    def __init__(self, dev, dist):
+        self.dev, self.dist = dev, dist
+
+    def sync(self):
+        self.dev.sync()
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
     def calibrate(self, launch, steps, min_seconds, fixed):
         """launches per step so that `steps` steps last >= min_seconds; the same number on every rank"""
         if fixed > 0:
             return fixed
-        a, b = self.event(), self.event()
+        a, b = self.dev.event(), self.dev.event()
         n = 8
-        self.cv.check(self.lib.chv_event_record(self.ctx.handle, a))
+        self.dev.record(a)
         for _ in range(n):
             launch()
-        self.cv.check(self.lib.chv_event_record(self.ctx.handle, b))
+        self.dev.record(b)
         self.sync()
-        ms = max(self.elapsed_ms(a, b) / n, 1e-3)
+        ms = max(self.dev.elapsed_ms(a, b) / n, 1e-3)
         for e in (a, b):
-            self.cv.check(self.lib.chv_event_destroy(e))
+            self.dev.destroy(e)
         # 15 % on top: the calibration launches run at least as slow as the timed ones
         r = max(1, math.ceil(1.15 * min_seconds * 1e3 / (steps * ms)))
         return int(reduce_max(self.dist, r))
 
     def run(self, launch, steps, per_step):
-        evs = [self.event() for _ in range(steps + 1)]
+        evs = [self.dev.event() for _ in range(steps + 1)]
         self.barrier()
         self.sync()
         t0 = time.perf_counter()
-        self.cv.check(self.lib.chv_event_record(self.ctx.handle, evs[0]))
+        self.dev.record(evs[0])
         for k in range(steps):
             for _ in range(per_step):
                 launch()
-            self.cv.check(self.lib.chv_event_record(self.ctx.handle, evs[k + 1]))
+            self.dev.record(evs[k + 1])
         self.sync()
         self.barrier()
         t1 = time.perf_counter()
         local = t1 - t0
         elapsed = reduce_max(self.dist, local)
-        step_ms = [self.elapsed_ms(evs[k], evs[k + 1]) for k in range(steps)]
+        step_ms = [self.dev.elapsed_ms(evs[k], evs[k + 1]) for k in range(steps)]
         for e in evs:
-            self.cv.check(self.lib.chv_event_destroy(e))
+            self.dev.destroy(e)
         return elapsed, local, float(np.mean(step_ms)) / per_step
+
+
+def report_of(name, wl, args, tm, n_gpus, frames, per_step, elapsed, local, launch_ms, kernel, verified):
+    locals_ = gather_floats(tm.dist, local, n_gpus)
+    px_per_launch = frames * wl["dw"] * wl["dh"] if "lanczos" not in wl else frames * wl["lanczos"][0] * wl["lanczos"][1]
+    bytes_per_launch = frames * wl["bytes"]
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    return {
+        "workload": f"{name}: {wl['desc']}",
+        "value": whole_job_gpix(n_gpus, px_per_launch * per_step, args.steps, elapsed), "unit": "Gpix/s",
+        "ms_per_step": elapsed / args.steps * 1e3, "launches_per_step": per_step, "timed_seconds": elapsed,
+        "frames_per_launch_per_gpu": frames, "kernel": kernel, "verified_vs_oracle": verified,
+        "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "frac_of_copy_ceiling": achieved / HBM_COPY_GBS},
+        "per_gpu_gpix": [px_per_launch * per_step * args.steps / t / 1e9 for t in locals_],
+        # a tick belongs to one PictureSample bus: `frames` streams per GPU advance by one tick per launch
+        "per_stream_ticks_per_s": 1e3 / launch_ms,
+        "source_mpix_per_launch_per_gpu": frames * wl["sw"] * wl["sh"] * (wl["layers"] if wl["kind"] != "mixer420" else 1) / 1e6,
+    }
+
+
+def measure_stub(name, args, tm, rank, n_gpus, headline):
+    """--stub-device: the control flow of measure() with sleeps for launches (rank r is (1 + r/4) x slower than rank 0)"""
+    wl = WORKLOADS[name]
+    frames = args.frames if (args.frames and headline) else wl["frames"]
+    pause = 0.0004 * (1.0 + rank / 4.0)
+
+    def launch():
+        time.sleep(pause)
+
+    for _ in range(max(args.warmup, 1)):
+        launch()
+    per_step = tm.calibrate(launch, args.steps, args.min_seconds if headline else args.min_seconds_other, args.launches_per_step)
+    elapsed, local, launch_ms = tm.run(launch, args.steps, per_step)
+    return report_of(name, wl, args, tm, n_gpus, frames, per_step, elapsed, local, launch_ms, "stub", None), None
 
 
 def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
@@ -483,23 +558,7 @@ def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
         verified = verify_frame(sv, ctx, wl, w, 0) and verify_frame(sv, ctx, wl, w, frames - 1)
     per_step = tm.calibrate(launch, args.steps, args.min_seconds if headline else args.min_seconds_other, args.launches_per_step)
     elapsed, local, launch_ms = tm.run(launch, args.steps, per_step)
-    locals_ = gather_floats(tm.dist, local, n_gpus)
-    px_per_launch = frames * wl["dw"] * wl["dh"] if "lanczos" not in wl else frames * wl["lanczos"][0] * wl["lanczos"][1]
-    bytes_per_launch = frames * wl["bytes"]
-    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    rep = {
-        "workload": f"{name}: {wl['desc']}",
-        "value": whole_job_gpix(n_gpus, px_per_launch * per_step, args.steps, elapsed), "unit": "Gpix/s",
-        "ms_per_step": elapsed / args.steps * 1e3, "launches_per_step": per_step, "timed_seconds": elapsed,
-        "frames_per_launch_per_gpu": frames, "kernel": w["kernel"], "verified_vs_oracle": verified,
-        "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "frac_of_copy_ceiling": achieved / HBM_COPY_GBS},
-        "per_gpu_gpix": [px_per_launch * per_step * args.steps / t / 1e9 for t in locals_],
-        # a tick belongs to one PictureSample bus: `frames` streams per GPU advance by one tick per launch
-        "per_stream_ticks_per_s": 1e3 / launch_ms,
-        "source_mpix_per_launch_per_gpu": frames * wl["sw"] * wl["sh"] * (wl["layers"] if wl["kind"] != "mixer420" else 1) / 1e6,
-    }
+    rep = report_of(name, wl, args, tm, n_gpus, frames, per_step, elapsed, local, launch_ms, w["kernel"], verified)
     cpu = None
     if headline and rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and w["verify"] is not None:
         cpu = cpu_baseline(wl, w, args.cpu_seconds)
@@ -590,14 +649,20 @@ def main(argv=None):
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     n_gpus = max(world, 1)
 
-    from swiftvideo_amd import chipvideo as cv
-    from swiftvideo_amd import compute as sv
-    lib = cv.load()
-    dev = pick_device(args, local, cv.device_count())
-    ctx = sv.makeComputeContext(forType="GPU", index=dev)
-    tm = Timer(cv, lib, ctx, dist)
+    if args.stub_device:
+        sv = cv = lib = ctx = None
+        tm = Timer(StubDevice(), dist)
+    else:
+        from swiftvideo_amd import chipvideo as cv
+        from swiftvideo_amd import compute as sv
+        lib = cv.load()
+        dev = pick_device(args, local, cv.device_count())
+        ctx = sv.makeComputeContext(forType="GPU", index=dev)
+        tm = Timer(HipDevice(cv, lib, ctx), dist)
+    do = (lambda name, headline: measure_stub(name, args, tm, rank, n_gpus, headline)) if args.stub_device else \
+         (lambda name, headline: measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline))
 
-    if args.with_upload:
+    if args.with_upload and not args.stub_device:
         rep = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": rep["value"], "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -612,15 +677,15 @@ def main(argv=None):
             dist.destroy_process_group()
         return
 
-    head, cpu = measure(args.workload, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline=True)
+    head, cpu = do(args.workload, True)
     if args.also is None:
         others = [n for n in DEFAULT_SET if n != args.workload] if args.workload == HEADLINE else []
     else:
         others = [n for n in args.also.split(",") if n and n != "none"]
     reports = {args.workload: head}
     for name in others:
-        reports[name], _ = measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline=False)
-    if others and not args.no_upload_leg:
+        reports[name], _ = do(name, False)
+    if others and not args.no_upload_leg and not args.stub_device:
         reports["cfg2_upload"] = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus)
 
     if rank == 0:
@@ -652,6 +717,9 @@ def main(argv=None):
             "roofline": roof,
             "workloads": {k: {kk: vv for kk, vv in v.items() if kk not in ("source_mpix_per_launch_per_gpu",)} for k, v in reports.items()},
         }
+        if args.stub_device:
+            out["data"] = "STUB --stub-device: launches are sleeps; control-plane self-test, not a benchmark result"
+            out["roofline"]["frac"] = None
         if args.alias != "none":
             out["data"] = f"DIAGNOSTIC --alias {args.alias}: ticks share frame 0's buffers, cache-resident traffic; not a benchmark result"
             out["roofline"]["frac"] = None

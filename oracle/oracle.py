@@ -21,6 +21,8 @@ KERNEL_IDS = {
     "img_bgra_y420p": 12, "snd_s16i_s16i": 13, "me_fullsearch": 14,
     "img_nv12_bgra": 32, "img_y420p_bgra": 33, "img_bgra_bgra_tx": 34, "img_rgba_bgra_tx": 35,
 }
+# unit-scale envelope evaluators of the BGRA-target family (tests only; ref_kernels.c::px_to_bgra_unit)
+ENVELOPE_IDS = {"img_nv12_bgra": 64, "img_y420p_bgra": 65, "img_bgra_bgra_tx": 66, "img_rgba_bgra_tx": 67}
 CSC = {"bt601": 0, "bt709": 1, "bt601_full": 2, "bt709_full": 3}
 
 

@@ -360,6 +360,50 @@ INL void px_to_bgra(int SRC, const job_t *j, int x, int y) {
     d[0] = st8_code(r0); d[1] = st8_code(r1); d[2] = st8_code(r2); d[3] = 255;
 }
 
+/* ENVELOPE EVALUATOR (tests only; ids 64..67, never dispatched by the product): the BGRA-target family evaluated
+ * the way the reference's own kernels evaluate theirs — on the UNIT scale, texels through ld8 (c / 255), the Khronos
+ * filter with sequential roundings (lin_fetch), unfused blends in the source order of px_yuv_to_yuv / px_rgb_to_yuv
+ * (cur * (1 - a) + p * a), st8 (* 255, RTE) at the store.  Same geometry, same integer colour matrix on the quantised
+ * YUV sample, same structure (fill under the picture, picture over it).  tests/test_oracle_golden.py measures how far
+ * the code-scale specification above is from this evaluation, per layer and through stacks of layers. */
+INL void px_to_bgra_unit(int SRC, const job_t *j, int x, int y) {
+    geom_t g = geometry(j, x, y);
+    if (!g.in_border) return;
+    uint8_t *d = (uint8_t *)texel(&j->t[0], x, y);
+    float af = j->u->opacity * j->u->fillColor[3];
+    float r0 = clampf(ld8(d[0]) * (1.f - af) + j->u->fillColor[2] * af, 0.f, 1.f);   /* B */
+    float r1 = clampf(ld8(d[1]) * (1.f - af) + j->u->fillColor[1] * af, 0.f, 1.f);   /* G */
+    float r2 = clampf(ld8(d[2]) * (1.f - af) + j->u->fillColor[0] * af, 0.f, 1.f);   /* R */
+    if (g.in_tx && g.in_uv) {
+        float p0, p1, p2, a;
+        if (SRC == SRC_BGRA || SRC == SRC_RGBA) {
+            lin2 l = lin_setup(&j->in[0], g.uv.x, g.uv.y);
+            float q0 = lin_fetch(&j->in[0], &l, 0), q1 = lin_fetch(&j->in[0], &l, 1);
+            float q2 = lin_fetch(&j->in[0], &l, 2), q3 = lin_fetch(&j->in[0], &l, 3);
+            p0 = SRC == SRC_BGRA ? q0 : q2; p1 = q1; p2 = SRC == SRC_BGRA ? q2 : q0;
+            a = q3 * j->u->opacity;
+        } else {
+            lin2 ly = lin_setup(&j->in[0], g.uv.x, g.uv.y);
+            lin2 lc = lin_setup(&j->in[1], g.uv.x, g.uv.y);
+            float fy = lin_fetch(&j->in[0], &ly, 0), fu, fv;
+            if (SRC == SRC_NV12) { fu = lin_fetch(&j->in[1], &lc, 0); fv = lin_fetch(&j->in[1], &lc, 1); }
+            else {
+                fu = lin_fetch(&j->in[1], &lc, 0);
+                lin2 lv = lin_setup(&j->in[2], g.uv.x, g.uv.y);
+                fv = lin_fetch(&j->in[2], &lv, 0);
+            }
+            uint8_t R, G, B;
+            yuv2rgb_int(&CSC[j->csc & 3], st8(fy), st8(fu), st8(fv), &R, &G, &B);
+            p0 = ld8(B); p1 = ld8(G); p2 = ld8(R);
+            a = 1.0f * j->u->opacity;
+        }
+        r0 = r0 * (1.f - a) + p0 * a;
+        r1 = r1 * (1.f - a) + p1 * a;
+        r2 = r2 * (1.f - a) + p2 * a;
+    }
+    d[0] = st8(r0); d[1] = st8(r1); d[2] = st8(r2); d[3] = 255;
+}
+
 /* Clear kernels: img_clear_nv12 (kernels.cl.swift:38-46), img_clear_y420p
  * (:174-185), img_clear_bgra (:257-265).  Every work-item writes chroma at
  * gid/2 (idempotent). */
@@ -394,6 +438,10 @@ static void run_rows(const job_t *j, int y0, int y1) {
     case ORC_IMG_Y420P_BGRA:  ROWS(px_to_bgra(SRC_Y420P, j, x, y)) break;
     case ORC_IMG_BGRA_BGRA_TX: ROWS(px_to_bgra(SRC_BGRA, j, x, y)) break;
     case ORC_IMG_RGBA_BGRA_TX: ROWS(px_to_bgra(SRC_RGBA, j, x, y)) break;
+    case ORC_ENV_NV12_BGRA_UNIT:   ROWS(px_to_bgra_unit(SRC_NV12, j, x, y)) break;
+    case ORC_ENV_Y420P_BGRA_UNIT:  ROWS(px_to_bgra_unit(SRC_Y420P, j, x, y)) break;
+    case ORC_ENV_BGRA_BGRA_UNIT:   ROWS(px_to_bgra_unit(SRC_BGRA, j, x, y)) break;
+    case ORC_ENV_RGBA_BGRA_UNIT:   ROWS(px_to_bgra_unit(SRC_RGBA, j, x, y)) break;
     case ORC_IMG_CLEAR_NV12:  ROWS(px_clear(DST_NV12, j, x, y)) break;
     case ORC_IMG_CLEAR_Y420P: ROWS(px_clear(DST_Y420P, j, x, y)) break;
     case ORC_IMG_CLEAR_BGRA:
@@ -450,8 +498,9 @@ int orc_run_kernel(int kernel, const orc_plane *target, int n_target,
     case ORC_IMG_BGRA_Y420P: case ORC_IMG_RGBA_Y420P: sfmt = SRC_BGRA; dfmt = SRC_Y420P; break;
     case ORC_IMG_BGRA_BGRA: case ORC_IMG_BGRA_BGRA_TX: case ORC_IMG_RGBA_BGRA_TX:
         sfmt = SRC_BGRA; dfmt = SRC_BGRA; break;
-    case ORC_IMG_NV12_BGRA: sfmt = SRC_NV12; dfmt = SRC_BGRA; break;
-    case ORC_IMG_Y420P_BGRA: sfmt = SRC_Y420P; dfmt = SRC_BGRA; break;
+    case ORC_IMG_NV12_BGRA: case ORC_ENV_NV12_BGRA_UNIT: sfmt = SRC_NV12; dfmt = SRC_BGRA; break;
+    case ORC_IMG_Y420P_BGRA: case ORC_ENV_Y420P_BGRA_UNIT: sfmt = SRC_Y420P; dfmt = SRC_BGRA; break;
+    case ORC_ENV_BGRA_BGRA_UNIT: case ORC_ENV_RGBA_BGRA_UNIT: sfmt = SRC_BGRA; dfmt = SRC_BGRA; break;
     case ORC_IMG_CLEAR_NV12: clear = 1; dfmt = SRC_NV12; break;
     case ORC_IMG_CLEAR_Y420P: clear = 1; dfmt = SRC_Y420P; break;
     case ORC_IMG_CLEAR_BGRA: case ORC_IMG_CLEAR_RGBA: clear = 1; dfmt = SRC_BGRA; break;

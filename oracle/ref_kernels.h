@@ -62,7 +62,13 @@ enum {
     ORC_IMG_NV12_BGRA = 32,
     ORC_IMG_Y420P_BGRA = 33,
     ORC_IMG_BGRA_BGRA_TX = 34,
-    ORC_IMG_RGBA_BGRA_TX = 35
+    ORC_IMG_RGBA_BGRA_TX = 35,
+    /* envelope evaluators of 32..35 on the unit scale, in the reference family's style
+     * (tests only; see px_to_bgra_unit) */
+    ORC_ENV_NV12_BGRA_UNIT = 64,
+    ORC_ENV_Y420P_BGRA_UNIT = 65,
+    ORC_ENV_BGRA_BGRA_UNIT = 66,
+    ORC_ENV_RGBA_BGRA_UNIT = 67
 };
 
 enum { ORC_OK = 0, ORC_ERR_INVALID_VALUE = 1, ORC_ERR_NOT_IMPLEMENTED = 6,

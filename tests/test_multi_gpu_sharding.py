@@ -52,3 +52,65 @@ def test_two_rank_timing_reduction_and_stream_binding():
     # whole-job throughput: all ranks' pixels over the max time
     assert bench.whole_job_gpix(2, 1e9, 4, 0.8) == pytest.approx(2 * 1e9 * 4 / 0.8 / 1e9)
     assert bench.reduce_max(None, 1.25) == 1.25
+
+
+def _run_bench(argv, timeout=600):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}: {p.stdout[-500:]}"
+    return json.loads(lines[0])
+
+
+def test_self_launch_spawns_one_rank_per_gpu_and_reports_the_slowest():
+    """`python bench.py --gpus 2` with no launcher environment: the script starts its two ranks itself (the real spawn,
+    rendezvous, calibration, barrier and reduction code), here with --stub-device (launches are sleeps; rank 1 is 25 % slower)."""
+    d = _run_bench(["--gpus", "2", "--stub-device", "--steps", "4", "--warmup", "1", "--min-seconds", "0.3",
+                    "--min-seconds-other", "0.05", "--also", "cfg2"])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["data"].startswith("STUB") and d["roofline"]["frac"] is None            # never mistaken for a measurement
+    cfg = d["config"]
+    assert len(cfg["per_gpu_gpix"]) == 2
+    assert cfg["per_gpu_gpix"][0] >= cfg["per_gpu_gpix"][1] * 0.95                    # rank 1 sleeps longer per launch
+    # whole job = both ranks' pixels over the slowest rank's time: not more than twice the slower rank's own rate
+    assert d["value"] <= 2.0 * min(cfg["per_gpu_gpix"]) * 1.02
+    assert d["value"] >= 2.0 * min(cfg["per_gpu_gpix"]) * 0.7
+    assert d["ms_per_step"] * d["steps"] >= 300 * 0.9                                 # the calibrated region lasts >= --min-seconds
+    assert set(d["workloads"]) == {"pipeline", "cfg2"}
+    assert d["workloads"]["cfg2"]["launches_per_step"] >= 1
+    assert "cpu_baseline" not in d                                                    # N = 1 only
+
+
+def test_rank_without_a_device_is_an_error_not_a_silent_single_rank_run():
+    import bench
+    args = bench.parse_args(["--gpus", "2"])
+    assert bench.pick_device(args, 0, 1) == 0
+    with pytest.raises(SystemExit):
+        bench.pick_device(args, 1, 1)                      # LOCAL_RANK 1 on a 1-GPU box
+    args = bench.parse_args(["--gpus", "2", "--device", "0"])
+    assert bench.pick_device(args, 1, 1) == 0              # --device pins every rank (1-GPU boxes)
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_end_to_end():
+    """The N > 1 data path for real, on the one GPU of the test box: `--gpus 2 --device 0` self-launches two ranks, each with
+    its own context, frames and canvases on device 0; every rank's output is verified against the oracle by rank 0's twin
+    logic (verified_vs_oracle) and the line reports both ranks."""
+    d = _run_bench(["--gpus", "2", "--device", "0", "--steps", "3", "--warmup", "1", "--min-seconds", "0.2", "--frames", "32",
+                    "--also", "none", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and len(d["config"]["per_gpu_gpix"]) == 2
+    assert d["config"]["verified_vs_oracle"] is True
+    assert d["config"]["kernel"] == "tick_bgra_wave"
+    assert 0 < d["roofline"]["frac"] < 1
+    assert d["value"] <= sum(d["config"]["per_gpu_gpix"]) * 1.01
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_uploads_on_one_device():
+    """the end-to-end (H2D-inclusive) mode at N = 2: per-rank pinned frames, side-stream uploads, per-buffer events"""
+    d = _run_bench(["--gpus", "2", "--device", "0", "--with-upload", "--steps", "3", "--warmup", "2", "--min-seconds-other", "0.2"])
+    assert d["n_gpus"] == 2 and d["config"]["h2d_GBps_per_gpu"] > 1.0
+    assert "END-TO-END" in d["config"]["mode"]

@@ -4,6 +4,8 @@ definitions.  CPU only."""
 from fractions import Fraction
 from pathlib import Path
 
+import zlib
+
 import numpy as np
 import pytest
 
@@ -284,3 +286,79 @@ def test_oracle_argument_checks():
     assert O.run_kernel("img_bgra_nv12", bg, bg, u) == 4    # bad target
     assert O.run_kernel("img_bgra_nv12", nv, nv, u) == 5    # bad input
     assert O.run_kernel("img_bgra_nv12", nv, bg, None) == 1
+
+
+# ---- the whole owned family against a unit-scale evaluation in the reference family's style -----------------------
+# oracle/ref_kernels.c::px_to_bgra_unit evaluates img_{nv12,y420p}_bgra / img_{bgra,rgba}_bgra_tx the way the reference's
+# OpenCL kernels evaluate theirs: texels through c/255, the Khronos filter with sequential roundings, unfused blends in
+# the source order of px_yuv_to_yuv / px_rgb_to_yuv, *255 RTE at the store.  The code-scale specification
+# is held to that evaluation here, class by class.  Bounds (codes, per output channel):
+#   RGB sources: <= 1 in EVERY class, stacks of 2..8 re-quantised layers included — the two evaluations round the same exact
+#                value and part only at rounding ties; a one-code difference does not grow through later layers because it
+#                is scaled by (1 - alpha) <= 1 and re-rounded.
+#   YUV sources: the two samplers differ by <= 1 code in Y, U or V (at ties), and the INTEGER colour matrix that follows —
+#                identical in both — amplifies that: |dB| <= (cy + cbu) / 65536 = 3.3, |dG| <= 2.4, |dR| <= 3.0, so <= 4.  That is a
+#                property of putting an integer matrix behind ANY float sampler that is allowed 1 ULP, not of the code scale.
+ENVELOPE_BOUND = {"rgb": 1, "yuv": 4}
+ENVELOPE_OBSERVED = {   # max |code-scale - unit-scale| seen per class (asserted as upper bounds; they document the envelope)
+    ("scale", "rgb"): 1, ("alpha", "rgb"): 1, ("fill", "rgb"): 1, ("rotated", "rgb"): 1, ("stack", "rgb"): 1,
+    ("scale", "yuv"): 3, ("alpha", "yuv"): 3, ("fill", "yuv"): 3, ("rotated", "yuv"): 3, ("stack", "yuv"): 3,
+}
+_ENV_KINDS = {"yuv": ["img_nv12_bgra", "img_y420p_bgra"], "rgb": ["img_bgra_bgra_tx", "img_rgba_bgra_tx"]}
+
+
+def _envelope_layer(rng, cw, ch, cls, kinds):
+    k = kinds[int(rng.integers(0, len(kinds)))]
+    s = k.split("_")[1]
+    sw, sh = int(rng.integers(8, 120)) * 2, int(rng.integers(4, 70)) * 2
+    kw = {}
+    if cls != "scale" and rng.random() < 0.7:
+        kw["rect"] = (float(rng.uniform(-0.3, 0.6) * cw), float(rng.uniform(-0.3, 0.6) * ch),
+                      float(rng.uniform(0.2, 1.5) * cw), float(rng.uniform(0.2, 1.5) * ch))
+    if cls in ("fill", "rotated", "stack"):
+        if rng.random() < 0.6:
+            kw["border"] = tuple(float(v) for v in rng.uniform(0, 10, 4))
+        if rng.random() < 0.6:
+            kw["fill"] = tuple(float(v) for v in rng.uniform(0, 1, 4))
+    if cls == "rotated" or (cls == "stack" and rng.random() < 0.3):
+        kw["rotation"] = float(rng.uniform(-0.6, 0.6))
+    if cls != "scale":
+        kw["opacity"] = float(rng.choice([1.0, rng.uniform(0, 1)]))
+    if rng.random() < 0.4:
+        kw["tex"] = (float(rng.uniform(0, 0.4)), float(rng.uniform(0, 0.4)),
+                     float(rng.uniform(0.3, 1.0)) * (1 if rng.random() < 0.8 else -1), float(rng.uniform(0.3, 1.0)))
+    u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+    src = util.alloc_image(s, sw, sh, seed=int(rng.integers(1, 1 << 20)))
+    if cls == "scale" and s in ("bgra", "rgba"):
+        src[0][..., 3] = 255                                   # opaque pictures: the sampler alone
+    return k, src, u, int(rng.integers(0, 4))
+
+
+@pytest.mark.parametrize("family", ["rgb", "yuv"])
+@pytest.mark.parametrize("cls", ["scale", "alpha", "fill", "rotated", "stack"])
+def test_code_scale_family_envelope(cls, family):
+    """scale: opaque full-canvas pictures at random up / down scales (the sampler alone);  alpha: per-pixel alpha and
+    opacity < 1, partial cover;  fill: borders and fill colours with alpha;  rotated: rotated quads;  stack: 2..8 layers
+    with the canvas re-quantised in between, un-cleared canvases included."""
+    worst, differing, total, touched = 0, 0, 0, 0
+    for t in range(36):
+        rng = np.random.default_rng(zlib.crc32(f"{cls}/{family}".encode()) % 1000 * 1000 + t)
+        cw, ch = int(rng.integers(16, 200)), int(rng.integers(8, 120))
+        c0 = util.alloc_image("bgra", cw, ch, seed=int(rng.integers(1, 1 << 20)))
+        own, unit = util.copy_image(c0), util.copy_image(c0)
+        if rng.random() < 0.5:
+            assert O.run_kernel("img_clear_bgra", own) == 0 and O.run_kernel("img_clear_bgra", unit) == 0
+        before = own[0].copy()
+        for _ in range(int(rng.integers(2, 9)) if cls == "stack" else 1):
+            k, src, u, csc = _envelope_layer(rng, cw, ch, cls, _ENV_KINDS[family])
+            assert O.run_kernel(k, own, src, u, csc=csc) == 0
+            assert O.run_kernel(O.ENVELOPE_IDS[k], unit, src, u, csc=csc) == 0
+        d = np.abs(own[0][..., :3].astype(int) - unit[0][..., :3].astype(int))
+        worst = max(worst, int(d.max()))
+        differing += int((d != 0).sum()); total += d.size
+        touched += int((own[0] != before).any(axis=2).sum())
+        assert np.array_equal(own[0][..., 3], unit[0][..., 3])              # alpha bytes: identical rules
+    assert touched > 0.1 * total / 3, "the cases must actually paint"
+    assert worst <= ENVELOPE_BOUND[family], (cls, family, worst)
+    assert worst <= ENVELOPE_OBSERVED[(cls, family)], f"{cls}/{family}: deviation {worst} exceeds the recorded envelope"
+    assert differing <= 2e-3 * total, f"{cls}/{family}: {differing} of {total} channel values differ — more than rounding ties explain"
