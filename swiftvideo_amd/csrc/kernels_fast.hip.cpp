@@ -32,15 +32,15 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_WAVE_LAYERS = 3, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_WAVE_LAYERS = 3, FP_WAVE_NV12 = 4, FP_WAVE_Y420P = 5, FP_COUNT };
 
 // kernels_fast_rgb.hip.cpp
 bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
 hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                              int n_ticks, int maxW, int maxH, hipStream_t stream);
-// kernels_wave.hip.cpp
-bool wave_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
-hipError_t launch_wave_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
+// kernels_wave.hip.cpp / kernels_wave_yuv.hip.cpp
+bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
+hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream);
 
 #ifndef CHV_TW
@@ -390,6 +390,8 @@ const char *fast_path_name(int path) {
     case FP_RGB_LAYERS_TILED: return "tick_rgb_layers_tiled";
     case FP_Y420P_BGRA_TILED: return "tick_y420p_bgra_tiled";
     case FP_WAVE_LAYERS: return "tick_bgra_wave";
+    case FP_WAVE_NV12: return "tick_yuv_wave<nv12>";
+    case FP_WAVE_Y420P: return "tick_yuv_wave<y420p>";
     default: return "none";
     }
 }
@@ -420,21 +422,24 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     //                         layer per tick; RGB layers only) would be chosen
     const char *fg = getenv("CHV_FORCE_GENERAL"), *bp = getenv("CHV_BGRA_PATH");
     if (fg && fg[0] == '1') return FP_NONE;
-    // 4:2:0 canvases: kernels_fast_yuv.hip.cpp decides
-    if (target_format != TF_BGRA) return FP_NONE;
+    // 4:2:0 canvases (the reference's own kernels): one wave per strip, or the general quad kernel
+    if (target_format != TF_BGRA)
+        return wave_layers_eligible(target_format, ticks, layers, n_ticks) ? (target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P) : FP_NONE;
     if (!(bp && bp[0] == 'w')) {
         int p = select_single_purpose(ticks, layers, n_ticks);
         if (p != FP_NONE) return p;
     }
     // any mix of NV12 / y420p / BGRA / RGBA layers, any number of them
-    return wave_layers_eligible(ticks, layers, n_ticks) ? FP_WAVE_LAYERS : FP_NONE;
+    return wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks) ? FP_WAVE_LAYERS : FP_NONE;
 }
 
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
     if (path == FP_RGB_LAYERS_TILED) return launch_rgb_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
-    if (path == FP_WAVE_LAYERS) return launch_wave_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
+    if (path == FP_WAVE_LAYERS) return launch_wave_layers(TF_BGRA, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
+    if (path == FP_WAVE_NV12) return launch_wave_layers(TF_NV12, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
+    if (path == FP_WAVE_Y420P) return launch_wave_layers(TF_Y420P, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path != FP_NV12_BGRA_TILED && path != FP_Y420P_BGRA_TILED) return hipErrorNotSupported;
     const bool clear = ticks_host[0].clear_first != 0, planar = path == FP_Y420P_BGRA_TILED;
     const int tiles_x = (maxW + TW - 1) / TW;

@@ -1,0 +1,373 @@
+// kernels_wave_yuv.hip.cpp — axis-aligned tick kernel for 4:2:0 canvases (NV12, y420p), one wave per canvas strip.
+//
+// These are the reference's own kernels — img_nv12_nv12, img_y420p_nv12, img_y420p_y420p, img_{bgra,rgba}_{nv12,y420p}
+// (kernels.cl.swift:47-532) — and the default Linux canvas is 4:2:0 (composer.swift:52-56; x264 wants y420p,
+// enc.video.ffmpeg.swift:211-224).  The general quad kernel (kernels_general.hip.cpp) evaluates the geometry per pixel and
+// gathers every tap from global memory: ~260 VALU instructions per canvas pixel, HBM fetch 2.4x the algorithmic bytes
+// (profiles/r01_notes.md).  Here the structure of kernels_wave.hip.cpp is applied to the reference's unit-scale arithmetic:
+//   * lane = canvas column, a wave owns 64 columns x WTH rows; luma codes of the lane's pixels packed four to a register,
+//     the chroma sample of every 2x2 quad held by the quad's even/even pixel — the reference's `handleChroma` owner
+//     (kernels.cl.swift:76) — so even lanes carry (u, v) codes for the even rows;
+//   * column entries in registers, row entries in the wave's LDS table, source rectangles staged wave-privately as bytes
+//     (wave_common.hip.h); strips of one frame on one XCD;
+//   * UNORM8 loads (c / 255, correctly rounded: OpenCL 1.2 section 8.3.1.1) come out of a 256-entry LDS table instead of
+//     three VALU instructions per tap; every sum keeps the reference's order and roundings (no contraction);
+//   * strips that lie entirely inside a layer's picture run branch-free; every other strip (picture or border edges, fill
+//     paint, unstaged rectangles) applies the layer pixel by pixel with the general kernel's own code (yuv_pixel.hip.h).
+// Bytes: those of kernels_general.hip.cpp = oracle/ref_kernels.c (px_yuv_to_yuv, px_rgb_to_yuv), layer by layer.
+#include "wave_common.hip.h"
+#include "yuv_pixel.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace chv {
+
+#ifndef CHV_UNORM_TABLE
+#define CHV_UNORM_TABLE 1
+#endif
+constexpr int UNORM_TAB_BYTES = 1024;          // float[256] at the start of the block's LDS
+
+// c / 255.0f, correctly rounded: table lookup (byte index) or the two-term product of pixel_math.hip.h
+CHV_DEV float T8(const float *tab, uint32_t byte) {
+#if CHV_UNORM_TABLE
+    return tab[byte];
+#else
+    (void)tab;
+    return unorm8(byte);
+#endif
+}
+// the same for byte k of a packed word
+template <int K>
+CHV_DEV float T8k(const float *tab, uint32_t w) {
+#if CHV_UNORM_TABLE
+    const uint32_t idx4 = K == 0 ? (w << 2) & 0x3FCu : (w >> (8 * K - 2)) & 0x3FCu;     // byte * 4
+    return *(const float *)((const uint8_t *)tab + idx4);
+#else
+    (void)tab;
+    return unorm8f(K == 0 ? (float)(w & 255u) : K == 1 ? (float)((w >> 8) & 255u) : K == 2 ? (float)((w >> 16) & 255u) : (float)(w >> 24));
+#endif
+}
+// convert_uchar_sat_rte(f * 255) into byte K of w (v_cvt_pk_u8_f32: RTE, clamp to [0, 255], NaN -> 0 = to_code)
+template <int K>
+CHV_DEV uint32_t put_code(uint32_t w, float f) {
+    const float v = f * 255.0f;
+    if (K == 0) asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(w) : "v"(v));
+    if (K == 1) asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(w) : "v"(v));
+    if (K == 2) asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(w) : "v"(v));
+    if (K == 3) asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(w) : "v"(v));
+    return w;
+}
+CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float t10, float t01, float t11) {
+    return ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;      // lin_mix's order (OpenCL 1.2 section 8.2)
+}
+
+#ifndef CHV_WAVEY_MINW
+#define CHV_WAVEY_MINW 5
+#endif
+template <int TF, bool CLEAR>
+__global__ __launch_bounds__(NTHREADS, CHV_WAVEY_MINW) void tick_yuv_wave(const DTick *__restrict__ ticks,
+                                                                         const DLayer *__restrict__ layers,
+                                                                         int n_ticks, int strips_x, int strips_y,
+                                                                         int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
+    static_assert(WTH == 8, "canvas packing below: 8 luma rows = 2 registers, 4 chroma rows = 1 register per component");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
+    float *tab = (float *)smem_all;
+#if CHV_UNORM_TABLE
+    if (threadIdx.x < 256) tab[threadIdx.x] = unorm8((uint32_t)threadIdx.x);
+    __syncthreads();                      // the only block barrier, before any wave leaves
+#endif
+    WaveStrip S;
+    if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, smem_all + UNORM_TAB_BYTES, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;
+    const DTick &T = *S.T;
+    const DLayer *L = S.L;
+    const int nl = S.nl, x = S.x, y0 = S.y0;
+    const bool col_in = S.col_in;
+    const uint8_t *smem = S.smem;
+    const uint4 *rowtab = S.rowtab;
+    const int voff = S.voff;
+    const DPlane &PY = T.dst.pl[0];
+    const DPlane &PC = T.dst.pl[1];
+    const DPlane &PV = T.dst.pl[TF == TF_Y420P ? 2 : 1];
+    const float sx = S.sx, sy = S.sy;
+
+    // ---- canvas codes of this lane: luma rows 0..3 in ly0, 4..7 in ly1 (byte = row & 3); even lanes: chroma rows 0..3 of
+    //      the strip (canvas rows y0/2 ..) in cu / cv -------------------------------------------------------------------------
+    const bool owner_lane = (x & 1) == 0 && col_in;          // (canvas sizes are even on this path: host-checked)
+    const int qx = x >> 1, qy0 = y0 >> 1;
+    uint32_t ly0 = 0, ly1 = 0, cu = 0x80808080u, cv = 0x80808080u;     // img_clear_*: Y = 0.0, chroma = 0.5 -> 128 (RTE)
+    if (!CLEAR && col_in) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (y0 + j < T.H) {
+                const uint32_t b = gld<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x);
+                if (j < 4) ly0 |= b << (8 * j); else ly1 |= b << (8 * (j - 4));
+            }
+        }
+        if (owner_lane) {
+            cu = 0; cv = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                if (y0 + 2 * jj < T.H) {
+                    uint32_t ub, vb;
+                    if (TF == TF_NV12) {
+                        const uint32_t p = gld<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + (size_t)qx * 2);
+                        ub = p & 255u; vb = p >> 8;
+                    } else {
+                        ub = gld<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + qx);
+                        vb = gld<uint8_t>(PV.ptr + (size_t)(qy0 + jj) * PV.pitch + qx);
+                    }
+                    cu |= ub << (8 * jj); cv |= vb << (8 * jj);
+                }
+            }
+        }
+    }
+
+    WLayer cur;
+    int l = S.next_hit(0);
+    while (l < nl) {
+        const DLayer &Ly = L[l];
+        S.setup(l, cur);                  // (overwrites the row table: the previous layer's pixels are done)
+        const bool fast = cur.staged && cur.all_inside;
+        if (fast) S.stage(l, cur);
+        wave_lds_fence();
+        const int ln = S.next_hit(l + 1);
+        const float *U = Ly.u;
+
+        if (fast && Ly.kind != LK_YUV_FROM_RGB) {
+            // ---- YUV picture over the whole strip (kernels.cl.swift:78-94): cur * (1 - opacity) + sample * opacity ----
+            const float alpha = U[U_OPACITY], ialpha = 1.f - alpha;
+            const float a = cur.cya, ia = 1.0f - a, ca = cur.cca, ica = 1.0f - ca;
+            auto body = [&](auto planar_c, auto opaque_c) {
+                constexpr bool PL = decltype(planar_c)::value, OP = decltype(opaque_c)::value;
+                auto row = [&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
+                    const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
+                    const uint8_t *py = smem + ((int)ra.x + cur.cyo);
+                    const float luma = mix4(ia * ib, a * ib, ia * b, a * b, T8(tab, py[0]), T8(tab, py[1]), T8(tab, py[p0pitch]), T8(tab, py[p0pitch + 1]));
+                    uint32_t &lw = j < 4 ? ly0 : ly1;
+                    // opacity == 1: cur * 0 + luma * 1 = luma exactly
+                    const float v = OP ? luma : T8k<j & 3>(tab, lw) * ialpha + luma * alpha;
+                    lw = put_code<j & 3>(lw, v);
+                    if constexpr ((j & 1) == 0) {
+                        if (owner_lane) {          // the quad's chroma: sampled at THIS pixel's uv on the half-size plane(s)
+                            const float cbw = __uint_as_float(rb.z), icb = __uint_as_float(rb.w);
+                            const uint8_t *pc = smem + ((int)ra.y + cur.cco);
+                            const float c00 = ica * icb, c10 = ca * icb, c01 = ica * cbw, c11 = ca * cbw;
+                            float fu, fv;
+                            if constexpr (PL) {
+                                fu = mix4(c00, c10, c01, c11, T8(tab, pc[0]), T8(tab, pc[1]), T8(tab, pc[p1pitch]), T8(tab, pc[p1pitch + 1]));
+                                const uint8_t *pv = pc + voff;
+                                fv = mix4(c00, c10, c01, c11, T8(tab, pv[0]), T8(tab, pv[1]), T8(tab, pv[p1pitch]), T8(tab, pv[p1pitch + 1]));
+                            } else {
+                                fu = mix4(c00, c10, c01, c11, T8(tab, pc[0]), T8(tab, pc[2]), T8(tab, pc[p1pitch]), T8(tab, pc[p1pitch + 2]));
+                                fv = mix4(c00, c10, c01, c11, T8(tab, pc[1]), T8(tab, pc[3]), T8(tab, pc[p1pitch + 1]), T8(tab, pc[p1pitch + 3]));
+                            }
+                            constexpr int jj = j >> 1;
+                            cu = put_code<jj>(cu, OP ? fu : T8k<jj>(tab, cu) * ialpha + fu * alpha);
+                            cv = put_code<jj>(cv, OP ? fv : T8k<jj>(tab, cv) * ialpha + fv * alpha);
+                        }
+                    }
+                };
+                row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+                row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{}); row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
+            };
+            const bool planar = Ly.kind == LK_YUV_FROM_Y420P, opaque = (Ly.flags & LF_OPAQUE) != 0;
+            if (planar) { if (opaque) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+            else        { if (opaque) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+        } else if (fast) {
+            // ---- RGB picture over the whole strip (kernels.cl.swift:509-529): fill pre-blend, sample, rgb2yuv of the
+            //      pre-multiplied pixel, blend by alpha x opacity; staged texels are R,G,B,A whatever the source order ----
+            const float opacity = U[U_OPACITY];
+            const float af = opacity * U[U_FILL + 3], iaf = 1.f - af;
+            float fy, fu, fv;
+            rgb2yuv(U[U_FILL + 0] * af, U[U_FILL + 1] * af, U[U_FILL + 2] * af, fy, fu, fv);
+            const float fya = fy * af, fua = fu * af, fva = fv * af;
+            const float a = cur.cya, ia = 1.0f - a;
+            auto row = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
+                const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
+                const uint8_t *p0 = smem + ((int)ra.x + cur.cyo);
+                const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
+                const uint32_t u01 = ((const uint32_t *)(p0 + p0pitch))[0], u11 = ((const uint32_t *)(p0 + p0pitch))[1];
+                const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
+                const float r = mix4(w00, w10, w01, w11, T8k<0>(tab, u00), T8k<0>(tab, u10), T8k<0>(tab, u01), T8k<0>(tab, u11));
+                const float g = mix4(w00, w10, w01, w11, T8k<1>(tab, u00), T8k<1>(tab, u10), T8k<1>(tab, u01), T8k<1>(tab, u11));
+                const float bl = mix4(w00, w10, w01, w11, T8k<2>(tab, u00), T8k<2>(tab, u10), T8k<2>(tab, u01), T8k<2>(tab, u11));
+                const float q3 = mix4(w00, w10, w01, w11, T8k<3>(tab, u00), T8k<3>(tab, u10), T8k<3>(tab, u01), T8k<3>(tab, u11));
+                const float a2 = q3 * opacity, ia2 = 1.f - a2;
+                float yy, uu, vv;
+                rgb2yuv(r * a2, g * a2, bl * a2, yy, uu, vv);
+                uint32_t &lw = j < 4 ? ly0 : ly1;
+                const float rx = T8k<j & 3>(tab, lw) * iaf + fya;
+                lw = put_code<j & 3>(lw, rx * ia2 + yy * a2);
+                if constexpr ((j & 1) == 0) {
+                    if (owner_lane) {
+                        constexpr int jj = j >> 1;
+                        const float ry = clampf(T8k<jj>(tab, cu) * iaf + fua, -1.f, 1.f);
+                        const float rz = clampf(T8k<jj>(tab, cv) * iaf + fva, -1.f, 1.f);
+                        cu = put_code<jj>(cu, ry * ia2 + uu * a2);
+                        cv = put_code<jj>(cv, rz * ia2 + vv * a2);
+                    }
+                }
+            };
+            row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+            row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{}); row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
+        } else if (col_in) {
+            // ---- any other strip: the layer pixel by pixel, the general kernel's code (geometry per pixel, taps from global
+            //      memory); chroma of non-owner pixels is computed by the reference and never stored ----
+#pragma unroll 1
+            for (int j = 0; j < 8; j++) {
+                const int y = y0 + j;
+                if (y >= T.H) break;
+                const int sh = 8 * (j & 3);
+                const uint32_t lw = j < 4 ? ly0 : ly1;
+                uint32_t cy = (lw >> sh) & 255u;
+                const bool owner = owner_lane && (j & 1) == 0;
+                const int csh = 8 * (j >> 1);
+                uint32_t pu = owner ? (cu >> csh) & 255u : 0u, pv = owner ? (cv >> csh) & 255u : 0u;
+                if (Ly.kind == LK_YUV_FROM_RGB) apply_yuv_from_rgb(Ly, x, y, sx, sy, owner, cy, pu, pv);
+                else apply_yuv_from_yuv(Ly, x, y, sx, sy, owner, cy, pu, pv);
+                const uint32_t nw = (lw & ~(255u << sh)) | (cy << sh);
+                if (j < 4) ly0 = nw; else ly1 = nw;
+                if (owner) { cu = (cu & ~(255u << csh)) | (pu << csh); cv = (cv & ~(255u << csh)) | (pv << csh); }
+            }
+        }
+        wave_lds_fence();                 // the taps of layer l are read before the next layer's setup overwrites table and rectangles
+        l = ln;
+    }
+
+    if (col_in) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (y0 + j < T.H) gst<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x, (uint8_t)(((j < 4 ? ly0 : ly1) >> (8 * (j & 3))) & 255u));
+        if (owner_lane) {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                if (y0 + 2 * jj < T.H) {
+                    const uint32_t ub = (cu >> (8 * jj)) & 255u, vb = (cv >> (8 * jj)) & 255u;
+                    if (TF == TF_NV12) gst<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + (size_t)qx * 2, (uint16_t)(ub | (vb << 8)));
+                    else {
+                        gst<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + qx, (uint8_t)ub);
+                        gst<uint8_t>(PV.ptr + (size_t)(qy0 + jj) * PV.pitch + qx, (uint8_t)vb);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side: eligibility and launch of both wave kernels
+// ---------------------------------------------------------------------------
+static bool finite16w(const float *m) {
+    for (int i = 0; i < 16; i++) if (!(m[i] - m[i] == 0.f)) return false;
+    return true;
+}
+static bool aligned16w(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0 && p.w * p.comps >= 16; }
+static bool host_src_rgb(int kind) { return kind == LK_BGRA_FROM_RGB || kind == LK_YUV_FROM_RGB; }
+static bool host_src_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind == LK_YUV_FROM_Y420P; }
+static bool host_src_nv12(int kind) { return kind == LK_BGRA_FROM_NV12 || kind == LK_YUV_FROM_NV12; }
+
+struct WaveDims { int p0pitch, p0rows, p1pitch, p1rows; };
+
+// LDS rectangles one strip of this layer can touch, from the layer's scale factors
+static WaveDims wave_dims(const DTick &T, const DLayer &L) {
+    const float *U = L.u;
+    double sxr = std::fabs((double)U[U_TEXTURE + 0] * (double)U[U_TRANSFORM + 0] * 2.0 / (double)T.W);
+    double syr = std::fabs((double)U[U_TEXTURE + 5] * (double)U[U_TRANSFORM + 5] * 2.0 / (double)T.H);
+    WaveDims d{ 0, 0, 0, 0 };
+    const bool rgb = host_src_rgb(L.kind), planar = host_src_planar(L.kind);
+    const int bpt0 = rgb ? 4 : 1;
+    int span0 = (int)std::ceil(WTW * sxr * L.src.pl[0].w) + 4;           // texels incl. tap 1 and rounding slack
+    d.p0pitch = ((span0 * bpt0 + 15) / 16 + 3) * 16;                      // vectors + alignment + 2 pad vectors
+    d.p0rows = (int)std::ceil(WTH * syr * L.src.pl[0].h) + 3;
+    if (!rgb) {
+        const int bpt1 = planar ? 1 : 2;
+        int span1 = (int)std::ceil(WTW * sxr * L.src.pl[1].w) + 4;
+        d.p1pitch = ((span1 * bpt1 + 15) / 16 + 3) * 16;
+        d.p1rows = (int)std::ceil(WTH * syr * L.src.pl[1].h) + 3;
+    }
+    return d;
+}
+static size_t wave_lds(const WaveDims &d, bool planar, int target_format) {
+    return (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) +
+           (size_t)WAVES * ((size_t)ROWTAB_BYTES + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
+}
+
+bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
+    for (int i = 0; i < n_ticks; i++) {
+        const DTick &T = ticks[i];
+        if (T.n_layers < 1 || T.clear_first != ticks[0].clear_first) return false;
+        if (target_format == TF_BGRA) {
+            if (!aligned16w(T.dst.pl[0])) return false;
+        } else {
+            // 4:2:0: even canvas, chroma planes exactly half size (odd sizes, where gid/2 leaves the chroma plane, stay on the general kernel)
+            const int np = target_format == TF_NV12 ? 2 : 3;
+            if ((T.W & 1) || (T.H & 1) || T.dst.pl[0].w != T.W || T.dst.pl[0].h != T.H) return false;
+            for (int p = 1; p < np; p++) if (T.dst.pl[p].w != T.W / 2 || T.dst.pl[p].h != T.H / 2) return false;
+        }
+        for (int l = 0; l < T.n_layers; l++) {
+            const DLayer &L = layers[T.first_layer + l];
+            const bool rgb = host_src_rgb(L.kind), nv12 = host_src_nv12(L.kind), planar = host_src_planar(L.kind);
+            if (!(rgb || nv12 || planar) || !(L.flags & LF_AXIS_ALIGNED)) return false;
+            if (!finite16w(L.u + U_TRANSFORM) || !finite16w(L.u + U_TEXTURE) || !finite16w(L.u + U_BORDER)) return false;
+            const int np = rgb ? 1 : nv12 ? 2 : 3;
+            for (int p = 0; p < np; p++) if (!aligned16w(L.src.pl[p])) return false;
+            if (planar && (L.src.pl[2].w != L.src.pl[1].w || L.src.pl[2].h != L.src.pl[1].h)) return false;   // one staging geometry for U and V
+            if (wave_lds(wave_dims(T, L), planar, target_format) > (size_t)LDS_BUDGET) return false;
+        }
+    }
+    return true;
+}
+
+// kernels_wave.hip.cpp
+hipError_t launch_bgra_wave(bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
+                            int strips_x, int strips_y, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar);
+
+hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
+                              int n_ticks, int maxW, int maxH, hipStream_t stream) {
+    WaveDims m{ 0, 0, 0, 0 };
+    bool planar = false;
+    for (int i = 0; i < n_ticks; i++) {
+        for (int l = 0; l < ticks_host[i].n_layers; l++) {
+            const DLayer &L = layers_host[ticks_host[i].first_layer + l];
+            WaveDims d = wave_dims(ticks_host[i], L);
+            m.p0pitch = std::max(m.p0pitch, d.p0pitch); m.p0rows = std::max(m.p0rows, d.p0rows);
+            m.p1pitch = std::max(m.p1pitch, d.p1pitch); m.p1rows = std::max(m.p1rows, d.p1rows);
+            planar = planar || host_src_planar(L.kind);
+        }
+    }
+    size_t lds = wave_lds(m, planar, target_format);
+    if (lds > (size_t)LDS_BUDGET) {
+        // per-layer maxima combined exceed the budget: shrink the row counts; rectangles that do not fit fall back to
+        // unstaged taps inside the kernel
+        const size_t fixed = (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) + (size_t)WAVES * ROWTAB_BYTES;
+        const size_t per_row = (size_t)WAVES * ((size_t)m.p0pitch + (size_t)m.p1pitch * (planar ? 2 : 1));
+        int rows = std::max(1, (int)((LDS_BUDGET - fixed) / per_row));
+        m.p0rows = std::min(m.p0rows, rows); m.p1rows = std::min(m.p1rows, rows);
+        lds = wave_lds(m, planar, target_format);
+    }
+    int strips_x = (maxW + WTW - 1) / WTW, strips_y = (maxH + WTH - 1) / WTH;
+    long total = (long)n_ticks * strips_x * strips_y;
+    long per_xcd = (total + 7) / 8;
+    long blocks_per_xcd = (per_xcd + WAVES - 1) / WAVES;
+    dim3 grid((unsigned)(blocks_per_xcd * 8));
+    const bool clear = ticks_host[0].clear_first != 0;
+    if (target_format == TF_BGRA)
+        return launch_bgra_wave(clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0);
+#define CHV_LAUNCH_Y(TFV, C) hipLaunchKernelGGL((tick_yuv_wave<TFV, C>), grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
+                                                m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
+    if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_Y(TF_NV12, true); else CHV_LAUNCH_Y(TF_NV12, false); }
+    else { if (clear) CHV_LAUNCH_Y(TF_Y420P, true); else CHV_LAUNCH_Y(TF_Y420P, false); }
+#undef CHV_LAUNCH_Y
+    return hipGetLastError();
+}
+
+}  // namespace chv

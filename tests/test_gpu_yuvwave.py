@@ -1,0 +1,146 @@
+"""tick_yuv_wave — the reference's own kernels (img_nv12_nv12, img_y420p_nv12, img_y420p_y420p, img_{bgra,rgba}_{nv12,y420p},
+kernels.cl.swift:47-532) on 4:2:0 canvases, one wave per canvas strip — gives exactly the bytes of the oracle's clear +
+per-layer kernel calls (= the general quad kernel's): strips inside a picture (branch-free path), strips on picture / border
+edges and fill paint (per-pixel path), chroma ownership of the even/even pixel, un-cleared canvases, deep ticks."""
+import numpy as np
+import pytest
+
+import gpuutil as G
+import util
+from oracle import oracle as O
+from swiftvideo_amd import compute as sv
+
+pytestmark = pytest.mark.gpu
+
+
+def run_yuv_tick(ctx, d, cw, ch, clear, specs, seed=81, expect="wave"):
+    canvas0 = util.alloc_image(d, cw, ch, seed=seed)
+    exp = util.copy_image(canvas0)
+    if clear:
+        assert O.run_kernel(f"img_clear_{d}", exp) == 0
+    layers = []
+    for i, (k, sw, sh, kw) in enumerate(specs):
+        u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+        s = k.split("_")[1]
+        src = util.alloc_image(s, sw, sh, seed=seed + 9 + i)
+        assert O.run_kernel(k, exp, src, u, threads=4) == 0
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, 0))
+    gd = G.to_gpu(ctx, d, cw, ch, canvas0)
+    h, name, keep = G.make_batch(ctx, [(gd, clear, layers)])
+    if expect == "wave":
+        assert name == f"tick_yuv_wave<{d}>", name
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, d, cw, ch), exp, f"via {name}")
+    return name
+
+
+CASES = {
+    # name: (target, canvas w, h, clear_first, [(kernel, src w, h, make_uniforms kwargs)])
+    "nv12_copy":        ("nv12", 256, 64, True, [("img_nv12_nv12", 256, 64, dict())]),
+    "y420p_copy":       ("y420p", 256, 64, True, [("img_y420p_y420p", 256, 64, dict())]),
+    "y420p_to_nv12":    ("nv12", 256, 64, True, [("img_y420p_nv12", 256, 64, dict(opacity=0.7))]),
+    "nv12_down_1.5":    ("nv12", 320, 180, True, [("img_nv12_nv12", 480, 270, dict())]),
+    "y420p_down_1.5":   ("y420p", 320, 180, True, [("img_y420p_y420p", 480, 270, dict(opacity=0.5))]),
+    "nv12_up_3x":       ("nv12", 300, 90, True, [("img_nv12_nv12", 100, 30, dict(opacity=0.5))]),
+    "bgra_full":        ("nv12", 192, 64, True, [("img_bgra_nv12", 192, 64, dict())]),
+    "rgba_full_y420p":  ("y420p", 192, 64, True, [("img_rgba_y420p", 300, 100, dict(opacity=0.8, fill=(0.3, 0.8, 0.1, 0.6)))]),
+    "mixer":            ("y420p", 384, 216, True, [("img_y420p_y420p", 384, 216, dict()),
+                                                   ("img_bgra_y420p", 128, 72, dict(rect=(16, 16, 128, 72), opacity=0.8)),
+                                                   ("img_rgba_y420p", 128, 72, dict(rect=(240, 128, 128, 72), opacity=0.6, fill=(0.2, 0.9, 0.1, 0.5)))]),
+    "mixer_nv12":       ("nv12", 384, 216, True, [("img_nv12_nv12", 384, 216, dict()),
+                                                  ("img_bgra_nv12", 128, 72, dict(rect=(17, 15, 128, 72), opacity=0.8)),
+                                                  ("img_y420p_nv12", 128, 72, dict(rect=(241, 129, 130, 74), opacity=0.6, border=(4, 4, 4, 4), fill=(0.9, 0.2, 0.1, 0.8)))]),
+    "rect_border_fill": ("nv12", 260, 70, True, [("img_y420p_nv12", 96, 54, dict(rect=(33, 9, 180, 40), border=(5, 3, 7, 2), fill=(0.9, 0.2, 0.1, 0.6), opacity=0.8)),
+                                                 ("img_bgra_nv12", 50, 40, dict(rect=(-20, -10, 120, 60), fill=(0.1, 0.5, 0.9, 1.0), opacity=0.35)),
+                                                 ("img_nv12_nv12", 64, 64, dict(rect=(150, 5, 90, 60), tex=(0.25, 0.0, 0.5, 1.0), fill=(1, 1, 0, 1)))]),
+    "noclear":          ("y420p", 130, 38, False, [("img_y420p_y420p", 50, 20, dict(rect=(10, 5, 80, 30), opacity=0.5)),
+                                                   ("img_bgra_y420p", 50, 20, dict(rect=(60, 2, 60, 36)))]),
+    "noclear_full":     ("nv12", 192, 64, False, [("img_nv12_nv12", 192, 64, dict(opacity=0.4)), ("img_rgba_nv12", 192, 64, dict(opacity=0.5))]),
+    "flips":            ("nv12", 192, 40, True, [("img_nv12_nv12", 96, 54, dict(tex=(1.0, 0.0, -1.0, 1.0))),
+                                                 ("img_rgba_nv12", 96, 54, dict(tex=(0.2, 1.0, 0.5, -0.7), opacity=0.5))]),
+    "opacity_gt_1":     ("y420p", 128, 32, True, [("img_y420p_y420p", 128, 32, dict(opacity=1.7)), ("img_bgra_y420p", 128, 32, dict(opacity=-0.3))]),
+    "twelve_layers":    ("nv12", 128, 32, True, [("img_bgra_nv12" if i % 3 else "img_nv12_nv12", 64, 16, dict(rect=(4 * i, i, 64, 16), opacity=1.0 - 0.05 * i)) for i in range(12)]),
+    "odd_strip_edges":  ("y420p", 130, 22, True, [("img_y420p_y420p", 200, 60, dict()), ("img_rgba_y420p", 66, 34, dict(opacity=0.5))]),
+    "down_2.5":         ("nv12", 130, 50, True, [("img_nv12_nv12", 326, 124, dict()), ("img_bgra_nv12", 326, 124, dict(opacity=0.5))]),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_yuv_wave_matches_oracle(ctx, case):
+    d, cw, ch, clear, specs = CASES[case]
+    run_yuv_tick(ctx, d, cw, ch, clear, specs)
+
+
+@pytest.mark.parametrize("case", ["mixer", "rect_border_fill", "noclear", "flips"])
+def test_yuv_wave_equals_general_kernel(ctx, monkeypatch, case):
+    """the same tick through CHV_FORCE_GENERAL=1: both device paths are held to the same oracle bytes"""
+    monkeypatch.setenv("CHV_FORCE_GENERAL", "1")
+    d, cw, ch, clear, specs = CASES[case]
+    assert run_yuv_tick(ctx, d, cw, ch, clear, specs, expect=None) == f"tick_general_yuv<{d}>"
+
+
+def test_yuv_wave_fallbacks(ctx):
+    """odd canvas sizes (gid/2 leaves the chroma plane), rotated layers, sources too narrow to stage -> general quad kernel"""
+    assert run_yuv_tick(ctx, "nv12", 33, 17, True, [("img_bgra_nv12", 64, 36, dict())], expect=None) == "tick_general_yuv<nv12>"
+    assert run_yuv_tick(ctx, "y420p", 64, 36, True, [("img_y420p_y420p", 64, 36, dict(rect=(8, 4, 40, 24), rotation=0.3))], expect=None) == "tick_general_yuv<y420p>"
+    assert run_yuv_tick(ctx, "y420p", 64, 36, True, [("img_y420p_y420p", 24, 12, dict())], expect=None) == "tick_general_yuv<y420p>"
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_yuv_ticks(ctx, seed):
+    """Seeded random ticks on 4:2:0 canvases: 1..8 layers of random source kinds with random axis-aligned geometry, three ticks
+    of different (even) sizes per launch."""
+    rng = np.random.default_rng(11000 + seed)
+    d = "nv12" if seed % 2 == 0 else "y420p"
+    clear = bool(rng.integers(0, 2))
+    kinds = {"nv12": ["img_nv12_nv12", "img_y420p_nv12", "img_bgra_nv12", "img_rgba_nv12"],
+             "y420p": ["img_y420p_y420p", "img_bgra_y420p", "img_rgba_y420p"]}[d]
+    ticks, exps, gds = [], [], []
+    for t in range(3):
+        cw, ch = int(rng.integers(4, 165)) * 2, int(rng.integers(2, 70)) * 2
+        canvas0 = util.alloc_image(d, cw, ch, seed=int(rng.integers(1, 1 << 20)))
+        exp = util.copy_image(canvas0)
+        if clear:
+            assert O.run_kernel(f"img_clear_{d}", exp) == 0
+        layers = []
+        for l in range(int(rng.integers(1, 9))):
+            k = kinds[int(rng.integers(0, len(kinds)))]
+            s = k.split("_")[1]
+            sw, sh = int(rng.integers(16, 200)) * 2, int(rng.integers(2, 90)) * 2      # rows of >= 16 bytes in every plane
+            kw = {}
+            if rng.random() < 0.6:
+                kw["rect"] = (float(rng.uniform(-0.3, 0.6) * cw), float(rng.uniform(-0.3, 0.6) * ch),
+                              float(rng.uniform(0.2, 1.5) * cw), float(rng.uniform(0.2, 1.5) * ch))
+            if rng.random() < 0.3:
+                kw["border"] = tuple(float(v) for v in rng.uniform(0, 10, 4))
+            if rng.random() < 0.3:
+                kw["fill"] = tuple(float(v) for v in rng.uniform(0, 1, 4))
+            if rng.random() < 0.4:
+                kw["tex"] = (float(rng.uniform(0.0, 0.4)), float(rng.uniform(0.0, 0.4)),
+                             float(rng.uniform(0.3, 1.0)) * (1 if rng.random() < 0.8 else -1), float(rng.uniform(0.3, 1.0)))
+            kw["opacity"] = float(rng.choice([1.0, 1.0, rng.uniform(0, 1)]))
+            u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+            src = util.alloc_image(s, sw, sh, seed=int(rng.integers(1, 1 << 20)))
+            assert O.run_kernel(k, exp, src, u, threads=4) == 0
+            layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, 0))
+        gd = G.to_gpu(ctx, d, cw, ch, canvas0)
+        ticks.append((gd, clear, layers))
+        exps.append(exp)
+        gds.append((gd, cw, ch))
+    h, name, keep = G.make_batch(ctx, ticks)
+    assert name == f"tick_yuv_wave<{d}>", name
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    for i, ((gd, cw, ch), exp) in enumerate(zip(gds, exps)):
+        G.assert_same(G.from_gpu(ctx, gd, d, cw, ch), exp, f"seed {seed} tick {i} ({len(ticks[i][2])} layers) via {name}")
+
+
+@pytest.mark.parametrize("d", ["y420p", "nv12"])
+def test_reference_default_mixer_canvas_full_size(ctx, d):
+    """the bench's mixer workload at full size: 1080p 4:2:0 canvas <- full-canvas 1080p layer + two 640x360 BGRA overlays"""
+    cw, ch = 1920, 1080
+    specs = [(f"img_{d}_{d}", 1920, 1080, dict()),
+             (f"img_bgra_{d}", 640, 360, dict(rect=(64, 64, 640, 360), opacity=0.8)),
+             (f"img_bgra_{d}", 640, 360, dict(rect=(1200, 640, 640, 360), opacity=0.6))]
+    run_yuv_tick(ctx, d, cw, ch, True, specs, seed=0x5EED0000 + 64)
