@@ -1,24 +1,27 @@
 #!/bin/bash
-# profiles/collect_round.sh <rNN> — run on the GPU box (gpurun): the round's bench lines (with CPU baseline),
-# the rocprofv3 kernel-trace + PMC passes of the default workload, kernel-trace stats of the other workloads.
+# profiles/collect_round.sh <rNN> — run on the GPU box (gpurun): the round's default bench line (all workloads, CPU baseline),
+# rocprofv3 kernel-trace stats of that same command, and kernel-trace + separate PMC passes of the headline workload alone.
 # Everything lands under gpurun_out/<rNN>/; copy what should be judged into profiles/.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
-python bench.py > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
-python bench.py --workload cfg3 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
-python bench.py --workload cfg5 > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
-python bench.py --workload mixer_y420p --no-cpu-baseline > $OUT/bench_mixer_y420p.json 2> $OUT/bench_mixer.err
-python bench.py --workload cfg2_y420p --no-cpu-baseline > $OUT/bench_cfg2_y420p.json 2> $OUT/bench_cfg2_y420p.err
-CHV_FORCE_GENERAL=1 python bench.py --no-cpu-baseline > $OUT/bench_cfg2_general_kernel.json 2>/dev/null
-CHV_FORCE_GENERAL=1 python bench.py --workload cfg3 --no-cpu-baseline > $OUT/bench_cfg3_general_kernel.json 2>/dev/null
-bash profiles/run_profile.sh ${R}_cfg2 > /dev/null 2>&1
-python profiles/summarize.py gpurun_out/prof_${R}_cfg2 --pmc-json $OUT/pmc_latest.json --source profiles/${R}_cfg2_rocprofv3.txt > $OUT/cfg2_rocprofv3.txt 2>&1
 export TMPDIR=/tmp
-for w in cfg3 cfg5; do
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_$w/stats -o stats -- python $ROOT/bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline --no-verify > /dev/null 2>&1)
-  python profiles/summarize.py gpurun_out/prof_${R}_$w > $OUT/${w}_rocprofv3.txt 2>&1
-done
-tail -c 600 $OUT/bench_cfg2.json; echo; cat $OUT/cfg2_rocprofv3.txt | tail -5
+# 1. the default line, exactly as the driver runs it
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+# 2. kernel-trace stats of every workload's kernel (shorter timed regions: the profiler keeps every dispatch)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_all/stats -o stats -- python $ROOT/bench.py --no-cpu-baseline --no-verify --min-seconds 0.3 --min-seconds-other 0.15 --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> /dev/null)
+python profiles/summarize.py gpurun_out/prof_${R}_all > $OUT/all_workloads_rocprofv3.txt 2>&1
+# 3. the headline kernel alone: stats + PMC passes (each counter set in its own run, never combined with tracing beyond kernel-trace)
+bash profiles/run_profile.sh ${R}_pipeline --workload pipeline --also none --no-cpu-baseline --no-verify --steps 5 --warmup 2 --launches-per-step 1 > /dev/null 2>&1
+python profiles/summarize.py gpurun_out/prof_${R}_pipeline --kernel tick_bgra_wave --name tick_bgra_wave --workload pipeline --frames 256 \
+       --pmc-json $OUT/pmc_latest.json --source profiles/${R}_pipeline_rocprofv3.txt > $OUT/pipeline_rocprofv3.txt 2>&1
+# 4. the same for the reference's own kernels on their default canvas
+bash profiles/run_profile.sh ${R}_mixer --workload mixer_y420p --also none --no-cpu-baseline --no-verify --steps 5 --warmup 2 --launches-per-step 1 > /dev/null 2>&1
+python profiles/summarize.py gpurun_out/prof_${R}_mixer --kernel tick_yuv_wave > $OUT/mixer_y420p_rocprofv3.txt 2>&1
+# 5. A/B lines: general kernels, wave kernel on the single-purpose workloads
+for w in pipeline mixer_y420p cfg2; do CHV_FORCE_GENERAL=1 python bench.py --workload $w --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_${w}_general_kernel.json 2>/dev/null; done
+for w in cfg2 cfg3; do CHV_BGRA_PATH=wave python bench.py --workload $w --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_${w}_wave_kernel.json 2>/dev/null; done
+python bench.py --workload mixed --also y420p_main,mixer_nv12,cfg2_y420p --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_more_workloads.json 2>/dev/null
+tail -c 400 $OUT/bench_default.json; echo; tail -5 $OUT/pipeline_rocprofv3.txt

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
 
     // phase A: source rectangle -> LDS
     if (PREFETCH) {
-        touch_regs(pre);                 // the wait for the prefetch, on every path (see touch_regs)
+        touch_regs_volatile(pre);                 // the wait for the prefetch, on every path (see touch_regs)
         // block-uniform test: a rectangle inside the picture's columns needs no texel re-ordering
         if (col0 >= 0 && col0 + 4 * nvec <= src.w) {
 #pragma unroll

@@ -48,7 +48,7 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
 }
 
 #ifndef CHV_WAVE_MINW
-#define CHV_WAVE_MINW 5
+#define CHV_WAVE_MINW 6
 #endif
 // CHV_WAVE_FENCE = n > 0: keep the scheduler from interleaving more than n rows of a lane's pixels in the branch-free loops
 // (fewer live temporaries)
@@ -56,13 +56,19 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
 #define CHV_WAVE_FENCE 0
 #endif
 #define WAVE_ROW_FENCE(j) do { if (CHV_WAVE_FENCE > 0 && (j) > 0 && (j) % (CHV_WAVE_FENCE > 0 ? CHV_WAVE_FENCE : 1) == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef CHV_WAVE_ROWS
+#define CHV_WAVE_ROWS 8
+#endif
+constexpr int WTH = CHV_WAVE_ROWS;
+static_assert(WTH == 8, "kernels_wave_yuv.hip.cpp sizes the BGRA launch for 8-row strips (BGRA_WTH)");      // strip height: rows per lane (16: -14 % on the 4 x NV12 pipeline at 128 VGPRs, but the LDS
+                                        // footprint of 4-byte texel rectangles then halves the occupancy of mixed ticks: 3.0 vs 0.85 ms)
 template <bool CLEAR>
-__global__ __launch_bounds__(NTHREADS, CHV_WAVE_MINW) void tick_bgra_wave(const DTick *__restrict__ ticks,
+__global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVE_MINW) void tick_bgra_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
-    WaveStrip S;
+    WaveStrip<WTH> S;
     if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, smem_all, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;   // (no block barrier anywhere: waves may leave)
     const DTick &T = *S.T;
     const DLayer *L = S.L;
@@ -85,14 +91,16 @@ __global__ __launch_bounds__(NTHREADS, CHV_WAVE_MINW) void tick_bgra_wave(const 
     }
 
     WLayer cur;
-    int l = S.next_hit(0);
+    // (the layer index is wave-uniform; saying so keeps the descriptor reads on the scalar unit: left to its divergence analysis
+    // the compiler fetched every uniform of a layer with per-lane global loads — 90 vector loads per wave)
+    int l = __builtin_amdgcn_readfirstlane(S.next_hit(0));
 
     while (l < nl) {
         const DLayer &Ly = L[l];
         S.setup(l, cur);                  // (overwrites the row table: the previous layer's pixels are done)
         if (cur.staged) S.stage(l, cur);
         wave_lds_fence();
-        const int ln = S.next_hit(l + 1);
+        const int ln = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
 
         {
             const float *U = Ly.u;
@@ -247,10 +255,10 @@ __global__ __launch_bounds__(NTHREADS, CHV_WAVE_MINW) void tick_bgra_wave(const 
 hipError_t launch_bgra_wave(bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
                             int strips_x, int strips_y, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar) {
     if (clear)
-        hipLaunchKernelGGL(tick_bgra_wave<true>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, strips_x, strips_y,
+        hipLaunchKernelGGL(tick_bgra_wave<true>, grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y,
                            p0pitch, p0rows, p1pitch, p1rows, planar);
     else
-        hipLaunchKernelGGL(tick_bgra_wave<false>, grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, strips_x, strips_y,
+        hipLaunchKernelGGL(tick_bgra_wave<false>, grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y,
                            p0pitch, p0rows, p1pitch, p1rows, planar);
     return hipGetLastError();
 }

@@ -10,8 +10,8 @@
 //     (kernels.cl.swift:76) — so even lanes carry (u, v) codes for the even rows;
 //   * column entries in registers, row entries in the wave's LDS table, source rectangles staged wave-privately as bytes
 //     (wave_common.hip.h); strips of one frame on one XCD;
-//   * UNORM8 loads (c / 255, correctly rounded: OpenCL 1.2 section 8.3.1.1) come out of a 256-entry LDS table instead of
-//     three VALU instructions per tap; every sum keeps the reference's order and roundings (no contraction);
+//   * UNORM8 loads are c / 255 correctly rounded (OpenCL 1.2 section 8.3.1.1; two-term product, pixel_math.hip.h), every sum
+//     keeps the reference's order and roundings (no contraction);
 //   * strips that lie entirely inside a layer's picture run branch-free; every other strip (picture or border edges, fill
 //     paint, unstaged rectangles) applies the layer pixel by pixel with the general kernel's own code (yuv_pixel.hip.h).
 // Bytes: those of kernels_general.hip.cpp = oracle/ref_kernels.c (px_yuv_to_yuv, px_rgb_to_yuv), layer by layer.
@@ -27,8 +27,11 @@
 
 namespace chv {
 
+// CHV_UNORM_TABLE = 1: UNORM8 loads through a 256-entry LDS table (one shift + one LDS read per tap instead of three VALU
+// instructions).  Measured and left off: on uncorrelated bytes the lookups collide in the LDS banks (SQ_LDS_BANK_CONFLICT
+// 3.8 M -> 93 M cycles per launch) and the launch is 3 % slower than with the arithmetic form (profiles/r02_notes.md).
 #ifndef CHV_UNORM_TABLE
-#define CHV_UNORM_TABLE 1
+#define CHV_UNORM_TABLE 0
 #endif
 constexpr int UNORM_TAB_BYTES = 1024;          // float[256] at the start of the block's LDS
 
@@ -62,26 +65,42 @@ CHV_DEV uint32_t put_code(uint32_t w, float f) {
     if (K == 3) asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(w) : "v"(v));
     return w;
 }
+// row(integral_constant<int, j>) for j = 0 .. YTH - 1, in order (the row index is a compile-time constant in the body: byte
+// positions of the packed canvas codes are immediates)
+template <typename F, int... J>
+CHV_DEV void for_each_row_impl(F &f, std::integer_sequence<int, J...>) { (f(std::integral_constant<int, J>{}), ...); }
+template <int N, typename F>
+CHV_DEV void for_rows(F &f) { for_each_row_impl(f, std::make_integer_sequence<int, N>{}); }
+
 CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float t10, float t01, float t11) {
     return ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;      // lin_mix's order (OpenCL 1.2 section 8.2)
 }
 
 #ifndef CHV_WAVEY_MINW
-#define CHV_WAVEY_MINW 5
+#define CHV_WAVEY_MINW 6
 #endif
+// Strip height on 4:2:0 canvases.  A strip's fixed costs (index arithmetic, per-layer geometry, staging, stores: ~430 VALU
+// instructions) exceed the pixel work of one opaque layer over 64 x 8 pixels (~300); 16-row strips (the canvas codes pack
+// four to a register, so they cost only 4 more registers) execute 12 % fewer instructions per pixel — and measure 30 %
+// SLOWER (y420p_main 1.12 vs 0.86 ms per 128 ticks: 5 instead of 6 waves per SIMD, and twice as many strips of an overlay
+// straddle its edges and take the per-pixel path).  8 it is.
+#ifndef CHV_WAVEY_ROWS
+#define CHV_WAVEY_ROWS 8
+#endif
+constexpr int YTH = CHV_WAVEY_ROWS;
+constexpr int YLW = YTH / 4, YCW = YTH / 8;      // registers: luma rows (4 per register), chroma rows (YTH / 2, 4 per register)
 template <int TF, bool CLEAR>
-__global__ __launch_bounds__(NTHREADS, CHV_WAVEY_MINW) void tick_yuv_wave(const DTick *__restrict__ ticks,
+__global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
-    static_assert(WTH == 8, "canvas packing below: 8 luma rows = 2 registers, 4 chroma rows = 1 register per component");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     float *tab = (float *)smem_all;
 #if CHV_UNORM_TABLE
-    if (threadIdx.x < 256) tab[threadIdx.x] = unorm8((uint32_t)threadIdx.x);
+    for (int i = threadIdx.x; i < 256; i += WAVE_BLOCK) tab[i] = unorm8((uint32_t)i);
     __syncthreads();                      // the only block barrier, before any wave leaves
 #endif
-    WaveStrip S;
+    WaveStrip<YTH> S;
     if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, smem_all + UNORM_TAB_BYTES, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;
     const DTick &T = *S.T;
     const DLayer *L = S.L;
@@ -95,23 +114,25 @@ __global__ __launch_bounds__(NTHREADS, CHV_WAVEY_MINW) void tick_yuv_wave(const 
     const DPlane &PV = T.dst.pl[TF == TF_Y420P ? 2 : 1];
     const float sx = S.sx, sy = S.sy;
 
-    // ---- canvas codes of this lane: luma rows 0..3 in ly0, 4..7 in ly1 (byte = row & 3); even lanes: chroma rows 0..3 of
-    //      the strip (canvas rows y0/2 ..) in cu / cv -------------------------------------------------------------------------
+    // ---- canvas codes of this lane: luma row j in byte j & 3 of ly[j >> 2]; even lanes: chroma row jj (canvas row y0/2 + jj)
+    //      of the strip in byte jj & 3 of cu / cv[jj >> 2] ---------------------------------------------------------------------
     const bool owner_lane = (x & 1) == 0 && col_in;          // (canvas sizes are even on this path: host-checked)
     const int qx = x >> 1, qy0 = y0 >> 1;
-    uint32_t ly0 = 0, ly1 = 0, cu = 0x80808080u, cv = 0x80808080u;     // img_clear_*: Y = 0.0, chroma = 0.5 -> 128 (RTE)
+    uint32_t ly[YLW], cu[YCW], cv[YCW];
+#pragma unroll
+    for (int k = 0; k < YLW; k++) ly[k] = 0;                               // img_clear_*: Y = 0.0
+#pragma unroll
+    for (int k = 0; k < YCW; k++) { cu[k] = 0x80808080u; cv[k] = 0x80808080u; }   // chroma = 0.5 -> 128 (RTE)
     if (!CLEAR && col_in) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (y0 + j < T.H) {
-                const uint32_t b = gld<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x);
-                if (j < 4) ly0 |= b << (8 * j); else ly1 |= b << (8 * (j - 4));
-            }
+        for (int j = 0; j < YTH; j++) {
+            if (y0 + j < T.H) ly[j >> 2] |= (uint32_t)gld<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x) << (8 * (j & 3));
         }
         if (owner_lane) {
-            cu = 0; cv = 0;
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
+            for (int k = 0; k < YCW; k++) { cu[k] = 0; cv[k] = 0; }
+#pragma unroll
+            for (int jj = 0; jj < YTH / 2; jj++) {
                 if (y0 + 2 * jj < T.H) {
                     uint32_t ub, vb;
                     if (TF == TF_NV12) {
@@ -121,21 +142,23 @@ __global__ __launch_bounds__(NTHREADS, CHV_WAVEY_MINW) void tick_yuv_wave(const 
                         ub = gld<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + qx);
                         vb = gld<uint8_t>(PV.ptr + (size_t)(qy0 + jj) * PV.pitch + qx);
                     }
-                    cu |= ub << (8 * jj); cv |= vb << (8 * jj);
+                    cu[jj >> 2] |= ub << (8 * (jj & 3)); cv[jj >> 2] |= vb << (8 * (jj & 3));
                 }
             }
         }
     }
 
     WLayer cur;
-    int l = S.next_hit(0);
+    // (the layer index is wave-uniform; saying so keeps the descriptor reads on the scalar unit: left to its divergence analysis
+    // the compiler fetched every uniform of a layer with per-lane global loads — 90 vector loads per wave)
+    int l = __builtin_amdgcn_readfirstlane(S.next_hit(0));
     while (l < nl) {
         const DLayer &Ly = L[l];
         S.setup(l, cur);                  // (overwrites the row table: the previous layer's pixels are done)
         const bool fast = cur.staged && cur.all_inside;
         if (fast) S.stage(l, cur);
         wave_lds_fence();
-        const int ln = S.next_hit(l + 1);
+        const int ln = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
         const float *U = Ly.u;
 
         if (fast && Ly.kind != LK_YUV_FROM_RGB) {
@@ -150,7 +173,7 @@ __global__ __launch_bounds__(NTHREADS, CHV_WAVEY_MINW) void tick_yuv_wave(const 
                     const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
                     const uint8_t *py = smem + ((int)ra.x + cur.cyo);
                     const float luma = mix4(ia * ib, a * ib, ia * b, a * b, T8(tab, py[0]), T8(tab, py[1]), T8(tab, py[p0pitch]), T8(tab, py[p0pitch + 1]));
-                    uint32_t &lw = j < 4 ? ly0 : ly1;
+                    uint32_t &lw = ly[j >> 2];
                     // opacity == 1: cur * 0 + luma * 1 = luma exactly
                     const float v = OP ? luma : T8k<j & 3>(tab, lw) * ialpha + luma * alpha;
                     lw = put_code<j & 3>(lw, v);
@@ -169,13 +192,13 @@ __global__ __launch_bounds__(NTHREADS, CHV_WAVEY_MINW) void tick_yuv_wave(const 
                                 fv = mix4(c00, c10, c01, c11, T8(tab, pc[1]), T8(tab, pc[3]), T8(tab, pc[p1pitch + 1]), T8(tab, pc[p1pitch + 3]));
                             }
                             constexpr int jj = j >> 1;
-                            cu = put_code<jj>(cu, OP ? fu : T8k<jj>(tab, cu) * ialpha + fu * alpha);
-                            cv = put_code<jj>(cv, OP ? fv : T8k<jj>(tab, cv) * ialpha + fv * alpha);
+                            uint32_t &uw = cu[jj >> 2], &vw = cv[jj >> 2];
+                            uw = put_code<jj & 3>(uw, OP ? fu : T8k<jj & 3>(tab, uw) * ialpha + fu * alpha);
+                            vw = put_code<jj & 3>(vw, OP ? fv : T8k<jj & 3>(tab, vw) * ialpha + fv * alpha);
                         }
                     }
                 };
-                row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
-                row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{}); row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
+                for_rows<YTH>(row);
             };
             const bool planar = Ly.kind == LK_YUV_FROM_Y420P, opaque = (Ly.flags & LF_OPAQUE) != 0;
             if (planar) { if (opaque) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
@@ -204,39 +227,47 @@ __global__ __launch_bounds__(NTHREADS, CHV_WAVEY_MINW) void tick_yuv_wave(const 
                 const float a2 = q3 * opacity, ia2 = 1.f - a2;
                 float yy, uu, vv;
                 rgb2yuv(r * a2, g * a2, bl * a2, yy, uu, vv);
-                uint32_t &lw = j < 4 ? ly0 : ly1;
+                uint32_t &lw = ly[j >> 2];
                 const float rx = T8k<j & 3>(tab, lw) * iaf + fya;
                 lw = put_code<j & 3>(lw, rx * ia2 + yy * a2);
                 if constexpr ((j & 1) == 0) {
                     if (owner_lane) {
                         constexpr int jj = j >> 1;
-                        const float ry = clampf(T8k<jj>(tab, cu) * iaf + fua, -1.f, 1.f);
-                        const float rz = clampf(T8k<jj>(tab, cv) * iaf + fva, -1.f, 1.f);
-                        cu = put_code<jj>(cu, ry * ia2 + uu * a2);
-                        cv = put_code<jj>(cv, rz * ia2 + vv * a2);
+                        uint32_t &uw = cu[jj >> 2], &vw = cv[jj >> 2];
+                        const float ry = clampf(T8k<jj & 3>(tab, uw) * iaf + fua, -1.f, 1.f);
+                        const float rz = clampf(T8k<jj & 3>(tab, vw) * iaf + fva, -1.f, 1.f);
+                        uw = put_code<jj & 3>(uw, ry * ia2 + uu * a2);
+                        vw = put_code<jj & 3>(vw, rz * ia2 + vv * a2);
                     }
                 }
             };
-            row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
-            row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{}); row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
+            for_rows<YTH>(row);
         } else if (col_in) {
             // ---- any other strip: the layer pixel by pixel, the general kernel's code (geometry per pixel, taps from global
             //      memory); chroma of non-owner pixels is computed by the reference and never stored ----
 #pragma unroll 1
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < YTH; j++) {
                 const int y = y0 + j;
                 if (y >= T.H) break;
-                const int sh = 8 * (j & 3);
-                const uint32_t lw = j < 4 ? ly0 : ly1;
+                const int sh = 8 * (j & 3), csh = 8 * ((j >> 1) & 3);
+                uint32_t lw = ly[0], uw = cu[0], vw = cv[0];
+#pragma unroll
+                for (int k = 1; k < YLW; k++) lw = (j >> 2) == k ? ly[k] : lw;
+#pragma unroll
+                for (int k = 1; k < YCW; k++) { uw = (j >> 3) == k ? cu[k] : uw; vw = (j >> 3) == k ? cv[k] : vw; }
                 uint32_t cy = (lw >> sh) & 255u;
                 const bool owner = owner_lane && (j & 1) == 0;
-                const int csh = 8 * (j >> 1);
-                uint32_t pu = owner ? (cu >> csh) & 255u : 0u, pv = owner ? (cv >> csh) & 255u : 0u;
+                uint32_t pu = owner ? (uw >> csh) & 255u : 0u, pv = owner ? (vw >> csh) & 255u : 0u;
                 if (Ly.kind == LK_YUV_FROM_RGB) apply_yuv_from_rgb(Ly, x, y, sx, sy, owner, cy, pu, pv);
                 else apply_yuv_from_yuv(Ly, x, y, sx, sy, owner, cy, pu, pv);
-                const uint32_t nw = (lw & ~(255u << sh)) | (cy << sh);
-                if (j < 4) ly0 = nw; else ly1 = nw;
-                if (owner) { cu = (cu & ~(255u << csh)) | (pu << csh); cv = (cv & ~(255u << csh)) | (pv << csh); }
+                lw = (lw & ~(255u << sh)) | (cy << sh);
+#pragma unroll
+                for (int k = 0; k < YLW; k++) ly[k] = (j >> 2) == k ? lw : ly[k];
+                if (owner) {
+                    uw = (uw & ~(255u << csh)) | (pu << csh); vw = (vw & ~(255u << csh)) | (pv << csh);
+#pragma unroll
+                    for (int k = 0; k < YCW; k++) { cu[k] = (j >> 3) == k ? uw : cu[k]; cv[k] = (j >> 3) == k ? vw : cv[k]; }
+                }
             }
         }
         wave_lds_fence();                 // the taps of layer l are read before the next layer's setup overwrites table and rectangles
@@ -245,13 +276,13 @@ __global__ __launch_bounds__(NTHREADS, CHV_WAVEY_MINW) void tick_yuv_wave(const 
 
     if (col_in) {
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (y0 + j < T.H) gst<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x, (uint8_t)(((j < 4 ? ly0 : ly1) >> (8 * (j & 3))) & 255u));
+        for (int j = 0; j < YTH; j++)
+            if (y0 + j < T.H) gst<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x, (uint8_t)((ly[j >> 2] >> (8 * (j & 3))) & 255u));
         if (owner_lane) {
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
+            for (int jj = 0; jj < YTH / 2; jj++) {
                 if (y0 + 2 * jj < T.H) {
-                    const uint32_t ub = (cu >> (8 * jj)) & 255u, vb = (cv >> (8 * jj)) & 255u;
+                    const uint32_t ub = (cu[jj >> 2] >> (8 * (jj & 3))) & 255u, vb = (cv[jj >> 2] >> (8 * (jj & 3))) & 255u;
                     if (TF == TF_NV12) gst<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + (size_t)qx * 2, (uint16_t)(ub | (vb << 8)));
                     else {
                         gst<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + qx, (uint8_t)ub);
@@ -276,9 +307,11 @@ static bool host_src_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kin
 static bool host_src_nv12(int kind) { return kind == LK_BGRA_FROM_NV12 || kind == LK_YUV_FROM_NV12; }
 
 struct WaveDims { int p0pitch, p0rows, p1pitch, p1rows; };
+constexpr int BGRA_WTH = 8;      // = WTH of kernels_wave.hip.cpp (static_assert there)
+static int strip_rows(int target_format) { return target_format == TF_BGRA ? BGRA_WTH : YTH; }
 
 // LDS rectangles one strip of this layer can touch, from the layer's scale factors
-static WaveDims wave_dims(const DTick &T, const DLayer &L) {
+static WaveDims wave_dims(const DTick &T, const DLayer &L, int WTH) {
     const float *U = L.u;
     double sxr = std::fabs((double)U[U_TEXTURE + 0] * (double)U[U_TRANSFORM + 0] * 2.0 / (double)T.W);
     double syr = std::fabs((double)U[U_TEXTURE + 5] * (double)U[U_TRANSFORM + 5] * 2.0 / (double)T.H);
@@ -298,7 +331,7 @@ static WaveDims wave_dims(const DTick &T, const DLayer &L) {
 }
 static size_t wave_lds(const WaveDims &d, bool planar, int target_format) {
     return (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) +
-           (size_t)WAVES * ((size_t)ROWTAB_BYTES + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
+           (size_t)WAVES * ((size_t)strip_rows(target_format) * 32 + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
 }
 
 bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
@@ -321,7 +354,7 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
             const int np = rgb ? 1 : nv12 ? 2 : 3;
             for (int p = 0; p < np; p++) if (!aligned16w(L.src.pl[p])) return false;
             if (planar && (L.src.pl[2].w != L.src.pl[1].w || L.src.pl[2].h != L.src.pl[1].h)) return false;   // one staging geometry for U and V
-            if (wave_lds(wave_dims(T, L), planar, target_format) > (size_t)LDS_BUDGET) return false;
+            if (wave_lds(wave_dims(T, L, strip_rows(target_format)), planar, target_format) > (size_t)LDS_BUDGET) return false;
         }
     }
     return true;
@@ -338,7 +371,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     for (int i = 0; i < n_ticks; i++) {
         for (int l = 0; l < ticks_host[i].n_layers; l++) {
             const DLayer &L = layers_host[ticks_host[i].first_layer + l];
-            WaveDims d = wave_dims(ticks_host[i], L);
+            WaveDims d = wave_dims(ticks_host[i], L, strip_rows(target_format));
             m.p0pitch = std::max(m.p0pitch, d.p0pitch); m.p0rows = std::max(m.p0rows, d.p0rows);
             m.p1pitch = std::max(m.p1pitch, d.p1pitch); m.p1rows = std::max(m.p1rows, d.p1rows);
             planar = planar || host_src_planar(L.kind);
@@ -348,12 +381,13 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     if (lds > (size_t)LDS_BUDGET) {
         // per-layer maxima combined exceed the budget: shrink the row counts; rectangles that do not fit fall back to
         // unstaged taps inside the kernel
-        const size_t fixed = (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) + (size_t)WAVES * ROWTAB_BYTES;
+        const size_t fixed = (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) + (size_t)WAVES * strip_rows(target_format) * 32;
         const size_t per_row = (size_t)WAVES * ((size_t)m.p0pitch + (size_t)m.p1pitch * (planar ? 2 : 1));
         int rows = std::max(1, (int)((LDS_BUDGET - fixed) / per_row));
         m.p0rows = std::min(m.p0rows, rows); m.p1rows = std::min(m.p1rows, rows);
         lds = wave_lds(m, planar, target_format);
     }
+    const int WTH = strip_rows(target_format);
     int strips_x = (maxW + WTW - 1) / WTW, strips_y = (maxH + WTH - 1) / WTH;
     long total = (long)n_ticks * strips_x * strips_y;
     long per_xcd = (total + 7) / 8;
@@ -362,7 +396,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     const bool clear = ticks_host[0].clear_first != 0;
     if (target_format == TF_BGRA)
         return launch_bgra_wave(clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0);
-#define CHV_LAUNCH_Y(TFV, C) hipLaunchKernelGGL((tick_yuv_wave<TFV, C>), grid, dim3(NTHREADS), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
+#define CHV_LAUNCH_Y(TFV, C) hipLaunchKernelGGL((tick_yuv_wave<TFV, C>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                 m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
     if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_Y(TF_NV12, true); else CHV_LAUNCH_Y(TF_NV12, false); }
     else { if (clear) CHV_LAUNCH_Y(TF_Y420P, true); else CHV_LAUNCH_Y(TF_Y420P, false); }

@@ -46,8 +46,18 @@ CHV_DEV void gst_stream(void *p, uint32_t v) { __builtin_nontemporal_store(v, (C
 // (staged? lane owns a slot?) the registers stay "maybe pending" on the paths that skip the use, and every load
 // of the NEXT prefetch then gets `s_waitcnt vmcnt(0)` in front of it, which serialises the loads.  A use on
 // every path, right where the wait belongs anyway, settles it.
+// The asm has outputs ("+v") and is NOT volatile on purpose: an `asm volatile` (and any asm without outputs is
+// implicitly volatile) counts as a possible write to memory, after which the compiler no longer proves the tick / layer
+// descriptors unclobbered and reads every uniform of a layer with per-lane global loads instead of scalar loads
+// (tick_yuv_wave: 90 vector loads per wave, profiles/r02_notes.md).
 template <int N>
-CHV_DEV void touch_regs(const uint4 (&regs)[N]) {
+CHV_DEV void touch_regs(uint4 (&regs)[N]) {
+#pragma unroll
+    for (int n = 0; n < N; n++) asm("" : "+v"(regs[n].x), "+v"(regs[n].y), "+v"(regs[n].z), "+v"(regs[n].w));
+}
+// the volatile, input-only form (kernels that read no descriptors after it: it constrains the register allocator less)
+template <int N>
+CHV_DEV void touch_regs_volatile(const uint4 (&regs)[N]) {
 #pragma unroll
     for (int n = 0; n < N; n++) asm volatile("" :: "v"(regs[n].x), "v"(regs[n].y), "v"(regs[n].z), "v"(regs[n].w));
 }

@@ -9,25 +9,34 @@
 
 namespace chv {
 
-#ifndef CHV_WAVE_ROWS
-#define CHV_WAVE_ROWS 8
-#endif
 constexpr int WTW = 64;                 // strip width: one lane per column
-constexpr int WTH = CHV_WAVE_ROWS;      // strip height: rows per lane
+// Waves per block.  The waves of a block share nothing but the launch (every wave has its own LDS region and there is no block
+// barrier on the data path), so the block size only sets the granularity at which LDS is handed out.
+#ifndef CHV_WAVE_WAVES
+#define CHV_WAVE_WAVES 4
+#endif
+constexpr int WAVES = CHV_WAVE_WAVES;
+constexpr int WAVE_BLOCK = WAVES * 64;
+// Per strip height H (rows per lane; 8 for BGRA canvases, 16 for 4:2:0 canvases whose codes pack four to a register):
 // staging registers (16-byte vectors) per lane, 64 slots each, sized for the rectangles of a 1.5x downscale (YUV) / of a
-// native-resolution picture (RGB); larger rectangles finish through the on-the-spot tail of wstage_store:
+// native-resolution picture (RGB); larger rectangles finish through wstage_tail:
 //   RGB layer: [0 .. WN_RGB) plane 0;   YUV layer: [0 .. WN_Y) luma, then WN_C for chroma / U, then WN_C for V (planar)
-constexpr int WN_Y = WTH / 4, WN_C = WTH / 8, WN_RGB = WTH / 4 + 1;
-constexpr int WNR = (WN_RGB > WN_Y + 2 * WN_C) ? WN_RGB : (WN_Y + 2 * WN_C);
-static_assert(WTH == 8 || WTH == 16, "strip height: 8 or 16 rows");
-constexpr int WAVES = NTHREADS / 64;
-constexpr int ROWTAB_BYTES = WTH * 32;  // per wave: the current layer's row entries, 8 dwords per row
+template <int H>
+struct WaveCfg {
+    static_assert(H == 8 || H == 16, "strip height: 8 or 16 rows");
+    static constexpr int WN_Y = H / 4, WN_C = H / 8, WN_RGB = H / 4 + 1;
+    static constexpr int WNR = (WN_RGB > WN_Y + 2 * WN_C) ? WN_RGB : (WN_Y + 2 * WN_C);
+    static constexpr int ROWTAB_BYTES = H * 32;     // per wave: the current layer's row entries, 8 dwords per row
+};
 
 // ---- wave-level helpers ---------------------------------------------------------------------------------------
 CHV_DEV void wave_lds_fence() {
-    // the wave's own LDS writes are visible to its later reads (LDS operations of a wave execute in order); this only
-    // keeps the compiler from moving accesses across the point
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // The wave's own LDS writes are visible to its later reads (LDS operations of a wave execute in order); this only keeps
+    // the compiler from moving LDS accesses across the point.  The fence names the LDS address space: a fence over all
+    // memory makes every later read of the (read-only, uniform) tick and layer descriptors "possibly clobbered", and the
+    // compiler then fetches them with per-lane global loads instead of scalar loads — 90 vector loads per wave and
+    // +35 % run time on the 4:2:0 mixer workload (profiles/r02_notes.md).
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
 }
 CHV_DEV int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -64,8 +73,8 @@ struct WLayer {
 //                              unclamped tap-0 row positions), flags
 //   B = {yb, 1 - yb, cb, 1 - cb}: weights of tap row 1 (luma / RGB, chroma) and their complements
 
-template <int OFF, int N>
-CHV_DEV void wstage_load(uint4 (&regs)[WNR], const DPlane &P, const StageGeom &g, int lane) {
+template <int OFF, int N, int NR>
+CHV_DEV void wstage_load(uint4 (&regs)[NR], const DPlane &P, const StageGeom &g, int lane) {
     // exactly one global_load_dwordx4 per slot, straight into its final register (see stage_load, tile_common.hip.h)
 #pragma unroll
     for (int n = 0; n < N; n++) {
@@ -99,8 +108,8 @@ CHV_DEV void wstage_put(uint4 val, int i, uint8_t *lds, int lds_pitch, const DPl
         *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
     }
 }
-template <int BPT, int OFF, int N>
-CHV_DEV void wstage_store(const uint4 (&regs)[WNR], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int lane, bool swap02) {
+template <int BPT, int OFF, int N, int NR>
+CHV_DEV void wstage_store(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int lane, bool swap02) {
 #pragma unroll
     for (int n = 0; n < N; n++) wstage_put<BPT>(regs[OFF + n], lane + n * 64, lds, lds_pitch, P, g, swap02);
 }
@@ -140,7 +149,10 @@ CHV_DEV bool src_is_rgb(int kind) { return kind == LK_BGRA_FROM_RGB || kind == L
 CHV_DEV bool src_is_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind == LK_YUV_FROM_Y420P; }
 
 // One wave's strip of one tick: WTW columns (lane = column) x WTH rows of the canvas.
+template <int WTH>
 struct WaveStrip {
+    using Cfg = WaveCfg<WTH>;
+    static constexpr int WN_Y = Cfg::WN_Y, WN_C = Cfg::WN_C, WN_RGB = Cfg::WN_RGB, WNR = Cfg::WNR, ROWTAB_BYTES = Cfg::ROWTAB_BYTES;
     const DTick *T;
     const DLayer *L;
     int nl;
@@ -275,28 +287,28 @@ struct WaveStrip {
         const DLayer &Ly = L[l];
         uint4 regs[WNR];
         if (src_is_rgb(Ly.kind)) {
-            wstage_load<0, WN_RGB>(regs, Ly.src.pl[0], w.g0, lane);
+            wstage_load<0, WN_RGB, WNR>(regs, Ly.src.pl[0], w.g0, lane);
             touch_regs(regs);             // one wait for all of the layer's loads (see touch_regs, pixel_math.hip.h)
             // staged texels are byte-swapped where the layer asks for it (RGBA source on a BGRA canvas: -> BGRA; BGRA source on a
             // 4:2:0 canvas, kernels.cl.swift:518 `.zyxw`: -> RGBA), so the tap loops need no channel select
-            wstage_store<4, 0, WN_RGB>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
+            wstage_store<4, 0, WN_RGB, WNR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
             wstage_tail<4, WN_RGB>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
         } else if (!src_is_planar(Ly.kind)) {
-            wstage_load<0, WN_Y>(regs, Ly.src.pl[0], w.g0, lane);
-            wstage_load<WN_Y, WN_C>(regs, Ly.src.pl[1], w.g1, lane);
+            wstage_load<0, WN_Y, WNR>(regs, Ly.src.pl[0], w.g0, lane);
+            wstage_load<WN_Y, WN_C, WNR>(regs, Ly.src.pl[1], w.g1, lane);
             touch_regs(regs);
-            wstage_store<1, 0, WN_Y>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_store<2, WN_Y, WN_C>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
+            wstage_store<1, 0, WN_Y, WNR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
+            wstage_store<2, WN_Y, WN_C, WNR>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
             wstage_tail<1, WN_Y>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
             wstage_tail<2, WN_C>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
         } else {
-            wstage_load<0, WN_Y>(regs, Ly.src.pl[0], w.g0, lane);
-            wstage_load<WN_Y, WN_C>(regs, Ly.src.pl[1], w.g1, lane);
-            wstage_load<WN_Y + WN_C, WN_C>(regs, Ly.src.pl[2], w.g1, lane);
+            wstage_load<0, WN_Y, WNR>(regs, Ly.src.pl[0], w.g0, lane);
+            wstage_load<WN_Y, WN_C, WNR>(regs, Ly.src.pl[1], w.g1, lane);
+            wstage_load<WN_Y + WN_C, WN_C, WNR>(regs, Ly.src.pl[2], w.g1, lane);
             touch_regs(regs);
-            wstage_store<1, 0, WN_Y>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_store<1, WN_Y, WN_C>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
-            wstage_store<1, WN_Y + WN_C, WN_C>(regs, smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
+            wstage_store<1, 0, WN_Y, WNR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
+            wstage_store<1, WN_Y, WN_C, WNR>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
+            wstage_store<1, WN_Y + WN_C, WN_C, WNR>(regs, smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
             wstage_tail<1, WN_Y>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
             wstage_tail<1, WN_C>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
             wstage_tail<1, WN_C>(smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);

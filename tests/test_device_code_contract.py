@@ -12,7 +12,7 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "swiftvideo_amd" / "csrc"
 LLVM = Path("/opt/rocm/lib/llvm/bin")
-OBJECTS = ["kernels_general", "kernels_fast", "kernels_fast_rgb", "kernels_wave", "kernels_lanczos"]
+OBJECTS = ["kernels_general", "kernels_fast", "kernels_fast_rgb", "kernels_wave", "kernels_wave_yuv", "kernels_lanczos"]
 
 
 def _code_object(tmp_path, stem):
@@ -84,3 +84,20 @@ def test_lanczos_exact_tap_kernels_do_not_spill(tmp_path):
     for frag in ("lanczos3_bgraILi12ELb1ELb1ELi32ELi16E", "lanczos3_bgraILi6ELb1ELb1ELi32ELi16E"):
         for name, m in _find(k, frag).items():
             assert m["vgpr_count"] <= 128 and m["vgpr_spill_count"] == 0, (name, m)   # 4 blocks of 4 waves per CU (LDS-limited)
+
+
+@pytest.mark.parametrize("stem", ["kernels_wave", "kernels_wave_yuv"])
+def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem):
+    """One wave per strip: <= 80 VGPRs = 6 waves per SIMD (5 measured 8 % slower on the 4 x NV12
+    pipeline), at most the two spills of the per-pixel fallback; and the tick / layer descriptors — uniform, read-only — come
+    through the scalar unit.  They stopped doing so twice while these kernels were written: once through a fence over all
+    memory, once through an `asm volatile` (touch_regs), either of which makes the compiler treat later descriptor reads as
+    possibly clobbered and fetch every uniform with a per-lane global_load_dword (90 vector loads per wave, +35 % run time)."""
+    co = _code_object(tmp_path, stem)
+    for name, m in _find(_kernels(co), "wave").items():
+        assert m["vgpr_count"] <= 80, (name, m)
+        assert m["vgpr_spill_count"] <= 2, (name, m)
+    asm = subprocess.run([LLVM / "llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    scalar = len(re.findall(r"\bs_load_dword", asm))
+    vector1 = len(re.findall(r"\bglobal_load_dword\s", asm))        # single-dword vector loads: what a uniform read degrades to
+    assert scalar >= 300 and vector1 * 4 <= scalar, f"{stem}: {scalar} scalar loads, {vector1} single-dword vector loads"

@@ -69,7 +69,8 @@ CASES = {
 @pytest.mark.parametrize("case", list(CASES))
 def test_yuv_wave_matches_oracle(ctx, case):
     d, cw, ch, clear, specs = CASES[case]
-    run_yuv_tick(ctx, d, cw, ch, clear, specs)
+    # down_2.5: the 4-byte texel rectangles of four waves exceed the LDS budget -> general quad kernel
+    run_yuv_tick(ctx, d, cw, ch, clear, specs, expect=None if case == "down_2.5" else "wave")
 
 
 @pytest.mark.parametrize("case", ["mixer", "rect_border_fill", "noclear", "flips"])
@@ -129,7 +130,7 @@ def test_random_yuv_ticks(ctx, seed):
         exps.append(exp)
         gds.append((gd, cw, ch))
     h, name, keep = G.make_batch(ctx, ticks)
-    assert name == f"tick_yuv_wave<{d}>", name
+    assert name in (f"tick_yuv_wave<{d}>", f"tick_general_yuv<{d}>"), name     # (strong downscales of 4-byte texels exceed the LDS budget)
     G.run_batch(ctx, h)
     G.destroy_batch(h)
     for i, ((gd, cw, ch), exp) in enumerate(zip(gds, exps)):
