@@ -553,10 +553,12 @@ def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
     frames = args.frames if (args.frames and headline) else wl["frames"]
     w = build_workload(sv, ctx, wl, frames, seed_base=0x5EED0000 + 16 * 2 + rank, alias=args.alias if headline else "none")
 
+    lz = sv.LanczosBatch(w["lanczos"]) if w["lanczos"] else None      # one launch for the batch's resizes (chv_scale_lanczos_batch)
+
     def launch():
         cv.check(lib.chv_batch_run(ctx.handle, w["batch"]))
-        for small, big in w["lanczos"]:
-            sv.scaleLanczos(ctx, small, big)
+        if lz is not None:
+            lz.run(ctx)
 
     for _ in range(max(args.warmup, 1)):
         launch()

@@ -312,6 +312,9 @@ int chv_run_custom(chv_context *ctx, const char *name, const chv_image *target,
 /* Separable Lanczos-3 resize of a 4-component image (BGRA or RGBA) from `src`
  * to `dst` size.  No reference counterpart; DESIGN.md section 4.4. */
 int chv_scale_lanczos(chv_context *ctx, const chv_image *dst, const chv_image *src);
+/* n resizes of one geometry (every src of one size, every dst of one size) in one launch per 64 pairs; same bytes as n
+ * calls of chv_scale_lanczos.  Other geometries in the list -> CHV_ERR_INVALID_VALUE, nothing is launched. */
+int chv_scale_lanczos_batch(chv_context *ctx, const chv_image *dsts, const chv_image *srcs, int n);
 
 /* ---- timing (what the "gpu.upload"/"mix.video.compose" StatsReport timers
  *      measure on the host, compute.swift:185-187, mix.video.swift:110-126,

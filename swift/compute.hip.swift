@@ -434,4 +434,21 @@ func scaleLanczos(_ context: ComputeContext, src: PictureSample, target: Picture
     try check(chv_scale_lanczos(context.handle, &targetDesc, &desc))
     return context
 }
+
+/// n resizes of one geometry in one launch per 64 pairs (chv_scale_lanczos_batch): several PictureFilters / streams per tick
+func scaleLanczos(_ context: ComputeContext, pairs: [(src: PictureSample, target: PictureSample)]) throws -> ComputeContext {
+    var targets = [chv_image](), sources = [chv_image]()
+    for pair in pairs {
+        guard let targetImage = pair.target.imageBuffer(), let targetDesc = describe(targetImage, maxPlanes: 1) else {
+            throw ComputeError.badTarget
+        }
+        guard let image = pair.src.imageBuffer(), let desc = describe(image, maxPlanes: 1) else {
+            throw ComputeError.badInputData(description: "Bad input image")
+        }
+        targets.append(targetDesc)
+        sources.append(desc)
+    }
+    try check(chv_scale_lanczos_batch(context.handle, &targets, &sources, Int32(pairs.count)))
+    return context
+}
 #endif

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "chv_batch_destroy": (C.c_int, [C.c_void_p]),
     "chv_batch_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "chv_scale_lanczos": (C.c_int, [C.c_void_p, C.POINTER(Image), C.POINTER(Image)]),
+    "chv_scale_lanczos_batch": (C.c_int, [C.c_void_p, C.POINTER(Image), C.POINTER(Image), C.c_int]),
     "chv_custom_prelude": (C.c_char_p, []),
     "chv_kernel_build": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "chv_run_custom": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(Image), C.POINTER(Image), C.c_int, C.c_void_p,

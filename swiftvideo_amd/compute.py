@@ -29,7 +29,7 @@ __all__ = [
     "destroyComputeContext", "beginComputePass", "endComputePass", "usingContext", "runComputeKernel",
     "applyComputeImage", "uploadComputePicture", "downloadComputePicture", "uploadComputeBuffer",
     "downloadComputeBuffer", "createPictureSample", "GPUBarrierUpload", "GPUBarrierDownload", "VideoMixer",
-    "compositeTick", "scaleLanczos", "PictureFilter", "CustomKernel", "buildComputeKernel", "TickBatch", "VideoMixerGroup",
+    "compositeTick", "scaleLanczos", "LanczosBatch", "PictureFilter", "CustomKernel", "buildComputeKernel", "TickBatch", "VideoMixerGroup",
 ]
 
 
@@ -601,6 +601,29 @@ def scaleLanczos(ctx, dst, src):
         raise ComputeError(5, "Bad input image")
     cv.check(cv.load().chv_scale_lanczos(ctx.handle, C.byref(d), C.byref(s)))
     return ctx
+
+
+class LanczosBatch:
+    """n Lanczos-3 resizes of one geometry issued as one launch per 64 pairs (chv_scale_lanczos_batch): what a host with
+    several streams per device uses per tick instead of n launches.  pairs: [(dst PictureSample, src PictureSample)]; the
+    descriptors are built once, `run` can be called every tick (canvas rings make the same pairs recur)."""
+
+    def __init__(self, pairs):
+        n = len(pairs)
+        self.n = n
+        self._d, self._s = (cv.Image * max(1, n))(), (cv.Image * max(1, n))()
+        self._keep = list(pairs)
+        for i, (dst, src) in enumerate(pairs):
+            d, s = _image_desc(dst), _image_desc(src)
+            if d is None:
+                raise ComputeError(4, "target has no GPU image buffer")
+            if s is None:
+                raise ComputeError(5, "Bad input image")
+            self._d[i], self._s[i] = d, s
+
+    def run(self, ctx):
+        cv.check(cv.load().chv_scale_lanczos_batch(ctx.handle, self._d, self._s, self.n))
+        return ctx
 
 
 # ---- pipeline operators -----------------------------------------------------------------------

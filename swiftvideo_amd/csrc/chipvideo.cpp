@@ -38,7 +38,8 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
                             int maxW, int maxH, hipStream_t stream);
 // kernels_lanczos.hip.cpp
 hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *fx, const float *wx,
-                          int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream);
+                          int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream,
+                          const DPlane *batch, int n_batch);
 }  // namespace chv
 
 using namespace chv;
@@ -1245,8 +1246,57 @@ extern "C" int chv_scale_lanczos(chv_context *c, const chv_image *dst, const chv
     rc = lanczos_table(c, s.h, d.h, &ty);
     if (rc) return rc;
     (void)hipGetLastError();
-    hipError_t e = launch_lanczos(d, s, tx.first, tx.weights, tx.taps, ty.first, ty.weights, ty.taps, c->stream);
+    hipError_t e = launch_lanczos(d, s, tx.first, tx.weights, tx.taps, ty.first, ty.weights, ty.taps, c->stream, nullptr, 0);
     if (e != hipSuccess) return hip_fail(e, "lanczos launch");
+    return CHV_OK;
+}
+
+// Many resizes of ONE geometry (all sources of one size, all targets of one size) in one launch per chunk: what a host with
+// several streams per device issues per tick (a 2160p -> 1080p pass is 28 us of device time, of the order of a launch).
+extern "C" int chv_scale_lanczos_batch(chv_context *c, const chv_image *dsts, const chv_image *srcs, int n) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (n <= 0 || !dsts || !srcs) return fail(CHV_ERR_INVALID_VALUE, "empty batch");
+    std::vector<DPlane> pairs((size_t)2 * n);
+    DepScope deps;
+    for (int i = 0; i < n; i++) {
+        if (dsts[i].n_planes != 1) return fail(CHV_ERR_BAD_TARGET, "Lanczos target %d must be one 4-component plane", i);
+        if (srcs[i].n_planes != 1) return fail(CHV_ERR_BAD_INPUT, "Lanczos source %d must be one 4-component plane", i);
+        int rc = plane_to_device(dsts[i].planes[0], 4, c->device, &pairs[2 * i], CHV_ERR_BAD_TARGET, "target", i);
+        if (rc) return rc;
+        rc = plane_to_device(srcs[i].planes[0], 4, c->device, &pairs[2 * i + 1], CHV_ERR_BAD_INPUT, "input", i);
+        if (rc) return rc;
+        if (pairs[2 * i].w != pairs[0].w || pairs[2 * i].h != pairs[0].h || pairs[2 * i + 1].w != pairs[1].w || pairs[2 * i + 1].h != pairs[1].h)
+            return fail(CHV_ERR_INVALID_VALUE, "pair %d: %dx%d -> %dx%d, the batch is %dx%d -> %dx%d (one geometry per batch)", i,
+                        pairs[2 * i + 1].w, pairs[2 * i + 1].h, pairs[2 * i].w, pairs[2 * i].h, pairs[1].w, pairs[1].h, pairs[0].w, pairs[0].h);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    auto dp = deps.deps();
+    int rc = wait_for_uploads(c->stream, dp);
+    if (rc) return rc;
+    LanczosTable tx, ty;
+    rc = lanczos_table(c, pairs[1].w, pairs[0].w, &tx);
+    if (rc) return rc;
+    rc = lanczos_table(c, pairs[1].h, pairs[0].h, &ty);
+    if (rc) return rc;
+    // the pairs travel through the pinned, device-mapped descriptor ring (a slot per chunk), like a transient tick's descriptors
+    const int per_slot = (int)(kDescSlotBytes / (2 * sizeof(DPlane)));
+    for (int first = 0; first < n; first += per_slot) {
+        const int m = std::min(per_slot, n - first);
+        int slot = c->next_desc;
+        c->next_desc = (c->next_desc + 1) % kDescSlots;
+        DescSlot &ds = c->desc[slot];
+        if (ds.pending) { HIP_TRY(hipEventSynchronize(ds.done)); ds.pending = false; }
+        if (!ds.done) HIP_TRY(hipEventCreateWithFlags(&ds.done, hipEventDisableTiming));
+        DPlane *host = (DPlane *)(c->desc_host + (size_t)slot * kDescSlotBytes);
+        memcpy(host, pairs.data() + 2 * (size_t)first, sizeof(DPlane) * 2 * (size_t)m);
+        DPlane *dev = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&dev, host, 0));
+        (void)hipGetLastError();
+        hipError_t e = launch_lanczos(pairs[0], pairs[1], tx.first, tx.weights, tx.taps, ty.first, ty.weights, ty.taps, c->stream, dev, m);
+        if (e != hipSuccess) return hip_fail(e, "lanczos launch");
+        HIP_TRY(hipEventRecord(ds.done, c->stream));
+        ds.pending = true;
+    }
     return CHV_OK;
 }
 

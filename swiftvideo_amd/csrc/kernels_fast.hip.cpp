@@ -32,12 +32,8 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_RGB_LAYERS_TILED = 1, FP_Y420P_BGRA_TILED = 2, FP_WAVE_LAYERS = 3, FP_WAVE_NV12 = 4, FP_WAVE_Y420P = 5, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_Y420P_BGRA_TILED = 1, FP_WAVE_LAYERS = 2, FP_WAVE_NV12 = 3, FP_WAVE_Y420P = 4, FP_COUNT };
 
-// kernels_fast_rgb.hip.cpp
-bool rgb_layers_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
-hipError_t launch_rgb_layers(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
-                             int n_ticks, int maxW, int maxH, hipStream_t stream);
 // kernels_wave.hip.cpp / kernels_wave_yuv.hip.cpp
 bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
@@ -387,7 +383,6 @@ static bool aligned16(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 &
 const char *fast_path_name(int path) {
     switch (path) {
     case FP_NV12_BGRA_TILED: return "tick_nv12_bgra_tiled";
-    case FP_RGB_LAYERS_TILED: return "tick_rgb_layers_tiled";
     case FP_Y420P_BGRA_TILED: return "tick_y420p_bgra_tiled";
     case FP_WAVE_LAYERS: return "tick_bgra_wave";
     case FP_WAVE_NV12: return "tick_yuv_wave<nv12>";
@@ -396,10 +391,10 @@ const char *fast_path_name(int path) {
     }
 }
 
-// the single-purpose kernels: exactly one YUV layer per tick (cfg2 / cfg4), or RGB layers only (cfg3 / cfg5)
+// the single-purpose kernel: exactly one YUV layer per tick (cfg2 / cfg4): block-tiled, strips of four tiles with the next
+// tile's rectangle prefetched — 0.40-0.46 ms per 256 cfg2 ticks against 0.78 for the wave-per-strip kernel.  (RGB-only ticks
+// had a block-tiled kernel of their own until the wave kernel overtook it: cfg3 1.92 vs 2.23 ms, cfg5 3.36 vs 3.67.)
 static int select_single_purpose(const DTick *ticks, const DLayer *layers, int n_ticks) {
-    if (ticks[0].n_layers >= 1 && layers[ticks[0].first_layer].kind == LK_BGRA_FROM_RGB)
-        return rgb_layers_eligible(ticks, layers, n_ticks) ? FP_RGB_LAYERS_TILED : FP_NONE;
     for (int i = 0; i < n_ticks; i++) {
         const DTick &T = ticks[i];
         if (T.n_layers != 1 || T.clear_first != ticks[0].clear_first) return FP_NONE;
@@ -418,8 +413,8 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     if (n_ticks <= 0) return FP_NONE;
     // A/B switches for measurements and tests (read per call: tests flip them):
     //   CHV_FORCE_GENERAL=1   everything through the general kernels
-    //   CHV_BGRA_PATH=wave    BGRA canvases: the wave-per-strip kernel also where a single-purpose kernel (exactly one YUV
-    //                         layer per tick; RGB layers only) would be chosen
+    //   CHV_BGRA_PATH=wave    BGRA canvases: the wave-per-strip kernel also where the single-purpose kernel (exactly one YUV
+    //                         layer per tick) would be chosen
     const char *fg = getenv("CHV_FORCE_GENERAL"), *bp = getenv("CHV_BGRA_PATH");
     if (fg && fg[0] == '1') return FP_NONE;
     // 4:2:0 canvases (the reference's own kernels): one wave per strip, or the general quad kernel
@@ -436,7 +431,6 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
-    if (path == FP_RGB_LAYERS_TILED) return launch_rgb_layers(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_LAYERS) return launch_wave_layers(TF_BGRA, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_NV12) return launch_wave_layers(TF_NV12, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_Y420P) return launch_wave_layers(TF_Y420P, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);

@@ -30,7 +30,9 @@ template <int TAPS_IN_REGS, bool EXACT, bool PREFETCH, int LZ_TW, int LZ_TH>
 __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void lanczos3_bgra(DPlane dst, DPlane src,
                                                      const int32_t *__restrict__ fx, const float *__restrict__ wx, int tx,
                                                      const int32_t *__restrict__ fy, const float *__restrict__ wy, int ty,
-                                                     int max_rows, int max_cols, int ks) {
+                                                     int max_rows, int max_cols, int ks, const DPlane *__restrict__ batch) {
+    // batch != nullptr: grid.z images of one geometry in one launch, (dst, src) pairs in device-visible memory
+    if (batch) { dst = batch[2 * blockIdx.z]; src = batch[2 * blockIdx.z + 1]; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *hrow = (float4 *)smem;                                   // [max_rows][LZ_TW]
     uint32_t *stile = (uint32_t *)(smem + (size_t)max_rows * LZ_TW * sizeof(float4));   // [max_rows][max_cols]
@@ -244,7 +246,8 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
 }
 
 hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *fx, const float *wx,
-                          int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream) {
+                          int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream,
+                          const DPlane *batch, int n_batch) {
     // rows / columns of source one tile can need: first[] advances by at most ceil(scale) per output
     const double sy = (double)src.h / (double)dst.h, sxs = (double)src.w / (double)dst.w;
     auto dims = [&](int tw, int th, int *max_rows, int *max_cols) -> size_t {
@@ -265,11 +268,11 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
     const long resident = 256L * std::max<long>(1, (long)(160 * 1024 / lds));
     int ks = 2; long best = -1;
     for (int k = 2; k <= 8; k++) {
-        const long blocks = (long)((tiles_x + k - 1) / k) * tiles_y;
+        const long blocks = (long)((tiles_x + k - 1) / k) * tiles_y * (batch ? n_batch : 1);
         const long cost = ((blocks + resident - 1) / resident) * k;
         if (best < 0 || cost <= best) { best = cost; ks = k; }
     }
-    dim3 grid((tiles_x + ks - 1) / ks, tiles_y);
+    dim3 grid((tiles_x + ks - 1) / ks, tiles_y, batch ? n_batch : 1);
     // register prefetch of the next tile's rectangle: one vector per thread and 8-row group
     const bool prefetch = !small_tiles && max_rows <= 8 * LZ_NPRE && max_cols / 4 <= 32 && src.w >= 4;
     auto launch = [&](auto kernel) -> hipError_t {
@@ -277,7 +280,7 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
             hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, dst, src, fx, wx, tx, fy, wy, ty, max_rows, max_cols, ks);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, stream, dst, src, fx, wx, tx, fy, wy, ty, max_rows, max_cols, ks, batch);
         return hipGetLastError();
     };
     if (small_tiles) return tx <= LZ_MAXT ? launch(lanczos3_bgra<LZ_MAXT, false, false, 8, 4>) : launch(lanczos3_bgra<0, false, false, 8, 4>);

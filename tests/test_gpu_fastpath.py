@@ -158,7 +158,7 @@ def test_batch_of_mixed_sizes(ctx):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"tick {i}")
 
 
-# ---- BGRA/RGBA layers onto a BGRA canvas (tick_rgb_layers_tiled) -------------------------------------
+# ---- BGRA/RGBA layers onto a BGRA canvas (tick_bgra_wave) ---------------------------------------------------
 RGB_CASES = {
     # name: (canvas w, h, clear_first, [(kernel, src w, h, make_uniforms kwargs)])
     "one_full":      (200, 60, True, [("img_bgra_bgra_tx", 200, 60, dict())]),
@@ -195,14 +195,14 @@ def test_rgb_layers_tiled_matches_oracle(ctx, case):
     if case == "odd_tiny":        # rows shorter than one 16-byte vector cannot be staged -> general kernel
         assert name == "tick_general_bgra", name
     else:
-        assert name == "tick_rgb_layers_tiled", name
+        assert name == "tick_bgra_wave", name
     G.run_batch(ctx, h)
     G.destroy_batch(h)
     G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"{case} via {name}")
 
 
 def test_rgb_layers_fallbacks(ctx):
-    """More than 8 layers: beyond tick_rgb_layers_tiled, taken by the wave-per-strip kernel; same bytes."""
+    """Any number of layers per tick is fine for the wave-per-strip kernel; same bytes."""
     cw, ch = 96, 54
     src = util.alloc_image("bgra", 48, 27, seed=5)
     gs = G.to_gpu(ctx, "bgra", 48, 27, src)

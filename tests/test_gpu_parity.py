@@ -305,3 +305,28 @@ def test_lanczos_paths_match_oracle(ctx, iw, ih, ow, oh):
     gd = G.to_gpu(ctx, "bgra", ow, oh, util.alloc_image("bgra", ow, oh))
     sv.usingContext(ctx, lambda c: sv.scaleLanczos(c, gd, gs))
     G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"lanczos {iw}x{ih} -> {ow}x{oh}")
+
+
+@pytest.mark.parametrize("iw,ih,ow,oh,n", [(96, 54, 48, 27, 5), (64, 36, 128, 72, 3), (200, 120, 75, 45, 70), (33, 17, 20, 10, 2)])
+def test_lanczos_batch_equals_single_calls(ctx, iw, ih, ow, oh, n):
+    """chv_scale_lanczos_batch: n resizes of one geometry in one launch per 64 pairs == the oracle, image by image"""
+    srcs = [util.alloc_image("bgra", iw, ih, seed=900 + i) for i in range(n)]
+    pairs, exps = [], []
+    for s in srcs:
+        exp = util.alloc_image("bgra", ow, oh)
+        assert O.lanczos_bgra(exp[0], s[0]) == 0
+        exps.append(exp)
+        pairs.append((G.to_gpu(ctx, "bgra", ow, oh, util.alloc_image("bgra", ow, oh, seed=3)), G.to_gpu(ctx, "bgra", iw, ih, s)))
+    batch = sv.LanczosBatch(pairs)
+    sv.usingContext(ctx, lambda c: batch.run(c))
+    sv.usingContext(ctx, lambda c: batch.run(c))          # replayable
+    for i, ((gd, _), exp) in enumerate(zip(pairs, exps)):
+        G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"batched lanczos, image {i} of {n}")
+
+
+def test_lanczos_batch_rejects_mixed_geometry(ctx):
+    a = (G.to_gpu(ctx, "bgra", 32, 18, util.alloc_image("bgra", 32, 18)), G.to_gpu(ctx, "bgra", 64, 36, util.alloc_image("bgra", 64, 36, seed=1)))
+    b = (G.to_gpu(ctx, "bgra", 32, 18, util.alloc_image("bgra", 32, 18)), G.to_gpu(ctx, "bgra", 80, 36, util.alloc_image("bgra", 80, 36, seed=2)))
+    with pytest.raises(sv.ComputeError) as e:
+        sv.LanczosBatch([a, b]).run(ctx)
+    assert e.value.case == "invalidValue"
