@@ -56,14 +56,13 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
 #define CHV_WAVE_FENCE 0
 #endif
 #define WAVE_ROW_FENCE(j) do { if (CHV_WAVE_FENCE > 0 && (j) > 0 && (j) % (CHV_WAVE_FENCE > 0 ? CHV_WAVE_FENCE : 1) == 0) __builtin_amdgcn_sched_barrier(0); } while (0)
-#ifndef CHV_WAVE_ROWS
-#define CHV_WAVE_ROWS 8
-#endif
-constexpr int WTH = CHV_WAVE_ROWS;
-static_assert(WTH == 8, "kernels_wave_yuv.hip.cpp sizes the BGRA launch for 8-row strips (BGRA_WTH)");      // strip height: rows per lane (16: -14 % on the 4 x NV12 pipeline at 128 VGPRs, but the LDS
+// Strip height WTH (rows per lane), a template parameter picked per launch (launch_wave_layers): 16 rows halve a strip's fixed
+// costs per pixel (pipeline 2.14 -> 1.86 ms, cfg3 1.91 -> 1.68, cfg5 3.17 -> 2.92 at 96 VGPRs = 5 waves per SIMD) but double
+// the rows that go through the per-pixel path where a layer's edge crosses a strip (ticks with small overlays: 0.88 -> 1.05 ms),
+// so they are used when every layer of the launch covers (almost) the whole canvas; 8 rows otherwise (80 VGPRs, 6 waves).      // strip height: rows per lane (16: -14 % on the 4 x NV12 pipeline at 128 VGPRs, but the LDS
                                         // footprint of 4-byte texel rectangles then halves the occupancy of mixed ticks: 3.0 vs 0.85 ms)
-template <bool CLEAR>
-__global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVE_MINW) void tick_bgra_wave(const DTick *__restrict__ ticks,
+template <int WTH, bool CLEAR>
+__global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? 5 : CHV_WAVE_MINW)) void tick_bgra_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
@@ -74,7 +73,10 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVE_MINW) void tick_bgra_wave(cons
     const DLayer *L = S.L;
     const int nl = S.nl, lane = S.lane, x = S.x, y0 = S.y0;
     const bool col_in = S.col_in;
-    const DPlane &D = T.dst.pl[0];
+    // canvas plane BY VALUE, read once (see kernels_wave_yuv.hip.cpp: descriptor reads after the first canvas store would be
+    // vector loads with a full wait each)
+    const DPlane D = T.dst.pl[0];
+    const int TH = T.H;
     uint8_t *smem = S.smem;
     const uint4 *rowtab = S.rowtab;
     const int voff = S.voff;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVE_MINW) void tick_bgra_wave(cons
     if (!CLEAR && col_in) {
 #pragma unroll
         for (int j = 0; j < WTH; j++)
-            if (y0 + j < T.H) cv[j] = gld<uint32_t>(D.ptr + (size_t)(y0 + j) * D.pitch + (size_t)x * 4);
+            if (y0 + j < TH) cv[j] = gld<uint32_t>(D.ptr + (size_t)(y0 + j) * D.pitch + (size_t)x * 4);
     }
 
     WLayer cur;
@@ -245,21 +247,20 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVE_MINW) void tick_bgra_wave(cons
     if (col_in) {
 #pragma unroll
         for (int j = 0; j < WTH; j++)
-            if (y0 + j < T.H) gst<uint32_t>(D.ptr + (size_t)(y0 + j) * D.pitch + (size_t)x * 4, cv[j]);
+            if (y0 + j < TH) gst<uint32_t>(D.ptr + (size_t)(y0 + j) * D.pitch + (size_t)x * 4, cv[j]);
     }
 }
 
 // ---------------------------------------------------------------------------
 // launch (geometry, LDS sizing and eligibility of both wave kernels: kernels_wave_yuv.hip.cpp)
 // ---------------------------------------------------------------------------
-hipError_t launch_bgra_wave(bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
+hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
                             int strips_x, int strips_y, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar) {
-    if (clear)
-        hipLaunchKernelGGL(tick_bgra_wave<true>, grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y,
-                           p0pitch, p0rows, p1pitch, p1rows, planar);
-    else
-        hipLaunchKernelGGL(tick_bgra_wave<false>, grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y,
-                           p0pitch, p0rows, p1pitch, p1rows, planar);
+#define CHV_LAUNCH_B(R, C) hipLaunchKernelGGL((tick_bgra_wave<R, C>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
+                                              p0pitch, p0rows, p1pitch, p1rows, planar)
+    if (rows == 16) { if (clear) CHV_LAUNCH_B(16, true); else CHV_LAUNCH_B(16, false); }
+    else            { if (clear) CHV_LAUNCH_B(8, true); else CHV_LAUNCH_B(8, false); }
+#undef CHV_LAUNCH_B
     return hipGetLastError();
 }
 

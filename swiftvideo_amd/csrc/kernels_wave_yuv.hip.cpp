@@ -109,9 +109,11 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     const uint8_t *smem = S.smem;
     const uint4 *rowtab = S.rowtab;
     const int voff = S.voff;
-    const DPlane &PY = T.dst.pl[0];
-    const DPlane &PC = T.dst.pl[1];
-    const DPlane &PV = T.dst.pl[TF == TF_Y420P ? 2 : 1];
+    // canvas planes BY VALUE, read once: the stores at the end go through integer-cast pointers, after the first of them the
+    // compiler treats the descriptors as possibly overwritten and would re-read pitch and height before every row's store
+    // with a vector load and a full `s_waitcnt vmcnt(0)` (which also drains the previous store)
+    const DPlane PY = T.dst.pl[0], PC = T.dst.pl[1], PV = T.dst.pl[TF == TF_Y420P ? 2 : 1];
+    const int TH = T.H;
     const float sx = S.sx, sy = S.sy;
 
     // ---- canvas codes of this lane: luma row j in byte j & 3 of ly[j >> 2]; even lanes: chroma row jj (canvas row y0/2 + jj)
@@ -126,14 +128,14 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     if (!CLEAR && col_in) {
 #pragma unroll
         for (int j = 0; j < YTH; j++) {
-            if (y0 + j < T.H) ly[j >> 2] |= (uint32_t)gld<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x) << (8 * (j & 3));
+            if (y0 + j < TH) ly[j >> 2] |= (uint32_t)gld<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x) << (8 * (j & 3));
         }
         if (owner_lane) {
 #pragma unroll
             for (int k = 0; k < YCW; k++) { cu[k] = 0; cv[k] = 0; }
 #pragma unroll
             for (int jj = 0; jj < YTH / 2; jj++) {
-                if (y0 + 2 * jj < T.H) {
+                if (y0 + 2 * jj < TH) {
                     uint32_t ub, vb;
                     if (TF == TF_NV12) {
                         const uint32_t p = gld<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + (size_t)qx * 2);
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
 #pragma unroll 1
             for (int j = 0; j < YTH; j++) {
                 const int y = y0 + j;
-                if (y >= T.H) break;
+                if (y >= TH) break;
                 const int sh = 8 * (j & 3), csh = 8 * ((j >> 1) & 3);
                 uint32_t lw = ly[0], uw = cu[0], vw = cv[0];
 #pragma unroll
@@ -277,11 +279,11 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     if (col_in) {
 #pragma unroll
         for (int j = 0; j < YTH; j++)
-            if (y0 + j < T.H) gst<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x, (uint8_t)((ly[j >> 2] >> (8 * (j & 3))) & 255u));
+            if (y0 + j < TH) gst<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x, (uint8_t)((ly[j >> 2] >> (8 * (j & 3))) & 255u));
         if (owner_lane) {
 #pragma unroll
             for (int jj = 0; jj < YTH / 2; jj++) {
-                if (y0 + 2 * jj < T.H) {
+                if (y0 + 2 * jj < TH) {
                     const uint32_t ub = (cu[jj >> 2] >> (8 * (jj & 3))) & 255u, vb = (cv[jj >> 2] >> (8 * (jj & 3))) & 255u;
                     if (TF == TF_NV12) gst<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + (size_t)qx * 2, (uint16_t)(ub | (vb << 8)));
                     else {
@@ -307,8 +309,7 @@ static bool host_src_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kin
 static bool host_src_nv12(int kind) { return kind == LK_BGRA_FROM_NV12 || kind == LK_YUV_FROM_NV12; }
 
 struct WaveDims { int p0pitch, p0rows, p1pitch, p1rows; };
-constexpr int BGRA_WTH = 8;      // = WTH of kernels_wave.hip.cpp (static_assert there)
-static int strip_rows(int target_format) { return target_format == TF_BGRA ? BGRA_WTH : YTH; }
+static int strip_rows(int target_format) { return target_format == TF_BGRA ? 8 : YTH; }      // (BGRA launches may pick 16, see launch_wave_layers)
 
 // LDS rectangles one strip of this layer can touch, from the layer's scale factors
 static WaveDims wave_dims(const DTick &T, const DLayer &L, int WTH) {
@@ -329,9 +330,9 @@ static WaveDims wave_dims(const DTick &T, const DLayer &L, int WTH) {
     }
     return d;
 }
-static size_t wave_lds(const WaveDims &d, bool planar, int target_format) {
+static size_t wave_lds(const WaveDims &d, bool planar, int target_format, int rows) {
     return (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) +
-           (size_t)WAVES * ((size_t)strip_rows(target_format) * 32 + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
+           (size_t)WAVES * ((size_t)rows * 32 + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
 }
 
 bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
@@ -354,40 +355,61 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
             const int np = rgb ? 1 : nv12 ? 2 : 3;
             for (int p = 0; p < np; p++) if (!aligned16w(L.src.pl[p])) return false;
             if (planar && (L.src.pl[2].w != L.src.pl[1].w || L.src.pl[2].h != L.src.pl[1].h)) return false;   // one staging geometry for U and V
-            if (wave_lds(wave_dims(T, L, strip_rows(target_format)), planar, target_format) > (size_t)LDS_BUDGET) return false;
+            if (wave_lds(wave_dims(T, L, strip_rows(target_format)), planar, target_format, strip_rows(target_format)) > (size_t)LDS_BUDGET) return false;
         }
     }
     return true;
 }
 
 // kernels_wave.hip.cpp
-hipError_t launch_bgra_wave(bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
+hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
                             int strips_x, int strips_y, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar);
 
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream) {
+    // strip height: 16 rows on BGRA canvases when every layer of the launch covers (almost) the whole canvas, so that hardly any
+    // strip is crossed by a layer's edge, and the taller rectangles still fit the LDS budget; 8 rows otherwise
+    int WTH = strip_rows(target_format);
+    if (target_format == TF_BGRA) {
+        const char *env = getenv("CHV_WAVE_ROWS");           // A/B and test switch: 8 or 16
+        bool tall = true;
+        for (int i = 0; i < n_ticks && tall; i++) {
+            const DTick &T = ticks_host[i];
+            for (int l = 0; l < T.n_layers && tall; l++) {
+                const int32_t *bb = layers_host[T.first_layer + l].bbox;
+                tall = (double)(bb[2] - bb[0]) * (double)(bb[3] - bb[1]) >= 0.9 * (double)T.W * (double)T.H;
+            }
+        }
+        if (env && (env[0] == '8' || (env[0] == '1' && env[1] == '6'))) tall = env[0] == '1';
+        if (tall) WTH = 16;
+    }
     WaveDims m{ 0, 0, 0, 0 };
     bool planar = false;
-    for (int i = 0; i < n_ticks; i++) {
-        for (int l = 0; l < ticks_host[i].n_layers; l++) {
-            const DLayer &L = layers_host[ticks_host[i].first_layer + l];
-            WaveDims d = wave_dims(ticks_host[i], L, strip_rows(target_format));
-            m.p0pitch = std::max(m.p0pitch, d.p0pitch); m.p0rows = std::max(m.p0rows, d.p0rows);
-            m.p1pitch = std::max(m.p1pitch, d.p1pitch); m.p1rows = std::max(m.p1rows, d.p1rows);
-            planar = planar || host_src_planar(L.kind);
+    auto measure = [&](int rows) {
+        m = WaveDims{ 0, 0, 0, 0 };
+        planar = false;
+        for (int i = 0; i < n_ticks; i++) {
+            for (int l = 0; l < ticks_host[i].n_layers; l++) {
+                const DLayer &L = layers_host[ticks_host[i].first_layer + l];
+                WaveDims d = wave_dims(ticks_host[i], L, rows);
+                m.p0pitch = std::max(m.p0pitch, d.p0pitch); m.p0rows = std::max(m.p0rows, d.p0rows);
+                m.p1pitch = std::max(m.p1pitch, d.p1pitch); m.p1rows = std::max(m.p1rows, d.p1rows);
+                planar = planar || host_src_planar(L.kind);
+            }
         }
-    }
-    size_t lds = wave_lds(m, planar, target_format);
+        return wave_lds(m, planar, target_format, rows);
+    };
+    size_t lds = measure(WTH);
+    if (WTH == 16 && lds > (size_t)LDS_BUDGET / 2) { WTH = 8; lds = measure(WTH); }      // (keep at least two tall strips' worth per 64 KB)
     if (lds > (size_t)LDS_BUDGET) {
         // per-layer maxima combined exceed the budget: shrink the row counts; rectangles that do not fit fall back to
         // unstaged taps inside the kernel
-        const size_t fixed = (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) + (size_t)WAVES * strip_rows(target_format) * 32;
+        const size_t fixed = (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) + (size_t)WAVES * WTH * 32;
         const size_t per_row = (size_t)WAVES * ((size_t)m.p0pitch + (size_t)m.p1pitch * (planar ? 2 : 1));
         int rows = std::max(1, (int)((LDS_BUDGET - fixed) / per_row));
         m.p0rows = std::min(m.p0rows, rows); m.p1rows = std::min(m.p1rows, rows);
-        lds = wave_lds(m, planar, target_format);
+        lds = wave_lds(m, planar, target_format, WTH);
     }
-    const int WTH = strip_rows(target_format);
     int strips_x = (maxW + WTW - 1) / WTW, strips_y = (maxH + WTH - 1) / WTH;
     long total = (long)n_ticks * strips_x * strips_y;
     long per_xcd = (total + 7) / 8;
@@ -395,7 +417,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     dim3 grid((unsigned)(blocks_per_xcd * 8));
     const bool clear = ticks_host[0].clear_first != 0;
     if (target_format == TF_BGRA)
-        return launch_bgra_wave(clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0);
+        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0);
 #define CHV_LAUNCH_Y(TFV, C) hipLaunchKernelGGL((tick_yuv_wave<TFV, C>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                 m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
     if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_Y(TF_NV12, true); else CHV_LAUNCH_Y(TF_NV12, false); }

@@ -16,11 +16,12 @@ pytestmark = pytest.mark.gpu
 WAVE = "tick_bgra_wave"
 
 
-@pytest.fixture
-def path(monkeypatch):
-    """route every eligible BGRA-canvas batch through the wave kernel (also where a single-purpose kernel would be chosen);
-    yields the kernel name expected"""
+@pytest.fixture(params=["8", "16"])
+def path(request, monkeypatch):
+    """route every eligible BGRA-canvas batch through the wave kernel (also where the single-purpose kernel would be chosen),
+    once with 8-row and once with 16-row strips (the host picks per launch; CHV_WAVE_ROWS forces it); yields the kernel name"""
     monkeypatch.setenv("CHV_BGRA_PATH", "wave")
+    monkeypatch.setenv("CHV_WAVE_ROWS", request.param)
     return WAVE
 
 
@@ -83,7 +84,7 @@ MIXED_CASES = {
 @pytest.mark.parametrize("csc", [0, 1])
 def test_mixed_layers_match_oracle(ctx, path, case, csc):
     cw, ch, clear, specs = MIXED_CASES[case]
-    # down_4x: the four waves' rectangles exceed the LDS budget -> general kernel
+    # down_4x: the 4-byte texel rectangle of a strip exceeds the LDS budget -> general kernel
     run_tick_case(ctx, cw, ch, clear, specs, csc=csc, expect=None if case == "down_4x" else path)
 
 
