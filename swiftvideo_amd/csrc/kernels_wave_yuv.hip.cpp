@@ -157,7 +157,19 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     while (l < nl) {
         const DLayer &Ly = L[l];
         S.setup(l, cur);                  // (overwrites the row table: the previous layer's pixels are done)
-        const bool fast = cur.staged && cur.all_inside;
+        // Strips entirely inside the picture, and — when the layer paints no fill (alpha of opacity x fill exactly 0: pixels of
+        // the border quad outside the picture then keep their codes, to_code(c / 255) = c) — strips a picture edge crosses as
+        // well: rows outside the picture are skipped (uniform branch), lanes outside keep their codes.
+        const bool nofill = (Ly.flags & LF_NO_FILL) != 0;
+#ifndef CHV_WAVEY_MASKED
+#define CHV_WAVEY_MASKED 1
+#endif
+        const bool fast = cur.staged && (cur.all_inside || (CHV_WAVEY_MASKED && nofill));
+        const bool lane_pic = cur.cfl == AX_ALL;
+        // a pixel takes a row's result if its column and the row are inside the picture (row flags: uniform, from the row table);
+        // every row is computed (branch-free: a branch per row keeps the rows' LDS reads from overlapping), row offsets are
+        // clamped into the staged rectangle
+        auto take = [&](const uint4 &ra) { return lane_pic && ra.z == (uint32_t)AX_ALL; };
         if (fast) S.stage(l, cur);
         wave_lds_fence();
         const int ln = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
@@ -172,15 +184,17 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                 auto row = [&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
+                    const bool tk = take(ra);
                     const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
                     const uint8_t *py = smem + ((int)ra.x + cur.cyo);
                     const float luma = mix4(ia * ib, a * ib, ia * b, a * b, T8(tab, py[0]), T8(tab, py[1]), T8(tab, py[p0pitch]), T8(tab, py[p0pitch + 1]));
                     uint32_t &lw = ly[j >> 2];
                     // opacity == 1: cur * 0 + luma * 1 = luma exactly
                     const float v = OP ? luma : T8k<j & 3>(tab, lw) * ialpha + luma * alpha;
-                    lw = put_code<j & 3>(lw, v);
+                    const uint32_t nlw = put_code<j & 3>(lw, v);
+                    lw = tk ? nlw : lw;
                     if constexpr ((j & 1) == 0) {
-                        if (owner_lane) {          // the quad's chroma: sampled at THIS pixel's uv on the half-size plane(s)
+                        if (owner_lane && tk) {          // the quad's chroma: sampled at THIS pixel's uv on the half-size plane(s)
                             const float cbw = __uint_as_float(rb.z), icb = __uint_as_float(rb.w);
                             const uint8_t *pc = smem + ((int)ra.y + cur.cco);
                             const float c00 = ica * icb, c10 = ca * icb, c01 = ica * cbw, c11 = ca * cbw;
@@ -217,6 +231,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
             auto row = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
+                const bool tk = take(ra);
                 const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
                 const uint8_t *p0 = smem + ((int)ra.x + cur.cyo);
                 const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
@@ -231,9 +246,10 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                 rgb2yuv(r * a2, g * a2, bl * a2, yy, uu, vv);
                 uint32_t &lw = ly[j >> 2];
                 const float rx = T8k<j & 3>(tab, lw) * iaf + fya;
-                lw = put_code<j & 3>(lw, rx * ia2 + yy * a2);
+                const uint32_t nlw = put_code<j & 3>(lw, rx * ia2 + yy * a2);
+                lw = tk ? nlw : lw;
                 if constexpr ((j & 1) == 0) {
-                    if (owner_lane) {
+                    if (owner_lane && tk) {
                         constexpr int jj = j >> 1;
                         uint32_t &uw = cu[jj >> 2], &vw = cv[jj >> 2];
                         const float ry = clampf(T8k<jj & 3>(tab, uw) * iaf + fua, -1.f, 1.f);

@@ -257,7 +257,9 @@ struct WaveStrip {
                 w.g0.edge = cs.lo < 0 || cs.hi >= S0.w || rs.lo < 0 || rs.hi >= S0.h - 1 + (int)(col0 + nvec * tpv <= S0.w);
                 stage_slots_init(w.g0);
                 ok = (nvec + 2) * 16 <= p0pitch && w.g0.rows <= p0rows && stage_slots(w.g0) <= 1024;
-                c0off = base0 + 16 + ((cy - col0) << (4 - sh));     // byte of tap 0 in LDS row 0
+                // (positions clamped into the range of the fully-inside entries: lanes outside the picture then read staged
+                // bytes, whatever they are, instead of addresses outside the rectangle; inside lanes are unaffected)
+                c0off = base0 + 16 + ((min(max(cy, cs.lo), cs.hi - 1) - col0) << (4 - sh));     // byte of tap 0 in LDS row 0
             }
             if (ok && !rgb) {
                 const int sh = src_is_planar(Ly.kind) ? 4 : 3;
@@ -268,13 +270,13 @@ struct WaveStrip {
                 w.g1.edge = cs.clo < 0 || cs.chi >= S1.w || rs.clo < 0 || rs.chi >= S1.h - 1 + (int)(col0 + nvec * tpv <= S1.w);
                 stage_slots_init(w.g1);
                 ok = (nvec + 2) * 16 <= p1pitch && w.g1.rows <= p1rows && stage_slots(w.g1) <= 1024;
-                c1off = base1 + 16 + ((cc - col0) << (4 - sh));
-                r1off = (rc - rs.clo) * p1pitch;
+                c1off = base1 + 16 + ((min(max(cc, cs.clo), cs.chi - 1) - col0) << (4 - sh));
+                r1off = (min(max(rc, rs.clo), rs.chi - 1) - rs.clo) * p1pitch;
             }
             if (ok) {
                 w.staged = true;
                 cyo = c0off; cco = c1off;
-                yoff = (ry - rs.lo) * p0pitch; coff = r1off;
+                yoff = (min(max(ry, rs.lo), rs.hi - 1) - rs.lo) * p0pitch; coff = r1off;
             }
         }
         w.cyo = cyo; w.cco = cco;
