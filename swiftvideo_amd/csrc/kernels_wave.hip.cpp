@@ -50,6 +50,9 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
 #ifndef CHV_WAVE_MINW
 #define CHV_WAVE_MINW 6
 #endif
+#ifndef CHV_WAVE_MINW16
+#define CHV_WAVE_MINW16 5
+#endif
 // CHV_WAVE_FENCE = n > 0: keep the scheduler from interleaving more than n rows of a lane's pixels in the branch-free loops
 // (fewer live temporaries)
 #ifndef CHV_WAVE_FENCE
@@ -62,7 +65,7 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
 // so they are used when every layer of the launch covers (almost) the whole canvas; 8 rows otherwise (80 VGPRs, 6 waves).      // strip height: rows per lane (16: -14 % on the 4 x NV12 pipeline at 128 VGPRs, but the LDS
                                         // footprint of 4-byte texel rectangles then halves the occupancy of mixed ticks: 3.0 vs 0.85 ms)
 template <int WTH, bool CLEAR>
-__global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? 5 : CHV_WAVE_MINW)) void tick_bgra_wave(const DTick *__restrict__ ticks,
+__global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE_MINW)) void tick_bgra_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? 5 : CHV_WAVE_MINW)) void t
     if (!CLEAR && col_in) {
 #pragma unroll
         for (int j = 0; j < WTH; j++)
-            if (y0 + j < TH) cv[j] = gld<uint32_t>(D.ptr + (size_t)(y0 + j) * D.pitch + (size_t)x * 4);
+            if (y0 + j < TH) cv[j] = gld_at<uint32_t>(D.ptr + (size_t)(y0 + j) * D.pitch, (uint32_t)x * 4u);
     }
 
     WLayer cur;
@@ -120,6 +123,9 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? 5 : CHV_WAVE_MINW)) void t
             // it keeps the rows' LDS reads from overlapping.
 #ifndef CHV_WAVE_MASKED
 #define CHV_WAVE_MASKED 1
+#endif
+#ifndef CHV_WAVE_CARRY
+#define CHV_WAVE_CARRY 1
 #endif
 #ifndef CHV_WAVE_MASK16
 #define CHV_WAVE_MASK16 0
@@ -160,7 +166,37 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? 5 : CHV_WAVE_MINW)) void t
                                                                          __builtin_fmaf(q2, al, ub2(c) * ial), 0xFF000000u));
                     }
                 };
-                if constexpr (CAN_MASK) { if (cur.all_inside) rgb_rows(std::false_type{}); else rgb_rows(std::true_type{}); }
+                // Native-resolution layers (source rows advance one per canvas row, checked on the row table): the lower tap row
+                // of a pixel is the upper tap row of the pixel below it, so its eight code-to-float conversions — a third of the
+                // row's slow-class instructions — and its LDS reads are carried down the lane instead of repeated.
+                auto rgb_rows_carried = [&]() {
+                    const uint8_t *p = smem + ((int)rowtab[0].x + cur.cyo);
+                    uint32_t ut0 = ((const uint32_t *)p)[0], ut1 = ((const uint32_t *)p)[1];
+                    float t00 = ub0(ut0), t01 = ub1(ut0), t02 = ub2(ut0), t03 = ub3(ut0);
+                    float t10 = ub0(ut1), t11 = ub1(ut1), t12 = ub2(ut1), t13 = ub3(ut1);
+#pragma unroll
+                    for (int j = 0; j < WTH; j++) {
+                        WAVE_ROW_FENCE(j);
+                        const uint4 rb = rowtab[2 * j + 1];
+                        const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
+                        p += p0pitch;
+                        const uint32_t ub_0 = ((const uint32_t *)p)[0], ub_1 = ((const uint32_t *)p)[1];
+                        const float b00 = ub0(ub_0), b01 = ub1(ub_0), b02 = ub2(ub_0), b03 = ub3(ub_0);
+                        const float b10 = ub0(ub_1), b11 = ub1(ub_1), b12 = ub2(ub_1), b13 = ub3(ub_1);
+                        const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
+                        const float q0 = cs_mix(w00, w10, w01, w11, t00, t10, b00, b10);
+                        const float q1 = cs_mix(w00, w10, w01, w11, t01, t11, b01, b11);
+                        const float q2 = cs_mix(w00, w10, w01, w11, t02, t12, b02, b12);
+                        const float q3 = cs_mix(w00, w10, w01, w11, t03, t13, b03, b13);
+                        const float al = q3 * ka, ial = 1.f - al;
+                        const uint32_t c = cv[j];
+                        cv[j] = pack_codes(__builtin_fmaf(q0, al, ub0(c) * ial), __builtin_fmaf(q1, al, ub1(c) * ial),
+                                           __builtin_fmaf(q2, al, ub2(c) * ial), 0xFF000000u);
+                        t00 = b00; t01 = b01; t02 = b02; t03 = b03; t10 = b10; t11 = b11; t12 = b12; t13 = b13;
+                    }
+                };
+                if (CHV_WAVE_CARRY && cur.unit_rows && cur.all_inside) rgb_rows_carried();
+                else if constexpr (CAN_MASK) { if (cur.all_inside) rgb_rows(std::false_type{}); else rgb_rows(std::true_type{}); }
                 else rgb_rows(std::false_type{});
             } else if (fast) {
                 const CscFolded cscb = csc_fold_biased(kCsc[Ly.csc & 3]);
@@ -277,7 +313,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? 5 : CHV_WAVE_MINW)) void t
     if (col_in) {
 #pragma unroll
         for (int j = 0; j < WTH; j++)
-            if (y0 + j < TH) gst<uint32_t>(D.ptr + (size_t)(y0 + j) * D.pitch + (size_t)x * 4, cv[j]);
+            if (y0 + j < TH) gst_at<uint32_t>(D.ptr + (size_t)(y0 + j) * D.pitch, (uint32_t)x * 4u, cv[j]);     // (row base: scalar)
     }
 }
 

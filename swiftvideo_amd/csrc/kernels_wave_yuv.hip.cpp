@@ -76,24 +76,26 @@ CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float 
     return ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;      // lin_mix's order (OpenCL 1.2 section 8.2)
 }
 
+#ifndef CHV_WAVEY_CARRY
+#define CHV_WAVEY_CARRY 1
+#endif
 #ifndef CHV_WAVEY_MINW
 #define CHV_WAVEY_MINW 6
 #endif
-// Strip height on 4:2:0 canvases.  A strip's fixed costs (index arithmetic, per-layer geometry, staging, stores: ~430 VALU
-// instructions) exceed the pixel work of one opaque layer over 64 x 8 pixels (~300); 16-row strips (the canvas codes pack
-// four to a register, so they cost only 4 more registers) execute 12 % fewer instructions per pixel — and measure 30 %
-// SLOWER (y420p_main 1.12 vs 0.86 ms per 128 ticks: 5 instead of 6 waves per SIMD, and twice as many strips of an overlay
-// straddle its edges and take the per-pixel path).  8 it is.
-#ifndef CHV_WAVEY_ROWS
-#define CHV_WAVEY_ROWS 8
-#endif
-constexpr int YTH = CHV_WAVEY_ROWS;
-constexpr int YLW = YTH / 4, YCW = YTH / 8;      // registers: luma rows (4 per register), chroma rows (YTH / 2, 4 per register)
-template <int TF, bool CLEAR>
+// Strip height YTH on 4:2:0 canvases, a template parameter picked per launch (launch_wave_layers).  A strip's fixed costs
+// (index arithmetic, per-layer geometry, staging, stores: ~430 VALU instructions) exceed the pixel work of one opaque layer
+// over 64 x 8 pixels (~300), and the canvas codes pack four to a register, so 16 rows cost only 4 more registers: 16-row
+// strips execute 12 % fewer instructions per pixel.  They were SLOWER (1.12 vs 0.86 ms per 128 ticks of y420p_main) as long
+// as strips crossed by an overlay's edge took the per-pixel path and the build dropped to 5 waves per SIMD; with the masked
+// rows and 6 waves (80 VGPRs, 9 spilled) they are faster everywhere: y420p_main 0.668 -> 0.495 ms, mixer_y420p 0.863 ->
+// 0.829, mixer_nv12 0.828 -> 0.792 (profiles/r02_notes.md).  8-row strips remain for small launches (more waves) and for
+// source rectangles whose 16-row version would not leave room for two strips per 64 KB of LDS.
+template <int TF, bool CLEAR, int YTH>
 __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
+    constexpr int YLW = YTH / 4, YCW = YTH / 8;      // registers: luma rows (4 per register), chroma rows (YTH / 2, 4 per register)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     float *tab = (float *)smem_all;
 #if CHV_UNORM_TABLE
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     if (!CLEAR && col_in) {
 #pragma unroll
         for (int j = 0; j < YTH; j++) {
-            if (y0 + j < TH) ly[j >> 2] |= (uint32_t)gld<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x) << (8 * (j & 3));
+            if (y0 + j < TH) ly[j >> 2] |= (uint32_t)gld_at<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch, (uint32_t)x) << (8 * (j & 3));
         }
         if (owner_lane) {
 #pragma unroll
@@ -138,11 +140,11 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                 if (y0 + 2 * jj < TH) {
                     uint32_t ub, vb;
                     if (TF == TF_NV12) {
-                        const uint32_t p = gld<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + (size_t)qx * 2);
+                        const uint32_t p = gld_at<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch, (uint32_t)qx * 2u);
                         ub = p & 255u; vb = p >> 8;
                     } else {
-                        ub = gld<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + qx);
-                        vb = gld<uint8_t>(PV.ptr + (size_t)(qy0 + jj) * PV.pitch + qx);
+                        ub = gld_at<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch, (uint32_t)qx);
+                        vb = gld_at<uint8_t>(PV.ptr + (size_t)(qy0 + jj) * PV.pitch, (uint32_t)qx);
                     }
                     cu[jj >> 2] |= ub << (8 * (jj & 3)); cv[jj >> 2] |= vb << (8 * (jj & 3));
                 }
@@ -181,13 +183,26 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
             const float a = cur.cya, ia = 1.0f - a, ca = cur.cca, ica = 1.0f - ca;
             auto body = [&](auto planar_c, auto opaque_c) {
                 constexpr bool PL = decltype(planar_c)::value, OP = decltype(opaque_c)::value;
-                auto row = [&](auto jc) {
+                // (unit_rows: native-resolution layers — the lower luma tap row of a pixel is the upper one of the pixel below, its
+                // two UNORM8 conversions, three instructions each, are carried down the lane)
+                const bool carry = CHV_WAVEY_CARRY && cur.unit_rows;
+                float t0 = 0.f, t1 = 0.f;
+                if (carry) { const uint8_t *py = smem + ((int)rowtab[0].x + cur.cyo); t0 = T8(tab, py[0]); t1 = T8(tab, py[1]); }
+                auto row = [&](auto jc, auto carry_c) {
                     constexpr int j = decltype(jc)::value;
+                    constexpr bool CARRY = decltype(carry_c)::value;
                     const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
                     const bool tk = take(ra);
                     const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
                     const uint8_t *py = smem + ((int)ra.x + cur.cyo);
-                    const float luma = mix4(ia * ib, a * ib, ia * b, a * b, T8(tab, py[0]), T8(tab, py[1]), T8(tab, py[p0pitch]), T8(tab, py[p0pitch + 1]));
+                    float luma;
+                    if constexpr (CARRY) {
+                        const float b0 = T8(tab, py[p0pitch]), b1 = T8(tab, py[p0pitch + 1]);
+                        luma = mix4(ia * ib, a * ib, ia * b, a * b, t0, t1, b0, b1);
+                        t0 = b0; t1 = b1;
+                    } else {
+                        luma = mix4(ia * ib, a * ib, ia * b, a * b, T8(tab, py[0]), T8(tab, py[1]), T8(tab, py[p0pitch]), T8(tab, py[p0pitch + 1]));
+                    }
                     uint32_t &lw = ly[j >> 2];
                     // opacity == 1: cur * 0 + luma * 1 = luma exactly
                     const float v = OP ? luma : T8k<j & 3>(tab, lw) * ialpha + luma * alpha;
@@ -214,7 +229,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                         }
                     }
                 };
-                for_rows<YTH>(row);
+                if (carry) { auto r = [&](auto jc) { row(jc, std::true_type{}); }; for_rows<YTH>(r); }
+                else { auto r = [&](auto jc) { row(jc, std::false_type{}); }; for_rows<YTH>(r); }
             };
             const bool planar = Ly.kind == LK_YUV_FROM_Y420P, opaque = (Ly.flags & LF_OPAQUE) != 0;
             if (planar) { if (opaque) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
@@ -228,19 +244,35 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
             rgb2yuv(U[U_FILL + 0] * af, U[U_FILL + 1] * af, U[U_FILL + 2] * af, fy, fu, fv);
             const float fya = fy * af, fua = fu * af, fva = fv * af;
             const float a = cur.cya, ia = 1.0f - a;
-            auto row = [&](auto jc) {
+            const bool carry = CHV_WAVEY_CARRY && cur.unit_rows;       // (as above: eight conversions per row carried down the lane)
+            float t00 = 0.f, t01 = 0.f, t02 = 0.f, t03 = 0.f, t10 = 0.f, t11 = 0.f, t12 = 0.f, t13 = 0.f;
+            if (carry) {
+                const uint8_t *p0 = smem + ((int)rowtab[0].x + cur.cyo);
+                const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
+                t00 = T8k<0>(tab, u00); t01 = T8k<1>(tab, u00); t02 = T8k<2>(tab, u00); t03 = T8k<3>(tab, u00);
+                t10 = T8k<0>(tab, u10); t11 = T8k<1>(tab, u10); t12 = T8k<2>(tab, u10); t13 = T8k<3>(tab, u10);
+            }
+            auto row = [&](auto jc, auto carry_c) {
                 constexpr int j = decltype(jc)::value;
+                constexpr bool CARRY = decltype(carry_c)::value;
                 const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
                 const bool tk = take(ra);
                 const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
                 const uint8_t *p0 = smem + ((int)ra.x + cur.cyo);
-                const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
                 const uint32_t u01 = ((const uint32_t *)(p0 + p0pitch))[0], u11 = ((const uint32_t *)(p0 + p0pitch))[1];
                 const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
-                const float r = mix4(w00, w10, w01, w11, T8k<0>(tab, u00), T8k<0>(tab, u10), T8k<0>(tab, u01), T8k<0>(tab, u11));
-                const float g = mix4(w00, w10, w01, w11, T8k<1>(tab, u00), T8k<1>(tab, u10), T8k<1>(tab, u01), T8k<1>(tab, u11));
-                const float bl = mix4(w00, w10, w01, w11, T8k<2>(tab, u00), T8k<2>(tab, u10), T8k<2>(tab, u01), T8k<2>(tab, u11));
-                const float q3 = mix4(w00, w10, w01, w11, T8k<3>(tab, u00), T8k<3>(tab, u10), T8k<3>(tab, u01), T8k<3>(tab, u11));
+                const float b00 = T8k<0>(tab, u01), b01 = T8k<1>(tab, u01), b02 = T8k<2>(tab, u01), b03 = T8k<3>(tab, u01);
+                const float b10 = T8k<0>(tab, u11), b11 = T8k<1>(tab, u11), b12 = T8k<2>(tab, u11), b13 = T8k<3>(tab, u11);
+                if constexpr (!CARRY) {
+                    const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
+                    t00 = T8k<0>(tab, u00); t01 = T8k<1>(tab, u00); t02 = T8k<2>(tab, u00); t03 = T8k<3>(tab, u00);
+                    t10 = T8k<0>(tab, u10); t11 = T8k<1>(tab, u10); t12 = T8k<2>(tab, u10); t13 = T8k<3>(tab, u10);
+                }
+                const float r = mix4(w00, w10, w01, w11, t00, t10, b00, b10);
+                const float g = mix4(w00, w10, w01, w11, t01, t11, b01, b11);
+                const float bl = mix4(w00, w10, w01, w11, t02, t12, b02, b12);
+                const float q3 = mix4(w00, w10, w01, w11, t03, t13, b03, b13);
+                if constexpr (CARRY) { t00 = b00; t01 = b01; t02 = b02; t03 = b03; t10 = b10; t11 = b11; t12 = b12; t13 = b13; }
                 const float a2 = q3 * opacity, ia2 = 1.f - a2;
                 float yy, uu, vv;
                 rgb2yuv(r * a2, g * a2, bl * a2, yy, uu, vv);
@@ -259,7 +291,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                     }
                 }
             };
-            for_rows<YTH>(row);
+            if (carry) { auto r = [&](auto jc) { row(jc, std::true_type{}); }; for_rows<YTH>(r); }
+            else { auto r = [&](auto jc) { row(jc, std::false_type{}); }; for_rows<YTH>(r); }
         } else if (col_in) {
             // ---- any other strip: the layer pixel by pixel, the general kernel's code (geometry per pixel, taps from global
             //      memory); chroma of non-owner pixels is computed by the reference and never stored ----
@@ -295,16 +328,16 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     if (col_in) {
 #pragma unroll
         for (int j = 0; j < YTH; j++)
-            if (y0 + j < TH) gst<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch + x, (uint8_t)((ly[j >> 2] >> (8 * (j & 3))) & 255u));
+            if (y0 + j < TH) gst_at<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch, (uint32_t)x, (uint8_t)((ly[j >> 2] >> (8 * (j & 3))) & 255u));
         if (owner_lane) {
 #pragma unroll
             for (int jj = 0; jj < YTH / 2; jj++) {
                 if (y0 + 2 * jj < TH) {
                     const uint32_t ub = (cu[jj >> 2] >> (8 * (jj & 3))) & 255u, vb = (cv[jj >> 2] >> (8 * (jj & 3))) & 255u;
-                    if (TF == TF_NV12) gst<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + (size_t)qx * 2, (uint16_t)(ub | (vb << 8)));
+                    if (TF == TF_NV12) gst_at<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch, (uint32_t)qx * 2u, (uint16_t)(ub | (vb << 8)));
                     else {
-                        gst<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch + qx, (uint8_t)ub);
-                        gst<uint8_t>(PV.ptr + (size_t)(qy0 + jj) * PV.pitch + qx, (uint8_t)vb);
+                        gst_at<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch, (uint32_t)qx, (uint8_t)ub);
+                        gst_at<uint8_t>(PV.ptr + (size_t)(qy0 + jj) * PV.pitch, (uint32_t)qx, (uint8_t)vb);
                     }
                 }
             }
@@ -325,7 +358,7 @@ static bool host_src_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kin
 static bool host_src_nv12(int kind) { return kind == LK_BGRA_FROM_NV12 || kind == LK_YUV_FROM_NV12; }
 
 struct WaveDims { int p0pitch, p0rows, p1pitch, p1rows; };
-static int strip_rows(int target_format) { return target_format == TF_BGRA ? 8 : YTH; }      // (BGRA launches may pick 16, see launch_wave_layers)
+static int strip_rows(int) { return 8; }      // (the height every eligible tick must fit; launches may pick 16, see launch_wave_layers)
 
 // LDS rectangles one strip of this layer can touch, from the layer's scale factors
 static WaveDims wave_dims(const DTick &T, const DLayer &L, int WTH) {
@@ -383,17 +416,21 @@ hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStre
 
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream) {
-    // strip height: 16 rows on BGRA canvases when every layer of the launch covers (almost) the whole canvas, so that hardly any
-    // strip is crossed by a layer's edge, and the taller rectangles still fit the LDS budget; 8 rows otherwise
+    // Strip height.  16 rows when the launch has enough strips to fill the chip's wave slots with them and the taller
+    // rectangles leave room for two strips per 64 KB of LDS; on BGRA canvases (whose 16-row instantiation has no masked rows:
+    // registers) only when every layer covers (almost) the whole canvas, so that hardly any strip is crossed by a layer's
+    // edge.  8 rows otherwise.  CHV_WAVE_ROWS=8|16 is the A/B and test switch.
     int WTH = strip_rows(target_format);
-    if (target_format == TF_BGRA) {
-        const char *env = getenv("CHV_WAVE_ROWS");           // A/B and test switch: 8 or 16
-        bool tall = true;
-        for (int i = 0; i < n_ticks && tall; i++) {
-            const DTick &T = ticks_host[i];
-            for (int l = 0; l < T.n_layers && tall; l++) {
-                const int32_t *bb = layers_host[T.first_layer + l].bbox;
-                tall = (double)(bb[2] - bb[0]) * (double)(bb[3] - bb[1]) >= 0.9 * (double)T.W * (double)T.H;
+    {
+        const char *env = getenv("CHV_WAVE_ROWS");
+        bool tall = (long)n_ticks * ((maxW + WTW - 1) / WTW) * ((maxH + 15) / 16) >= 8192;
+        if (target_format == TF_BGRA) {
+            for (int i = 0; i < n_ticks && tall; i++) {
+                const DTick &T = ticks_host[i];
+                for (int l = 0; l < T.n_layers && tall; l++) {
+                    const int32_t *bb = layers_host[T.first_layer + l].bbox;
+                    tall = (double)(bb[2] - bb[0]) * (double)(bb[3] - bb[1]) >= 0.9 * (double)T.W * (double)T.H;
+                }
             }
         }
         if (env && (env[0] == '8' || (env[0] == '1' && env[1] == '6'))) tall = env[0] == '1';
@@ -434,10 +471,12 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     const bool clear = ticks_host[0].clear_first != 0;
     if (target_format == TF_BGRA)
         return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0);
-#define CHV_LAUNCH_Y(TFV, C) hipLaunchKernelGGL((tick_yuv_wave<TFV, C>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
-                                                m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
-    if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_Y(TF_NV12, true); else CHV_LAUNCH_Y(TF_NV12, false); }
-    else { if (clear) CHV_LAUNCH_Y(TF_Y420P, true); else CHV_LAUNCH_Y(TF_Y420P, false); }
+#define CHV_LAUNCH_Y(TFV, C, R) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
+                                                   m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
+#define CHV_LAUNCH_YR(TFV, C) do { if (WTH == 16) CHV_LAUNCH_Y(TFV, C, 16); else CHV_LAUNCH_Y(TFV, C, 8); } while (0)
+    if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_YR(TF_NV12, true); else CHV_LAUNCH_YR(TF_NV12, false); }
+    else { if (clear) CHV_LAUNCH_YR(TF_Y420P, true); else CHV_LAUNCH_YR(TF_Y420P, false); }
+#undef CHV_LAUNCH_YR
 #undef CHV_LAUNCH_Y
     return hipGetLastError();
 }

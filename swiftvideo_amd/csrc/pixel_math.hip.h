@@ -37,6 +37,10 @@ template <typename T> CHV_DEV T gld(const void *p) { return *(const CHV_GLOBAL T
 template <> CHV_DEV uint2 gld<uint2>(const void *p) { chv_u32x2 v = *(const CHV_GLOBAL chv_u32x2 *)(uintptr_t)p; return make_uint2(v.x, v.y); }
 template <> CHV_DEV uint4 gld<uint4>(const void *p) { chv_u32x4 v = *(const CHV_GLOBAL chv_u32x4 *)(uintptr_t)p; return make_uint4(v.x, v.y, v.z, v.w); }
 template <typename T> CHV_DEV void gst(void *p, T v) { *(CHV_GLOBAL T *)(uintptr_t)p = v; }
+// wave-uniform base + 32-bit unsigned per-lane byte offset: selects the `global_* v_off, ..., s[base:base+1]` addressing form (the row
+// base stays on the scalar unit; the generic pointer + size_t form costs a v_mad_i64_i32 per access)
+template <typename T> CHV_DEV T gld_at(const uint8_t *base, uint32_t off) { return *(const CHV_GLOBAL T *)((const CHV_GLOBAL uint8_t *)(uintptr_t)base + off); }
+template <typename T> CHV_DEV void gst_at(uint8_t *base, uint32_t off, T v) { *(CHV_GLOBAL T *)((CHV_GLOBAL uint8_t *)(uintptr_t)base + off) = v; }
 // streaming stores (nt): for data written once per launch and not read back by it
 CHV_DEV void gst_stream(void *p, uint2 v) { chv_u32x2 t = { v.x, v.y }; __builtin_nontemporal_store(t, (CHV_GLOBAL chv_u32x2 *)(uintptr_t)p); }
 CHV_DEV void gst_stream(void *p, uint4 v) { chv_u32x4 t = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(t, (CHV_GLOBAL chv_u32x4 *)(uintptr_t)p); }

@@ -69,6 +69,8 @@ struct WLayer {
     int cfl;
     StageGeom g0, g1;
     bool staged, all_inside;
+    bool unit_rows;          // staged, and tap row 0 of every row of the strip is tap row 1 of the row above (source rows advance
+                             // one per canvas row: native-resolution layers) — the row loops then convert every texel row once
 };
 // row entry in the wave's LDS table: two 16-byte halves
 //   A = {yoff, coff, rfl, -}: LDS byte offset of the row's first tap row in the plane-0 / chroma rectangle (unstaged: the
@@ -280,6 +282,11 @@ struct WaveStrip {
             }
         }
         w.cyo = cyo; w.cco = cco;
+        {
+            // lane j + 1's row offset (lanes 0 .. WTH - 1 sit in one DPP row of 16)
+            const int ynext = __builtin_amdgcn_update_dpp(yoff, yoff, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+            w.unit_rows = w.staged && __ballot(lane < WTH - 1 && ynext - yoff != p0pitch) == 0;
+        }
         if (lane < WTH) {
             rowtab[2 * lane] = make_uint4((uint32_t)yoff, (uint32_t)coff, (uint32_t)rfl, 0u);
             rowtab[2 * lane + 1] = make_uint4(__float_as_uint(rya), __float_as_uint(1.0f - rya), __float_as_uint(rca), __float_as_uint(1.0f - rca));

