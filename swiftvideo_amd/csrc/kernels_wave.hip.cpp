@@ -31,6 +31,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+// CHV_ABL: timing-only ablations (results are wrong): 1 = no staging, 2 = no pixel rows, 4 = no canvas stores
+#ifndef CHV_ABL
+#define CHV_ABL 0
+#endif
 #pragma clang fp contract(off)
 
 namespace chv {
@@ -103,11 +107,12 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
     while (l < nl) {
         const DLayer &Ly = L[l];
         S.setup(l, cur);                  // (overwrites the row table: the previous layer's pixels are done)
-        if (cur.staged) S.stage(l, cur);
+        if (cur.staged && !(CHV_ABL & 1)) S.stage(l, cur);
         wave_lds_fence();
         const int ln = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
 
-        {
+        if (CHV_ABL & 2) cv[0] += (uint32_t)(cur.cyo ^ cur.cco ^ __float_as_int(cur.cya) ^ __float_as_int(cur.cca) ^ cur.cfl);
+        else {
             const float *U = Ly.u;
             const float opacity = U[U_OPACITY];
             const bool rgb = Ly.kind == LK_BGRA_FROM_RGB;
@@ -310,7 +315,10 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
         l = ln;
     }
 
-    if (col_in) {
+    if (CHV_ABL & 4) {
+#pragma unroll
+        for (int j = 0; j < WTH; j++) asm volatile("" :: "v"(cv[j]));
+    } else if (col_in) {
 #pragma unroll
         for (int j = 0; j < WTH; j++)
             if (y0 + j < TH) gst_at<uint32_t>(D.ptr + (size_t)(y0 + j) * D.pitch, (uint32_t)x * 4u, cv[j]);     // (row base: scalar)

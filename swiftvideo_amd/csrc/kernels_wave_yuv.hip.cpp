@@ -23,6 +23,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+// CHV_ABL: timing-only ablations (results are wrong): 1 = no staging, 2 = no pixel rows, 4 = no canvas stores
+#ifndef CHV_ABL
+#define CHV_ABL 0
+#endif
 #pragma clang fp contract(off)
 
 namespace chv {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
-    constexpr int YLW = YTH / 4, YCW = YTH / 8;      // registers: luma rows (4 per register), chroma rows (YTH / 2, 4 per register)
+    constexpr int YLW = YTH / 4;                     // registers holding the lane's luma codes (4 rows per register)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     float *tab = (float *)smem_all;
 #if CHV_UNORM_TABLE
@@ -118,37 +122,44 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     const int TH = T.H;
     const float sx = S.sx, sy = S.sy;
 
-    // ---- canvas codes of this lane: luma row j in byte j & 3 of ly[j >> 2]; even lanes: chroma row jj (canvas row y0/2 + jj)
-    //      of the strip in byte jj & 3 of cu / cv[jj >> 2] ---------------------------------------------------------------------
-    const bool owner_lane = (x & 1) == 0 && col_in;          // (canvas sizes are even on this path: host-checked)
+    // ---- canvas codes of this lane: luma row j in byte j & 3 of ly[j >> 2].  Chroma: the two lanes of a column pair (2k, 2k + 1)
+    //      share quad column k; the even lane holds the strip's EVEN chroma rows, the odd lane the ODD ones — chroma row
+    //      jj = 2 m + (lane & 1) (canvas chroma row y0 / 2 + jj) in byte m of nu / nv.  The reference evaluates a quad's chroma at
+    //      its even/even pixel (`handleChroma`, kernels.cl.swift:76): with the chroma rows dealt out like this every lane works
+    //      on one (at the even lane's column entry and the even row's row entry) instead of half the lanes on two. -------------
+    constexpr int YCM = YTH / 4;                             // chroma rows per lane
+    const int par = x & 1;                                   // (x0 is a multiple of 64: lane parity = column parity)
+    const bool owner_lane = par == 0 && col_in;              // (canvas sizes are even on this path: host-checked)
     const int qx = x >> 1, qy0 = y0 >> 1;
-    uint32_t ly[YLW], cu[YCW], cv[YCW];
+    uint32_t ly[YLW], nu = 0x80808080u, nv = 0x80808080u;                  // chroma = 0.5 -> 128 (RTE)
 #pragma unroll
     for (int k = 0; k < YLW; k++) ly[k] = 0;                               // img_clear_*: Y = 0.0
-#pragma unroll
-    for (int k = 0; k < YCW; k++) { cu[k] = 0x80808080u; cv[k] = 0x80808080u; }   // chroma = 0.5 -> 128 (RTE)
+    // per-lane byte offsets of this lane's chroma rows relative to the (uniform) base of chroma row qy0 + 2 m
+    const uint32_t coff_c = (uint32_t)par * (uint32_t)PC.pitch + (TF == TF_NV12 ? (uint32_t)qx * 2u : (uint32_t)qx);
+    const uint32_t coff_v = (uint32_t)par * (uint32_t)PV.pitch + (uint32_t)qx;
     if (!CLEAR && col_in) {
 #pragma unroll
         for (int j = 0; j < YTH; j++) {
             if (y0 + j < TH) ly[j >> 2] |= (uint32_t)gld_at<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch, (uint32_t)x) << (8 * (j & 3));
         }
-        if (owner_lane) {
+        nu = 0; nv = 0;
 #pragma unroll
-            for (int k = 0; k < YCW; k++) { cu[k] = 0; cv[k] = 0; }
-#pragma unroll
-            for (int jj = 0; jj < YTH / 2; jj++) {
-                if (y0 + 2 * jj < TH) {
-                    uint32_t ub, vb;
-                    if (TF == TF_NV12) {
-                        const uint32_t p = gld_at<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch, (uint32_t)qx * 2u);
-                        ub = p & 255u; vb = p >> 8;
-                    } else {
-                        ub = gld_at<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch, (uint32_t)qx);
-                        vb = gld_at<uint8_t>(PV.ptr + (size_t)(qy0 + jj) * PV.pitch, (uint32_t)qx);
-                    }
-                    cu[jj >> 2] |= ub << (8 * (jj & 3)); cv[jj >> 2] |= vb << (8 * (jj & 3));
-                }
+        for (int m = 0; m < YCM; m++) {
+            // (uniform conditions only: chroma rows past the canvas are read from its last row instead of skipped per lane; they are
+            // never stored)
+            const int qr = min(qy0 + 2 * m, (TH >> 1) - 1);
+            const bool odd_row = qy0 + 2 * m + 1 < (TH >> 1);
+            const uint32_t oc = odd_row ? coff_c : coff_c - (uint32_t)par * (uint32_t)PC.pitch;
+            uint32_t ub, vb;
+            if (TF == TF_NV12) {
+                const uint32_t p = gld_at<uint16_t>(PC.ptr + (size_t)qr * PC.pitch, oc);
+                ub = p & 255u; vb = p >> 8;
+            } else {
+                const uint32_t ov = odd_row ? coff_v : coff_v - (uint32_t)par * (uint32_t)PV.pitch;
+                ub = gld_at<uint8_t>(PC.ptr + (size_t)qr * PC.pitch, oc);
+                vb = gld_at<uint8_t>(PV.ptr + (size_t)qr * PV.pitch, ov);
             }
+            nu |= ub << (8 * m); nv |= vb << (8 * m);
         }
     }
 
@@ -172,15 +183,22 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
         // every row is computed (branch-free: a branch per row keeps the rows' LDS reads from overlapping), row offsets are
         // clamped into the staged rectangle
         auto take = [&](const uint4 &ra) { return lane_pic && ra.z == (uint32_t)AX_ALL; };
-        if (fast) S.stage(l, cur);
+        if (fast && !(CHV_ABL & 1)) S.stage(l, cur);
         wave_lds_fence();
         const int ln = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
         const float *U = Ly.u;
 
-        if (fast && Ly.kind != LK_YUV_FROM_RGB) {
+        if (CHV_ABL & 2) ly[0] += (uint32_t)(cur.cyo ^ cur.cco ^ __float_as_int(cur.cya) ^ __float_as_int(cur.cca) ^ cur.cfl);
+        else if (fast && Ly.kind != LK_YUV_FROM_RGB) {
             // ---- YUV picture over the whole strip (kernels.cl.swift:78-94): cur * (1 - opacity) + sample * opacity ----
             const float alpha = U[U_OPACITY], ialpha = 1.f - alpha;
-            const float a = cur.cya, ia = 1.0f - a, ca = cur.cca, ica = 1.0f - ca;
+            const float a = cur.cya, ia = 1.0f - a;
+            // the even lane's column entry in both lanes of a pair (quad_perm [0, 0, 2, 2])
+            const int cco_q = __builtin_amdgcn_update_dpp(cur.cco, cur.cco, 0xA0, 0xf, 0xf, false);
+            const float cca_q = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(cur.cca), __float_as_int(cur.cca), 0xA0, 0xf, 0xf, false));
+            const float icaq = 1.0f - cca_q;
+            const int picw = lane_pic && col_in ? 1 : 0;
+            const bool pic_q = __builtin_amdgcn_update_dpp(picw, picw, 0xA0, 0xf, 0xf, false) != 0;
             auto body = [&](auto planar_c, auto opaque_c) {
                 constexpr bool PL = decltype(planar_c)::value, OP = decltype(opaque_c)::value;
                 // (unit_rows: native-resolution layers — the lower luma tap row of a pixel is the upper one of the pixel below, its
@@ -208,25 +226,28 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                     const float v = OP ? luma : T8k<j & 3>(tab, lw) * ialpha + luma * alpha;
                     const uint32_t nlw = put_code<j & 3>(lw, v);
                     lw = tk ? nlw : lw;
-                    if constexpr ((j & 1) == 0) {
-                        if (owner_lane && tk) {          // the quad's chroma: sampled at THIS pixel's uv on the half-size plane(s)
-                            const float cbw = __uint_as_float(rb.z), icb = __uint_as_float(rb.w);
-                            const uint8_t *pc = smem + ((int)ra.y + cur.cco);
-                            const float c00 = ica * icb, c10 = ca * icb, c01 = ica * cbw, c11 = ca * cbw;
-                            float fu, fv;
-                            if constexpr (PL) {
-                                fu = mix4(c00, c10, c01, c11, T8(tab, pc[0]), T8(tab, pc[1]), T8(tab, pc[p1pitch]), T8(tab, pc[p1pitch + 1]));
-                                const uint8_t *pv = pc + voff;
-                                fv = mix4(c00, c10, c01, c11, T8(tab, pv[0]), T8(tab, pv[1]), T8(tab, pv[p1pitch]), T8(tab, pv[p1pitch + 1]));
-                            } else {
-                                fu = mix4(c00, c10, c01, c11, T8(tab, pc[0]), T8(tab, pc[2]), T8(tab, pc[p1pitch]), T8(tab, pc[p1pitch + 2]));
-                                fv = mix4(c00, c10, c01, c11, T8(tab, pc[1]), T8(tab, pc[3]), T8(tab, pc[p1pitch + 1]), T8(tab, pc[p1pitch + 3]));
-                            }
-                            constexpr int jj = j >> 1;
-                            uint32_t &uw = cu[jj >> 2], &vw = cv[jj >> 2];
-                            uw = put_code<jj & 3>(uw, OP ? fu : T8k<jj & 3>(tab, uw) * ialpha + fu * alpha);
-                            vw = put_code<jj & 3>(vw, OP ? fv : T8k<jj & 3>(tab, vw) * ialpha + fv * alpha);
+                    if constexpr ((j & 3) == 0) {
+                        // chroma rows 2 m (even lanes) and 2 m + 1 (odd lanes), m = j / 4: sampled at the uv of the quad's even/even
+                        // pixel — the even lane's column entry (cco_q, cca_q), the row entry of luma row 4 m + 2 par — on the
+                        // half-size plane(s)
+                        constexpr int m = j >> 2;
+                        const uint4 qa = rowtab[8 * m + 4 * par], qb = rowtab[8 * m + 4 * par + 1];
+                        const bool tkc = pic_q && qa.z == (uint32_t)AX_ALL;
+                        const float cbw = __uint_as_float(qb.z), icb = __uint_as_float(qb.w);
+                        const uint8_t *pc = smem + ((int)qa.y + cco_q);
+                        const float c00 = icaq * icb, c10 = cca_q * icb, c01 = icaq * cbw, c11 = cca_q * cbw;
+                        float fu, fv;
+                        if constexpr (PL) {
+                            fu = mix4(c00, c10, c01, c11, T8(tab, pc[0]), T8(tab, pc[1]), T8(tab, pc[p1pitch]), T8(tab, pc[p1pitch + 1]));
+                            const uint8_t *pv = pc + voff;
+                            fv = mix4(c00, c10, c01, c11, T8(tab, pv[0]), T8(tab, pv[1]), T8(tab, pv[p1pitch]), T8(tab, pv[p1pitch + 1]));
+                        } else {
+                            fu = mix4(c00, c10, c01, c11, T8(tab, pc[0]), T8(tab, pc[2]), T8(tab, pc[p1pitch]), T8(tab, pc[p1pitch + 2]));
+                            fv = mix4(c00, c10, c01, c11, T8(tab, pc[1]), T8(tab, pc[3]), T8(tab, pc[p1pitch + 1]), T8(tab, pc[p1pitch + 3]));
                         }
+                        const uint32_t nnu = put_code<m>(nu, OP ? fu : T8k<m>(tab, nu) * ialpha + fu * alpha);
+                        const uint32_t nnv = put_code<m>(nv, OP ? fv : T8k<m>(tab, nv) * ialpha + fv * alpha);
+                        nu = tkc ? nnu : nu; nv = tkc ? nnv : nv;
                     }
                 };
                 if (carry) { auto r = [&](auto jc) { row(jc, std::true_type{}); }; for_rows<YTH>(r); }
@@ -281,14 +302,24 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                 const uint32_t nlw = put_code<j & 3>(lw, rx * ia2 + yy * a2);
                 lw = tk ? nlw : lw;
                 if constexpr ((j & 1) == 0) {
-                    if (owner_lane && tk) {
-                        constexpr int jj = j >> 1;
-                        uint32_t &uw = cu[jj >> 2], &vw = cv[jj >> 2];
-                        const float ry = clampf(T8k<jj & 3>(tab, uw) * iaf + fua, -1.f, 1.f);
-                        const float rz = clampf(T8k<jj & 3>(tab, vw) * iaf + fva, -1.f, 1.f);
-                        uw = put_code<jj & 3>(uw, ry * ia2 + uu * a2);
-                        vw = put_code<jj & 3>(vw, rz * ia2 + vv * a2);
+                    // the quad's chroma comes from the even lane's pixel of this (even) row; chroma row jj = j / 2 lives in the even
+                    // lane (jj even) or in its odd neighbour (jj odd: the values travel one lane up, quad_perm [0, 0, 2, 2])
+                    constexpr int jj = j >> 1, m = jj >> 1;
+                    float su = uu, sv = vv, sa = a2, sia = ia2;
+                    int stk = (tk && owner_lane) ? 1 : 0;
+                    if constexpr ((jj & 1) != 0) {
+                        su = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(uu), __float_as_int(uu), 0xA0, 0xf, 0xf, false));
+                        sv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(vv), __float_as_int(vv), 0xA0, 0xf, 0xf, false));
+                        sa = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a2), __float_as_int(a2), 0xA0, 0xf, 0xf, false));
+                        sia = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ia2), __float_as_int(ia2), 0xA0, 0xf, 0xf, false));
+                        stk = __builtin_amdgcn_update_dpp(stk, stk, 0xA0, 0xf, 0xf, false);
                     }
+                    const bool mine = stk != 0 && par == (jj & 1);
+                    const float ry = clampf(T8k<m>(tab, nu) * iaf + fua, -1.f, 1.f);
+                    const float rz = clampf(T8k<m>(tab, nv) * iaf + fva, -1.f, 1.f);
+                    const uint32_t nnu = put_code<m>(nu, ry * sia + su * sa);
+                    const uint32_t nnv = put_code<m>(nv, rz * sia + sv * sa);
+                    nu = mine ? nnu : nu; nv = mine ? nnv : nv;
                 }
             };
             if (carry) { auto r = [&](auto jc) { row(jc, std::true_type{}); }; for_rows<YTH>(r); }
@@ -300,45 +331,52 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
             for (int j = 0; j < YTH; j++) {
                 const int y = y0 + j;
                 if (y >= TH) break;
-                const int sh = 8 * (j & 3), csh = 8 * ((j >> 1) & 3);
-                uint32_t lw = ly[0], uw = cu[0], vw = cv[0];
+                const int sh = 8 * (j & 3), csh = 8 * (j >> 2);          // luma byte; chroma byte m = (j / 2) / 2 of the holding lane
+                uint32_t lw = ly[0];
 #pragma unroll
                 for (int k = 1; k < YLW; k++) lw = (j >> 2) == k ? ly[k] : lw;
-#pragma unroll
-                for (int k = 1; k < YCW; k++) { uw = (j >> 3) == k ? cu[k] : uw; vw = (j >> 3) == k ? cv[k] : vw; }
                 uint32_t cy = (lw >> sh) & 255u;
                 const bool owner = owner_lane && (j & 1) == 0;
-                uint32_t pu = owner ? (uw >> csh) & 255u : 0u, pv = owner ? (vw >> csh) & 255u : 0u;
+                // the owner pixel's chroma codes: its own (chroma row j / 2 even) or its odd neighbour's (odd; quad_perm [1, 1, 3, 3])
+                const bool from_odd = ((j >> 1) & 1) != 0;
+                const uint32_t ownu = (nu >> csh) & 255u, ownv = (nv >> csh) & 255u;
+                const uint32_t nbu = (uint32_t)__builtin_amdgcn_update_dpp((int)ownu, (int)ownu, 0xF5, 0xf, 0xf, false);
+                const uint32_t nbv = (uint32_t)__builtin_amdgcn_update_dpp((int)ownv, (int)ownv, 0xF5, 0xf, 0xf, false);
+                uint32_t pu = owner ? (from_odd ? nbu : ownu) : 0u, pv = owner ? (from_odd ? nbv : ownv) : 0u;
                 if (Ly.kind == LK_YUV_FROM_RGB) apply_yuv_from_rgb(Ly, x, y, sx, sy, owner, cy, pu, pv);
                 else apply_yuv_from_yuv(Ly, x, y, sx, sy, owner, cy, pu, pv);
                 lw = (lw & ~(255u << sh)) | (cy << sh);
 #pragma unroll
                 for (int k = 0; k < YLW; k++) ly[k] = (j >> 2) == k ? lw : ly[k];
-                if (owner) {
-                    uw = (uw & ~(255u << csh)) | (pu << csh); vw = (vw & ~(255u << csh)) | (pv << csh);
-#pragma unroll
-                    for (int k = 0; k < YCW; k++) { cu[k] = (j >> 3) == k ? uw : cu[k]; cv[k] = (j >> 3) == k ? vw : cv[k]; }
-                }
+                // back to the lane that holds the row (all lanes of the wave execute this: the loop runs over uniform j)
+                const int ow = owner ? 1 : 0;
+                const uint32_t bu = (uint32_t)__builtin_amdgcn_update_dpp((int)pu, (int)pu, 0xA0, 0xf, 0xf, false);
+                const uint32_t bv = (uint32_t)__builtin_amdgcn_update_dpp((int)pv, (int)pv, 0xA0, 0xf, 0xf, false);
+                const bool bo = __builtin_amdgcn_update_dpp(ow, ow, 0xA0, 0xf, 0xf, false) != 0;
+                const bool mine = (j & 1) == 0 && bo && par == (from_odd ? 1 : 0);
+                if (mine) { nu = (nu & ~(255u << csh)) | (bu << csh); nv = (nv & ~(255u << csh)) | (bv << csh); }
             }
         }
         wave_lds_fence();                 // the taps of layer l are read before the next layer's setup overwrites table and rectangles
         l = ln;
     }
 
-    if (col_in) {
+    if (CHV_ABL & 4) {
+#pragma unroll
+        for (int k = 0; k < YLW; k++) asm volatile("" :: "v"(ly[k]));
+        asm volatile("" :: "v"(nu), "v"(nv));
+    } else if (col_in) {
 #pragma unroll
         for (int j = 0; j < YTH; j++)
             if (y0 + j < TH) gst_at<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch, (uint32_t)x, (uint8_t)((ly[j >> 2] >> (8 * (j & 3))) & 255u));
-        if (owner_lane) {
 #pragma unroll
-            for (int jj = 0; jj < YTH / 2; jj++) {
-                if (y0 + 2 * jj < TH) {
-                    const uint32_t ub = (cu[jj >> 2] >> (8 * (jj & 3))) & 255u, vb = (cv[jj >> 2] >> (8 * (jj & 3))) & 255u;
-                    if (TF == TF_NV12) gst_at<uint16_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch, (uint32_t)qx * 2u, (uint16_t)(ub | (vb << 8)));
-                    else {
-                        gst_at<uint8_t>(PC.ptr + (size_t)(qy0 + jj) * PC.pitch, (uint32_t)qx, (uint8_t)ub);
-                        gst_at<uint8_t>(PV.ptr + (size_t)(qy0 + jj) * PV.pitch, (uint32_t)qx, (uint8_t)vb);
-                    }
+        for (int m = 0; m < YCM; m++) {
+            if (y0 + 4 * m + 2 * par < TH) {
+                const uint32_t ub = (nu >> (8 * m)) & 255u, vb = (nv >> (8 * m)) & 255u;
+                if (TF == TF_NV12) gst_at<uint16_t>(PC.ptr + (size_t)(qy0 + 2 * m) * PC.pitch, coff_c, (uint16_t)(ub | (vb << 8)));
+                else {
+                    gst_at<uint8_t>(PC.ptr + (size_t)(qy0 + 2 * m) * PC.pitch, coff_c, (uint8_t)ub);
+                    gst_at<uint8_t>(PV.ptr + (size_t)(qy0 + 2 * m) * PV.pitch, coff_v, (uint8_t)vb);
                 }
             }
         }

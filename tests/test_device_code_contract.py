@@ -31,7 +31,7 @@ def _kernels(co):
     notes = subprocess.run([LLVM / "llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
     out, cur = {}, None
     for line in notes.splitlines():
-        m = re.match(r"\s*\.(name|vgpr_count|vgpr_spill_count|sgpr_spill_count):\s+(\S+)", line)
+        m = re.match(r"\s*\.(name|vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\S+)", line)
         if not m:
             continue
         k, v = m.groups()
@@ -89,11 +89,13 @@ def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem)
     co = _code_object(tmp_path, stem)
     for name, m in _find(_kernels(co), "wave").items():
         tall = "tick_bgra_waveILi16E" in name             # BGRA canvas, 16-row strips: 96 VGPRs = 5 waves, no spills
-        tall_yuv = "tick_yuv_wave" in name and name.endswith("Li16EEEvPKNS_5DTickEPKNS_6DLayerEiiiiiiii")
         assert m["vgpr_count"] <= (96 if tall else 80), (name, m)
-        # 4:2:0 canvas, 16-row strips: 6 waves with nine to twelve spilled registers measured faster than 5 waves without
-        yuv = "tick_yuv_wave" in name                     # (its un-cleared 8-row instantiation: four)
-        assert m["vgpr_spill_count"] <= (0 if tall else 12 if tall_yuv else 4 if yuv else 2), (name, m)
+        if "tick_yuv_wave" in name:
+            # 4:2:0 canvases: 6 waves with a few registers in scratch measured faster than 5 waves without (16-row strips: 0.49
+            # vs 0.67 ms on y420p_main); bounded by the scratch footprint (the metadata's spill count is per spill instruction)
+            assert m["private_segment_fixed_size"] <= 64, (name, m)
+        else:
+            assert m["vgpr_spill_count"] <= (0 if tall else 2), (name, m)
     asm = subprocess.run([LLVM / "llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
     scalar = len(re.findall(r"\bs_load_dword", asm))
     vector1 = len(re.findall(r"\bglobal_load_dword\s", asm))        # single-dword vector loads: what a uniform read degrades to
