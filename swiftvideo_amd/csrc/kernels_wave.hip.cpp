@@ -71,11 +71,11 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
 template <int WTH, bool CLEAR>
 __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE_MINW)) void tick_bgra_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
-                                                                         int n_ticks, int strips_x, int strips_y,
+                                                                         int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     WaveStrip<WTH> S;
-    if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, smem_all, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;   // (no block barrier anywhere: waves may leave)
+    if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;   // (no block barrier anywhere: waves may leave)
     const DTick &T = *S.T;
     const DLayer *L = S.L;
     const int nl = S.nl, lane = S.lane, x = S.x, y0 = S.y0;
@@ -329,9 +329,9 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
 // launch (geometry, LDS sizing and eligibility of both wave kernels: kernels_wave_yuv.hip.cpp)
 // ---------------------------------------------------------------------------
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
-                            int strips_x, int strips_y, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar) {
+                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar) {
 #define CHV_LAUNCH_B(R, C) hipLaunchKernelGGL((tick_bgra_wave<R, C>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
-                                              p0pitch, p0rows, p1pitch, p1rows, planar)
+                                              strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar)
     if (rows == 16) { if (clear) CHV_LAUNCH_B(16, true); else CHV_LAUNCH_B(16, false); }
     else            { if (clear) CHV_LAUNCH_B(8, true); else CHV_LAUNCH_B(8, false); }
 #undef CHV_LAUNCH_B

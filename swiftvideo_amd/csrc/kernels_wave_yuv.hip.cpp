@@ -97,7 +97,7 @@ CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float 
 template <int TF, bool CLEAR, int YTH>
 __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
-                                                                         int n_ticks, int strips_x, int strips_y,
+                                                                         int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
     constexpr int YLW = YTH / 4;                     // registers holding the lane's luma codes (4 rows per register)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     __syncthreads();                      // the only block barrier, before any wave leaves
 #endif
     WaveStrip<YTH> S;
-    if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, smem_all + UNORM_TAB_BYTES, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;
+    if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all + UNORM_TAB_BYTES, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;
     const DTick &T = *S.T;
     const DLayer *L = S.L;
     const int nl = S.nl, x = S.x, y0 = S.y0;
@@ -437,7 +437,7 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
         for (int l = 0; l < T.n_layers; l++) {
             const DLayer &L = layers[T.first_layer + l];
             const bool rgb = host_src_rgb(L.kind), nv12 = host_src_nv12(L.kind), planar = host_src_planar(L.kind);
-            if (!(rgb || nv12 || planar) || !(L.flags & LF_AXIS_ALIGNED)) return false;
+            if (!(rgb || nv12 || planar) || (L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) return false;
             if (!finite16w(L.u + U_TRANSFORM) || !finite16w(L.u + U_TEXTURE) || !finite16w(L.u + U_BORDER)) return false;
             const int np = rgb ? 1 : nv12 ? 2 : 3;
             for (int p = 0; p < np; p++) if (!aligned16w(L.src.pl[p])) return false;
@@ -450,7 +450,7 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
 
 // kernels_wave.hip.cpp
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
-                            int strips_x, int strips_y, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar);
+                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar);
 
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream) {
@@ -502,15 +502,18 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
         lds = wave_lds(m, planar, target_format, WTH);
     }
     int strips_x = (maxW + WTW - 1) / WTW, strips_y = (maxH + WTH - 1) / WTH;
+    // floor(2^32 / d) for the kernels' scalar divisions by the strips per tick and per row (WaveStrip::udivmod)
+    auto magic = [](uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); };
+    const uint32_t strips_magic = magic((uint32_t)(strips_x * strips_y)), strips_x_magic = magic((uint32_t)strips_x);
     long total = (long)n_ticks * strips_x * strips_y;
     long per_xcd = (total + 7) / 8;
     long blocks_per_xcd = (per_xcd + WAVES - 1) / WAVES;
     dim3 grid((unsigned)(blocks_per_xcd * 8));
     const bool clear = ticks_host[0].clear_first != 0;
     if (target_format == TF_BGRA)
-        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0);
+        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0);
 #define CHV_LAUNCH_Y(TFV, C, R) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
-                                                   m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
+                                                   strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
 #define CHV_LAUNCH_YR(TFV, C) do { if (WTH == 16) CHV_LAUNCH_Y(TFV, C, 16); else CHV_LAUNCH_Y(TFV, C, 8); } while (0)
     if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_YR(TF_NV12, true); else CHV_LAUNCH_YR(TF_NV12, false); }
     else { if (clear) CHV_LAUNCH_YR(TF_Y420P, true); else CHV_LAUNCH_YR(TF_Y420P, false); }

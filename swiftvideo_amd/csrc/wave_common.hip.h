@@ -170,7 +170,16 @@ struct WaveStrip {
 
     // XCD-aware numbering: block b runs on XCD b % 8; every XCD gets one contiguous range of the launch's strips (whole
     // frames when there are >= 8 ticks), so halo rows are shared through that XCD's L2.  false: nothing to do for this wave.
-    CHV_DEV bool init(const DTick *ticks, const DLayer *layers, int n_ticks, int strips_x, int strips_y,
+    // n / d and n % d for wave-uniform operands from M = floor(2^32 / d), which the host passes in (launch_wave_layers):
+    // n M / 2^32 = n / d - n e / (d 2^32) with e = 2^32 mod d < d and n < 2^32, i.e. less than 1 below n / d — the estimate is
+    // the quotient or one less, one correction step.  All on the scalar unit; the compiler's expansion of a 32-bit division
+    // is ~30 instructions through v_rcp_iflag_f32 and v_readfirstlane, twice per strip.
+    static CHV_DEV void udivmod(uint32_t n, uint32_t d, uint32_t M, int &q, int &r) {
+        uint32_t qq = __umulhi(n, M), rr = n - qq * d;
+        if (rr >= d) { qq++; rr -= d; }
+        q = (int)qq; r = (int)rr;
+    }
+    CHV_DEV bool init(const DTick *ticks, const DLayer *layers, int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
                       uint8_t *smem_all, int p0pitch_, int p0rows_, int p1pitch_, int p1rows_, int planar_any) {
         const int tid = threadIdx.x;
         lane = tid & 63;
@@ -189,10 +198,11 @@ struct WaveStrip {
         const int widx = slot * WAVES + wave;                           // this wave's strip within the XCD's range
         const int index = xcd * per_xcd + widx;
         if (widx >= per_xcd || index >= total) return false;
-        const int tick = index / strips;
-        const int strip = index - tick * strips;
+        int tick, strip, sxi, syi;
+        udivmod((uint32_t)index, (uint32_t)strips, strips_magic, tick, strip);
+        udivmod((uint32_t)strip, (uint32_t)strips_x, strips_x_magic, syi, sxi);
         T = ticks + tick;
-        x0 = (strip % strips_x) * WTW; y0 = (strip / strips_x) * WTH;
+        x0 = sxi * WTW; y0 = syi * WTH;
         if (x0 >= T->W || y0 >= T->H) return false;
         L = layers + T->first_layer;
         nl = T->n_layers;
@@ -224,9 +234,10 @@ struct WaveStrip {
         const DPlane &S1 = Ly.src.pl[rgb ? 0 : 1];
         int fl, rfl, cy, cc, ry, rc;
         float rya, rca;
-        if ((Ly.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) == (LF_AXIS_ALIGNED | LF_BOUNDED)) {
-            // bounded matrices: the entries the axis-alignment flag guarantees to be zero contribute exact zeros, so the short
-            // form gives the bits of the full dot products (geometry_axis, pixel_math.hip.h)
+        {
+            // every layer on this path is flagged LF_AXIS_ALIGNED | LF_BOUNDED (host-checked, wave_layers_eligible): the entries the
+            // axis-alignment flag guarantees to be zero contribute exact zeros, so the short form gives the bits of the full dot
+            // products (geometry_axis, pixel_math.hip.h)
             const float *U = Ly.u;
             const float t3 = U[U_TRANSFORM + 15];
             const float t0 = nx * U[U_TRANSFORM + 0] + U[U_TRANSFORM + 3], t1 = ny * U[U_TRANSFORM + 5] + U[U_TRANSFORM + 7];
@@ -236,9 +247,6 @@ struct WaveStrip {
             rfl = ((b1 >= 0.f && b1 <= 1.f) ? AX_BORDER : 0) | ((t1 >= 0.f && t1 <= 1.f) ? AX_TX : 0) | ((v >= 0.f && v <= 1.f) ? AX_UV : 0);
             lin_axis_raw(u, S0.w, cy, w.cya); lin_axis_raw(u, S1.w, cc, w.cca);
             lin_axis_raw(v, S0.h, ry, rya); lin_axis_raw(v, S1.h, rc, rca);
-        } else {
-            axis_entry_x(Ly.u, xe, sx, sy, S0.w, S1.w, cy, w.cya, cc, w.cca, fl);
-            axis_entry_y(Ly.u, ye, sx, sy, S0.h, S1.h, ry, rya, rc, rca, rfl);
         }
         const AxisSum cs = axis_summary(~0ull, col_in, fl, cy, cc);
         w.cfl = col_in ? fl : AX_ALL;                               // past the canvas edge: never stored; copy of the last column

@@ -1,3 +1,3 @@
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/t.txt
+timeout 1500 python -m pytest tests/test_gpu_mixpath.py tests/test_gpu_yuvwave.py tests/test_gpu_fastpath.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py -x -q 2>&1 | tail -5 > gpurun_out/t.txt
 tools/gpu_ab.sh
 cat gpurun_out/t.txt
