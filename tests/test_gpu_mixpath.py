@@ -119,6 +119,10 @@ def test_mixed_fallbacks(ctx, monkeypatch):
     assert run_tick_case(ctx, 140, 60, True, twenty, expect=None) == WAVE
     rot = [("img_nv12_bgra", 48, 28, dict()), ("img_bgra_bgra_tx", 48, 28, dict(rect=(10, 5, 40, 20), rotation=0.3))]
     assert run_tick_case(ctx, 96, 54, True, rot, expect=None) == "tick_general_bgra"
+    # finite but unbounded matrix entries (a picture 1e-18 pixels wide: inverse entries beyond 2^60): the wave kernels evaluate the
+    # short form of the geometry only, whose zero terms could then meet an overflowed product -> general kernel
+    thin = [("img_nv12_bgra", 48, 28, dict()), ("img_bgra_bgra_tx", 48, 28, dict(rect=(10, 5, 1e-18, 20), border=(3, 3, 3, 3), fill=(0.2, 0.4, 0.9, 0.8)))]
+    assert run_tick_case(ctx, 96, 54, True, thin, expect=None) == "tick_general_bgra"
 
 
 @pytest.mark.parametrize("seed", range(32))
