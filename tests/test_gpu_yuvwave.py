@@ -153,3 +153,46 @@ def test_reference_default_mixer_canvas_full_size(ctx, rows, d):
              (f"img_bgra_{d}", 640, 360, dict(rect=(64, 64, 640, 360), opacity=0.8)),
              (f"img_bgra_{d}", 640, 360, dict(rect=(1200, 640, 640, 360), opacity=0.6))]
     run_yuv_tick(ctx, d, cw, ch, True, specs, seed=0x5EED0000 + 64)
+
+
+@pytest.mark.parametrize("cw,pitch", [(130, 130), (132, 132), (128, 134)])
+def test_wrapped_canvas_with_tight_pitch(ctx, rows, cw, pitch):
+    """A foreign NV12 canvas (one allocation, luma + chroma adjacent, pitch = width or any other value, no alignment promised):
+    never a byte outside the payload of a row is written."""
+    import ctypes as C
+    from swiftvideo_amd import chipvideo as cv
+    lib = cv.load()
+    ch, sw, sh = 38, 96, 54
+    canvas0 = util.alloc_image("nv12", cw, ch, seed=401)
+    frame = np.full(pitch * (ch + ch // 2) + 8, 0xA5, dtype=np.uint8)
+    frame[: pitch * ch].reshape(ch, pitch)[:, :cw] = canvas0[0]
+    frame[pitch * ch: pitch * (ch + ch // 2)].reshape(ch // 2, pitch)[:, :cw] = canvas0[1].reshape(ch // 2, cw)
+    owner = C.c_void_p()
+    cv.check(lib.chv_buffer_alloc(ctx.handle, frame.size, C.byref(owner)))
+    cv.check(lib.chv_upload(ctx.handle, owner, 0, frame.size, frame.ctypes.data, frame.size, frame.size, 1, 0))
+    devptr = C.c_void_p()
+    cv.check(lib.chv_buffer_info(owner, C.byref(devptr), None))
+    wrapped = C.c_void_p()
+    cv.check(lib.chv_buffer_wrap(ctx.handle, devptr, frame.size, C.byref(wrapped)))
+    img = cv.Image()
+    img.format, img.width, img.height, img.n_planes = cv.FMT_NV12, cw, ch, 2
+    img.planes[0] = cv.Plane(wrapped.value, 0, cw, ch, pitch, 1)
+    img.planes[1] = cv.Plane(wrapped.value, pitch * ch, cw // 2, ch // 2, pitch, 2)
+    src = util.alloc_image("nv12", sw, sh, seed=402)
+    gsrc = G.to_gpu(ctx, "nv12", sw, sh, src)
+    u = util.make_uniforms((cw, ch), in_size=(sw, sh), opacity=0.7)
+    sdesc = sv._image_desc(gsrc)
+    arr = (cv.Image * 1)(sdesc)
+    cv.check(lib.chv_pass_begin(ctx.handle))
+    cv.check(lib.chv_run_kernel(ctx.handle, cv.K_IMG_NV12_NV12, C.byref(img), arr, 1, u.ctypes.data, 236, 1, None))
+    cv.check(lib.chv_pass_end(ctx.handle, 1))
+    exp = util.copy_image(canvas0)
+    assert O.run_kernel("img_nv12_nv12", exp, src, u) == 0
+    back = np.zeros_like(frame)
+    cv.check(lib.chv_download(ctx.handle, back.ctypes.data, back.size, owner, 0, back.size, back.size, 1))
+    want = frame.copy()
+    want[: pitch * ch].reshape(ch, pitch)[:, :cw] = exp[0]
+    want[pitch * ch: pitch * (ch + ch // 2)].reshape(ch // 2, pitch)[:, :cw] = exp[1].reshape(ch // 2, cw)
+    assert np.array_equal(back, want), f"first difference at byte {int(np.argwhere(back != want)[0][0])}"
+    cv.check(lib.chv_buffer_free(wrapped))
+    cv.check(lib.chv_buffer_free(owner))
