@@ -26,6 +26,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/chipvideo.h"
@@ -428,6 +429,17 @@ inline ComputeContext scaleLanczos(ComputeContext ctx, const PictureSample &dst,
     if (!describe(dst, &d)) throw ComputeError(CHV_ERR_BAD_TARGET, "target has no GPU image buffer");
     if (!describe(src, &s)) throw ComputeError(CHV_ERR_BAD_INPUT, "Bad input image");
     check(chv_scale_lanczos(ctx.get(), &d, &s));
+    return ctx;
+}
+
+// n resizes of one geometry as one launch (chv_scale_lanczos_batch): same bytes as n scaleLanczos calls
+inline ComputeContext scaleLanczos(ComputeContext ctx, const std::vector<std::pair<PictureSample, PictureSample>> &dstSrcPairs) {
+    std::vector<chv_image> d(dstSrcPairs.size()), s(dstSrcPairs.size());
+    for (size_t i = 0; i < dstSrcPairs.size(); i++) {
+        if (!describe(dstSrcPairs[i].first, &d[i])) throw ComputeError(CHV_ERR_BAD_TARGET, "target has no GPU image buffer");
+        if (!describe(dstSrcPairs[i].second, &s[i])) throw ComputeError(CHV_ERR_BAD_INPUT, "Bad input image");
+    }
+    if (!d.empty()) check(chv_scale_lanczos_batch(ctx.get(), d.data(), s.data(), (int)d.size()));
     return ctx;
 }
 

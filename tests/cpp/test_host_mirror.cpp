@@ -261,6 +261,22 @@ static void gpuTests() {
         auto o3 = bad(src);
         EXPECT(o3.kind == o3.error && o3.err.source == "filter.pict");
     }
+    // Lanczos-3: three resizes of one geometry as one launch == the same three one by one
+    {
+        std::vector<std::pair<sv::PictureSample, sv::PictureSample>> pairs;
+        std::vector<sv::PictureSample> single;
+        for (int k = 0; k < 3; k++) {
+            sv::PictureSample src = sv::uploadComputePicture(ctx, randomPicture(sv::PixelFormat::BGRA, 96, 54, 90 + k));
+            sv::PictureSample a = sv::uploadComputePicture(ctx, sv::createPictureSample({ 40, 22 }, sv::PixelFormat::BGRA));
+            sv::PictureSample b = sv::uploadComputePicture(ctx, sv::createPictureSample({ 40, 22 }, sv::PixelFormat::BGRA));
+            pairs.push_back({ a, src });
+            ctx = sv::usingContext(ctx, [&](sv::ComputeContext c) { return sv::scaleLanczos(c, b, src); });
+            single.push_back(b);
+        }
+        ctx = sv::usingContext(ctx, [&](sv::ComputeContext c) { return sv::scaleLanczos(c, pairs); });
+        for (int k = 0; k < 3; k++)
+            EXPECT(samePlanes(sv::downloadComputePicture(ctx, pairs[k].first, true), sv::downloadComputePicture(ctx, single[k], true)));
+    }
     // VideoMixerGroup / TickBatch: three mixers ticked by one launch per canvas format == each mixer's own mix()
     {
         std::vector<std::unique_ptr<sv::VideoMixer>> grouped, solo;
