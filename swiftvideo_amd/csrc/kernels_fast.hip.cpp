@@ -79,7 +79,7 @@ struct TileTablesT {
 };
 
 // axis_entry_x / axis_entry_y, blend_bgra_general and the LDS / global YUV samplers live in tile_common.hip.h
-// (shared with kernels_fast_mix.hip.cpp)
+// (shared with the wave kernels)
 
 // ---------------------------------------------------------------------------
 // FP_NV12_BGRA_TILED / FP_Y420P_BGRA_TILED: one LK_BGRA_FROM_{NV12,Y420P} layer per tick, axis aligned.

@@ -1,5 +1,6 @@
-// tile_common.hip.h — building blocks shared by the axis-aligned LDS-tiled kernels
-// (kernels_fast.hip.cpp: NV12 -> BGRA; kernels_fast_rgb.hip.cpp: BGRA/RGBA layers -> BGRA).
+// tile_common.hip.h — building blocks shared by the axis-aligned LDS-staged kernels (kernels_fast.hip.cpp: one YUV layer ->
+// BGRA, block-tiled; wave_common.hip.h / kernels_wave*.hip.cpp: N layers, one wave per strip): staging of source rectangles
+// with CLAMP_TO_EDGE resolved at staging time, per-axis table entries, the LDS / global YUV samplers.
 #pragma once
 #include "pixel_math.hip.h"
 
