@@ -35,6 +35,12 @@
 #ifndef CHV_ABL
 #define CHV_ABL 0
 #endif
+// Rectangles that touch no picture edge staged by the instantiation without clamping / patching code: YUV sources only (bit 0).
+// Measured in one call: pipeline 1.834 -> 1.734 ms, mixed 0.839 -> 0.799 with it; RGB sources (bit 1) cfg3 1.444 -> 1.611 and the
+// 4:2:0 kernel 0.484 -> 0.507 (y420p_main) against it — the register allocation of the row loops shifts with the code around them.
+#ifndef CHV_WAVE_INTERIOR
+#define CHV_WAVE_INTERIOR 1
+#endif
 #ifndef CHV_WAVE_PRIO
 #define CHV_WAVE_PRIO 1
 #endif
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
                                                                          int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
-    WaveStrip<WTH> S;
+    WaveStrip<WTH, CHV_WAVE_INTERIOR> S;
     if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;   // (no block barrier anywhere: waves may leave)
     const DTick &T = *S.T;
     const DLayer *L = S.L;

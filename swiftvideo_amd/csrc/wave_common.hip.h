@@ -77,7 +77,9 @@ struct WLayer {
 //                              unclamped tap-0 row positions), flags
 //   B = {yb, 1 - yb, cb, 1 - cb}: weights of tap row 1 (luma / RGB, chroma) and their complements
 
-template <int OFF, int N, int NR>
+// EDGE = false: the caller knows (uniformly) that the rectangle touches no picture edge — no clamping, no patching, no
+// padding vector: the compact instantiation most strips run
+template <int OFF, int N, int NR, bool EDGE = true>
 CHV_DEV void wstage_load(uint4 (&regs)[NR], const DPlane &P, const StageGeom &g, int lane) {
     // exactly one global_load_dwordx4 per slot, straight into its final register (see stage_load, tile_common.hip.h)
 #pragma unroll
@@ -85,21 +87,25 @@ CHV_DEV void wstage_load(uint4 (&regs)[NR], const DPlane &P, const StageGeom &g,
         int i = lane + n * 64, r, vv;
         stage_slot(g, i, r, vv);
         if (r < g.rows) {
-            int row = min(max(g.r_lo + r, 0), P.h - 1);
-            int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
-            if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
-            regs[OFF + n] = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
+            if constexpr (EDGE) {
+                int row = min(max(g.r_lo + r, 0), P.h - 1);
+                int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
+                if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
+                regs[OFF + n] = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
+            } else {
+                regs[OFF + n] = gld<uint4>(P.ptr + (size_t)(g.r_lo + r) * P.pitch + (g.b0 + vv * 16));
+            }
         }
     }
 }
 // one slot: CLAMP_TO_EDGE patching (edge rectangles only), optional RGBA -> BGRA, LDS write
-template <int BPT>
+template <int BPT, bool EDGE = true>
 CHV_DEV void wstage_put(uint4 val, int i, uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, bool swap02) {
     int r, vv;
     stage_slot(g, i, r, vv);
     if (i < 1024 && r < g.rows) {
-        int v = g.edge ? vv - 1 : vv;
-        if (g.edge) {
+        int v = (EDGE && g.edge) ? vv - 1 : vv;
+        if (EDGE && g.edge) {
             int row = min(max(g.r_lo + r, 0), P.h - 1);
             int off = g.b0 + v * 16;
             if (off >= 0 && off < P.w * BPT && !vec_loadable(P, row, off)) val = load_tail_vec(P, row, off);
@@ -112,15 +118,15 @@ CHV_DEV void wstage_put(uint4 val, int i, uint8_t *lds, int lds_pitch, const DPl
         *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
     }
 }
-template <int BPT, int OFF, int N, int NR>
+template <int BPT, int OFF, int N, int NR, bool EDGE = true>
 CHV_DEV void wstage_store(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int lane, bool swap02) {
 #pragma unroll
-    for (int n = 0; n < N; n++) wstage_put<BPT>(regs[OFF + n], lane + n * 64, lds, lds_pitch, P, g, swap02);
+    for (int n = 0; n < N; n++) wstage_put<BPT, EDGE>(regs[OFF + n], lane + n * 64, lds, lds_pitch, P, g, swap02);
 }
 // Slots beyond the registers' share of a plane (stronger downscales, rectangles at a picture edge): further rounds of
 // WTAIL loads in flight, one wait, WTAIL LDS writes (not unrolled beyond that: the edge patching is large code).
 constexpr int WTAIL = 2;
-template <int BPT, int N>
+template <int BPT, int N, bool EDGE = true>
 CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int lane, bool swap02) {
 #pragma unroll 1
     for (int base = N * 64; base < stage_slots(g); base += WTAIL * 64) {
@@ -131,14 +137,18 @@ CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const Sta
             stage_slot(g, i, r, vv);
             t[n] = make_uint4(0, 0, 0, 0);
             if (i < 1024 && r < g.rows) {
-                int row = min(max(g.r_lo + r, 0), P.h - 1);
-                int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
-                if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
-                t[n] = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
+                if constexpr (EDGE) {
+                    int row = min(max(g.r_lo + r, 0), P.h - 1);
+                    int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
+                    if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
+                    t[n] = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
+                } else {
+                    t[n] = gld<uint4>(P.ptr + (size_t)(g.r_lo + r) * P.pitch + (g.b0 + vv * 16));
+                }
             }
         }
 #pragma unroll 1
-        for (int n = 0; n < WTAIL; n++) wstage_put<BPT>(n == 0 ? t[0] : t[WTAIL - 1], base + n * 64 + lane, lds, lds_pitch, P, g, swap02);
+        for (int n = 0; n < WTAIL; n++) wstage_put<BPT, EDGE>(n == 0 ? t[0] : t[WTAIL - 1], base + n * 64 + lane, lds, lds_pitch, P, g, swap02);
     }
 }
 
@@ -153,7 +163,9 @@ CHV_DEV bool src_is_rgb(int kind) { return kind == LK_BGRA_FROM_RGB || kind == L
 CHV_DEV bool src_is_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind == LK_YUV_FROM_Y420P; }
 
 // One wave's strip of one tick: WTW columns (lane = column) x WTH rows of the canvas.
-template <int WTH>
+// INTERIOR: bit 0 — YUV-source rectangles, bit 1 — RGB-source rectangles that touch no picture edge are staged by the compact
+// instantiation (stage_impl<false>); a measured choice per kernel (kernels_wave.hip.cpp)
+template <int WTH, int INTERIOR = 0>
 struct WaveStrip {
     using Cfg = WaveCfg<WTH>;
     static constexpr int WN_Y = Cfg::WN_Y, WN_C = Cfg::WN_C, WN_RGB = Cfg::WN_RGB, WNR = Cfg::WNR, ROWTAB_BYTES = Cfg::ROWTAB_BYTES;
@@ -302,36 +314,45 @@ struct WaveStrip {
     }
 
     // issue the global loads of layer l's rectangles, wait once for all of them, write them to this wave's LDS region
-    CHV_DEV void stage(int l, const WLayer &w) const {
+    template <bool EDGE>
+    CHV_DEV void stage_impl(int l, const WLayer &w) const {
         const DLayer &Ly = L[l];
         uint4 regs[WNR];
         if (src_is_rgb(Ly.kind)) {
-            wstage_load<0, WN_RGB, WNR>(regs, Ly.src.pl[0], w.g0, lane);
+            wstage_load<0, WN_RGB, WNR, EDGE>(regs, Ly.src.pl[0], w.g0, lane);
             touch_regs(regs);             // one wait for all of the layer's loads (see touch_regs, pixel_math.hip.h)
             // staged texels are byte-swapped where the layer asks for it (RGBA source on a BGRA canvas: -> BGRA; BGRA source on a
             // 4:2:0 canvas, kernels.cl.swift:518 `.zyxw`: -> RGBA), so the tap loops need no channel select
-            wstage_store<4, 0, WN_RGB, WNR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
-            wstage_tail<4, WN_RGB>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
+            wstage_store<4, 0, WN_RGB, WNR, EDGE>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
+            wstage_tail<4, WN_RGB, EDGE>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
         } else if (!src_is_planar(Ly.kind)) {
-            wstage_load<0, WN_Y, WNR>(regs, Ly.src.pl[0], w.g0, lane);
-            wstage_load<WN_Y, WN_C, WNR>(regs, Ly.src.pl[1], w.g1, lane);
+            wstage_load<0, WN_Y, WNR, EDGE>(regs, Ly.src.pl[0], w.g0, lane);
+            wstage_load<WN_Y, WN_C, WNR, EDGE>(regs, Ly.src.pl[1], w.g1, lane);
             touch_regs(regs);
-            wstage_store<1, 0, WN_Y, WNR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_store<2, WN_Y, WN_C, WNR>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
-            wstage_tail<1, WN_Y>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_tail<2, WN_C>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
+            wstage_store<1, 0, WN_Y, WNR, EDGE>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
+            wstage_store<2, WN_Y, WN_C, WNR, EDGE>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
+            wstage_tail<1, WN_Y, EDGE>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
+            wstage_tail<2, WN_C, EDGE>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
         } else {
-            wstage_load<0, WN_Y, WNR>(regs, Ly.src.pl[0], w.g0, lane);
-            wstage_load<WN_Y, WN_C, WNR>(regs, Ly.src.pl[1], w.g1, lane);
-            wstage_load<WN_Y + WN_C, WN_C, WNR>(regs, Ly.src.pl[2], w.g1, lane);
+            wstage_load<0, WN_Y, WNR, EDGE>(regs, Ly.src.pl[0], w.g0, lane);
+            wstage_load<WN_Y, WN_C, WNR, EDGE>(regs, Ly.src.pl[1], w.g1, lane);
+            wstage_load<WN_Y + WN_C, WN_C, WNR, EDGE>(regs, Ly.src.pl[2], w.g1, lane);
             touch_regs(regs);
-            wstage_store<1, 0, WN_Y, WNR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_store<1, WN_Y, WN_C, WNR>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
-            wstage_store<1, WN_Y + WN_C, WN_C, WNR>(regs, smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
-            wstage_tail<1, WN_Y>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_tail<1, WN_C>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
-            wstage_tail<1, WN_C>(smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
+            wstage_store<1, 0, WN_Y, WNR, EDGE>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
+            wstage_store<1, WN_Y, WN_C, WNR, EDGE>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
+            wstage_store<1, WN_Y + WN_C, WN_C, WNR, EDGE>(regs, smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
+            wstage_tail<1, WN_Y, EDGE>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
+            wstage_tail<1, WN_C, EDGE>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
+            wstage_tail<1, WN_C, EDGE>(smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
         }
+    }
+    // (rectangles that touch no picture edge — most strips — take the instantiation without clamping and patching code)
+    CHV_DEV void stage(int l, const WLayer &w) const {
+        const bool rgb = src_is_rgb(L[l].kind);
+        if constexpr (INTERIOR != 0) {
+            if ((INTERIOR & (rgb ? 2 : 1)) && !w.g0.edge && (rgb || !w.g1.edge)) { stage_impl<false>(l, w); return; }
+        }
+        stage_impl<true>(l, w);
     }
 };
 
