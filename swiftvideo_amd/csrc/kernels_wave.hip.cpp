@@ -77,13 +77,14 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
 // the rows that go through the per-pixel path where a layer's edge crosses a strip (ticks with small overlays: 0.88 -> 1.05 ms),
 // so they are used when every layer of the launch covers (almost) the whole canvas; 8 rows otherwise (80 VGPRs, 6 waves).      // strip height: rows per lane (16: -14 % on the 4 x NV12 pipeline at 128 VGPRs, but the LDS
                                         // footprint of 4-byte texel rectangles then halves the occupancy of mixed ticks: 3.0 vs 0.85 ms)
-template <int WTH, bool CLEAR>
+template <int WTH, bool CLEAR, int KINDS>
 __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE_MINW)) void tick_bgra_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
-    WaveStrip<WTH, CHV_WAVE_INTERIOR> S;
+    using Strip = WaveStrip<WTH, CHV_WAVE_INTERIOR, KINDS>;
+    Strip S;
     if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;   // (no block barrier anywhere: waves may leave)
     const DTick &T = *S.T;
     const DLayer *L = S.L;
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
         else {
             const float *U = Ly.u;
             const float opacity = U[U_OPACITY];
-            const bool rgb = Ly.kind == LK_BGRA_FROM_RGB;
-            const bool planar = Ly.kind == LK_BGRA_FROM_Y420P;
+            const bool rgb = Strip::is_rgb(Ly.kind);                 // (compile-time constants in the single-class instantiations)
+            const bool planar = !rgb && Strip::is_planar(Ly.kind);
             const bool nofill = (Ly.flags & LF_NO_FILL) != 0;
             // opacity in [0,1] and no fill: every blend is a convex combination of code values, so neither the clamp of the
             // fill step nor the saturation of the store can trigger; with every pixel of the strip inside the picture the
@@ -345,11 +346,14 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
 // launch (geometry, LDS sizing and eligibility of both wave kernels: kernels_wave_yuv.hip.cpp)
 // ---------------------------------------------------------------------------
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
-                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar) {
-#define CHV_LAUNCH_B(R, C) hipLaunchKernelGGL((tick_bgra_wave<R, C>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
-                                              strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar)
-    if (rows == 16) { if (clear) CHV_LAUNCH_B(16, true); else CHV_LAUNCH_B(16, false); }
-    else            { if (clear) CHV_LAUNCH_B(8, true); else CHV_LAUNCH_B(8, false); }
+                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds) {
+#define CHV_LAUNCH_B(R, C, K) hipLaunchKernelGGL((tick_bgra_wave<R, C, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
+                                                 strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar)
+#define CHV_LAUNCH_BK(R, C) do { if (kinds == 1) CHV_LAUNCH_B(R, C, 1); else if (kinds == 2) CHV_LAUNCH_B(R, C, 2); \
+                                 else if (kinds == 4) CHV_LAUNCH_B(R, C, 4); else CHV_LAUNCH_B(R, C, 7); } while (0)
+    if (rows == 16) { if (clear) CHV_LAUNCH_BK(16, true); else CHV_LAUNCH_BK(16, false); }
+    else            { if (clear) CHV_LAUNCH_BK(8, true); else CHV_LAUNCH_BK(8, false); }
+#undef CHV_LAUNCH_BK
 #undef CHV_LAUNCH_B
     return hipGetLastError();
 }

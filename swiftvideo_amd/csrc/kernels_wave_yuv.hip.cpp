@@ -460,7 +460,7 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
 
 // kernels_wave.hip.cpp
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
-                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar);
+                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds);
 
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream) {
@@ -486,6 +486,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     }
     WaveDims m{ 0, 0, 0, 0 };
     bool planar = false;
+    int kinds = 0;               // source classes in the launch: bit 0 NV12, bit 1 y420p, bit 2 RGB
     auto measure = [&](int rows) {
         m = WaveDims{ 0, 0, 0, 0 };
         planar = false;
@@ -496,6 +497,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
                 m.p0pitch = std::max(m.p0pitch, d.p0pitch); m.p0rows = std::max(m.p0rows, d.p0rows);
                 m.p1pitch = std::max(m.p1pitch, d.p1pitch); m.p1rows = std::max(m.p1rows, d.p1rows);
                 planar = planar || host_src_planar(L.kind);
+                kinds |= host_src_rgb(L.kind) ? 4 : host_src_planar(L.kind) ? 2 : 1;
             }
         }
         return wave_lds(m, planar, target_format, rows);
@@ -521,7 +523,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     dim3 grid((unsigned)(blocks_per_xcd * 8));
     const bool clear = ticks_host[0].clear_first != 0;
     if (target_format == TF_BGRA)
-        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0);
+        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0, kinds);
 #define CHV_LAUNCH_Y(TFV, C, R) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                    strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
 #define CHV_LAUNCH_YR(TFV, C) do { if (WTH == 16) CHV_LAUNCH_Y(TFV, C, 16); else CHV_LAUNCH_Y(TFV, C, 8); } while (0)

@@ -165,8 +165,13 @@ CHV_DEV bool src_is_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind
 // One wave's strip of one tick: WTW columns (lane = column) x WTH rows of the canvas.
 // INTERIOR: bit 0 — YUV-source rectangles, bit 1 — RGB-source rectangles that touch no picture edge are staged by the compact
 // instantiation (stage_impl<false>); a measured choice per kernel (kernels_wave.hip.cpp)
-template <int WTH, int INTERIOR = 0>
+// KINDS: the source classes the launch contains (bit 0 NV12, bit 1 y420p, bit 2 RGB; host-checked).  A launch of one class runs
+// an instantiation that holds no code for the others — the kernels are 70-100 KB of code, and the executed footprint counts
+// (the NV12-only instantiation: pipeline -3.4 %).
+template <int WTH, int INTERIOR = 0, int KINDS = 7>
 struct WaveStrip {
+    static CHV_DEV bool is_rgb(int kind) { return KINDS == 4 ? true : (KINDS & 4) ? src_is_rgb(kind) : false; }
+    static CHV_DEV bool is_planar(int kind) { return KINDS == 2 ? true : (KINDS & 2) ? src_is_planar(kind) : false; }
     using Cfg = WaveCfg<WTH>;
     static constexpr int WN_Y = Cfg::WN_Y, WN_C = Cfg::WN_C, WN_RGB = Cfg::WN_RGB, WNR = Cfg::WNR, ROWTAB_BYTES = Cfg::ROWTAB_BYTES;
     const DTick *T;
@@ -241,7 +246,7 @@ struct WaveStrip {
     CHV_DEV void setup(int l, WLayer &w) const {
         constexpr unsigned long long ROWMASK = WTH >= 64 ? ~0ull : ((1ull << WTH) - 1ull);
         const DLayer &Ly = L[l];
-        const bool rgb = src_is_rgb(Ly.kind);
+        const bool rgb = is_rgb(Ly.kind);
         const DPlane &S0 = Ly.src.pl[0];
         const DPlane &S1 = Ly.src.pl[rgb ? 0 : 1];
         int fl, rfl, cy, cc, ry, rc;
@@ -284,7 +289,7 @@ struct WaveStrip {
                 c0off = base0 + 16 + ((min(max(cy, cs.lo), cs.hi - 1) - col0) << (4 - sh));     // byte of tap 0 in LDS row 0
             }
             if (ok && !rgb) {
-                const int sh = src_is_planar(Ly.kind) ? 4 : 3;
+                const int sh = is_planar(Ly.kind) ? 4 : 3;
                 const int tpv = 1 << sh;
                 const int col0 = max(cs.clo, 0) & ~(tpv - 1);
                 const int nvec = ((min(cs.chi, S1.w - 1) - col0) >> sh) + 1;
@@ -318,14 +323,14 @@ struct WaveStrip {
     CHV_DEV void stage_impl(int l, const WLayer &w) const {
         const DLayer &Ly = L[l];
         uint4 regs[WNR];
-        if (src_is_rgb(Ly.kind)) {
+        if (is_rgb(Ly.kind)) {
             wstage_load<0, WN_RGB, WNR, EDGE>(regs, Ly.src.pl[0], w.g0, lane);
             touch_regs(regs);             // one wait for all of the layer's loads (see touch_regs, pixel_math.hip.h)
             // staged texels are byte-swapped where the layer asks for it (RGBA source on a BGRA canvas: -> BGRA; BGRA source on a
             // 4:2:0 canvas, kernels.cl.swift:518 `.zyxw`: -> RGBA), so the tap loops need no channel select
             wstage_store<4, 0, WN_RGB, WNR, EDGE>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
             wstage_tail<4, WN_RGB, EDGE>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
-        } else if (!src_is_planar(Ly.kind)) {
+        } else if (!is_planar(Ly.kind)) {
             wstage_load<0, WN_Y, WNR, EDGE>(regs, Ly.src.pl[0], w.g0, lane);
             wstage_load<WN_Y, WN_C, WNR, EDGE>(regs, Ly.src.pl[1], w.g1, lane);
             touch_regs(regs);
@@ -348,7 +353,7 @@ struct WaveStrip {
     }
     // (rectangles that touch no picture edge — most strips — take the instantiation without clamping and patching code)
     CHV_DEV void stage(int l, const WLayer &w) const {
-        const bool rgb = src_is_rgb(L[l].kind);
+        const bool rgb = is_rgb(L[l].kind);
         if constexpr (INTERIOR != 0) {
             if ((INTERIOR & (rgb ? 2 : 1)) && !w.g0.edge && (rgb || !w.g1.edge)) { stage_impl<false>(l, w); return; }
         }
