@@ -86,6 +86,9 @@ CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float 
 #ifndef CHV_WAVEY_CARRY
 #define CHV_WAVEY_CARRY 1
 #endif
+#ifndef CHV_WAVEY_INTERIOR
+#define CHV_WAVEY_INTERIOR 1
+#endif
 #ifndef CHV_WAVEY_MINW
 #define CHV_WAVEY_MINW 6
 #endif
@@ -97,7 +100,9 @@ CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float 
 // rows and 6 waves (80 VGPRs, 9 spilled) they are faster everywhere: y420p_main 0.668 -> 0.495 ms, mixer_y420p 0.863 ->
 // 0.829, mixer_nv12 0.828 -> 0.792 (profiles/r02_notes.md).  8-row strips remain for small launches (more waves) and for
 // source rectangles whose 16-row version would not leave room for two strips per 64 KB of LDS.
-template <int TF, bool CLEAR, int YTH>
+// KINDS: source classes in the launch (wave_common.hip.h): 1 / 2 = pictures of the canvas' own format only (NV12 / y420p), 5 / 6 = those
+// plus RGB overlays (the reference's usual mixer), 7 = any
+template <int TF, bool CLEAR, int YTH, int KINDS>
 __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
@@ -109,7 +114,9 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     for (int i = threadIdx.x; i < 256; i += WAVE_BLOCK) tab[i] = unorm8((uint32_t)i);
     __syncthreads();                      // the only block barrier, before any wave leaves
 #endif
-    WaveStrip<YTH> S;
+    // (compact staging of interior rectangles: measured better for the mixed-class instantiations, worse for the own-format one)
+    using Strip = WaveStrip<YTH, (KINDS == 1 || KINDS == 2) ? 0 : CHV_WAVEY_INTERIOR, KINDS>;
+    Strip S;
     if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all + UNORM_TAB_BYTES, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;
     const DTick &T = *S.T;
     const DLayer *L = S.L;
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
         const float *U = Ly.u;
 
         if (CHV_ABL & 2) ly[0] += (uint32_t)(cur.cyo ^ cur.cco ^ __float_as_int(cur.cya) ^ __float_as_int(cur.cca) ^ cur.cfl);
-        else if (fast && Ly.kind != LK_YUV_FROM_RGB) {
+        else if (fast && !Strip::is_rgb(Ly.kind)) {
             // ---- YUV picture over the whole strip (kernels.cl.swift:78-94): cur * (1 - opacity) + sample * opacity ----
             const float alpha = U[U_OPACITY], ialpha = 1.f - alpha;
             const float a = cur.cya, ia = 1.0f - a;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                 if (carry) { auto r = [&](auto jc) { row(jc, std::true_type{}); }; for_rows<YTH>(r); }
                 else { auto r = [&](auto jc) { row(jc, std::false_type{}); }; for_rows<YTH>(r); }
             };
-            const bool planar = Ly.kind == LK_YUV_FROM_Y420P, opaque = (Ly.flags & LF_OPAQUE) != 0;
+            const bool planar = Strip::is_planar(Ly.kind), opaque = (Ly.flags & LF_OPAQUE) != 0;
             if (planar) { if (opaque) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
             else        { if (opaque) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
         } else if (fast) {
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                 const uint32_t nbu = (uint32_t)__builtin_amdgcn_update_dpp((int)ownu, (int)ownu, 0xF5, 0xf, 0xf, false);
                 const uint32_t nbv = (uint32_t)__builtin_amdgcn_update_dpp((int)ownv, (int)ownv, 0xF5, 0xf, 0xf, false);
                 uint32_t pu = owner ? (from_odd ? nbu : ownu) : 0u, pv = owner ? (from_odd ? nbv : ownv) : 0u;
-                if (Ly.kind == LK_YUV_FROM_RGB) apply_yuv_from_rgb(Ly, x, y, sx, sy, owner, cy, pu, pv);
+                if (Strip::is_rgb(Ly.kind)) apply_yuv_from_rgb(Ly, x, y, sx, sy, owner, cy, pu, pv);
                 else apply_yuv_from_yuv(Ly, x, y, sx, sy, owner, cy, pu, pv);
                 lw = (lw & ~(255u << sh)) | (cy << sh);
 #pragma unroll
@@ -524,11 +531,14 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     const bool clear = ticks_host[0].clear_first != 0;
     if (target_format == TF_BGRA)
         return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0, kinds);
-#define CHV_LAUNCH_Y(TFV, C, R) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
-                                                   strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
-#define CHV_LAUNCH_YR(TFV, C) do { if (WTH == 16) CHV_LAUNCH_Y(TFV, C, 16); else CHV_LAUNCH_Y(TFV, C, 8); } while (0)
-    if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_YR(TF_NV12, true); else CHV_LAUNCH_YR(TF_NV12, false); }
-    else { if (clear) CHV_LAUNCH_YR(TF_Y420P, true); else CHV_LAUNCH_YR(TF_Y420P, false); }
+#define CHV_LAUNCH_Y(TFV, C, R, K) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
+                                                      strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
+#define CHV_LAUNCH_YK(TFV, C, R, OWN) do { if (kinds == OWN) CHV_LAUNCH_Y(TFV, C, R, OWN); else if (kinds == (OWN | 4)) CHV_LAUNCH_Y(TFV, C, R, (OWN | 4)); \
+                                           else CHV_LAUNCH_Y(TFV, C, R, 7); } while (0)
+#define CHV_LAUNCH_YR(TFV, C, OWN) do { if (WTH == 16) CHV_LAUNCH_YK(TFV, C, 16, OWN); else CHV_LAUNCH_YK(TFV, C, 8, OWN); } while (0)
+    if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_YR(TF_NV12, true, 1); else CHV_LAUNCH_YR(TF_NV12, false, 1); }
+    else { if (clear) CHV_LAUNCH_YR(TF_Y420P, true, 2); else CHV_LAUNCH_YR(TF_Y420P, false, 2); }
+#undef CHV_LAUNCH_YK
 #undef CHV_LAUNCH_YR
 #undef CHV_LAUNCH_Y
     return hipGetLastError();
