@@ -350,7 +350,8 @@ hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStre
 #define CHV_LAUNCH_B(R, C, K) hipLaunchKernelGGL((tick_bgra_wave<R, C, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                  strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar)
 #define CHV_LAUNCH_BK(R, C) do { if (kinds == 1) CHV_LAUNCH_B(R, C, 1); else if (kinds == 2) CHV_LAUNCH_B(R, C, 2); \
-                                 else if (kinds == 4) CHV_LAUNCH_B(R, C, 4); else CHV_LAUNCH_B(R, C, 7); } while (0)
+                                 else if (kinds == 4) CHV_LAUNCH_B(R, C, 4); else if (kinds == 5) CHV_LAUNCH_B(R, C, 5); \
+                                 else CHV_LAUNCH_B(R, C, 7); } while (0)      /* (y420p + RGB alone: its instantiation spills, 7 does not) */
     if (rows == 16) { if (clear) CHV_LAUNCH_BK(16, true); else CHV_LAUNCH_BK(16, false); }
     else            { if (clear) CHV_LAUNCH_BK(8, true); else CHV_LAUNCH_BK(8, false); }
 #undef CHV_LAUNCH_BK
