@@ -414,7 +414,7 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     // A/B switches for measurements and tests (read per call: tests flip them):
     //   CHV_FORCE_GENERAL=1   everything through the general kernels
     //   CHV_BGRA_PATH=wave    BGRA canvases: the wave-per-strip kernel also where the single-purpose kernel (exactly one YUV
-    //                         layer per tick) would be chosen
+    //                         layer per tick) would be chosen;  =tiled: the single-purpose kernel wherever it applies
     const char *fg = getenv("CHV_FORCE_GENERAL"), *bp = getenv("CHV_BGRA_PATH");
     if (fg && fg[0] == '1') return FP_NONE;
     // 4:2:0 canvases (the reference's own kernels): one wave per strip, or the general quad kernel
@@ -422,6 +422,13 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
         return wave_layers_eligible(target_format, ticks, layers, n_ticks) ? (target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P) : FP_NONE;
     if (!(bp && bp[0] == 'w')) {
         int p = select_single_purpose(ticks, layers, n_ticks);
+        // planar sources in launches that fill the chip: the y420p-only instantiation of the wave kernel is the faster one
+        // (cfg2_y420p 0.574 -> 0.532 ms; NV12 stays: 0.467 tiled vs 0.487 wave); small launches keep the tiled kernel's short strips
+        if (p == FP_Y420P_BGRA_TILED && !(bp && bp[0] == 't')) {
+            long strips = 0;
+            for (int i = 0; i < n_ticks; i++) strips += (long)((ticks[i].W + 63) / 64) * ((ticks[i].H + 15) / 16);
+            if (strips >= 8192 && wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks)) return FP_WAVE_LAYERS;
+        }
         if (p != FP_NONE) return p;
     }
     // any mix of NV12 / y420p / BGRA / RGBA layers, any number of them
