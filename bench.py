@@ -486,8 +486,8 @@ class Timer:
         ms = max(self.dev.elapsed_ms(a, b) / n, 1e-3)
         for e in (a, b):
             self.dev.destroy(e)
-        # 15 % on top: the calibration launches run at least as slow as the timed ones
-        r = max(1, math.ceil(1.15 * min_seconds * 1e3 / (steps * ms)))
+        # 30 % on top: the calibration launches (clocks still ramping) run up to 15 % slower than the timed ones
+        r = max(1, math.ceil(1.3 * min_seconds * 1e3 / (steps * ms)))
         return int(reduce_max(self.dist, r))
 
     def run(self, launch, steps, per_step):
