@@ -217,6 +217,13 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     const bool opaque = (L.flags & LF_OPAQUE) != 0;
 
     for (int j = 0; j < ntiles; j++) {
+#ifndef CHV_TILED_PRIO
+#define CHV_TILED_PRIO 1
+#endif
+        // issue priority for the wait-and-write phase and the next tile's loads, back to 0 for the pixel rows (cfg2 -1.5 %; from
+        // non-volatile asm with a token operand — the builtin is a side effect hipcc orders everything around)
+        int ptok = j;
+        if (CHV_TILED_PRIO) asm("s_setprio 3" : "+s"(ptok));
         // ---- phase 1: the prefetched rectangle of tile j goes to LDS ------------------------
         touch_regs(yregs); touch_regs(cregs);          // the wait for the prefetch, on every path (see touch_regs)
         if (PLANAR) touch_regs(vregs);
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
 
         // ---- phase 2: 4 px x 2 rows per thread ------------------------------------------------
         const bool uniform_inside = staged && cols_inside && tb.rsum[j][5];
-        const int yr0 = gy.r_lo, cr0 = gc.r_lo;
+        if (CHV_TILED_PRIO) asm("s_setprio 0" : "+s"(ptok));
+        const int yr0 = gy.r_lo + (CHV_TILED_PRIO ? ptok - j : 0), cr0 = gc.r_lo;
         // one row of the common case: every pixel of the tile is inside the picture and the layer is
         // opaque, so result = fma(px, 1, cur*0) = px exactly: the colour-matrix word is the output
         // (no canvas read, no float round trip)
