@@ -58,6 +58,10 @@ WORKLOADS = {
                           "alpha composite (opacity 1/.75/.5/.25) onto one 720p BGRA canvas, one launch per batch of ticks",
                      kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=4, frames=256,
                      bytes=4 * NV12_1080 + BGRA_720),
+    "pipeline_logo": dict(desc="the pipeline tick + one ROTATED 320x180 RGBA logo (opacity .9) on top: the rotated layer is applied per pixel "
+                               "inside the wave kernel, the rest stays on the staged path",
+                          kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=4, frames=128, logo=True,
+                          bytes=4 * NV12_1080 + BGRA_720 + 320 * 180 * 4),
     "cfg2": dict(desc="1920x1080 NV12 -> BGRA (BT.601 int) + bilinear downscale to 1280x720",
                  kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=1, frames=256,
                  bytes=NV12_1080 + BGRA_720),
@@ -270,6 +274,12 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
         ops = (1.0, 0.75, 0.5, 0.25)
         us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=ops[l]) for l in range(nl)]
         first_src = first_dst = None
+        logo = logo_u = glogo = None
+        if wl.get("logo"):
+            logo = util.alloc_image("rgba", 320, 180, seed=seed_base + 200)
+            logo_u = util.make_uniforms((dw, dh), rect=(820, 60, 320, 180), rotation=0.3, opacity=0.9, in_size=(320, 180))
+            glogo = up(sv.PixelFormat.RGBA, (320, 180), logo)
+            keep.append(glogo)
         for f in range(frames):
             layers = []
             for l in range(nl):
@@ -287,8 +297,11 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
             if f > 0 and alias in ("dst", "both"):
                 dst = first_dst
             canvases.append(dst)
+            if glogo is not None:
+                layers.append((sv.ComputeKernel.img_rgba_bgra_tx, glogo, logo_u, 0))
             finish_tick(f, dst, layers)
-        verify = dict(target="bgra", layers=lambda f: [(f"img_{sfmt}_bgra", host_src[(f + l) % distinct], us[l]) for l in range(nl)])
+        verify = dict(target="bgra", layers=lambda f: [(f"img_{sfmt}_bgra", host_src[(f + l) % distinct], us[l]) for l in range(nl)] +
+                                                      ([("img_rgba_bgra_tx", logo, logo_u)] if logo is not None else []))
     elif wl["kind"] == "rgb_layers":
         nl = wl["layers"]
         for i in range(distinct):

@@ -25,6 +25,7 @@
 // Same instruction sequence as the general kernel for the coordinates and the same operations on the pixels, so the
 // bytes are those of kernels_general.hip.cpp (= oracle/ref_kernels.c::px_to_bgra layer by layer).
 #include "wave_common.hip.h"
+#include "bgra_pixel.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -116,6 +117,26 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
 
     while (l < nl) {
         const DLayer &Ly = L[l];
+        if constexpr ((KINDS & 8) != 0) {
+            // Layers the strip machinery cannot stage (rotation, shear, unbounded matrices — the launch has some: KINDS bit 3)
+            // are applied pixel by pixel with the general kernel's code, in z order with everything else: one rotated logo does
+            // not send the whole tick to the general kernel.
+            if ((Ly.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) {
+                const float gsx = (float)T.W, gsy = (float)TH;
+#pragma unroll 1
+                for (int j = 0; j < WTH; j++) {
+                    const int y = y0 + j;
+                    uint32_t c = cv[0];
+#pragma unroll
+                    for (int k = 1; k < WTH; k++) c = j == k ? cv[k] : c;
+                    if (col_in && y < TH && x >= Ly.bbox[0] && x < Ly.bbox[2] && y >= Ly.bbox[1] && y < Ly.bbox[3]) c = apply_layer_bgra(Ly, x, y, gsx, gsy, c);
+#pragma unroll
+                    for (int k = 0; k < WTH; k++) cv[k] = j == k ? c : cv[k];
+                }
+                l = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
+                continue;
+            }
+        }
         // Issue priority for the latency-bound phases (geometry, staging): a wave in them has few instructions to issue and long
         // waits between them, so letting it go first whenever it can shortens its chain, and more of the resident waves are in
         // their row loops at any time (pipeline -1.4 %, cfg3 -2.2 %).  Through non-volatile asm with a token operand: the
@@ -351,6 +372,7 @@ hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStre
                                                  strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar)
 #define CHV_LAUNCH_BK(R, C) do { if (kinds == 1) CHV_LAUNCH_B(R, C, 1); else if (kinds == 2) CHV_LAUNCH_B(R, C, 2); \
                                  else if (kinds == 4) CHV_LAUNCH_B(R, C, 4); else if (kinds == 5) CHV_LAUNCH_B(R, C, 5); \
+                                 else if (kinds & 8) CHV_LAUNCH_B(R, C, 15); \
                                  else CHV_LAUNCH_B(R, C, 7); } while (0)      /* (y420p + RGB alone: its instantiation spills, 7 does not) */
     if (rows == 16) { if (clear) CHV_LAUNCH_BK(16, true); else CHV_LAUNCH_BK(16, false); }
     else            { if (clear) CHV_LAUNCH_BK(8, true); else CHV_LAUNCH_BK(8, false); }

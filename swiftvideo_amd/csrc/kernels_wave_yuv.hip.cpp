@@ -183,9 +183,14 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
         // waits between them, so letting it go first whenever it can shortens its chain, and more of the resident waves are in
         // their row loops at any time (pipeline -1.4 %, cfg3 -2.2 %).  Through non-volatile asm with a token operand: the
         // __builtin_amdgcn_s_setprio call counts as a side effect after which hipcc reads the descriptors per lane (+44 %).
+        // layers the strip machinery cannot stage (rotation, shear, unbounded matrices; the launch has some: KINDS bit 3): straight to
+        // the per-pixel path below, no geometry tables, no staging
+        bool general_layer = false;
+        if constexpr ((KINDS & 8) != 0) general_layer = (Ly.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED);
         int ptok = l;
         if (CHV_WAVE_PRIO) asm("s_setprio 3" : "+s"(ptok));
-        S.setup(ptok, cur);               // (overwrites the row table: the previous layer's pixels are done)
+        if (!general_layer) S.setup(ptok, cur);               // (overwrites the row table: the previous layer's pixels are done)
+        else { cur.staged = false; cur.all_inside = false; cur.unit_rows = false; cur.cfl = 0; cur.cyo = 0; cur.cco = 0; cur.cya = 0.f; cur.cca = 0.f; }
         // Strips entirely inside the picture, and — when the layer paints no fill (alpha of opacity x fill exactly 0: pixels of
         // the border quad outside the picture then keep their codes, to_code(c / 255) = c) — strips a picture edge crosses as
         // well: rows outside the picture are skipped (uniform branch), lanes outside keep their codes.
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
 #ifndef CHV_WAVEY_MASKED
 #define CHV_WAVEY_MASKED 1
 #endif
-        const bool fast = cur.staged && (cur.all_inside || (CHV_WAVEY_MASKED && nofill));
+        const bool fast = !general_layer && cur.staged && (cur.all_inside || (CHV_WAVEY_MASKED && nofill));
         const bool lane_pic = cur.cfl == AX_ALL;
         // a pixel takes a row's result if its column and the row are inside the picture (row flags: uniform, from the row table);
         // every row is computed (branch-free: a branch per row keeps the rows' LDS reads from overlapping), row offsets are
@@ -440,6 +445,7 @@ static size_t wave_lds(const WaveDims &d, bool planar, int target_format, int ro
 }
 
 bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
+    bool any_general = false, any_staged = false;
     for (int i = 0; i < n_ticks; i++) {
         const DTick &T = ticks[i];
         if (T.n_layers < 1 || T.clear_first != ticks[0].clear_first) return false;
@@ -454,7 +460,10 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
         for (int l = 0; l < T.n_layers; l++) {
             const DLayer &L = layers[T.first_layer + l];
             const bool rgb = host_src_rgb(L.kind), nv12 = host_src_nv12(L.kind), planar = host_src_planar(L.kind);
-            if (!(rgb || nv12 || planar) || (L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) return false;
+            if (!(rgb || nv12 || planar)) return false;
+            // layers that cannot be staged (rotation, shear, unbounded matrices) are applied per pixel inside the kernel: nothing to check
+            if ((L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) { any_general = true; continue; }
+            any_staged = true;
             if (!finite16w(L.u + U_TRANSFORM) || !finite16w(L.u + U_TEXTURE) || !finite16w(L.u + U_BORDER)) return false;
             const int np = rgb ? 1 : nv12 ? 2 : 3;
             for (int p = 0; p < np; p++) if (!aligned16w(L.src.pl[p])) return false;
@@ -462,7 +471,8 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
             if (wave_lds(wave_dims(T, L, strip_rows(target_format)), planar, target_format, strip_rows(target_format)) > (size_t)LDS_BUDGET) return false;
         }
     }
-    return true;
+    // (a launch whose layers ALL need the per-pixel path gains nothing here: the general kernel it is)
+    return any_staged || !any_general;
 }
 
 // kernels_wave.hip.cpp
@@ -500,6 +510,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
         for (int i = 0; i < n_ticks; i++) {
             for (int l = 0; l < ticks_host[i].n_layers; l++) {
                 const DLayer &L = layers_host[ticks_host[i].first_layer + l];
+                if ((L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) { kinds |= 8; continue; }     // not staged
                 WaveDims d = wave_dims(ticks_host[i], L, rows);
                 m.p0pitch = std::max(m.p0pitch, d.p0pitch); m.p0rows = std::max(m.p0rows, d.p0rows);
                 m.p1pitch = std::max(m.p1pitch, d.p1pitch); m.p1rows = std::max(m.p1rows, d.p1rows);
@@ -534,7 +545,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
 #define CHV_LAUNCH_Y(TFV, C, R, K) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                       strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
 #define CHV_LAUNCH_YK(TFV, C, R, OWN) do { if (kinds == OWN) CHV_LAUNCH_Y(TFV, C, R, OWN); else if (kinds == (OWN | 4)) CHV_LAUNCH_Y(TFV, C, R, (OWN | 4)); \
-                                           else CHV_LAUNCH_Y(TFV, C, R, 7); } while (0)
+                                           else if (kinds & 8) CHV_LAUNCH_Y(TFV, C, R, 15); else CHV_LAUNCH_Y(TFV, C, R, 7); } while (0)
 #define CHV_LAUNCH_YR(TFV, C, OWN) do { if (WTH == 16) CHV_LAUNCH_YK(TFV, C, 16, OWN); else CHV_LAUNCH_YK(TFV, C, 8, OWN); } while (0)
     if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_YR(TF_NV12, true, 1); else CHV_LAUNCH_YR(TF_NV12, false, 1); }
     else { if (clear) CHV_LAUNCH_YR(TF_Y420P, true, 2); else CHV_LAUNCH_YR(TF_Y420P, false, 2); }

@@ -170,7 +170,8 @@ CHV_DEV bool src_is_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind
 // (the NV12-only instantiation: pipeline -3.4 %).
 template <int WTH, int INTERIOR = 0, int KINDS = 7>
 struct WaveStrip {
-    static CHV_DEV bool is_rgb(int kind) { return KINDS == 4 ? true : (KINDS & 4) ? src_is_rgb(kind) : false; }
+    // (bit 3: the launch also has layers that are not staged at all — any transform, applied per pixel by the kernels)
+    static CHV_DEV bool is_rgb(int kind) { return (KINDS & 15) == 4 ? true : (KINDS & 4) ? src_is_rgb(kind) : false; }
     static CHV_DEV bool is_planar(int kind) { return (KINDS & 3) == 2 ? !is_rgb(kind) : (KINDS & 2) ? src_is_planar(kind) : false; }
     using Cfg = WaveCfg<WTH>;
     static constexpr int WN_Y = Cfg::WN_Y, WN_C = Cfg::WN_C, WN_RGB = Cfg::WN_RGB, WNR = Cfg::WNR, ROWTAB_BYTES = Cfg::ROWTAB_BYTES;

@@ -117,12 +117,33 @@ def test_mixed_fallbacks(ctx, monkeypatch):
     twenty = [(("img_nv12_bgra", "img_rgba_bgra_tx", "img_y420p_bgra", "img_bgra_bgra_tx")[i % 4], 64, 36,
                dict(rect=(3 * i, i, 64, 36), opacity=0.95 - 0.04 * i)) for i in range(20)]
     assert run_tick_case(ctx, 140, 60, True, twenty, expect=None) == WAVE
+    # a rotated layer among axis-aligned ones stays in the wave kernel (applied per pixel with the general kernel's code, in z order)
     rot = [("img_nv12_bgra", 48, 28, dict()), ("img_bgra_bgra_tx", 48, 28, dict(rect=(10, 5, 40, 20), rotation=0.3))]
-    assert run_tick_case(ctx, 96, 54, True, rot, expect=None) == "tick_general_bgra"
-    # finite but unbounded matrix entries (a picture 1e-18 pixels wide: inverse entries beyond 2^60): the wave kernels evaluate the
-    # short form of the geometry only, whose zero terms could then meet an overflowed product -> general kernel
+    assert run_tick_case(ctx, 96, 54, True, rot, expect=None) == WAVE
+    # finite but unbounded matrix entries (a picture 1e-18 pixels wide: inverse entries beyond 2^60): the strip machinery evaluates the
+    # short form of the geometry only, whose zero terms could then meet an overflowed product -> that layer per pixel as well
     thin = [("img_nv12_bgra", 48, 28, dict()), ("img_bgra_bgra_tx", 48, 28, dict(rect=(10, 5, 1e-18, 20), border=(3, 3, 3, 3), fill=(0.2, 0.4, 0.9, 0.8)))]
-    assert run_tick_case(ctx, 96, 54, True, thin, expect=None) == "tick_general_bgra"
+    assert run_tick_case(ctx, 96, 54, True, thin, expect=None) == WAVE
+    # nothing but such layers: the general kernel
+    only = [("img_bgra_bgra_tx", 48, 28, dict(rect=(10, 5, 40, 20), rotation=0.3)), ("img_nv12_bgra", 48, 28, dict(rotation=-0.1, opacity=0.5))]
+    assert run_tick_case(ctx, 96, 54, True, only, expect=None) == "tick_general_bgra"
+
+
+ROTATED_CASES = {
+    "logo_over_videos": (320, 180, True, [("img_nv12_bgra", 480, 270, dict()), ("img_y420p_bgra", 480, 270, dict(opacity=0.5)),
+                                          ("img_rgba_bgra_tx", 64, 36, dict(rect=(200, 100, 100, 60), rotation=0.4, opacity=0.8, border=(3, 3, 3, 3), fill=(0.1, 0.9, 0.2, 0.7)))]),
+    "rotated_video_first": (260, 70, False, [("img_nv12_bgra", 96, 54, dict(rect=(20, 5, 200, 60), rotation=-0.2)),
+                                             ("img_bgra_bgra_tx", 64, 36, dict(rect=(40, 10, 64, 36), opacity=0.6)),
+                                             ("img_y420p_bgra", 96, 54, dict(rect=(100, 0, 150, 70), rotation=0.7, opacity=0.9, fill=(0.3, 0.3, 0.9, 0.5)))]),
+    "every_other": (200, 120, True, [(("img_nv12_bgra", "img_bgra_bgra_tx")[i % 2], 64, 36,
+                                      dict(rect=(12 * i, 8 * i, 90, 50), rotation=(0.15 * i if i % 2 else 0.0), opacity=0.9 - 0.05 * i)) for i in range(7)]),
+}
+
+
+@pytest.mark.parametrize("case", list(ROTATED_CASES))
+def test_rotated_layers_inside_wave_ticks(ctx, path, case):
+    cw, ch, clear, specs = ROTATED_CASES[case]
+    assert run_tick_case(ctx, cw, ch, clear, specs, expect=None) == WAVE
 
 
 @pytest.mark.parametrize("seed", range(32))
@@ -156,6 +177,8 @@ def test_random_mixed_ticks(ctx, path, seed):
                 kw["tex"] = (float(rng.uniform(0.0, 0.4)), float(rng.uniform(0.0, 0.4)),
                              float(rng.uniform(0.3, 1.0)) * (1 if rng.random() < 0.8 else -1), float(rng.uniform(0.3, 1.0)))
             kw["opacity"] = float(rng.choice([1.0, 1.0, rng.uniform(0, 1)]))
+            if seed % 4 == 3 and rng.random() < 0.25:
+                kw["rotation"] = float(rng.uniform(-0.8, 0.8))
             u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
             src = util.alloc_image(s, sw, sh, seed=int(rng.integers(1, 1 << 20)))
             csc = int(rng.integers(0, 4))

@@ -96,6 +96,17 @@ def test_yuv_wave_fallbacks(ctx):
     assert run_yuv_tick(ctx, "y420p", 64, 36, True, [("img_y420p_y420p", 24, 12, dict())], expect=None) == "tick_general_yuv<y420p>"
 
 
+@pytest.mark.parametrize("d", ["nv12", "y420p"])
+def test_rotated_overlay_stays_in_the_wave_kernel(ctx, rows, d):
+    """a rotated overlay among axis-aligned layers is applied per pixel inside tick_yuv_wave (z order kept)"""
+    own = f"img_{d}_{d}"
+    specs = [(own, 384, 216, dict()),
+             (f"img_bgra_{d}", 128, 72, dict(rect=(40, 30, 128, 72), rotation=0.35, opacity=0.8, border=(4, 4, 4, 4), fill=(0.2, 0.9, 0.1, 0.5))),
+             (f"img_rgba_{d}", 128, 72, dict(rect=(240, 128, 128, 72), opacity=0.6)),
+             (own, 96, 54, dict(rect=(150, 20, 120, 70), rotation=-0.5, opacity=0.7))]
+    assert run_yuv_tick(ctx, d, 384, 216, True, specs, expect=None) == f"tick_yuv_wave<{d}>"
+
+
 @pytest.mark.parametrize("seed", range(32))
 def test_random_yuv_ticks(ctx, rows, seed):
     """Seeded random ticks on 4:2:0 canvases: 1..8 layers of random source kinds with random axis-aligned geometry, three ticks
@@ -129,6 +140,8 @@ def test_random_yuv_ticks(ctx, rows, seed):
                 kw["tex"] = (float(rng.uniform(0.0, 0.4)), float(rng.uniform(0.0, 0.4)),
                              float(rng.uniform(0.3, 1.0)) * (1 if rng.random() < 0.8 else -1), float(rng.uniform(0.3, 1.0)))
             kw["opacity"] = float(rng.choice([1.0, 1.0, rng.uniform(0, 1)]))
+            if seed % 4 == 3 and rng.random() < 0.25:
+                kw["rotation"] = float(rng.uniform(-0.8, 0.8))
             u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
             src = util.alloc_image(s, sw, sh, seed=int(rng.integers(1, 1 << 20)))
             assert O.run_kernel(k, exp, src, u, threads=4) == 0
