@@ -122,10 +122,50 @@ def parse_args(argv=None):
                     help="control-plane self-test without a GPU (tests only): every launch is a short sleep, nothing is loaded or "
                          "computed; spawn, rendezvous, calibration, barriers, reductions and the report are the real ones; the line "
                          "is marked and is not a benchmark result")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short `rocprofv3 --kernel-trace --pmc` passes of the headline "
+                         "workload in child processes, after the timed regions); the committed profiles/pmc_latest.json is reported instead")
     ap.add_argument("--pmc-json", default=None,
                     help="a profiles/pmc_*.json produced by profiles/run_profile.sh for THIS command: its HBM bytes per launch "
                          "are copied into roofline.traffic with roofline.traffic_source naming the file")
     return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HBM traffic of the headline kernel, measured in this run
+# ---------------------------------------------------------------------------------------------------------------
+def live_traffic(workload, frames, kernel_substr, device):
+    """FETCH_SIZE and WRITE_SIZE of the workload's kernel in two separate `rocprofv3 --kernel-trace --pmc` passes (never combined
+    with another tracing domain), each a short child run of this script; bytes per launch with the gfx950 correction of
+    MI355X_MICROARCH.md (FETCH_SIZE x 2, KB = 1024 B).  None on any failure — the caller falls back to the committed figure."""
+    import shutil, sqlite3, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or os.environ.get("CHV_BENCH_CHILD"):
+        return None, "rocprofv3 not available"
+    vals = {}
+    try:
+        with tempfile.TemporaryDirectory(prefix="chv_pmc_", dir="/tmp") as tmp:
+            env = dict(os.environ, CHV_BENCH_CHILD="1", TMPDIR="/tmp")
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(tmp, counter)
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, str(ROOT / "bench.py"),
+                       "--workload", workload, "--frames", str(frames), "--also", "none", "--no-cpu-baseline", "--no-verify", "--no-live-pmc",
+                       "--steps", "3", "--warmup", "1", "--launches-per-step", "1", "--device", str(device)]
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+                dbs = list(Path(out).glob("**/*_results.db"))
+                if not dbs:
+                    return None, f"no rocprofv3 database for {counter}"
+                con = sqlite3.connect(str(dbs[0]))
+                rows = con.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? "
+                                   "group by kernel_name", (counter,)).fetchall()
+                con.close()
+                hit = [r for r in rows if kernel_substr in r[0]]
+                if not hit:
+                    return None, f"kernel {kernel_substr} not in the {counter} pass"
+                vals[counter] = float(max(hit, key=lambda r: r[2])[1])
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, None
+    except Exception as e:    # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -719,13 +759,24 @@ def main(argv=None):
         # HBM traffic cannot be counted inside this process (PMC needs rocprofv3 around it, in passes of their own); what is
         # reported is the committed measurement of the same workload and batch size — and the field says so
         pmc_path = Path(args.pmc_json) if args.pmc_json else ROOT / "profiles" / "pmc_latest.json"
-        if pmc_path.exists():
+        live_err = None
+        # (the default run only — what the driver times; `--also …` runs are the builder's A/Bs and profiling passes)
+        if n_gpus == 1 and args.also is None and not args.no_live_pmc and not args.stub_device and args.alias == "none" and not args.pmc_json:
+            kname = head["kernel"].split("<")[0]
+            t, live_err = live_traffic(args.workload, head["frames_per_launch_per_gpu"], kname, args.device if args.device is not None else 0)
+            if t is not None:
+                roof["traffic"] = t
+                roof["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in two separate child passes of "
+                                          f"`bench.py --workload {args.workload}` (3 launches each), FETCH_SIZE x 2 (gfx950), KB = 1024 B, kernel {kname}")
+        if roof["traffic"] is None and pmc_path.exists():
             try:
                 j = json.loads(pmc_path.read_text())
                 if j.get("workload") == args.workload and j.get("frames") == head["frames_per_launch_per_gpu"]:
                     roof["traffic"] = j.get("hbm_bytes_per_launch")
                     roof["traffic_source"] = (f"NOT measured in this run: {pmc_path.name}, rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE "
                                               f"in separate passes of `bench.py --workload {args.workload}` (profiles/collect_round.sh), kernel {j.get('kernel')}")
+                    if live_err:
+                        roof["traffic_source"] += f" (live measurement unavailable: {live_err})"
             except Exception as e:    # noqa: BLE001
                 roof["traffic_source"] = f"unreadable {pmc_path}: {e}"
         out = {
