@@ -114,3 +114,21 @@ def test_two_ranks_with_uploads_on_one_device():
     d = _run_bench(["--gpus", "2", "--device", "0", "--with-upload", "--steps", "3", "--warmup", "2", "--min-seconds-other", "0.2"])
     assert d["n_gpus"] == 2 and d["config"]["h2d_GBps_per_gpu"] > 1.0
     assert "END-TO-END" in d["config"]["mode"]
+
+
+@pytest.mark.gpu
+def test_default_run_measures_its_hbm_traffic():
+    """The driver's command shape (no --also): every workload of the default set timed and verified, and roofline.traffic measured
+    in the run itself by two rocprofv3 --pmc child passes (or, where rocprofv3 is missing, the committed figure — and the line says
+    which)."""
+    import shutil
+    d = _run_bench(["--steps", "2", "--warmup", "1", "--min-seconds", "0.1", "--min-seconds-other", "0.05", "--no-cpu-baseline"])
+    assert set(d["workloads"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p"}
+    assert all(v["verified_vs_oracle"] is True for k, v in d["workloads"].items() if k != "cfg2_upload")
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    if shutil.which("rocprofv3"):
+        assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
+        assert 0.97 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.10 * r["algorithmic_bytes_per_launch"], r
+    else:
+        assert r["traffic"] is None or "NOT measured in this run" in r["traffic_source"]
