@@ -148,3 +148,50 @@ def test_opacity_zero_layer_is_identity_and_constant_stays_constant(ctx):
     got = G.from_gpu(ctx, out, "bgra", 1280, 720)[0]
     r, g, b = O.yuv2rgb_int(0, 120, 90, 200)
     assert np.all(got == np.array([b, g, r, 255], dtype=np.uint8))
+
+
+def test_pipeline_with_a_rotated_logo_full_size(ctx):
+    """The headline tick plus one rotated RGBA logo at full size: the rotated layer is applied per pixel inside tick_bgra_wave, the
+    video layers stay on the staged path; a batch of 12 ticks (enough strips for 16-row selection logic to be exercised either way)."""
+    sw, sh, dw, dh = 1920, 1080, 1280, 720
+    srcs = [util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 300 + i) for i in range(4)]
+    us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in (1.0, 0.75, 0.5, 0.25)]
+    logo = util.alloc_image("rgba", 320, 180, seed=0x5EED0000 + 310)
+    lu = util.make_uniforms((dw, dh), rect=(820, 60, 320, 180), rotation=0.3, opacity=0.9, in_size=(320, 180))
+    exp = util.alloc_image("bgra", dw, dh)
+    assert O.run_kernel("img_clear_bgra", exp, threads=CORES) == 0
+    for s, u in zip(srcs, us):
+        assert O.run_kernel("img_nv12_bgra", exp, s, u, threads=CORES) == 0
+    assert O.run_kernel("img_rgba_bgra_tx", exp, logo, lu, threads=CORES) == 0
+    gs = [G.to_gpu(ctx, "nv12", sw, sh, s) for s in srcs]
+    gl = G.to_gpu(ctx, "rgba", 320, 180, logo)
+    K = sv.ComputeKernel
+    layers = [(K.img_nv12_bgra, g, u, 0) for g, u in zip(gs, us)] + [(K.img_rgba_bgra_tx, gl, lu, 0)]
+    gds = [G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=7 + i)) for i in range(12)]
+    h, name, keep = G.make_batch(ctx, [(gd, True, layers) for gd in gds])
+    assert name == "tick_bgra_wave", name
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    for i in (0, 5, 11):
+        G.assert_same(G.from_gpu(ctx, gds[i], "bgra", dw, dh), exp, f"tick {i}")
+
+
+def test_large_launch_of_planar_layers_takes_the_wave_instantiation(ctx):
+    """cfg2 with a y420p source: small launches use tick_y420p_bgra_tiled, launches of >= 8192 strips the y420p-only instantiation of
+    tick_bgra_wave (the faster one there) — same bytes either way."""
+    sw, sh, dw, dh = 1920, 1080, 1280, 720
+    src = util.alloc_image("y420p", sw, sh, seed=0x5EED0000 + 320)
+    u = util.full_canvas_uniforms((dw, dh), (sw, sh))
+    exp = util.alloc_image("bgra", dw, dh)
+    assert O.run_kernel("img_clear_bgra", exp, threads=CORES) == 0
+    assert O.run_kernel("img_y420p_bgra", exp, src, u, threads=CORES) == 0
+    gs = G.to_gpu(ctx, "y420p", sw, sh, src)
+    K = sv.ComputeKernel
+    for n, want in ((2, "tick_y420p_bgra_tiled"), (12, "tick_bgra_wave")):
+        gds = [G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=9 + i)) for i in range(n)]
+        h, name, keep = G.make_batch(ctx, [(gd, True, [(K.img_y420p_bgra, gs, u, 0)]) for gd in gds])
+        assert name == want, (n, name)
+        G.run_batch(ctx, h)
+        G.destroy_batch(h)
+        for gd in (gds[0], gds[-1]):
+            G.assert_same(G.from_gpu(ctx, gd, "bgra", dw, dh), exp, f"{n} ticks via {name}")
