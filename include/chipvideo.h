@@ -56,6 +56,13 @@ const char *chv_error_string(int status);
 /* Thread-local detail text of the last failing call on this thread ("" if none). */
 const char *chv_last_error_detail(void);
 int chv_version(void);
+/* What the library was built with: "arch=gfx950;...;tick_bgra_wave:abl=0,...".  `abl` != 0 marks a timing-only ablation
+ * build whose pixels are wrong by design (profiles/r02_notes.md section 6); tests/test_abi.py asserts 0, bench.py prints it. */
+const char *chv_build_flags(void);
+/* Measurement / test hook: path-selection switches.  Names and values are those of the environment variables read once at
+ * first use (CHV_FORCE_GENERAL=1, CHV_BGRA_PATH=wave|tiled, CHV_WAVE_ROWS=8|16, CHV_TILE_ROWS=16|32, CHV_SAME_GEOM=0);
+ * NULL or "" restores the default.  Process-wide, atomic; not part of the Swift-facing contract. */
+int chv_debug_set_switch(const char *name, const char *value);
 
 /* ---- kernels: `enum ComputeKernel`, compute.swift:49-74 ------------------ */
 typedef enum chv_kernel {
@@ -312,8 +319,9 @@ int chv_run_custom(chv_context *ctx, const char *name, const chv_image *target,
 /* Separable Lanczos-3 resize of a 4-component image (BGRA or RGBA) from `src`
  * to `dst` size.  No reference counterpart; DESIGN.md section 4.4. */
 int chv_scale_lanczos(chv_context *ctx, const chv_image *dst, const chv_image *src);
-/* n resizes of one geometry (every src of one size, every dst of one size) in one launch per 64 pairs; same bytes as n
- * calls of chv_scale_lanczos.  Other geometries in the list -> CHV_ERR_INVALID_VALUE, nothing is launched. */
+/* n resizes of one geometry (every src of one size, every dst of one size) in one launch per CHV_LANCZOS_BATCH_CHUNK pairs;
+ * same bytes as n calls of chv_scale_lanczos.  Other geometries in the list -> CHV_ERR_INVALID_VALUE, nothing is launched. */
+#define CHV_LANCZOS_BATCH_CHUNK 64
 int chv_scale_lanczos_batch(chv_context *ctx, const chv_image *dsts, const chv_image *srcs, int n);
 
 /* ---- timing (what the "gpu.upload"/"mix.video.compose" StatsReport timers

@@ -85,6 +85,8 @@ _SIGNATURES = {
     "chv_error_string": (C.c_char_p, [C.c_int]),
     "chv_last_error_detail": (C.c_char_p, []),
     "chv_version": (C.c_int, []),
+    "chv_build_flags": (C.c_char_p, []),
+    "chv_debug_set_switch": (C.c_int, [C.c_char_p, C.c_char_p]),
     "chv_kernel_from_string": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "chv_kernel_name": (C.c_char_p, [C.c_int]),
     "chv_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -155,6 +157,16 @@ def check(status):
     if status != OK:
         detail = load().chv_last_error_detail()
         raise ComputeError(status, detail.decode() if detail else "")
+
+
+def build_flags():
+    """chv_build_flags(): what the loaded library was built with (arch, ablation switches)."""
+    return load().chv_build_flags().decode()
+
+
+def set_switch(name, value):
+    """chv_debug_set_switch: measurement / test hook for the path-selection switches (None restores the default)."""
+    check(load().chv_debug_set_switch(name.encode(), None if value is None else str(value).encode()))
 
 
 def kernel_from_string(name):

@@ -604,7 +604,7 @@ def scaleLanczos(ctx, dst, src):
 
 
 class LanczosBatch:
-    """n Lanczos-3 resizes of one geometry issued as one launch per 64 pairs (chv_scale_lanczos_batch): what a host with
+    """n Lanczos-3 resizes of one geometry issued as one launch per 64 pairs (CHV_LANCZOS_BATCH_CHUNK; chv_scale_lanczos_batch): what a host with
     several streams per device uses per tick instead of n launches.  pairs: [(dst PictureSample, src PictureSample)]; the
     descriptors are built once, `run` can be called every tick (canvas rings make the same pairs recur)."""
 
@@ -622,6 +622,8 @@ class LanczosBatch:
             self._d[i], self._s[i] = d, s
 
     def run(self, ctx):
+        if self.n == 0:          # an empty list is a no-op, as in the C++ host (scaleLanczos(ctx, pairs))
+            return ctx
         cv.check(cv.load().chv_scale_lanczos_batch(ctx.handle, self._d, self._s, self.n))
         return ctx
 

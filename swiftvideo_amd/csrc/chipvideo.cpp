@@ -22,8 +22,11 @@
 #include <vector>
 
 #include "device_types.h"
+#include "switches.h"
 
 namespace chv {
+const char *bgra_wave_build_flags();      // kernels_wave.hip.cpp
+const char *yuv_wave_build_flags();       // kernels_wave_yuv.hip.cpp
 hipError_t launch_tick_general(int target_format, const DTick *ticks, const DLayer *layers,
                                int n_ticks, int maxW, int maxH, hipStream_t stream);
 hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
@@ -44,10 +47,56 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
 
 using namespace chv;
 
+static void g_detail_set(const char *msg);
+
+// ---------------------------------------------------------------------------
+// switches (switches.h) and build flags
+// ---------------------------------------------------------------------------
+static int parse_switch(const char *name, const char *value, int *out) {
+    const std::string n = name ? name : "", v = value ? value : "";
+    if (n == "CHV_FORCE_GENERAL") { *out = v == "1" ? 1 : 0; return 0; }
+    if (n == "CHV_BGRA_PATH") { *out = v == "wave" ? 1 : v == "tiled" ? 2 : 0; return 1; }
+    if (n == "CHV_WAVE_ROWS") { *out = v == "8" ? 8 : v == "16" ? 16 : 0; return 2; }
+    if (n == "CHV_TILE_ROWS") { *out = v == "16" ? 16 : v == "32" ? 32 : 0; return 3; }
+    if (n == "CHV_SAME_GEOM") { *out = v == "0" ? 0 : 1; return 4; }
+    return -1;
+}
+static void store_switch(Switches &s, int which, int val) {
+    std::atomic<int> *slots[5] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom };
+    slots[which]->store(val, std::memory_order_relaxed);
+}
+Switches &chv::switches() {
+    static Switches s;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        static const char *const names[5] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM" };
+        for (const char *n : names) {
+            const char *v = getenv(n);
+            int val = 0, which = v ? parse_switch(n, v, &val) : -1;
+            if (which >= 0) store_switch(s, which, val);
+        }
+    });
+    return s;
+}
+extern "C" int chv_debug_set_switch(const char *name, const char *value) {
+    int val = 0;
+    Switches &s = switches();                     // (environment first, so that a later first use cannot overwrite this)
+    const int which = parse_switch(name, value, &val);
+    if (which < 0) { g_detail_set("unknown switch"); return CHV_ERR_INVALID_VALUE; }
+    if (!value || !*value) val = which == 4 ? 1 : 0;      // empty / NULL: back to "the library decides"
+    store_switch(s, which, val);
+    return CHV_OK;
+}
+extern "C" const char *chv_build_flags(void) {
+    static const std::string flags = std::string("arch=gfx950;fp_contract=off;") + bgra_wave_build_flags() + ";" + yuv_wave_build_flags();
+    return flags.c_str();
+}
+
 // ---------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------
 static thread_local std::string g_detail;
+static void g_detail_set(const char *msg) { g_detail = msg; }
 
 static int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 static int fail(int code, const char *fmt, ...) {
@@ -156,25 +205,39 @@ extern "C" const char *chv_kernel_name(int kernel) {
 // ---------------------------------------------------------------------------
 // objects
 // ---------------------------------------------------------------------------
+// Device-side Lanczos tables of one (in, out) size pair.  Shared ownership: the cache holds one reference, every call that
+// looked the pair up holds another until its launch is enqueued — an eviction by another context of the device can therefore
+// never free tables between a lookup and the launch that reads them.  The memory goes back with hipFree, which waits for the
+// work already queued on the device (i.e. for the launches that read the tables).
 struct LanczosTable {
+    int device = 0;
     int taps = 0;
     int32_t *first = nullptr;  // device
     float *weights = nullptr;  // device
+    LanczosTable() = default;
+    LanczosTable(const LanczosTable &) = delete;
+    LanczosTable &operator=(const LanczosTable &) = delete;
+    ~LanczosTable() {
+        if (first || weights) { (void)hipSetDevice(device); (void)hipFree(first); (void)hipFree(weights); }
+    }
+};
+typedef std::shared_ptr<LanczosTable> LanczosRef;
+struct LanczosEntry {
+    LanczosRef tab;
     uint64_t last_use = 0;     // LRU stamp
 };
 static constexpr size_t kLanczosCacheEntries = 64;   // (in, out) size pairs kept per device; least recently used goes first
+static constexpr size_t kLanczosRetireBatch = 32;    // evicted tables are freed this many at a time (hipFree synchronises the device)
 
 // State shared by a context and everything created with chv_context_share
 // (the role of InternalContext, compute.cl.swift:60-74).
 struct DeviceShared {
     int device = 0;
     std::mutex mu;
-    std::map<std::pair<int, int>, LanczosTable> lanczos;  // (in, out) -> tables
+    std::map<std::pair<int, int>, LanczosEntry> lanczos;  // (in, out) -> tables
+    std::vector<LanczosRef> lanczos_retired;               // evicted, not yet freed (see lanczos_table)
     uint64_t lanczos_clock = 0;
-    ~DeviceShared() {
-        (void)hipSetDevice(device);
-        for (auto &kv : lanczos) { (void)hipFree(kv.second.first); (void)hipFree(kv.second.weights); }
-    }
+    ~DeviceShared() { (void)hipSetDevice(device); }         // (the tables free themselves)
 };
 
 // A run-time compiled kernel (`ComputeKernel.custom`): the module lives as long as any context's library names it.
@@ -771,6 +834,21 @@ static int tick_to_device(const chv_tick &t, int device, int forced_target_forma
         if (L.kind == LK_BGRA_METAL) { L.bbox[0] = 0; L.bbox[1] = 0; L.bbox[2] = dt->W; L.bbox[3] = dt->H; }
         else layer_bbox(&L, dt->W, dt->H);
     }
+    // LF_SAME_GEOM (device_types.h): a layer whose geometry inputs equal its predecessor's
+    if (switches().same_geom.load(std::memory_order_relaxed)) {
+        for (int i = first + 1; i < (int)layers->size(); i++) {
+            DLayer &L = (*layers)[i];
+            const DLayer &P = (*layers)[i - 1];
+            bool same = L.kind == P.kind && L.kind != LK_BGRA_METAL && memcmp(L.u, P.u, 48 * sizeof(float)) == 0 &&
+                        memcmp(L.bbox, P.bbox, sizeof L.bbox) == 0 &&
+                        ((L.flags ^ P.flags) & (LF_AXIS_ALIGNED | LF_BOUNDED)) == 0;
+            for (int p = 0; p < 3 && same; p++) {
+                const DPlane &a = L.src.pl[p], &b = P.src.pl[p];
+                same = a.w == b.w && a.h == b.h && a.pitch == b.pitch && a.comps == b.comps && (a.ptr == nullptr) == (b.ptr == nullptr);
+            }
+            if (same) L.flags |= LF_SAME_GEOM;
+        }
+    }
     dt->clear_first = t.clear_first ? 1 : 0;
     dt->n_layers = t.n_layers;
     dt->first_layer = first;
@@ -1174,55 +1252,59 @@ static int lanczos_host_table(int in_size, int out_size, int *taps_out, std::vec
     return CHV_OK;
 }
 
-static int lanczos_table(chv_context *c, int in_size, int out_size, LanczosTable *out) {
+static int lanczos_table(chv_context *c, int in_size, int out_size, LanczosRef *out) {
     DeviceShared &sh = *c->shared;
     auto key = std::make_pair(in_size, out_size);
     {
         std::lock_guard<std::mutex> lock(sh.mu);
         auto it = sh.lanczos.find(key);
-        if (it != sh.lanczos.end()) { it->second.last_use = ++sh.lanczos_clock; *out = it->second; return CHV_OK; }
+        if (it != sh.lanczos.end()) { it->second.last_use = ++sh.lanczos_clock; *out = it->second.tab; return CHV_OK; }
     }
     // build and upload outside the lock: other contexts of the device keep running meanwhile
     std::vector<int32_t> first;
     std::vector<float> weights;
-    LanczosTable t;
-    int rc = lanczos_host_table(in_size, out_size, &t.taps, &first, &weights);
+    LanczosRef t = std::make_shared<LanczosTable>();
+    t->device = c->device;
+    int rc = lanczos_host_table(in_size, out_size, &t->taps, &first, &weights);
     if (rc) return rc;
-    HIP_TRY(hipMalloc((void **)&t.first, first.size() * sizeof(int32_t)));
-    hipError_t e = hipMalloc((void **)&t.weights, weights.size() * sizeof(float));
-    if (e != hipSuccess) t.weights = nullptr;
+    HIP_TRY(hipMalloc((void **)&t->first, first.size() * sizeof(int32_t)));
+    hipError_t e = hipMalloc((void **)&t->weights, weights.size() * sizeof(float));
+    if (e != hipSuccess) t->weights = nullptr;
     if (e == hipSuccess)
-        e = hipMemcpy(t.first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        e = hipMemcpy(t->first, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
-        e = hipMemcpy(t.weights, weights.data(), weights.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        (void)hipFree(t.first);
-        if (t.weights) (void)hipFree(t.weights);
-        return hip_fail(e, "lanczos table upload");
-    }
-    LanczosTable evicted, duplicate;
+        e = hipMemcpy(t->weights, weights.data(), weights.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "lanczos table upload");     // (t frees what it holds)
+    // Evicted tables are parked and freed kLanczosRetireBatch at a time — an animated resize makes a new (in, out) pair per
+    // frame, and one hipFree per miss would put a device-wide synchronisation into every tick.  Only tables nobody else
+    // holds are freed: a context between its lookup and its launch keeps its reference, and the table with it.
+    std::vector<LanczosRef> to_free;
     {
         std::lock_guard<std::mutex> lock(sh.mu);
         auto it = sh.lanczos.find(key);
         if (it != sh.lanczos.end()) {                       // another context built the same table meanwhile: keep theirs
-            duplicate = t;
             it->second.last_use = ++sh.lanczos_clock;
-            *out = it->second;
+            *out = it->second.tab;
+            to_free.push_back(std::move(t));
         } else {
             if (sh.lanczos.size() >= kLanczosCacheEntries) {
                 auto lru = sh.lanczos.begin();
                 for (auto jt = sh.lanczos.begin(); jt != sh.lanczos.end(); ++jt) if (jt->second.last_use < lru->second.last_use) lru = jt;
-                evicted = lru->second;
+                sh.lanczos_retired.push_back(std::move(lru->second.tab));
                 sh.lanczos.erase(lru);
             }
-            t.last_use = ++sh.lanczos_clock;
-            sh.lanczos[key] = t;
-            *out = t;
+            LanczosEntry en;
+            en.tab = t; en.last_use = ++sh.lanczos_clock;
+            sh.lanczos[key] = en;
+            *out = std::move(t);
+            if (sh.lanczos_retired.size() >= kLanczosRetireBatch) {
+                std::vector<LanczosRef> keep;
+                for (LanczosRef &r : sh.lanczos_retired) (r.use_count() == 1 ? to_free : keep).push_back(std::move(r));
+                sh.lanczos_retired.swap(keep);
+            }
         }
     }
-    // hipFree waits for in-flight work that may still read an evicted table
-    if (evicted.first) { (void)hipFree(evicted.first); (void)hipFree(evicted.weights); }
-    if (duplicate.first) { (void)hipFree(duplicate.first); (void)hipFree(duplicate.weights); }
+    to_free.clear();      // outside the lock: ~LanczosTable -> hipFree, which waits for queued work that may still read the tables
     return CHV_OK;
 }
 
@@ -1240,13 +1322,13 @@ extern "C" int chv_scale_lanczos(chv_context *c, const chv_image *dst, const chv
     auto dp = deps.deps();
     rc = wait_for_uploads(c->stream, dp);
     if (rc) return rc;
-    LanczosTable tx, ty;
+    LanczosRef tx, ty;      // held until the launch is enqueued (see LanczosTable)
     rc = lanczos_table(c, s.w, d.w, &tx);
     if (rc) return rc;
     rc = lanczos_table(c, s.h, d.h, &ty);
     if (rc) return rc;
     (void)hipGetLastError();
-    hipError_t e = launch_lanczos(d, s, tx.first, tx.weights, tx.taps, ty.first, ty.weights, ty.taps, c->stream, nullptr, 0);
+    hipError_t e = launch_lanczos(d, s, tx->first, tx->weights, tx->taps, ty->first, ty->weights, ty->taps, c->stream, nullptr, 0);
     if (e != hipSuccess) return hip_fail(e, "lanczos launch");
     return CHV_OK;
 }
@@ -1273,13 +1355,14 @@ extern "C" int chv_scale_lanczos_batch(chv_context *c, const chv_image *dsts, co
     auto dp = deps.deps();
     int rc = wait_for_uploads(c->stream, dp);
     if (rc) return rc;
-    LanczosTable tx, ty;
+    LanczosRef tx, ty;
     rc = lanczos_table(c, pairs[1].w, pairs[0].w, &tx);
     if (rc) return rc;
     rc = lanczos_table(c, pairs[1].h, pairs[0].h, &ty);
     if (rc) return rc;
     // the pairs travel through the pinned, device-mapped descriptor ring (a slot per chunk), like a transient tick's descriptors
-    const int per_slot = (int)(kDescSlotBytes / (2 * sizeof(DPlane)));
+    const int per_slot = CHV_LANCZOS_BATCH_CHUNK;
+    static_assert((size_t)CHV_LANCZOS_BATCH_CHUNK * 2 * sizeof(DPlane) <= kDescSlotBytes, "a chunk's plane pairs must fit one descriptor slot");
     for (int first = 0; first < n; first += per_slot) {
         const int m = std::min(per_slot, n - first);
         int slot = c->next_desc;
@@ -1292,7 +1375,7 @@ extern "C" int chv_scale_lanczos_batch(chv_context *c, const chv_image *dsts, co
         DPlane *dev = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&dev, host, 0));
         (void)hipGetLastError();
-        hipError_t e = launch_lanczos(pairs[0], pairs[1], tx.first, tx.weights, tx.taps, ty.first, ty.weights, ty.taps, c->stream, dev, m);
+        hipError_t e = launch_lanczos(pairs[0], pairs[1], tx->first, tx->weights, tx->taps, ty->first, ty->weights, ty->taps, c->stream, dev, m);
         if (e != hipSuccess) return hip_fail(e, "lanczos launch");
         HIP_TRY(hipEventRecord(ds.done, c->stream));
         ds.pending = true;

@@ -49,7 +49,13 @@ enum LayerFlags : int32_t {
     LF_AXIS_ALIGNED = 1,  // no rotation/shear: tx.x/uv.x depend on x only, tx.y/uv.y on y only
     LF_NO_FILL = 2,       // opacity * fillColor.w == 0 exactly
     LF_OPAQUE = 4,        // opacity == 1 exactly
-    LF_BOUNDED = 8        // all 48 matrix entries finite and < 2^60 in magnitude: no product in the prologue overflows
+    LF_BOUNDED = 8,       // all 48 matrix entries finite and < 2^60 in magnitude: no product in the prologue overflows
+    // Same geometry as the layer below it in the tick: the three matrices are bit-identical, the source planes have the same
+    // sizes, pitches and layout class, the bounding boxes are equal (only opacity, fill colour, times, colourspace and the plane
+    // POINTERS may differ).  Every geometry value the strip kernels derive (column entries, row table, rectangles, slot maps) is
+    // a function of exactly these inputs, so they keep the predecessor's — same inputs, same bits.  True for every layer but
+    // the first of the BASELINE composite configurations (N full-canvas pictures of one size: mix.video.swift:114-124).
+    LF_SAME_GEOM = 16
 };
 
 enum TargetFormat : int32_t { TF_NV12 = 0, TF_Y420P = 1, TF_BGRA = 2 };

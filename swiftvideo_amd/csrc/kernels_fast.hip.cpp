@@ -23,6 +23,7 @@
 // Every path here produces exactly the bytes of kernels_general.hip.cpp; the host
 // picks a path per batch (select_fast_path) and falls back to the general kernel.
 #include "tile_common.hip.h"
+#include "switches.h"
 
 #include <algorithm>
 #include <cmath>
@@ -208,8 +209,10 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
 #pragma unroll
     for (int k = 0; k < PXT; k++) {
         int c = txi * PXT + k;
-        cya[k] = tb.cya[c]; icya[k] = 1.0f - cya[k];
-        cca[k] = tb.cca[c]; icca[k] = 1.0f - cca[k];
+        // (times 2^24: the fast rows feed their taps to v_fma_mix_f32 as binary16 denormals — tap_h, pixel_math.hip.h; the slow
+        // per-pixel path below re-reads the tables)
+        cya[k] = tb.cya[c]; icya[k] = (1.0f - cya[k]) * kTapScale; cya[k] *= kTapScale;
+        cca[k] = tb.cca[c]; icca[k] = (1.0f - cca[k]) * (PLANAR ? kTapScale : kChromaTapScale); cca[k] *= (PLANAR ? kTapScale : kChromaTapScale);
         cyo[k] = tb.cy[c] - ycol0 + 16; cco[k] = (tb.cc[c] - ccol0 + CVEC) * CTB;
     }
     const CscFolded csc = csc_fold(kCsc[L.csc & 3]);
@@ -263,13 +266,13 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
             for (int k = 0; k < PXT; k++) {
                 float fy, fu, fv;
                 if constexpr (PLANAR)
-                    sample_y420p_lds_bytes(smem, yrow + cyo[k], ypitch, crow + cco[k], voff, cpitch,
-                                           icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
-                                           icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                    sample_y420p_lds_mix(smem, yrow + cyo[k], ypitch, crow + cco[k], voff, cpitch,
+                                         icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                         icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
                 else
-                    sample_nv12_lds_bytes(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
-                                          icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
-                                          icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
+                    sample_nv12_lds_mix(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
+                                        icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
+                                        icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
                 outw[k] = yuv_to_bgra_word(cscb, (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv));
             }
         };
@@ -419,20 +422,20 @@ static int select_single_purpose(const DTick *ticks, const DLayer *layers, int n
 
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
     if (n_ticks <= 0) return FP_NONE;
-    // A/B switches for measurements and tests (read per call: tests flip them):
-    //   CHV_FORCE_GENERAL=1   everything through the general kernels
-    //   CHV_BGRA_PATH=wave    BGRA canvases: the wave-per-strip kernel also where the single-purpose kernel (exactly one YUV
-    //                         layer per tick) would be chosen;  =tiled: the single-purpose kernel wherever it applies
-    const char *fg = getenv("CHV_FORCE_GENERAL"), *bp = getenv("CHV_BGRA_PATH");
-    if (fg && fg[0] == '1') return FP_NONE;
+    // A/B switches for measurements and tests (switches.h: environment read once, chv_debug_set_switch afterwards):
+    //   force_general (CHV_FORCE_GENERAL=1)  everything through the general kernels
+    //   bgra_path (CHV_BGRA_PATH=wave)       BGRA canvases: the wave-per-strip kernel also where the single-purpose kernel (exactly
+    //                                        one YUV layer per tick) would be chosen;  =tiled: the single-purpose kernel wherever it applies
+    const int bp = switches().bgra_path.load(std::memory_order_relaxed);
+    if (switches().force_general.load(std::memory_order_relaxed)) return FP_NONE;
     // 4:2:0 canvases (the reference's own kernels): one wave per strip, or the general quad kernel
     if (target_format != TF_BGRA)
         return wave_layers_eligible(target_format, ticks, layers, n_ticks) ? (target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P) : FP_NONE;
-    if (!(bp && bp[0] == 'w')) {
+    if (bp != 1) {
         int p = select_single_purpose(ticks, layers, n_ticks);
         // planar sources in launches that fill the chip: the y420p-only instantiation of the wave kernel is the faster one
         // (cfg2_y420p 0.574 -> 0.532 ms; NV12 stays: 0.467 tiled vs 0.487 wave); small launches keep the tiled kernel's short strips
-        if (p == FP_Y420P_BGRA_TILED && !(bp && bp[0] == 't')) {
+        if (p == FP_Y420P_BGRA_TILED && bp != 2) {
             long strips = 0;
             for (int i = 0; i < n_ticks; i++) strips += (long)((ticks[i].W + 63) / 64) * ((ticks[i].H + 15) / 16);
             if (strips >= 8192 && wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks)) return FP_WAVE_LAYERS;
@@ -475,8 +478,7 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
     // into stage_tail as long as slot numbers stay below 1024.
     // CHV_TILE_ROWS (A/B and test switch): 16 = never; 32 = whatever the launch size, and even when interior rectangles
     // overflow the prefetch registers (everything beyond them then goes through stage_tail).
-    const char *rows_env = getenv("CHV_TILE_ROWS");
-    const int rows_forced = rows_env ? atoi(rows_env) : 0;
+    const int rows_forced = switches().tile_rows.load(std::memory_order_relaxed);
     const bool tail_ok = slots_fit(m, 4, 4, 2);
     const bool large_wanted = rows_forced == TH_LARGE || (rows_forced != TH_SMALL && blocks_large >= 1024 && slots_fit(m, 3, 2, 0));
     if (!(large_wanted && tail_ok && lds <= (size_t)LDS_BUDGET)) {

@@ -39,8 +39,9 @@
 // Rectangles that touch no picture edge staged by the instantiation without clamping / patching code: YUV sources only (bit 0).
 // Measured in one call: pipeline 1.834 -> 1.734 ms, mixed 0.839 -> 0.799 with it; RGB sources (bit 1) cfg3 1.444 -> 1.611 and the
 // 4:2:0 kernel 0.484 -> 0.507 (y420p_main) against it — the register allocation of the row loops shifts with the code around them.
+// bit 2: narrow interior YUV rectangles through the shift-and-mask slot map (wstage_load_p2)
 #ifndef CHV_WAVE_INTERIOR
-#define CHV_WAVE_INTERIOR 1
+#define CHV_WAVE_INTERIOR 5
 #endif
 #ifndef CHV_WAVE_PRIO
 #define CHV_WAVE_PRIO 1
@@ -49,16 +50,16 @@
 
 namespace chv {
 
-// Integer colour matrix on biased codes, channels returned as float codes (cf. yuv_to_bgra_word)
+// Integer colour matrix on biased codes, channels returned as float codes (cf. yuv_to_bgra_word).
+// clip8(x >> 16) = byte 2 of clamp(x, 0, 0xFFFFFF): v_med3_i32 + v_cvt_f32_ubyte2 per channel (two slow-class instructions,
+// 3.6 ns per wave) — v_ashr_pk_u8_i32 + v_cvt_f32_ubyteN measured 3.45 + 1.8 per channel pair / channel
+// (the packing instruction issues at a quarter of the rate, tools/ubench_tput.cpp).
 CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &fb, float &fg, float &fr) {
     int32_t t = __mul24(y, k.cy);
     int32_t r = mad24_uniform(v, k.crv, t) + k.kr;
     int32_t g = mad24_uniform(v, k.ncgv, mad24_uniform(u, k.ncgu, t)) + k.kg;
     int32_t b = mad24_uniform(u, k.cbu, t) + k.kb;
-    uint32_t bg, ra;
-    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(bg) : "v"(b), "v"(g));          // byte0 = B, byte1 = G
-    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(ra) : "v"(r), "v"(0));          // byte0 = R
-    fb = ub0(bg); fg = ub1(bg); fr = ub0(ra);
+    fb = ub2((uint32_t)min(max(b, 0), 0xFFFFFF)); fg = ub2((uint32_t)min(max(g, 0), 0xFFFFFF)); fr = ub2((uint32_t)min(max(r, 0), 0xFFFFFF));
 }
 
 #ifndef CHV_WAVE_MINW
@@ -79,7 +80,7 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
 // so they are used when every layer of the launch covers (almost) the whole canvas; 8 rows otherwise (80 VGPRs, 6 waves).      // strip height: rows per lane (16: -14 % on the 4 x NV12 pipeline at 128 VGPRs, but the LDS
                                         // footprint of 4-byte texel rectangles then halves the occupancy of mixed ticks: 3.0 vs 0.85 ms)
 template <int WTH, bool CLEAR, int KINDS>
-__global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE_MINW)) void tick_bgra_wave(const DTick *__restrict__ ticks,
+__global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAVE_MINW16) : ((KINDS & 8) ? 5 : CHV_WAVE_MINW))) void tick_bgra_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
     }
 
     WLayer cur;
+    bool have_geom = false;            // `cur` and the row table hold the geometry of the layer handled just before (LF_SAME_GEOM)
     // (the layer index is wave-uniform; saying so keeps the descriptor reads on the scalar unit: left to its divergence analysis
     // the compiler fetched every uniform of a layer with per-lane global loads — 90 vector loads per wave)
     int l = __builtin_amdgcn_readfirstlane(S.next_hit(0));
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
                     for (int k = 0; k < WTH; k++) cv[k] = j == k ? c : cv[k];
                 }
                 l = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
+                have_geom = false;
                 continue;
             }
         }
@@ -143,7 +146,10 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
         // __builtin_amdgcn_s_setprio call counts as a side effect after which hipcc reads the descriptors per lane (+44 %).
         int ptok = l;
         if (CHV_WAVE_PRIO) asm("s_setprio 3" : "+s"(ptok));
-        S.setup(ptok, cur);               // (overwrites the row table: the previous layer's pixels are done)
+        // Layers whose geometry inputs are bit-identical to their predecessor's (LF_SAME_GEOM, host-checked: equal bounding boxes, so
+        // the predecessor was a hit for this strip as well) keep its column entry, row table and rectangles; only the planes change.
+        if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) S.setup(ptok, cur);      // (overwrites the row table: the previous layer's pixels are done)
+        have_geom = true;
         if (cur.staged && !(CHV_ABL & 1)) S.stage(l, cur);
         wave_lds_fence();
         const int ln = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
@@ -177,9 +183,10 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
             const bool fast = cur.staged && (CAN_MASK || cur.all_inside) && nofill && opacity >= 0.f && opacity <= 1.f;
             const bool lane_pic = cur.cfl == AX_ALL, lane_border = (cur.cfl & AX_BORDER) != 0;
             // MASKED: the pixel's new value, given its row's flags (uniform, from the row table)
-            auto commit_px = [&](auto masked_c, uint32_t rfl, uint32_t old, uint32_t nv) {
+            auto commit_px = [&](auto masked_c, int j, uint32_t old, uint32_t nv) {
                 if constexpr (!decltype(masked_c)::value) return nv;
                 else {
+                    const uint32_t rfl = row_fast_flags<WTH>(rowtab, j);
                     const bool pic = lane_pic && rfl == (uint32_t)AX_ALL;
                     const bool border = lane_border && (rfl & AX_BORDER) != 0;
                     return pic ? nv : (border ? (old | 0xFF000000u) : old);
@@ -192,9 +199,9 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
 #pragma unroll
                     for (int j = 0; j < WTH; j++) {
                         WAVE_ROW_FENCE(j);
-                        const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
-                        const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
-                        const uint8_t *p0 = smem + ((int)ra.x + cur.cyo);
+                        const RowFast rw = row_fast<WTH, false>(rowtab, j);
+                        const float b = rw.yb, ib = rw.iyb;
+                        const uint8_t *p0 = smem + (rw.yoff + cur.cyo);
                         const uint8_t *p1 = p0 + p0pitch;
                         const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
                         const uint32_t u01 = ((const uint32_t *)p1)[0], u11 = ((const uint32_t *)p1)[1];
@@ -205,23 +212,22 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
                         const float q3 = cs_mix(w00, w10, w01, w11, ub3(u00), ub3(u10), ub3(u01), ub3(u11));
                         const float al = q3 * ka, ial = 1.f - al;
                         const uint32_t c = cv[j];                                      // staged texels are BGRA whatever the source order
-                        cv[j] = commit_px(masked_c, ra.z, c, pack_codes(__builtin_fmaf(q0, al, ub0(c) * ial), __builtin_fmaf(q1, al, ub1(c) * ial),
-                                                                         __builtin_fmaf(q2, al, ub2(c) * ial), 0xFF000000u));
+                        cv[j] = commit_px(masked_c, j, c, pack_codes(__builtin_fmaf(q0, al, ub0(c) * ial), __builtin_fmaf(q1, al, ub1(c) * ial),
+                                                                      __builtin_fmaf(q2, al, ub2(c) * ial), 0xFF000000u));
                     }
                 };
                 // Native-resolution layers (source rows advance one per canvas row, checked on the row table): the lower tap row
                 // of a pixel is the upper tap row of the pixel below it, so its eight code-to-float conversions — a third of the
                 // row's slow-class instructions — and its LDS reads are carried down the lane instead of repeated.
                 auto rgb_rows_carried = [&]() {
-                    const uint8_t *p = smem + ((int)rowtab[0].x + cur.cyo);
+                    const uint8_t *p = smem + (row_fast<WTH, false>(rowtab, 0).yoff + cur.cyo);
                     uint32_t ut0 = ((const uint32_t *)p)[0], ut1 = ((const uint32_t *)p)[1];
                     float t00 = ub0(ut0), t01 = ub1(ut0), t02 = ub2(ut0), t03 = ub3(ut0);
                     float t10 = ub0(ut1), t11 = ub1(ut1), t12 = ub2(ut1), t13 = ub3(ut1);
 #pragma unroll
                     for (int j = 0; j < WTH; j++) {
                         WAVE_ROW_FENCE(j);
-                        const uint4 rb = rowtab[2 * j + 1];
-                        const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
+                        const float b = *(const float *)(rowtab + 2 * WTH + j), ib = 1.0f - b;
                         p += p0pitch;
                         const uint32_t ub_0 = ((const uint32_t *)p)[0], ub_1 = ((const uint32_t *)p)[1];
                         const float b00 = ub0(ub_0), b01 = ub1(ub_0), b02 = ub2(ub_0), b03 = ub3(ub_0);
@@ -244,28 +250,32 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
             } else if (fast) {
                 const CscFolded cscb = csc_fold_biased(kCsc[Ly.csc & 3]);
                 const float al = 1.0f * opacity, ial = 1.f - al;
-                const float ya = cur.cya, iya = 1.0f - ya, ca = cur.cca, ica = 1.0f - ca;
+                // column weights times 2^24: the taps enter v_fma_mix_f32 as binary16 denormals (tap_h, pixel_math.hip.h); the
+                // products with the row weights below are the reference's products times 2^24, exactly
+                const float iya0 = 1.0f - cur.cya, ica0 = 1.0f - cur.cca;
+                const float ya = cur.cya * kTapScale, iya = iya0 * kTapScale;
+                const float cts = planar ? kTapScale : kChromaTapScale, ca = cur.cca * cts, ica = ica0 * cts;
                 auto yuv_fast = [&](auto planar_c, auto opaque_c, auto masked_c) {
                     constexpr bool PL = decltype(planar_c)::value, OP = decltype(opaque_c)::value;
 #pragma unroll
                     for (int j = 0; j < WTH; j++) {
                         WAVE_ROW_FENCE(j);
-                        const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
-                        const float yb = __uint_as_float(rb.x), iyb = __uint_as_float(rb.y), cbw = __uint_as_float(rb.z), icb = __uint_as_float(rb.w);
-                        const int yo = (int)ra.x + cur.cyo, co = (int)ra.y + cur.cco;
+                        const RowFast rw = row_fast<WTH, true>(rowtab, (CHV_ABL & 16) ? 0 : j);
+                        const float yb = rw.yb, iyb = rw.iyb, cbw = rw.cb, icb = rw.icb;
+                        const int yo = rw.yoff + cur.cyo + ((CHV_ABL & 16) ? j * p0pitch : 0), co = rw.coff + cur.cco;
                         const float w00 = iya * iyb, w10 = ya * iyb, w01 = iya * yb, w11 = ya * yb;
                         const float c00 = ica * icb, c10 = ca * icb, c01 = ica * cbw, c11 = ca * cbw;
                         float fy, fu, fv;
-                        if constexpr (PL) sample_y420p_lds_bytes(smem, yo, p0pitch, co, voff, p1pitch, w00, w10, w01, w11, c00, c10, c01, c11, fy, fu, fv);
-                        else sample_nv12_lds_bytes(smem, yo, p0pitch, co, p1pitch, w00, w10, w01, w11, c00, c10, c01, c11, fy, fu, fv);
+                        if constexpr (PL) sample_y420p_lds_mix(smem, yo, p0pitch, co, voff, p1pitch, w00, w10, w01, w11, c00, c10, c01, c11, fy, fu, fv);
+                        else sample_nv12_lds_mix(smem, yo, p0pitch, co, p1pitch, w00, w10, w01, w11, c00, c10, c01, c11, fy, fu, fv);
                         if constexpr (OP) {
-                            cv[j] = commit_px(masked_c, ra.z, cv[j], yuv_to_bgra_word(cscb, (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv)));   // fma(p, 1, c * 0) = p exactly
+                            cv[j] = commit_px(masked_c, j, cv[j], yuv_to_bgra_word(cscb, (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv)));   // fma(p, 1, c * 0) = p exactly
                         } else {
                             float pb, pg, pr;
                             yuv_to_bgr_floats(cscb, (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv), pb, pg, pr);
                             const uint32_t c = cv[j];
-                            cv[j] = commit_px(masked_c, ra.z, c, pack_codes(__builtin_fmaf(pb, al, ub0(c) * ial), __builtin_fmaf(pg, al, ub1(c) * ial),
-                                                                             __builtin_fmaf(pr, al, ub2(c) * ial), 0xFF000000u));
+                            cv[j] = commit_px(masked_c, j, c, pack_codes(__builtin_fmaf(pb, al, ub0(c) * ial), __builtin_fmaf(pg, al, ub1(c) * ial),
+                                                                          __builtin_fmaf(pr, al, ub2(c) * ial), 0xFF000000u));
                         }
                     }
                 };
@@ -366,6 +376,11 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? CHV_WAVE_MINW16 : CHV_WAVE
 // ---------------------------------------------------------------------------
 // launch (geometry, LDS sizing and eligibility of both wave kernels: kernels_wave_yuv.hip.cpp)
 // ---------------------------------------------------------------------------
+#define CHV_STR2(x) #x
+#define CHV_STR(x) CHV_STR2(x)
+// what this translation unit was built with (chv_build_flags; a timing-only CHV_ABL build must never ship)
+const char *bgra_wave_build_flags() { return "tick_bgra_wave:abl=" CHV_STR(CHV_ABL) ",waves_per_block=" CHV_STR(CHV_WAVE_WAVES) ",strip_rows=8|16"; }
+
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
                             int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds) {
 #define CHV_LAUNCH_B(R, C, K) hipLaunchKernelGGL((tick_bgra_wave<R, C, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \

@@ -17,6 +17,7 @@
 // Bytes: those of kernels_general.hip.cpp = oracle/ref_kernels.c (px_yuv_to_yuv, px_rgb_to_yuv), layer by layer.
 #include "wave_common.hip.h"
 #include "yuv_pixel.hip.h"
+#include "switches.h"
 
 #include <algorithm>
 #include <cmath>
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     }
 
     WLayer cur;
+    bool have_geom = false;            // `cur` and the row table hold the geometry of the layer handled just before (LF_SAME_GEOM)
     // (the layer index is wave-uniform; saying so keeps the descriptor reads on the scalar unit: left to its divergence analysis
     // the compiler fetched every uniform of a layer with per-lane global loads — 90 vector loads per wave)
     int l = __builtin_amdgcn_readfirstlane(S.next_hit(0));
@@ -189,8 +191,9 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
         if constexpr ((KINDS & 8) != 0) general_layer = (Ly.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED);
         int ptok = l;
         if (CHV_WAVE_PRIO) asm("s_setprio 3" : "+s"(ptok));
-        if (!general_layer) S.setup(ptok, cur);               // (overwrites the row table: the previous layer's pixels are done)
-        else { cur.staged = false; cur.all_inside = false; cur.unit_rows = false; cur.cfl = 0; cur.cyo = 0; cur.cco = 0; cur.cya = 0.f; cur.cca = 0.f; }
+        // (LF_SAME_GEOM: geometry inputs bit-identical to the predecessor's — its column entry, row table and rectangles stand)
+        if (!general_layer) { if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) S.setup(ptok, cur); have_geom = true; }      // (setup overwrites the row table: the previous layer's pixels are done)
+        else { have_geom = false; cur.staged = false; cur.all_inside = false; cur.unit_rows = false; cur.cfl = 0; cur.cyo = 0; cur.cco = 0; cur.cya = 0.f; cur.cca = 0.f; }
         // Strips entirely inside the picture, and — when the layer paints no fill (alpha of opacity x fill exactly 0: pixels of
         // the border quad outside the picture then keep their codes, to_code(c / 255) = c) — strips a picture edge crosses as
         // well: rows outside the picture are skipped (uniform branch), lanes outside keep their codes.
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
         // a pixel takes a row's result if its column and the row are inside the picture (row flags: uniform, from the row table);
         // every row is computed (branch-free: a branch per row keeps the rows' LDS reads from overlapping), row offsets are
         // clamped into the staged rectangle
-        auto take = [&](const uint4 &ra) { return lane_pic && ra.z == (uint32_t)AX_ALL; };
+        auto take = [&](uint32_t rfl) { return lane_pic && rfl == (uint32_t)AX_ALL; };
         if (fast && !(CHV_ABL & 1)) S.stage(l, cur);
         wave_lds_fence();
         const int ln = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
@@ -227,14 +230,14 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                 // two UNORM8 conversions, three instructions each, are carried down the lane)
                 const bool carry = CHV_WAVEY_CARRY && cur.unit_rows;
                 float t0 = 0.f, t1 = 0.f;
-                if (carry) { const uint8_t *py = smem + ((int)rowtab[0].x + cur.cyo); t0 = T8(tab, py[0]); t1 = T8(tab, py[1]); }
+                if (carry) { const uint8_t *py = smem + (row_fast<YTH, false>(rowtab, 0).yoff + cur.cyo); t0 = T8(tab, py[0]); t1 = T8(tab, py[1]); }
                 auto row = [&](auto jc, auto carry_c) {
                     constexpr int j = decltype(jc)::value;
                     constexpr bool CARRY = decltype(carry_c)::value;
-                    const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
-                    const bool tk = take(ra);
-                    const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
-                    const uint8_t *py = smem + ((int)ra.x + cur.cyo);
+                    const RowFast rw = row_fast<YTH, false>(rowtab, j);       // (compact row entries: wave_common.hip.h)
+                    const bool tk = take(row_fast_flags<YTH>(rowtab, j));
+                    const float b = rw.yb, ib = rw.iyb;
+                    const uint8_t *py = smem + (rw.yoff + cur.cyo);
                     float luma;
                     if constexpr (CARRY) {
                         const float b0 = T8(tab, py[p0pitch]), b1 = T8(tab, py[p0pitch + 1]);
@@ -253,10 +256,10 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
                         // pixel — the even lane's column entry (cco_q, cca_q), the row entry of luma row 4 m + 2 par — on the
                         // half-size plane(s)
                         constexpr int m = j >> 2;
-                        const uint4 qa = rowtab[8 * m + 4 * par], qb = rowtab[8 * m + 4 * par + 1];
-                        const bool tkc = pic_q && qa.z == (uint32_t)AX_ALL;
-                        const float cbw = __uint_as_float(qb.z), icb = __uint_as_float(qb.w);
-                        const uint8_t *pc = smem + ((int)qa.y + cco_q);
+                        const RowFast qw = row_fast<YTH, true>(rowtab, 4 * m + 2 * par);
+                        const bool tkc = pic_q && row_fast_flags<YTH>(rowtab, 4 * m + 2 * par) == (uint32_t)AX_ALL;
+                        const float cbw = qw.cb, icb = qw.icb;
+                        const uint8_t *pc = smem + (qw.coff + cco_q);
                         const float c00 = icaq * icb, c10 = cca_q * icb, c01 = icaq * cbw, c11 = cca_q * cbw;
                         float fu, fv;
                         if constexpr (PL) {
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
             const bool carry = CHV_WAVEY_CARRY && cur.unit_rows;       // (as above: eight conversions per row carried down the lane)
             float t00 = 0.f, t01 = 0.f, t02 = 0.f, t03 = 0.f, t10 = 0.f, t11 = 0.f, t12 = 0.f, t13 = 0.f;
             if (carry) {
-                const uint8_t *p0 = smem + ((int)rowtab[0].x + cur.cyo);
+                const uint8_t *p0 = smem + (row_fast<YTH, false>(rowtab, 0).yoff + cur.cyo);
                 const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
                 t00 = T8k<0>(tab, u00); t01 = T8k<1>(tab, u00); t02 = T8k<2>(tab, u00); t03 = T8k<3>(tab, u00);
                 t10 = T8k<0>(tab, u10); t11 = T8k<1>(tab, u10); t12 = T8k<2>(tab, u10); t13 = T8k<3>(tab, u10);
@@ -298,10 +301,10 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
             auto row = [&](auto jc, auto carry_c) {
                 constexpr int j = decltype(jc)::value;
                 constexpr bool CARRY = decltype(carry_c)::value;
-                const uint4 ra = rowtab[2 * j], rb = rowtab[2 * j + 1];
-                const bool tk = take(ra);
-                const float b = __uint_as_float(rb.x), ib = __uint_as_float(rb.y);
-                const uint8_t *p0 = smem + ((int)ra.x + cur.cyo);
+                const RowFast rw = row_fast<YTH, false>(rowtab, j);
+                const bool tk = take(row_fast_flags<YTH>(rowtab, j));
+                const float b = rw.yb, ib = rw.iyb;
+                const uint8_t *p0 = smem + (rw.yoff + cur.cyo);
                 const uint32_t u01 = ((const uint32_t *)(p0 + p0pitch))[0], u11 = ((const uint32_t *)(p0 + p0pitch))[1];
                 const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
                 const float b00 = T8k<0>(tab, u01), b01 = T8k<1>(tab, u01), b02 = T8k<2>(tab, u01), b03 = T8k<3>(tab, u01);
@@ -412,7 +415,8 @@ static bool finite16w(const float *m) {
     for (int i = 0; i < 16; i++) if (!(m[i] - m[i] == 0.f)) return false;
     return true;
 }
-static bool aligned16w(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0 && p.w * p.comps >= 16; }
+// (pitch < 2^24: the staging address arithmetic uses 24-bit multiplies)
+static bool aligned16w(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0 && p.w * p.comps >= 16 && p.pitch < (1 << 24) && p.h < (1 << 24); }
 static bool host_src_rgb(int kind) { return kind == LK_BGRA_FROM_RGB || kind == LK_YUV_FROM_RGB; }
 static bool host_src_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind == LK_YUV_FROM_Y420P; }
 static bool host_src_nv12(int kind) { return kind == LK_BGRA_FROM_NV12 || kind == LK_YUV_FROM_NV12; }
@@ -441,7 +445,7 @@ static WaveDims wave_dims(const DTick &T, const DLayer &L, int WTH) {
 }
 static size_t wave_lds(const WaveDims &d, bool planar, int target_format, int rows) {
     return (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) +
-           (size_t)WAVES * ((size_t)rows * 32 + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
+           (size_t)WAVES * ((size_t)rows * 48 + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
 }
 
 bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
@@ -475,6 +479,10 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
     return any_staged || !any_general;
 }
 
+#define CHV_STR2(x) #x
+#define CHV_STR(x) CHV_STR2(x)
+const char *yuv_wave_build_flags() { return "tick_yuv_wave:abl=" CHV_STR(CHV_ABL) ",unorm_table=" CHV_STR(CHV_UNORM_TABLE) ",strip_rows=8|16"; }
+
 // kernels_wave.hip.cpp
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
                             int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds);
@@ -487,7 +495,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     // edge.  8 rows otherwise.  CHV_WAVE_ROWS=8|16 is the A/B and test switch.
     int WTH = strip_rows(target_format);
     {
-        const char *env = getenv("CHV_WAVE_ROWS");
+        const int forced = switches().wave_rows.load(std::memory_order_relaxed);
         bool tall = (long)n_ticks * ((maxW + WTW - 1) / WTW) * ((maxH + 15) / 16) >= 8192;
         if (target_format == TF_BGRA) {
             for (int i = 0; i < n_ticks && tall; i++) {
@@ -498,7 +506,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
                 }
             }
         }
-        if (env && (env[0] == '8' || (env[0] == '1' && env[1] == '6'))) tall = env[0] == '1';
+        if (forced == 8 || forced == 16) tall = forced == 16;
         if (tall) WTH = 16;
     }
     WaveDims m{ 0, 0, 0, 0 };
@@ -525,7 +533,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     if (lds > (size_t)LDS_BUDGET) {
         // per-layer maxima combined exceed the budget: shrink the row counts; rectangles that do not fit fall back to
         // unstaged taps inside the kernel
-        const size_t fixed = (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) + (size_t)WAVES * WTH * 32;
+        const size_t fixed = (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) + (size_t)WAVES * WTH * 48;     // (row table: WaveCfg::ROWTAB_BYTES)
         const size_t per_row = (size_t)WAVES * ((size_t)m.p0pitch + (size_t)m.p1pitch * (planar ? 2 : 1));
         int rows = std::max(1, (int)((LDS_BUDGET - fixed) / per_row));
         m.p0rows = std::min(m.p0rows, rows); m.p1rows = std::min(m.p1rows, rows);

@@ -239,6 +239,24 @@ CHV_DEV float cs_fetch(const DPlane &p, const Lin2 &l, int c) {
     const uint8_t *b = p.ptr + c;
     return cs_mix(l, (float)gld<uint8_t>(b + l.o00), (float)gld<uint8_t>(b + l.o10), (float)gld<uint8_t>(b + l.o01), (float)gld<uint8_t>(b + l.o11));
 }
+// ---- taps without a conversion instruction --------------------------------------------------------------------------
+// A staged byte b, zero-extended to 16 bits, IS the binary16 denormal b * 2^-24 (exact for b < 1024).  v_fma_mix_f32 widens
+// a binary16 operand inside the multiplier, so with the weight pre-multiplied by 2^24 (exact: a power of two, no overflow
+// for weights in [0, 1])
+//     fma_mix(h = 0x00bb, w * 2^24, acc)  =  RN(b * 2^-24 * w * 2^24 + acc)  =  fmaf(w, (float)b, acc)       bit for bit,
+// and `fma(w, T, +0)` is `w * T` for the non-negative operands of the filter.  One slow-class instruction (1.8 ns per wave on
+// a SIMD) where v_cvt_f32_ubyteN + v_fma_f32 cost 1.8 + 1.1 (tools/ubench_tput.cpp, profiles/r03_ubench_tput_gfx950.txt);
+// the kernels' FP mode keeps binary16 denormals (.amdhsa_float_denorm_mode_16_64 3, asserted by tests/test_device_code_contract.py)
+// and tests/test_gpu_primitives.py checks the identity on the device for every byte.
+typedef _Float16 chv_half;
+constexpr float kTapScale = 16777216.0f;       // 2^24
+CHV_DEV chv_half tap_h(uint32_t byte) { return __builtin_bit_cast(chv_half, (unsigned short)byte); }
+CHV_DEV chv_half tap_h(const uint8_t *p) { return tap_h((uint32_t)*p); }
+// cs_mix with the four weights already multiplied by kTapScale
+CHV_DEV float cs_mix_h(float w00, float w10, float w01, float w11, chv_half t00, chv_half t10, chv_half t01, chv_half t11) {
+    return __builtin_fmaf(w11, (float)t11, __builtin_fmaf(w01, (float)t01, __builtin_fmaf(w10, (float)t10, __builtin_fmaf(w00, (float)t00, 0.0f))));
+}
+
 // RTE of a code-scale value known to lie in [0, 255 + a few ulp] and not NaN (a convex combination
 // of codes), through the float adder: returns the raw bits 0x4B400000 + rint(v)
 CHV_DEV uint32_t code_biased(float v) { return __float_as_uint(v + 12582912.0f); }

@@ -1,0 +1,21 @@
+// switches.h — measurement / test switches of the path selection (host side only).
+//
+// The environment is read ONCE, at the first use in the process (getenv on a hot path is undefined behaviour next to a
+// setenv in another thread, and the mixer and uploader threads run concurrently): CHV_FORCE_GENERAL, CHV_BGRA_PATH,
+// CHV_WAVE_ROWS, CHV_TILE_ROWS.  Tests and A/B tools change them afterwards through chv_debug_set_switch (include/chipvideo.h),
+// never through the environment.  Every value is an atomic int; 0 = "the library decides".
+#pragma once
+#include <atomic>
+
+namespace chv {
+
+struct Switches {
+    std::atomic<int> force_general{0};   // 1: every tick through the general kernels
+    std::atomic<int> bgra_path{0};       // 1: wave kernel also for one-YUV-layer BGRA ticks; 2: the tiled kernel wherever it applies
+    std::atomic<int> wave_rows{0};       // 8 | 16: strip height of the wave kernels
+    std::atomic<int> tile_rows{0};       // 16 | 32: tile height of the tiled YUV -> BGRA kernel
+    std::atomic<int> same_geom{1};       // 0: do not share a layer's geometry with its predecessor (A/B of LF_SAME_GEOM)
+};
+Switches &switches();                    // (chipvideo.cpp; initialised from the environment on first use)
+
+}  // namespace chv

@@ -250,6 +250,51 @@ CHV_DEV void sample_nv12_lds_bytes(const uint8_t *smem, int ya, int ypitch, int 
     fv = cs_mix(c00, c10, c01, c11, (float)(q00 >> 8), (float)(q10 >> 8), (float)(q01 >> 8), (float)(q11 >> 8));
 }
 
+// The same sample with every tap read as its own byte and fed to v_fma_mix_f32 as a binary16 denormal (tap_h, pixel_math.hip.h):
+// no conversion instructions, 12 instead of 8 LDS reads.  The eight weights arrive multiplied by kTapScale.
+// CHV_TAPS (measurement): 0 = every tap its own byte read (12 LDS reads, no conversions); 1 = luma bytes through v_fma_mix_f32,
+// chroma as four aligned (u, v) pair reads widened with v_cvt_f32_ubyte0/1 (8 LDS reads, 8 conversions); CHV_ABL & 8 (timing only):
+// the chroma taps reuse the luma registers (no chroma LDS reads at all)
+#ifndef CHV_TAPS
+#define CHV_TAPS 0
+#endif
+#ifndef CHV_ABL
+#define CHV_ABL_T 0
+#else
+#define CHV_ABL_T CHV_ABL
+#endif
+constexpr float kChromaTapScale = CHV_TAPS == 1 ? 1.0f : kTapScale;      // what sample_nv12_lds_mix expects its chroma weights multiplied by
+CHV_DEV void sample_nv12_lds_mix(const uint8_t *smem, int ya, int ypitch, int ca, int cpitch,
+                                 float w00, float w10, float w01, float w11,
+                                 float c00, float c10, float c01, float c11,
+                                 float &fy, float &fu, float &fv) {
+    const uint8_t *py = smem + ya, *pc = smem + ca;
+    const chv_half y00 = tap_h(py), y10 = tap_h(py + 1), y01 = tap_h(py + ypitch), y11 = tap_h(py + ypitch + 1);
+    fy = cs_mix_h(w00, w10, w01, w11, y00, y10, y01, y11);
+    if (CHV_ABL_T & 8) {
+        fu = cs_mix_h(c00, c10, c01, c11, y10, y00, y11, y01);
+        fv = cs_mix_h(c00, c10, c01, c11, y01, y11, y00, y10);
+    } else if (CHV_TAPS == 1) {
+        // (the chroma weights arrive UNSCALED in this mode: kChromaTapScale)
+        const uint32_t q00 = *(const uint16_t *)pc, q10 = *(const uint16_t *)(pc + 2);
+        const uint32_t q01 = *(const uint16_t *)(pc + cpitch), q11 = *(const uint16_t *)(pc + cpitch + 2);
+        fu = cs_mix(c00, c10, c01, c11, (float)(q00 & 255), (float)(q10 & 255), (float)(q01 & 255), (float)(q11 & 255));
+        fv = cs_mix(c00, c10, c01, c11, (float)(q00 >> 8), (float)(q10 >> 8), (float)(q01 >> 8), (float)(q11 >> 8));
+    } else {
+        fu = cs_mix_h(c00, c10, c01, c11, tap_h(pc), tap_h(pc + 2), tap_h(pc + cpitch), tap_h(pc + cpitch + 2));
+        fv = cs_mix_h(c00, c10, c01, c11, tap_h(pc + 1), tap_h(pc + 3), tap_h(pc + cpitch + 1), tap_h(pc + cpitch + 3));
+    }
+}
+CHV_DEV void sample_y420p_lds_mix(const uint8_t *smem, int ya, int ypitch, int ca, int voff, int cpitch,
+                                  float w00, float w10, float w01, float w11,
+                                  float c00, float c10, float c01, float c11,
+                                  float &fy, float &fu, float &fv) {
+    const uint8_t *py = smem + ya, *pu = smem + ca, *pv = smem + ca + voff;
+    fy = cs_mix_h(w00, w10, w01, w11, tap_h(py), tap_h(py + 1), tap_h(py + ypitch), tap_h(py + ypitch + 1));
+    fu = cs_mix_h(c00, c10, c01, c11, tap_h(pu), tap_h(pu + 1), tap_h(pu + cpitch), tap_h(pu + cpitch + 1));
+    fv = cs_mix_h(c00, c10, c01, c11, tap_h(pv), tap_h(pv + 1), tap_h(pv + cpitch), tap_h(pv + cpitch + 1));
+}
+
 // the same sample straight from the source planes (tile did not fit the LDS budget);
 // SV != nullptr: planar chroma (y420p: U from SC, V from SV), else interleaved (NV12)
 CHV_DEV void sample_nv12_global(const DPlane &SY, const DPlane &SC, const DPlane *SV, int ix, int iy, int cx, int cy,

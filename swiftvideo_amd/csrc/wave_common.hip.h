@@ -28,7 +28,9 @@ struct WaveCfg {
     static_assert(H == 8 || H == 16, "strip height: 8 or 16 rows");
     static constexpr int WN_Y = H / 4, WN_C = H / 8, WN_RGB = H / 4 + 1;
     static constexpr int WNR = (WN_RGB > WN_Y + 2 * WN_C) ? WN_RGB : (WN_Y + 2 * WN_C);
-    static constexpr int ROWTAB_BYTES = H * 32;     // per wave: the current layer's row entries, 8 dwords per row
+    // per wave: the current layer's row entries — 8 dwords per row (A, B: what the per-pixel paths read), then one compact
+    // 4-dword entry per row for the branch-free row loops (see RowFast)
+    static constexpr int ROWTAB_BYTES = H * 32 + H * 16;
 };
 
 // ---- wave-level helpers ---------------------------------------------------------------------------------------
@@ -76,6 +78,30 @@ struct WLayer {
 //   A = {yoff, coff, rfl, -}: LDS byte offset of the row's first tap row in the plane-0 / chroma rectangle (unstaged: the
 //                              unclamped tap-0 row positions), flags
 //   B = {yb, 1 - yb, cb, 1 - cb}: weights of tap row 1 (luma / RGB, chroma) and their complements
+
+// The compact entry the branch-free row loops read: C = {yb, cb, yoff | coff << 16, rfl} at rowtab[2 H + j] (staged layers: both
+// offsets are LDS byte offsets < 2^16).  A row then costs one ds_read_b64 and two ds_read_u16 (three dwords written to the register
+// file per lane) instead of two broadcast ds_read_b128 (eight): LDS return data competes with the VALU for the register file's write
+// ports, and the two wide reads per row measured ~9 ns each per wave on a SIMD (profiles/r03_notes.md) — a quarter of the pipeline
+// tick's time.  The complements 1 - yb, 1 - cb are recomputed (one v_sub_f32 each: the operation that produced the table's values).
+struct RowFast { float yb, iyb, cb, icb; int yoff, coff; };
+template <int H, bool CHROMA>
+CHV_DEV RowFast row_fast(const uint4 *rowtab, int j) {
+    const uint8_t *e = (const uint8_t *)(rowtab + 2 * H + j);
+    RowFast r;
+    if constexpr (CHROMA) {
+        const float2 w = *(const float2 *)e;
+        r.yb = w.x; r.cb = w.y;
+        r.coff = (int)((const uint16_t *)e)[5];
+    } else {
+        r.yb = *(const float *)e; r.cb = 0.f; r.coff = 0;
+    }
+    r.yoff = (int)((const uint16_t *)e)[4];
+    r.iyb = 1.0f - r.yb; r.icb = 1.0f - r.cb;
+    return r;
+}
+template <int H>
+CHV_DEV uint32_t row_fast_flags(const uint4 *rowtab, int j) { return ((const uint32_t *)(rowtab + 2 * H + j))[3]; }
 
 // EDGE = false: the caller knows (uniformly) that the rectangle touches no picture edge — no clamping, no patching, no
 // padding vector: the compact instantiation most strips run
@@ -149,6 +175,43 @@ CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const Sta
         }
 #pragma unroll 1
         for (int n = 0; n < WTAIL; n++) wstage_put<BPT, EDGE>(n == 0 ? t[0] : t[WTAIL - 1], base + n * 64 + lane, lds, lds_pitch, P, g, swap02);
+    }
+}
+
+// ---- shift-and-mask staging of narrow interior rectangles ------------------------------------------------------------
+// Rectangles that touch no picture edge and are at most 8 vectors wide (luma and chroma of YUV pictures up to ~1.9x downscale: the
+// pipeline, cfg2, every native-resolution video layer): lane -> (row of the round, vector) is lane >> sh, lane & mask with
+// 2^sh >= nvec, a round covers 64 >> sh rows.  No slot division, no bounds branches: lanes beyond the last vector / the last
+// row are clamped onto it and load and write the same bytes as their neighbour.  ~7 VALU instructions per slot where the general
+// slot map (stage_slot: two multiplies, bounds tests, 64-bit addresses) costs ~20; the wave kernels are VALU-bound
+// (profiles/r03_notes.md), so this is run time.
+struct P2Map { int rsub, vcol, rstep, ok; };
+template <int N>
+CHV_DEV P2Map p2_map(const StageGeom &g, int lane) {
+    // sh = ceil(log2(nvec)), uniform
+    const int sh = g.nvec <= 1 ? 0 : 32 - __builtin_clz((unsigned)(g.nvec - 1));
+    P2Map m;
+    m.rstep = 64 >> sh;
+    m.ok = sh <= 6 && N * m.rstep >= g.rows;
+    m.rsub = lane >> sh;
+    m.vcol = min(lane & ((1 << sh) - 1), g.nvec - 1) * 16;
+    return m;
+}
+template <int OFF, int N, int NR>
+CHV_DEV void wstage_load_p2(uint4 (&regs)[NR], const DPlane &P, const StageGeom &g, const P2Map &m) {
+    const uint8_t *base = P.ptr + (size_t)g.r_lo * P.pitch + g.b0;          // (uniform: scalar unit)
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        const int r = min(m.rsub + n * m.rstep, g.rows - 1);
+        regs[OFF + n] = gld_at<uint4>(base, __umul24((uint32_t)r, (uint32_t)P.pitch) + (uint32_t)m.vcol);       // (24-bit multiply: v_mul_lo_u32 issues at a quarter of the rate; pitches < 2^24 on this path, host-checked)
+    }
+}
+template <int OFF, int N, int NR>
+CHV_DEV void wstage_store_p2(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, const StageGeom &g, const P2Map &m) {
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        const int r = min(m.rsub + n * m.rstep, g.rows - 1);
+        *(uint4 *)(lds + (__umul24((uint32_t)r, (uint32_t)lds_pitch) + 16u + (uint32_t)m.vcol)) = regs[OFF + n];
     }
 }
 
@@ -316,6 +379,7 @@ struct WaveStrip {
         if (lane < WTH) {
             rowtab[2 * lane] = make_uint4((uint32_t)yoff, (uint32_t)coff, (uint32_t)rfl, 0u);
             rowtab[2 * lane + 1] = make_uint4(__float_as_uint(rya), __float_as_uint(1.0f - rya), __float_as_uint(rca), __float_as_uint(1.0f - rca));
+            rowtab[2 * WTH + lane] = make_uint4(__float_as_uint(rya), __float_as_uint(rca), ((uint32_t)yoff & 0xFFFFu) | ((uint32_t)coff << 16), (uint32_t)rfl);
         }
     }
 
@@ -352,9 +416,28 @@ struct WaveStrip {
             wstage_tail<1, WN_C, EDGE>(smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
         }
     }
+    // YUV pictures, both rectangles interior and narrow: shift-and-mask slot map (wstage_load_p2)
+    CHV_DEV bool stage_p2(int l, const WLayer &w) const {
+        const DLayer &Ly = L[l];
+        const P2Map m0 = p2_map<WN_Y>(w.g0, lane), m1 = p2_map<WN_C>(w.g1, lane);
+        if (!(m0.ok && m1.ok)) return false;
+        uint4 regs[WNR];
+        const bool planar = is_planar(Ly.kind);
+        wstage_load_p2<0, WN_Y, WNR>(regs, Ly.src.pl[0], w.g0, m0);
+        wstage_load_p2<WN_Y, WN_C, WNR>(regs, Ly.src.pl[1], w.g1, m1);
+        if (planar) wstage_load_p2<WN_Y + WN_C, WN_C, WNR>(regs, Ly.src.pl[2], w.g1, m1);
+        touch_regs(regs);                 // one wait for all of the layer's loads
+        wstage_store_p2<0, WN_Y, WNR>(regs, smem + base0, p0pitch, w.g0, m0);
+        wstage_store_p2<WN_Y, WN_C, WNR>(regs, smem + base1, p1pitch, w.g1, m1);
+        if (planar) wstage_store_p2<WN_Y + WN_C, WN_C, WNR>(regs, smem + base1 + voff, p1pitch, w.g1, m1);
+        return true;
+    }
     // (rectangles that touch no picture edge — most strips — take the instantiation without clamping and patching code)
     CHV_DEV void stage(int l, const WLayer &w) const {
         const bool rgb = is_rgb(L[l].kind);
+        if constexpr ((INTERIOR & 4) != 0) {
+            if (!rgb && !w.g0.edge && !w.g1.edge && stage_p2(l, w)) return;
+        }
         if constexpr (INTERIOR != 0) {
             if ((INTERIOR & (rgb ? 2 : 1)) && !w.g0.edge && (rgb || !w.g1.edge)) { stage_impl<false>(l, w); return; }
         }

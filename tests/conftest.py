@@ -32,3 +32,19 @@ def ctx(built):
     c = sv.makeComputeContext(forType="GPU")
     yield c
     sv.destroyComputeContext(c)
+
+
+@pytest.fixture
+def switch(built):
+    """Path-selection switches through the library's own hook (chv_debug_set_switch) instead of the environment: the library
+    reads the environment once per process.  Everything set through the fixture goes back to its default afterwards."""
+    from swiftvideo_amd import chipvideo
+    touched = []
+
+    def _set(name, value):
+        chipvideo.set_switch(name, value)
+        touched.append(name)
+
+    yield _set
+    for name in touched:
+        chipvideo.set_switch(name, None)

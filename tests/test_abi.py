@@ -109,3 +109,22 @@ int main(void) {
     assert sizes[7] == 6 * 80 + 8 + 256                      # chv_custom_args: 6 images, two counts, 256 uniform bytes
     assert offsets == [cv.Plane.pitch.offset, cv.Image.planes.offset, cv.Layer.uniforms.offset, cv.Layer.opts.offset,
                        cv.Tick.layers.offset]
+
+
+def test_build_flags_report_a_product_build(built):
+    """chv_build_flags(): the shipped library is a gfx950 build with every timing-only ablation off (a -DCHV_ABL=n build
+    produces wrong pixels by design, profiles/r02_notes.md section 6)."""
+    flags = cv.build_flags()
+    assert flags.startswith("arch=gfx950;")
+    abl = re.findall(r"abl=(\d+)", flags)
+    assert len(abl) >= 2 and all(a == "0" for a in abl), flags
+    assert "unorm_table=0" in flags
+
+
+def test_switch_hook_validates_names(built):
+    lib = cv.load()
+    assert lib.chv_debug_set_switch(b"CHV_NO_SUCH_SWITCH", b"1") == 1
+    assert lib.chv_debug_set_switch(None, b"1") == 1
+    for name in ("CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM"):
+        assert lib.chv_debug_set_switch(name.encode(), b"") == 0
+        assert lib.chv_debug_set_switch(name.encode(), None) == 0

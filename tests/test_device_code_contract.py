@@ -89,7 +89,10 @@ def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem)
     co = _code_object(tmp_path, stem)
     for name, m in _find(_kernels(co), "wave").items():
         tall = "tick_bgra_waveILi16E" in name             # BGRA canvas, 16-row strips: 96 VGPRs = 5 waves, no spills
-        assert m["vgpr_count"] <= (96 if tall else 80), (name, m)
+        # (the instantiation that also carries the per-pixel code for rotated layers — KINDS bit 3 — gets one wave less instead of
+        # scratch traffic: the kernels are VALU-bound, profiles/r03_notes.md, and a fifth / sixth wave buys ~3 %)
+        with_general = "tick_bgra_wave" in name and re.search(r"ELi15EEEv", name) is not None
+        assert m["vgpr_count"] <= ((128 if with_general else 96) if tall else (96 if with_general else 80)), (name, m)
         if "tick_yuv_wave" in name:
             # 4:2:0 canvases: 6 waves with a few registers in scratch measured faster than 5 waves without (16-row strips: 0.49
             # vs 0.67 ms on y420p_main); bounded by the scratch footprint (the metadata's spill count is per spill instruction)

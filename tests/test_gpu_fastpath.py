@@ -63,8 +63,8 @@ TILE32_CASES = {
 
 @pytest.mark.parametrize("case", list(TILE32_CASES))
 @pytest.mark.parametrize("fmt", ["nv12", "y420p"])
-def test_yuv_bgra_32_row_tiles_match_oracle(ctx, monkeypatch, case, fmt):
-    monkeypatch.setenv("CHV_TILE_ROWS", "32")
+def test_yuv_bgra_32_row_tiles_match_oracle(ctx, switch, case, fmt):
+    switch("CHV_TILE_ROWS", "32")
     cw, ch, sw, sh, kw = TILE32_CASES[case]
     u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
     src = util.alloc_image(fmt, sw, sh, seed=31)
@@ -82,10 +82,10 @@ def test_yuv_bgra_32_row_tiles_match_oracle(ctx, monkeypatch, case, fmt):
 
 @pytest.mark.parametrize("seed", range(24))
 @pytest.mark.parametrize("rows", ["16", "32"])
-def test_random_axis_aligned_yuv_bgra_ticks(ctx, monkeypatch, seed, rows):
+def test_random_axis_aligned_yuv_bgra_ticks(ctx, switch, seed, rows):
     """Seeded random axis-aligned geometry (placement, crop, flips, borders, fill, opacity, up- and downscales), three ticks of
     different sizes per launch, both tile heights: tiled kernels == oracle."""
-    monkeypatch.setenv("CHV_TILE_ROWS", rows)
+    switch("CHV_TILE_ROWS", rows)
     rng = np.random.default_rng(7000 + seed)
     fmt = "nv12" if seed % 2 == 0 else "y420p"
     kname = f"img_{fmt}_bgra"

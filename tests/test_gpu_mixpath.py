@@ -17,11 +17,11 @@ WAVE = "tick_bgra_wave"
 
 
 @pytest.fixture(params=["8", "16"])
-def path(request, monkeypatch):
+def path(request, switch):
     """route every eligible BGRA-canvas batch through the wave kernel (also where the single-purpose kernel would be chosen),
     once with 8-row and once with 16-row strips (the host picks per launch; CHV_WAVE_ROWS forces it); yields the kernel name"""
-    monkeypatch.setenv("CHV_BGRA_PATH", "wave")
-    monkeypatch.setenv("CHV_WAVE_ROWS", request.param)
+    switch("CHV_BGRA_PATH", "wave")
+    switch("CHV_WAVE_ROWS", request.param)
     return WAVE
 
 
@@ -78,6 +78,39 @@ MIXED_CASES = {
     "down_2x_tail":   (160, 64, True, [("img_nv12_bgra", 320, 128, dict()), ("img_y420p_bgra", 352, 140, dict(opacity=0.5))]),   # luma rectangles > 512 slots: staging tail
     "down_4x":        (96, 40, True, [("img_nv12_bgra", 384, 160, dict(opacity=0.6)), ("img_bgra_bgra_tx", 384, 160, dict(opacity=0.5))]),
 }
+
+
+# LF_SAME_GEOM (device_types.h): a layer whose three matrices, source plane sizes / pitches / class and bounding box equal its
+# predecessor's keeps the predecessor's column entry, row table and rectangles — only opacity, fill colour, colourspace and the
+# plane pointers differ.  Ticks that interleave such layers with layers of other geometry, source class or size:
+A = dict()
+R = dict(rect=(40, 20, 200, 120))
+OFF = dict(rect=(-30, -12, 300, 170))           # crosses every canvas edge: edge staging + masked rows
+BF = dict(rect=(50, 30, 180, 100), border=(6, 4, 6, 4), fill=(0.9, 0.2, 0.1, 0.6))
+SAME_GEOM_CASES = {
+    "interleaved": (320, 180, True, [("img_nv12_bgra", 480, 270, dict(A)), ("img_nv12_bgra", 480, 270, dict(A, opacity=0.75)),
+                                     ("img_nv12_bgra", 480, 270, dict(R, opacity=0.9)), ("img_nv12_bgra", 480, 270, dict(R, opacity=0.5)),
+                                     ("img_y420p_bgra", 480, 270, dict(R, opacity=0.5)), ("img_y420p_bgra", 480, 270, dict(R, opacity=0.25)),
+                                     ("img_nv12_bgra", 480, 270, dict(A, opacity=0.3)), ("img_nv12_bgra", 240, 134, dict(A, opacity=0.3)),
+                                     ("img_bgra_bgra_tx", 96, 54, dict(R, opacity=0.8)), ("img_bgra_bgra_tx", 96, 54, dict(R, opacity=0.6)),
+                                     ("img_rgba_bgra_tx", 96, 54, dict(R, opacity=0.6))]),
+    "off_canvas": (320, 180, False, [("img_nv12_bgra", 300, 170, dict(OFF, opacity=0.8)), ("img_nv12_bgra", 300, 170, dict(OFF, opacity=0.6)),
+                                     ("img_y420p_bgra", 300, 170, dict(OFF, opacity=0.6)), ("img_y420p_bgra", 300, 170, dict(OFF))]),
+    "border_fill": (320, 180, True, [("img_nv12_bgra", 200, 110, dict(BF, opacity=0.8)), ("img_nv12_bgra", 200, 110, dict(BF, opacity=0.5)),
+                                     ("img_nv12_bgra", 200, 110, dict(BF, opacity=0.5, fill=(0.1, 0.3, 0.9, 0.0))),
+                                     ("img_bgra_bgra_tx", 200, 110, dict(BF, opacity=0.5)), ("img_bgra_bgra_tx", 200, 110, dict(BF, opacity=1.0))]),
+    "native_rgb": (256, 96, True, [("img_bgra_bgra_tx", 256, 96, dict(opacity=o)) for o in (1.0, 0.75, 0.5, 0.25)]),
+    "csc_differs": (192, 64, True, [("img_nv12_bgra", 288, 96, dict()), ("img_nv12_bgra", 288, 96, dict(opacity=0.5))]),
+}
+
+
+@pytest.mark.parametrize("case", list(SAME_GEOM_CASES))
+@pytest.mark.parametrize("share", ["1", "0"])
+def test_layers_sharing_geometry_match_oracle(ctx, path, switch, case, share):
+    """same- and different-geometry layers interleaved in one tick, both strip heights, with and without the sharing"""
+    switch("CHV_SAME_GEOM", share)
+    cw, ch, clear, specs = SAME_GEOM_CASES[case]
+    run_tick_case(ctx, cw, ch, clear, specs, expect=path, seed=131)
 
 
 @pytest.mark.parametrize("case", list(MIXED_CASES))

@@ -307,7 +307,7 @@ def test_lanczos_paths_match_oracle(ctx, iw, ih, ow, oh):
     G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"lanczos {iw}x{ih} -> {ow}x{oh}")
 
 
-@pytest.mark.parametrize("iw,ih,ow,oh,n", [(96, 54, 48, 27, 5), (64, 36, 128, 72, 3), (200, 120, 75, 45, 70), (33, 17, 20, 10, 2)])
+@pytest.mark.parametrize("iw,ih,ow,oh,n", [(96, 54, 48, 27, 5), (64, 36, 128, 72, 3), (200, 120, 75, 45, 70), (33, 17, 20, 10, 2), (40, 24, 20, 12, 130)])
 def test_lanczos_batch_equals_single_calls(ctx, iw, ih, ow, oh, n):
     """chv_scale_lanczos_batch: n resizes of one geometry in one launch per 64 pairs == the oracle, image by image"""
     srcs = [util.alloc_image("bgra", iw, ih, seed=900 + i) for i in range(n)]
@@ -322,6 +322,25 @@ def test_lanczos_batch_equals_single_calls(ctx, iw, ih, ow, oh, n):
     sv.usingContext(ctx, lambda c: batch.run(c))          # replayable
     for i, ((gd, _), exp) in enumerate(zip(pairs, exps)):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"batched lanczos, image {i} of {n}")
+
+
+def test_lanczos_empty_batch_is_a_noop(ctx):
+    assert sv.LanczosBatch([]).run(ctx) is ctx
+
+
+def test_lanczos_table_cache_eviction_keeps_results_exact(ctx):
+    """More live geometries than the table cache holds (64 per device, evicted tables freed 32 at a time): an animated resize
+    makes a new (in, out) pair per frame.  Every result stays exact, including a geometry that was evicted and comes back."""
+    src = util.alloc_image("bgra", 96, 40, seed=77)
+    gs = G.to_gpu(ctx, "bgra", 96, 40, src)
+    sizes = [(20 + i, 9 + (i % 7)) for i in range(110)] + [(20, 9), (21, 10)]
+    for ow, oh in sizes:
+        gd = G.to_gpu(ctx, "bgra", ow, oh, util.alloc_image("bgra", ow, oh))
+        sv.usingContext(ctx, lambda c: sv.scaleLanczos(c, gd, gs))
+        if ow % 10 == 0 or (ow, oh) in ((21, 10),):
+            exp = util.alloc_image("bgra", ow, oh)
+            assert O.lanczos_bgra(exp[0], src[0]) == 0
+            G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"lanczos 96x40 -> {ow}x{oh} after evictions")
 
 
 def test_lanczos_batch_rejects_mixed_geometry(ctx):

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=["8", "16"])
-def rows(request, monkeypatch):
+def rows(request, switch):
     """both strip heights of tick_yuv_wave (the host picks per launch: 16 rows for launches of >= 8192 strips; CHV_WAVE_ROWS
     forces it for any launch whose 16-row rectangles fit the LDS)"""
-    monkeypatch.setenv("CHV_WAVE_ROWS", request.param)
+    switch("CHV_WAVE_ROWS", request.param)
     return request.param
 
 
@@ -70,6 +70,17 @@ CASES = {
     "opacity_gt_1":     ("y420p", 128, 32, True, [("img_y420p_y420p", 128, 32, dict(opacity=1.7)), ("img_bgra_y420p", 128, 32, dict(opacity=-0.3))]),
     "twelve_layers":    ("nv12", 128, 32, True, [("img_bgra_nv12" if i % 3 else "img_nv12_nv12", 64, 16, dict(rect=(4 * i, i, 64, 16), opacity=1.0 - 0.05 * i)) for i in range(12)]),
     "odd_strip_edges":  ("y420p", 130, 22, True, [("img_y420p_y420p", 200, 60, dict()), ("img_rgba_y420p", 66, 34, dict(opacity=0.5))]),
+    # LF_SAME_GEOM: a layer whose matrices, plane sizes and bounding box equal its predecessor's keeps that layer's geometry (only
+    # opacity, fill colour and the plane pointers differ); interleaved with layers of other geometry / other source classes
+    "same_geom":        ("y420p", 320, 180, True, [("img_y420p_y420p", 480, 270, dict()), ("img_y420p_y420p", 480, 270, dict(opacity=0.5)),
+                                                   ("img_bgra_y420p", 96, 54, dict(rect=(30, 20, 96, 54), opacity=0.8)),
+                                                   ("img_bgra_y420p", 96, 54, dict(rect=(30, 20, 96, 54), opacity=0.4, fill=(0.2, 0.9, 0.1, 0.5))),
+                                                   ("img_y420p_y420p", 480, 270, dict(opacity=0.25)),
+                                                   ("img_rgba_y420p", 96, 54, dict(rect=(30, 20, 96, 54), opacity=0.4))]),
+    "same_geom_nv12":   ("nv12", 256, 64, False, [("img_nv12_nv12", 128, 32, dict(rect=(-20, -6, 200, 50), opacity=0.6)),
+                                                  ("img_nv12_nv12", 128, 32, dict(rect=(-20, -6, 200, 50), opacity=0.3)),
+                                                  ("img_y420p_nv12", 128, 32, dict(rect=(-20, -6, 200, 50), opacity=0.5)),
+                                                  ("img_y420p_nv12", 128, 32, dict(rect=(-20, -6, 200, 50)))]),
     "down_2.5":         ("nv12", 130, 50, True, [("img_nv12_nv12", 326, 124, dict()), ("img_bgra_nv12", 326, 124, dict(opacity=0.5))]),
 }
 
@@ -81,10 +92,10 @@ def test_yuv_wave_matches_oracle(ctx, rows, case):
     run_yuv_tick(ctx, d, cw, ch, clear, specs, expect=None if case == "down_2.5" else "wave")
 
 
-@pytest.mark.parametrize("case", ["mixer", "rect_border_fill", "noclear", "flips"])
-def test_yuv_wave_equals_general_kernel(ctx, monkeypatch, case):
+@pytest.mark.parametrize("case", ["mixer", "rect_border_fill", "noclear", "flips", "same_geom"])
+def test_yuv_wave_equals_general_kernel(ctx, switch, case):
     """the same tick through CHV_FORCE_GENERAL=1: both device paths are held to the same oracle bytes"""
-    monkeypatch.setenv("CHV_FORCE_GENERAL", "1")
+    switch("CHV_FORCE_GENERAL", "1")
     d, cw, ch, clear, specs = CASES[case]
     assert run_yuv_tick(ctx, d, cw, ch, clear, specs, expect=None) == f"tick_general_yuv<{d}>"
 
