@@ -110,6 +110,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the end-to-end (H2D-inclusive) cfg2 measurement")
+    ap.add_argument("--no-per-tick", action="store_true", help="skip the one-tick-at-a-time legs (pipeline_per_tick, pipeline_reference_sequence)")
+    ap.add_argument("--per-tick", action="store_true", help="run the one-tick-at-a-time legs even with --also none")
     ap.add_argument("--alias", default="none", choices=("none", "src", "dst", "both"),
                     help="DIAGNOSTIC (single-layer YUV workloads): every tick reads frame 0's source and/or writes frame 0's "
                          "canvas, so that side of the traffic stays in cache; the line is marked and is not a benchmark result")
@@ -702,6 +704,118 @@ def run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=64):
     return rep
 
 
+def run_per_tick(args, sv, cv, lib, ctx, seconds=0.35, ring=10, distinct=4, mixers=8):
+    """The path a Swift VideoMixer takes: ONE tick at a time with the reference's host wait after it (usingContext,
+    compute.swift:131-134).  Two ways of issuing the headline tick (4 x 1080p NV12 -> 720p BGRA canvas from a ring of 10):
+      fused     — one chv_composite + chv_pass_end(wait): the optional `#if GPGPU_HIP` hunk of mix.video.swift
+      sequence  — img_clear_bgra + 4 x chv_run_kernel(img_nv12_bgra, blends) + chv_pass_end(wait): an UNCHANGED
+                  mix.video.swift:116-124
+    each from one host thread, and from `mixers` threads with their own context, sources and canvas ring (many mixers per
+    device, composer.swift:203-224).  Host: this process (Python, ctypes: ~2-3 us per call on top of the library)."""
+    import threading
+    import util
+    wl = WORKLOADS["pipeline"]
+    sw, sh, dw, dh = wl["sw"], wl["sh"], wl["dw"], wl["dh"]
+    ops = (1.0, 0.75, 0.5, 0.25)
+    us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in ops]
+    host = [util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 48 + i) for i in range(distinct)]
+    k_layer, k_clear = sv.ComputeKernel.img_nv12_bgra, sv.ComputeKernel.img_clear_bgra
+
+    class Mixer:
+        def __init__(self, c):
+            self.ctx = c
+            self.src = [sv.uploadComputePicture(c, sv.pictureFromArrays(sv.PixelFormat.nv12, (sw, sh), h), retainCpuBuffer=False) for h in host]
+            self.canvas = [sv.uploadComputePicture(c, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False) for _ in range(ring)]
+            self.tdesc = [sv._image_desc(cn) for cn in self.canvas]
+            # the four layers of tick t: sources rotate like the batch workload's
+            self.layer_arr = [sv._layer_array([(k_layer, self.src[(t + l) % distinct], us[l], cv.CSC_BT601_LIMITED) for l in range(4)]) for t in range(distinct)]
+            self.sdesc = [sv._image_desc(x) for x in self.src]
+            self.uni = [(cv.Uniforms).from_buffer_copy(np.asarray(u, dtype=np.float32).tobytes()) for u in us]
+            self.opts = cv.KernelOpts(cv.CSC_BT601_LIMITED)
+            self.n = 0
+
+        def tick_fused(self):
+            t = self.n; self.n += 1
+            h = self.ctx.handle
+            lib.chv_pass_begin(h)
+            rc = lib.chv_composite(h, C.byref(self.tdesc[t % ring]), 1, self.layer_arr[t % distinct], 4)
+            rc |= lib.chv_pass_end(h, 1)
+            if rc:
+                cv.check(rc)
+
+        def tick_sequence(self):
+            t = self.n; self.n += 1
+            h = self.ctx.handle
+            td = C.byref(self.tdesc[t % ring])
+            lib.chv_pass_begin(h)
+            rc = lib.chv_run_kernel(h, int(k_clear), td, None, 0, None, 0, 0, None)
+            for l in range(4):
+                rc |= lib.chv_run_kernel(h, int(k_layer), td, C.byref(self.sdesc[(t + l) % distinct]), 1, C.byref(self.uni[l]), 236, 1, C.byref(self.opts))
+            rc |= lib.chv_pass_end(h, 1)
+            if rc:
+                cv.check(rc)
+
+    def timed(fn, secs):
+        for _ in range(20):
+            fn()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(20):
+                fn()
+            n += 20
+            el = time.perf_counter() - t0
+            if el >= secs:
+                return el / n * 1e6, n
+
+    out = {}
+    m0 = Mixer(ctx)
+    for mode in ("fused", "sequence"):
+        us_tick, n = timed(getattr(m0, "tick_" + mode), seconds)
+        out[mode] = {"us_per_tick": us_tick, "ticks": n}
+    # oracle check of the last canvas written by each mode's final tick is covered by the batch workloads' verification of the same
+    # kernels; here: fused == sequence on one tick (same sources, two canvases), byte for byte
+    a, b = Mixer(ctx), Mixer(ctx)
+    a.tick_fused(); b.tick_sequence()
+    ga = sv.downloadComputePicture(ctx, a.canvas[0], retainGpuBuffer=True).imageBuffer().buffers[0]
+    gb = sv.downloadComputePicture(ctx, b.canvas[0], retainGpuBuffer=True).imageBuffer().buffers[0]
+    same = bool(np.array_equal(ga, gb))
+    # `mixers` threads, one context + ring each
+    ctxs = [sv.createComputeContext(sharing=ctx) for _ in range(mixers)]
+    ms = [Mixer(c) for c in ctxs]
+    for mode in ("fused", "sequence"):
+        counts = [0] * mixers
+        stop = [0.0]
+
+        def worker(i, mode=mode):
+            fn = getattr(ms[i], "tick_" + mode)
+            n = 0
+            while time.perf_counter() < stop[0]:
+                fn(); n += 1
+            counts[i] = n
+
+        for m in ms:
+            getattr(m, "tick_" + mode)()
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(mixers)]
+        t0 = time.perf_counter(); stop[0] = t0 + seconds
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        out[mode].update({f"us_per_tick_per_mixer_{mixers}_threads": el / (sum(counts) / mixers) * 1e6, f"ticks_per_s_{mixers}_mixers": sum(counts) / el})
+    for c in ctxs:
+        sv.destroyComputeContext(c)
+    desc = ("the headline tick issued ONE AT A TIME with a host wait after every tick (what a Swift VideoMixer does): {} — {}; "
+            "Python host (ctypes), canvas ring of %d" % ring)
+    return {
+        "pipeline_per_tick": dict(out["fused"], workload=desc.format("one chv_composite + chv_pass_end(wait)", "the optional GPGPU_HIP hunk of mix.video.swift"),
+                                  launches_per_tick=1, fused_equals_sequence=same, gpix_per_s=dw * dh / out["fused"]["us_per_tick"] / 1e3),
+        "pipeline_reference_sequence": dict(out["sequence"], workload=desc.format("img_clear_bgra + 4 x chv_run_kernel(img_nv12_bgra) + chv_pass_end(wait)",
+                                                                                   "an unchanged mix.video.swift:116-124"),
+                                            launches_per_tick=5, fused_equals_sequence=same, gpix_per_s=dw * dh / out["sequence"]["us_per_tick"] / 1e3),
+    }
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -750,6 +864,8 @@ def main(argv=None):
         reports[name], _ = do(name, False)
     if others and not args.no_upload_leg and not args.stub_device:
         reports["cfg2_upload"] = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus)
+    if (others or args.per_tick) and not args.stub_device and not args.no_per_tick and n_gpus == 1:
+        reports.update(run_per_tick(args, sv, cv, lib, ctx))
 
     if rank == 0:
         wl = WORKLOADS[args.workload]
@@ -791,7 +907,8 @@ def main(argv=None):
                        "parallelism": f"{n_gpus} process(es), one per GPU; {head['frames_per_launch_per_gpu']} independent picture "
                                       f"buses per device, bus s -> device s mod {n_gpus}; no collective",
                        "per_gpu_gpix": head["per_gpu_gpix"], "per_stream_ticks_per_s": head["per_stream_ticks_per_s"],
-                       "kernel": head["kernel"], "verified_vs_oracle": head["verified_vs_oracle"]},
+                       "kernel": head["kernel"], "verified_vs_oracle": head["verified_vs_oracle"],
+                       "build_flags": None if args.stub_device else cv.build_flags()},
             "roofline": roof,
             "workloads": {k: {kk: vv for kk, vv in v.items() if kk not in ("source_mpix_per_launch_per_gpu",)} for k, v in reports.items()},
         }

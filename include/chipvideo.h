@@ -86,11 +86,18 @@ typedef enum chv_kernel {
     CHV_K_IMG_NV12_BGRA = 32,
     CHV_K_IMG_Y420P_BGRA = 33,
     CHV_K_IMG_BGRA_BGRA_TX = 34, /* transform/opacity/fill-aware BGRA over BGRA */
-    CHV_K_IMG_RGBA_BGRA_TX = 35
+    CHV_K_IMG_RGBA_BGRA_TX = 35,
+    /* The encoder side of "integer BT.601/709 YUV <-> RGB": an RGB picture onto a 4:2:0 canvas through the 16.16 integer
+     * matrix of chv_kernel_opts.colorspace (the reference's img_bgra_nv12 family is a float full-range matrix with a 0.113
+     * blue weight, kernels.cl.swift:96-99).  Specification in DESIGN.md section 4.5. */
+    CHV_K_IMG_BGRA_NV12_INT = 36,
+    CHV_K_IMG_RGBA_NV12_INT = 37,
+    CHV_K_IMG_BGRA_Y420P_INT = 38,
+    CHV_K_IMG_RGBA_Y420P_INT = 39
 } chv_kernel;
 
 /* defaultComputeKernelFromString, compute.swift:90-110, plus the entries of the
- * compute.swift hunk in INTEGRATION.md section 1: the four names above and
+ * compute.swift hunk in INTEGRATION.md section 1: the eight names above and
  * "img_rgba_bgra" (-> CHV_K_IMG_RGBA_BGRA_TX; what VideoMixer.findKernel,
  * mix.video.swift:142-146, synthesises for an RGBA layer on a BGRA canvas).
  * Unknown name -> CHV_ERR_INVALID_VALUE, as the reference throws. */

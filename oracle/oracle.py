@@ -20,6 +20,7 @@ KERNEL_IDS = {
     "img_clear_bgra": 8, "img_clear_y420p": 9, "img_clear_rgba": 10, "img_rgba_y420p": 11,
     "img_bgra_y420p": 12, "snd_s16i_s16i": 13, "me_fullsearch": 14,
     "img_nv12_bgra": 32, "img_y420p_bgra": 33, "img_bgra_bgra_tx": 34, "img_rgba_bgra_tx": 35,
+    "img_bgra_nv12_int": 36, "img_rgba_nv12_int": 37, "img_bgra_y420p_int": 38, "img_rgba_y420p_int": 39,
 }
 # unit-scale envelope evaluators of the BGRA-target family (tests only; ref_kernels.c::px_to_bgra_unit)
 ENVELOPE_IDS = {"img_nv12_bgra": 64, "img_y420p_bgra": 65, "img_bgra_bgra_tx": 66, "img_rgba_bgra_tx": 67}
@@ -64,6 +65,8 @@ def lib():
         _lib.orc_load_unorm8.argtypes = [C.c_uint8]
         _lib.orc_yuv2rgb_int.restype = None
         _lib.orc_yuv2rgb_int.argtypes = [C.c_int, C.c_uint8, C.c_uint8, C.c_uint8, C.c_void_p]
+        _lib.orc_rgb2yuv_int.restype = None
+        _lib.orc_rgb2yuv_int.argtypes = [C.c_int, C.c_uint8, C.c_uint8, C.c_uint8, C.c_void_p]
     return _lib
 
 
@@ -142,4 +145,10 @@ def lanczos_table(in_size, out_size, max_taps=256):
 def yuv2rgb_int(csc, y, u, v):
     out = (C.c_uint8 * 3)()
     lib().orc_yuv2rgb_int(csc, y, u, v, out)
+    return tuple(out)
+
+
+def rgb2yuv_int(csc, r, g, b):
+    out = (C.c_uint8 * 3)()
+    lib().orc_rgb2yuv_int(csc, r, g, b, out)
     return tuple(out)

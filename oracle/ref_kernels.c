@@ -160,6 +160,32 @@ void orc_yuv2rgb_int(int csc, uint8_t y, uint8_t u, uint8_t v, uint8_t rgb[3]) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* Integer RGB -> YUV (spec owned by this repo)        */
+/* 16.16 fixed point, the transpose of the matrices above: coefficients       */
+/* round(K * 65536 * 219/255) (luma) / round(K * 65536 * 224/255) (chroma)    */
+/* for limited range, green adjusted so that every luma row sums to           */
+/* round(65536 * 219/255) = 56284 (65536 full range) and every chroma row     */
+/* to 0 exactly: white is (235, 128, 128) / (255, 128, 128), grey has         */
+/* neutral chroma, and the BT.601 limited row gives the colour-bar values     */
+/* red (81, 90, 240), green (145, 54, 34), blue (41, 240, 110).               */
+/* ------------------------------------------------------------------------ */
+typedef struct { int32_t yoff, y[3], u[3], v[3]; } r2y_t;
+static const r2y_t R2Y[4] = {
+    { 16, { 16829, 33039, 6416 }, { -9714, -19070, 28784 }, { 28784, -24103, -4681 } },  /* BT.601 limited */
+    { 16, { 11966, 40254, 4064 }, { -6596, -22188, 28784 }, { 28784, -26145, -2639 } },  /* BT.709 limited */
+    { 0, { 19595, 38470, 7471 }, { -11058, -21710, 32768 }, { 32768, -27439, -5329 } },  /* BT.601 full    */
+    { 0, { 13933, 46871, 4732 }, { -7509, -25259, 32768 }, { 32768, -29763, -3005 } },   /* BT.709 full    */
+};
+INL void rgb2yuv_int(const r2y_t *k, int r, int g, int b, uint8_t *y, uint8_t *u, uint8_t *v) {
+    *y = clip8((k->y[0] * r + k->y[1] * g + k->y[2] * b + (k->yoff << 16) + 32768) >> 16);
+    *u = clip8((k->u[0] * r + k->u[1] * g + k->u[2] * b + (128 << 16) + 32768) >> 16);
+    *v = clip8((k->v[0] * r + k->v[1] * g + k->v[2] * b + (128 << 16) + 32768) >> 16);
+}
+void orc_rgb2yuv_int(int csc, uint8_t r, uint8_t g, uint8_t b, uint8_t yuv[3]) {
+    rgb2yuv_int(&R2Y[csc & 3], r, g, b, &yuv[0], &yuv[1], &yuv[2]);
+}
+
+/* ------------------------------------------------------------------------ */
 /* Kernel bodies                                                             */
 /* ------------------------------------------------------------------------ */
 enum { SRC_NV12, SRC_Y420P, SRC_BGRA, SRC_RGBA };
@@ -360,6 +386,51 @@ INL void px_to_bgra(int SRC, const job_t *j, int x, int y) {
     d[0] = st8_code(r0); d[1] = st8_code(r1); d[2] = st8_code(r2); d[3] = 255;
 }
 
+/* Integer RGB -> YUV family (spec owned by this repo): img_{bgra,rgba}_{nv12,y420p}_int, the mirror
+ * image of px_to_bgra for the encoder side (BGRA canvas -> 4:2:0 picture for x264, composer.swift:52-56,
+ * enc.video.ffmpeg.swift:211-224).  Geometry, tap addresses and weights are the composite family's (geometry(), lin_setup);
+ * chroma belongs to the quad's even/even pixel and is computed from THAT pixel's sample (`handleChroma`,
+ * kernels.cl.swift:76 — with the reference's non-centred out_uv a same-size layer samples at gid - 0.5, i.e. the chroma
+ * sample already is a 2 x 2 box average of the source).  Arithmetic on the code scale with fused multiply-adds, like 4.1:
+ *   fill:   F = rgb2yuv_int(RTE_sat(fill.rgb * 255));  r_k = clamp(fma(F_k, af, cur_k * (1 - af)), 0, 255),  af = opacity * fill.a
+ *   sample: s_c = fma(w11,T11, fma(w01,T01, fma(w10,T10, w00*T00)));  (R, G, B) = RTE_sat(s);  P = rgb2yuv_int(R, G, B)
+ *   blend:  a = s_A * (opacity * RN(1/255));  r_k = fma(P_k, a, r_k * (1 - a));  store RTE_sat
+ * (both inside the border quad; the picture only where tx and uv are inside [0,1]^2).  k = Y at every pixel, U and V at owners. */
+INL void px_rgb_to_yuv_int(int SRC, int DST, const job_t *j, int x, int y) {
+    geom_t g = geometry(j, x, y);
+    int hc = (x % 2) == 0 && (y % 2) == 0;
+    if (!g.in_border) return;
+    const r2y_t *k = &R2Y[j->csc & 3];
+    uint8_t *dy = (uint8_t *)texel(&j->t[0], x, y);
+    uint8_t *du = 0, *dv = 0;
+    if (hc && inside(&j->t[1], x / 2, y / 2)) {
+        if (DST == DST_NV12) { du = (uint8_t *)texel(&j->t[1], x / 2, y / 2); dv = du + 1; }
+        else { du = (uint8_t *)texel(&j->t[1], x / 2, y / 2); dv = (uint8_t *)texel(&j->t[2], x / 2, y / 2); }
+    }
+    float af = j->u->opacity * j->u->fillColor[3];
+    float iaf = 1.f - af;
+    uint8_t fy, fu, fv;
+    rgb2yuv_int(k, st8_code(j->u->fillColor[0] * 255.0f), st8_code(j->u->fillColor[1] * 255.0f), st8_code(j->u->fillColor[2] * 255.0f), &fy, &fu, &fv);
+    float r0 = clampf(fmaf((float)fy, af, (float)dy[0] * iaf), 0.f, 255.f);
+    float r1 = du ? clampf(fmaf((float)fu, af, (float)du[0] * iaf), 0.f, 255.f) : 0.f;
+    float r2 = dv ? clampf(fmaf((float)fv, af, (float)dv[0] * iaf), 0.f, 255.f) : 0.f;
+    if (g.in_tx && g.in_uv) {
+        lin2 l = lin_setup(&j->in[0], g.uv.x, g.uv.y);
+        float q0 = cs_fetch(&j->in[0], &l, 0), q1 = cs_fetch(&j->in[0], &l, 1);
+        float q2 = cs_fetch(&j->in[0], &l, 2), q3 = cs_fetch(&j->in[0], &l, 3);
+        uint8_t R = st8_code(SRC == SRC_BGRA ? q2 : q0), G = st8_code(q1), B = st8_code(SRC == SRC_BGRA ? q0 : q2);
+        uint8_t py, pu, pv;
+        rgb2yuv_int(k, R, G, B, &py, &pu, &pv);
+        float a = q3 * (j->u->opacity * ORC_INV255), ia = 1.f - a;
+        r0 = fmaf((float)py, a, r0 * ia);
+        r1 = fmaf((float)pu, a, r1 * ia);
+        r2 = fmaf((float)pv, a, r2 * ia);
+    }
+    dy[0] = st8_code(r0);
+    if (du) du[0] = st8_code(r1);
+    if (dv) dv[0] = st8_code(r2);
+}
+
 /* ENVELOPE EVALUATOR (tests only; ids 64..67, never dispatched by the product): the BGRA-target family evaluated
  * the way the reference's own kernels evaluate theirs — on the UNIT scale, texels through ld8 (c / 255), the Khronos
  * filter with sequential roundings (lin_fetch), unfused blends in the source order of px_yuv_to_yuv / px_rgb_to_yuv
@@ -434,6 +505,10 @@ static void run_rows(const job_t *j, int y0, int y1) {
     case ORC_IMG_BGRA_Y420P:  ROWS(px_rgb_to_yuv(SRC_BGRA, DST_Y420P, j, x, y)) break;
     case ORC_IMG_RGBA_Y420P:  ROWS(px_rgb_to_yuv(SRC_RGBA, DST_Y420P, j, x, y)) break;
     case ORC_IMG_BGRA_BGRA:   ROWS(px_bgra_bgra_metal(j, x, y)) break;
+    case ORC_IMG_BGRA_NV12_INT:  ROWS(px_rgb_to_yuv_int(SRC_BGRA, DST_NV12, j, x, y)) break;
+    case ORC_IMG_RGBA_NV12_INT:  ROWS(px_rgb_to_yuv_int(SRC_RGBA, DST_NV12, j, x, y)) break;
+    case ORC_IMG_BGRA_Y420P_INT: ROWS(px_rgb_to_yuv_int(SRC_BGRA, DST_Y420P, j, x, y)) break;
+    case ORC_IMG_RGBA_Y420P_INT: ROWS(px_rgb_to_yuv_int(SRC_RGBA, DST_Y420P, j, x, y)) break;
     case ORC_IMG_NV12_BGRA:   ROWS(px_to_bgra(SRC_NV12, j, x, y)) break;
     case ORC_IMG_Y420P_BGRA:  ROWS(px_to_bgra(SRC_Y420P, j, x, y)) break;
     case ORC_IMG_BGRA_BGRA_TX: ROWS(px_to_bgra(SRC_BGRA, j, x, y)) break;
@@ -494,8 +569,8 @@ int orc_run_kernel(int kernel, const orc_plane *target, int n_target,
     case ORC_IMG_NV12_NV12: sfmt = SRC_NV12; dfmt = SRC_NV12; break;
     case ORC_IMG_Y420P_NV12: sfmt = SRC_Y420P; dfmt = SRC_NV12; break;
     case ORC_IMG_Y420P_Y420P: sfmt = SRC_Y420P; dfmt = SRC_Y420P; break;
-    case ORC_IMG_BGRA_NV12: case ORC_IMG_RGBA_NV12: sfmt = SRC_BGRA; dfmt = SRC_NV12; break;
-    case ORC_IMG_BGRA_Y420P: case ORC_IMG_RGBA_Y420P: sfmt = SRC_BGRA; dfmt = SRC_Y420P; break;
+    case ORC_IMG_BGRA_NV12: case ORC_IMG_RGBA_NV12: case ORC_IMG_BGRA_NV12_INT: case ORC_IMG_RGBA_NV12_INT: sfmt = SRC_BGRA; dfmt = SRC_NV12; break;
+    case ORC_IMG_BGRA_Y420P: case ORC_IMG_RGBA_Y420P: case ORC_IMG_BGRA_Y420P_INT: case ORC_IMG_RGBA_Y420P_INT: sfmt = SRC_BGRA; dfmt = SRC_Y420P; break;
     case ORC_IMG_BGRA_BGRA: case ORC_IMG_BGRA_BGRA_TX: case ORC_IMG_RGBA_BGRA_TX:
         sfmt = SRC_BGRA; dfmt = SRC_BGRA; break;
     case ORC_IMG_NV12_BGRA: case ORC_ENV_NV12_BGRA_UNIT: sfmt = SRC_NV12; dfmt = SRC_BGRA; break;

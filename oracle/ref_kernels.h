@@ -63,6 +63,11 @@ enum {
     ORC_IMG_Y420P_BGRA = 33,
     ORC_IMG_BGRA_BGRA_TX = 34,
     ORC_IMG_RGBA_BGRA_TX = 35,
+    /* integer BT.601/709 RGB -> YUV onto 4:2:0 canvases (the encoder side) */
+    ORC_IMG_BGRA_NV12_INT = 36,
+    ORC_IMG_RGBA_NV12_INT = 37,
+    ORC_IMG_BGRA_Y420P_INT = 38,
+    ORC_IMG_RGBA_Y420P_INT = 39,
     /* envelope evaluators of 32..35 on the unit scale, in the reference family's style
      * (tests only; see px_to_bgra_unit) */
     ORC_ENV_NV12_BGRA_UNIT = 64,
@@ -121,6 +126,7 @@ int orc_lanczos_bgra(const orc_plane *dst, const orc_plane *src, int threads);
 uint8_t orc_store_unorm8(float f);
 float orc_load_unorm8(uint8_t c);
 void orc_yuv2rgb_int(int csc, uint8_t y, uint8_t u, uint8_t v, uint8_t rgb[3]);
+void orc_rgb2yuv_int(int csc, uint8_t r, uint8_t g, uint8_t b, uint8_t yuv[3]);
 
 #ifdef __cplusplus
 }

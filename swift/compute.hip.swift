@@ -95,6 +95,12 @@ private func check(_ status: Int32, kernel: ComputeKernel? = nil) throws {
     }
 }
 
+/// chv_status -> ComputeError for the other HIP-only source files (mixgroup.hip.swift); nil for success.
+func computeError(fromStatus status: Int32) -> Error {
+    do { try check(status) } catch let error { return error }
+    return ComputeError.unknownError
+}
+
 /// ComputeKernel -> chv_kernel.  Every case's name is its own description ("img_nv12_bgra", ...), and the library's name
 /// table (chv_kernel_from_string) is defaultComputeKernelFromString's table plus the cases the compute.swift hunk adds, so
 /// one lookup serves the reference's thirteen cases and the four new ones.  A `.custom(name:)` whose name the table knows
@@ -108,6 +114,8 @@ private func kernelId(_ kernel: ComputeKernel) throws -> Int32 {
     try check(chv_kernel_from_string(String(describing: kernel), &id), kernel: kernel)
     return id
 }
+
+func kernelIdentifier(_ kernel: ComputeKernel) throws -> Int32 { try kernelId(kernel) }      // (for mixgroup.hip.swift)
 
 // MARK: - Devices and contexts (compute.cl.swift:107-151)
 
@@ -200,6 +208,8 @@ private func describe(_ image: ImageBuffer, maxPlanes: Int) -> chv_image? {
     }
     return desc
 }
+
+func describeImage(_ image: ImageBuffer, maxPlanes: Int) -> chv_image? { describe(image, maxPlanes: maxPlanes) }      // (for mixgroup.hip.swift)
 
 private func pixelFormatCode(_ fmt: PixelFormat) -> Int {
     switch fmt {

@@ -80,7 +80,10 @@ public class PictureFilter: Tx<PictureSample, PictureSample> {
     private func findKernel(_ image: PictureSample?) throws -> ComputeKernel {
         let inp = image <??> { String(describing: $0.pixelFormat()).lowercased() } <|> "clear"
         let outp = String(describing: outputFormat).lowercased()
-        let suffix = (image != nil && outp == "bgra" && (inp == "bgra" || inp == "rgba")) ? "_tx" : ""
+        let rgbIn = image != nil && (inp == "bgra" || inp == "rgba")
+        // BGRA targets: the transform-aware kernels; 4:2:0 targets from RGB pictures: the integer BT.601/709 matrix
+        // (img_*_int, what an encoder expects) instead of the reference's float full-range rows (kernels.cl.swift:96-99)
+        let suffix = (rgbIn && outp == "bgra") ? "_tx" : (rgbIn && (outp == "nv12" || outp == "y420p")) ? "_int" : ""
         return try defaultComputeKernelFromString("img_\(inp)_\(outp)\(suffix)")
     }
 

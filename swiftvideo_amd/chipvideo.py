@@ -25,6 +25,7 @@ K_IMG_Y420P_Y420P, K_IMG_Y420P_NV12, K_IMG_CLEAR_NV12, K_IMG_CLEAR_YUVS = 4, 5, 
 K_IMG_CLEAR_BGRA, K_IMG_CLEAR_Y420P, K_IMG_CLEAR_RGBA, K_IMG_RGBA_Y420P = 8, 9, 10, 11
 K_IMG_BGRA_Y420P, K_SND_S16I_S16I, K_ME_FULLSEARCH = 12, 13, 14
 K_IMG_NV12_BGRA, K_IMG_Y420P_BGRA, K_IMG_BGRA_BGRA_TX, K_IMG_RGBA_BGRA_TX = 32, 33, 34, 35
+K_IMG_BGRA_NV12_INT, K_IMG_RGBA_NV12_INT, K_IMG_BGRA_Y420P_INT, K_IMG_RGBA_Y420P_INT = 36, 37, 38, 39
 
 FMT_NV12, FMT_NV21, FMT_YUVS, FMT_ZVUY, FMT_Y420P, FMT_Y422P, FMT_Y444P, FMT_RGBA, FMT_BGRA = range(9)
 FMT_INVALID = 11

@@ -55,6 +55,11 @@ class ComputeKernel(enum.IntEnum):
     img_y420p_bgra = cv.K_IMG_Y420P_BGRA
     img_bgra_bgra_tx = cv.K_IMG_BGRA_BGRA_TX
     img_rgba_bgra_tx = cv.K_IMG_RGBA_BGRA_TX
+    # integer BT.601/709 RGB -> YUV onto 4:2:0 canvases (the encoder side)
+    img_bgra_nv12_int = cv.K_IMG_BGRA_NV12_INT
+    img_rgba_nv12_int = cv.K_IMG_RGBA_NV12_INT
+    img_bgra_y420p_int = cv.K_IMG_BGRA_Y420P_INT
+    img_rgba_y420p_int = cv.K_IMG_RGBA_Y420P_INT
 
     def __str__(self):  # String(describing:)
         return self.name
@@ -674,7 +679,11 @@ class PictureFilter:
     numberBackingImages = 10
 
     def __init__(self, outputSize, outputFormat=PixelFormat.BGRA, computeContext=None, scaler="bilinear",
-                 colorspace=cv.CSC_BT601_LIMITED):
+                 colorspace=cv.CSC_BT601_LIMITED, integerMatrix=True):
+        """integerMatrix: an RGB picture converted to a 4:2:0 format goes through the integer BT.601/709 matrix of `colorspace`
+        (img_*_int, DESIGN.md 4.5: what an encoder expects); False selects the reference's own float kernels (img_bgra_nv12 ...,
+        full range, kernels.cl.swift:96-99)."""
+        self.integerMatrix = integerMatrix
         if scaler not in ("bilinear", "lanczos"):
             raise ComputeError(0, f"unknown scaler {scaler!r}")
         try:
@@ -692,6 +701,8 @@ class PictureFilter:
         name = f"img_{inp}_{outp}"
         if outp == "bgra" and inp in ("bgra", "rgba"):
             name += "_tx"
+        if outp in ("nv12", "y420p") and inp in ("bgra", "rgba") and self.integerMatrix:
+            name += "_int"
         return defaultComputeKernelFromString(name)
 
     def _backing(self, like):

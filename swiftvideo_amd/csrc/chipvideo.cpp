@@ -168,6 +168,8 @@ static const KernelName kNames[] = {
     // an RGBA layer on a BGRA canvas: no reference backend has a kernel of that name; it resolves to the transform-aware
     // one (as "img_clear_rgba" resolves to img_clear_bgra, compute.swift:101)
     { "img_rgba_bgra", CHV_K_IMG_RGBA_BGRA_TX },
+    { "img_bgra_nv12_int", CHV_K_IMG_BGRA_NV12_INT }, { "img_rgba_nv12_int", CHV_K_IMG_RGBA_NV12_INT },
+    { "img_bgra_y420p_int", CHV_K_IMG_BGRA_Y420P_INT }, { "img_rgba_y420p_int", CHV_K_IMG_RGBA_Y420P_INT },
 };
 
 extern "C" int chv_kernel_from_string(const char *name, int *kernel) {
@@ -198,6 +200,10 @@ extern "C" const char *chv_kernel_name(int kernel) {
     case CHV_K_IMG_Y420P_BGRA: return "img_y420p_bgra";
     case CHV_K_IMG_BGRA_BGRA_TX: return "img_bgra_bgra_tx";
     case CHV_K_IMG_RGBA_BGRA_TX: return "img_rgba_bgra_tx";
+    case CHV_K_IMG_BGRA_NV12_INT: return "img_bgra_nv12_int";
+    case CHV_K_IMG_RGBA_NV12_INT: return "img_rgba_nv12_int";
+    case CHV_K_IMG_BGRA_Y420P_INT: return "img_bgra_y420p_int";
+    case CHV_K_IMG_RGBA_Y420P_INT: return "img_rgba_y420p_int";
     default: return NULL;
     }
 }
@@ -644,6 +650,10 @@ static int kernel_shape(int kernel, KernelShape *s) {
     case CHV_K_IMG_Y420P_BGRA: yuv_420p(TF_BGRA, LK_BGRA_FROM_Y420P); break;
     case CHV_K_IMG_BGRA_BGRA_TX: rgb(TF_BGRA, LK_BGRA_FROM_RGB, 0); break;
     case CHV_K_IMG_RGBA_BGRA_TX: rgb(TF_BGRA, LK_BGRA_FROM_RGB, 1); break;
+    case CHV_K_IMG_BGRA_NV12_INT: rgb(TF_NV12, LK_YUV_FROM_RGB_INT, 1); break;
+    case CHV_K_IMG_RGBA_NV12_INT: rgb(TF_NV12, LK_YUV_FROM_RGB_INT, 0); break;
+    case CHV_K_IMG_BGRA_Y420P_INT: rgb(TF_Y420P, LK_YUV_FROM_RGB_INT, 1); break;
+    case CHV_K_IMG_RGBA_Y420P_INT: rgb(TF_Y420P, LK_YUV_FROM_RGB_INT, 0); break;
     case CHV_K_IMG_CLEAR_NV12: s->is_clear = true; s->target_format = TF_NV12; break;
     case CHV_K_IMG_CLEAR_Y420P: s->is_clear = true; s->target_format = TF_Y420P; break;
     case CHV_K_IMG_CLEAR_BGRA: case CHV_K_IMG_CLEAR_RGBA: s->is_clear = true; s->target_format = TF_BGRA; break;
@@ -896,6 +906,8 @@ extern "C" int chv_pass_end(chv_context *c, int wait) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
     c->in_pass = false;
     HIP_TRY(hipSetDevice(c->device));
+    // (hipStreamSynchronize already polls before it blocks: a hand-written hipStreamQuery loop in front of it measured the
+    // same 16-17 us for an empty tick, tools/tick_latency.py — that floor is the launch + completion path of the runtime)
     if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
     else (void)hipStreamQuery(c->stream);  // nudge submission, the clFlush analogue
     return CHV_OK;

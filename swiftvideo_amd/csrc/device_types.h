@@ -28,7 +28,8 @@ enum LayerKind : int32_t {
     LK_BGRA_FROM_NV12 = 3,  // img_nv12_bgra
     LK_BGRA_FROM_Y420P = 4, // img_y420p_bgra
     LK_BGRA_FROM_RGB = 5,   // img_{bgra,rgba}_bgra_tx; swizzle flag for rgba
-    LK_BGRA_METAL = 6       // img_bgra_bgra, kernels.metal:52-62
+    LK_BGRA_METAL = 6,      // img_bgra_bgra, kernels.metal:52-62
+    LK_YUV_FROM_RGB_INT = 7 // img_{bgra,rgba}_{nv12,y420p}_int: integer BT.601/709 RGB -> YUV, code-scale blend; swizzle flag for bgra
 };
 
 struct DLayer {

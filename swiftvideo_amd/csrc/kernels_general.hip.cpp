@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void tick_general_yuv(const DTick *__restrict_
             int i = k & 1, j = k >> 1;
             if ((i && !hx) || (j && !hy)) continue;
             bool owner = (k == 0);
-            if (Ly.kind == LK_YUV_FROM_RGB)
+            if (Ly.kind == LK_YUV_FROM_RGB || Ly.kind == LK_YUV_FROM_RGB_INT)
                 apply_yuv_from_rgb(Ly, x0 + i, y0 + j, sx, sy, owner, s.y[k], owner ? s.u : du, owner ? s.v : dv);
             else
                 apply_yuv_from_yuv(Ly, x0 + i, y0 + j, sx, sy, owner, s.y[k], owner ? s.u : du, owner ? s.v : dv);

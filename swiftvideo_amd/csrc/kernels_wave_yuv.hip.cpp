@@ -201,7 +201,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
 #ifndef CHV_WAVEY_MASKED
 #define CHV_WAVEY_MASKED 1
 #endif
-        const bool fast = !general_layer && cur.staged && (cur.all_inside || (CHV_WAVEY_MASKED && nofill));
+        // (the integer-matrix RGB kind, DESIGN.md 4.5, has no branch-free row loop here: per pixel below, taps from global memory)
+        const bool fast = !general_layer && cur.staged && (cur.all_inside || (CHV_WAVEY_MASKED && nofill)) && Ly.kind != LK_YUV_FROM_RGB_INT;
         const bool lane_pic = cur.cfl == AX_ALL;
         // a pixel takes a row's result if its column and the row are inside the picture (row flags: uniform, from the row table);
         // every row is computed (branch-free: a branch per row keeps the rows' LDS reads from overlapping), row offsets are
@@ -417,7 +418,7 @@ static bool finite16w(const float *m) {
 }
 // (pitch < 2^24: the staging address arithmetic uses 24-bit multiplies)
 static bool aligned16w(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0 && p.w * p.comps >= 16 && p.pitch < (1 << 24) && p.h < (1 << 24); }
-static bool host_src_rgb(int kind) { return kind == LK_BGRA_FROM_RGB || kind == LK_YUV_FROM_RGB; }
+static bool host_src_rgb(int kind) { return kind == LK_BGRA_FROM_RGB || kind == LK_YUV_FROM_RGB || kind == LK_YUV_FROM_RGB_INT; }
 static bool host_src_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind == LK_YUV_FROM_Y420P; }
 static bool host_src_nv12(int kind) { return kind == LK_BGRA_FROM_NV12 || kind == LK_YUV_FROM_NV12; }
 

@@ -281,6 +281,21 @@ __device__ __constant__ const Csc kCsc[4] = {
 };
 CHV_DEV uint32_t clip8(int32_t v) { return (uint32_t)min(max(v, 0), 255); }
 
+// Integer RGB -> YUV, 16.16 fixed point: the encoder-side counterpart of kCsc.  Luma rows sum to 56284
+// (= round(65536 * 219 / 255); 65536 full range), chroma rows to 0: white -> (235, 128, 128), grey has neutral chroma.
+struct R2Y { int32_t yoff, y[3], u[3], v[3]; };
+__device__ __constant__ const R2Y kR2Y[4] = {
+    { 16, { 16829, 33039, 6416 }, { -9714, -19070, 28784 }, { 28784, -24103, -4681 } },  // BT.601 limited
+    { 16, { 11966, 40254, 4064 }, { -6596, -22188, 28784 }, { 28784, -26145, -2639 } },  // BT.709 limited
+    { 0, { 19595, 38470, 7471 }, { -11058, -21710, 32768 }, { 32768, -27439, -5329 } },  // BT.601 full
+    { 0, { 13933, 46871, 4732 }, { -7509, -25259, 32768 }, { 32768, -29763, -3005 } },   // BT.709 full
+};
+CHV_DEV void rgb_to_yuv_int(const R2Y &k, int r, int g, int b, uint32_t &y, uint32_t &u, uint32_t &v) {
+    y = clip8((k.y[0] * r + k.y[1] * g + k.y[2] * b + (k.yoff << 16) + 32768) >> 16);
+    u = clip8((k.u[0] * r + k.u[1] * g + k.u[2] * b + (128 << 16) + 32768) >> 16);
+    v = clip8((k.v[0] * r + k.v[1] * g + k.v[2] * b + (128 << 16) + 32768) >> 16);
+}
+
 // Pack three 16.16 fixed-point channels into a memory-order BGRA word:
 // clip8(x >> 16) == clamp(x, 0, 0xFFFFFF) >> 16, so saturate first and then move the
 // integer byte of each channel into place.  (Written this way on purpose: for the

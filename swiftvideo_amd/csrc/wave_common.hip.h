@@ -222,7 +222,7 @@ CHV_DEV float ub3(uint32_t w) { return (float)(w >> 24); }
 
 
 // source classes of a layer, whatever the canvas: one 4-byte plane; luma + interleaved chroma; three planes
-CHV_DEV bool src_is_rgb(int kind) { return kind == LK_BGRA_FROM_RGB || kind == LK_YUV_FROM_RGB; }
+CHV_DEV bool src_is_rgb(int kind) { return kind == LK_BGRA_FROM_RGB || kind == LK_YUV_FROM_RGB || kind == LK_YUV_FROM_RGB_INT; }
 CHV_DEV bool src_is_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind == LK_YUV_FROM_Y420P; }
 
 // One wave's strip of one tick: WTW columns (lane = column) x WTH rows of the canvas.

@@ -46,9 +46,45 @@ CHV_DEV void apply_yuv_from_yuv(const DLayer &L, int x, int y, float sx, float s
     }
 }
 
+// RGB source, integer matrix (img_{bgra,rgba}_{nv12,y420p}_int; spec owned by this repository; statement of
+// record: oracle/ref_kernels.c::px_rgb_to_yuv_int): code-scale sample and blend like the BGRA-target family, 16.16 matrix on
+// the quantised sample, fill painted inside the whole border quad.  Chroma only at owner pixels (cu / cv untouched otherwise).
+CHV_DEV void apply_yuv_from_rgb_int(const DLayer &L, int x, int y, float sx, float sy, bool owner,
+                                    uint32_t &cy, uint32_t &cu, uint32_t &cv) {
+    const float *U = L.u;
+    Geo g = geometry_for(L, x, y, sx, sy);
+    if (!g.in_border) return;
+    const R2Y &k = kR2Y[L.csc & 3];
+    const float af = U[U_OPACITY] * U[U_FILL + 3], iaf = 1.f - af;
+    uint32_t fy, fu, fv;
+    rgb_to_yuv_int(k, (int)to_code_raw(U[U_FILL + 0] * 255.0f), (int)to_code_raw(U[U_FILL + 1] * 255.0f), (int)to_code_raw(U[U_FILL + 2] * 255.0f), fy, fu, fv);
+    float r0 = clampf(__builtin_fmaf((float)fy, af, (float)cy * iaf), 0.f, 255.f);
+    float r1 = clampf(__builtin_fmaf((float)fu, af, (float)cu * iaf), 0.f, 255.f);
+    float r2 = clampf(__builtin_fmaf((float)fv, af, (float)cv * iaf), 0.f, 255.f);
+    if (g.in_tx && g.in_uv) {
+        const DPlane &P = L.src.pl[0];
+        Lin2 l = lin_setup(P, g.u, g.v);
+        const uint32_t t00 = gld<uint32_t>(P.ptr + l.o00), t10 = gld<uint32_t>(P.ptr + l.o10);
+        const uint32_t t01 = gld<uint32_t>(P.ptr + l.o01), t11 = gld<uint32_t>(P.ptr + l.o11);
+        const float q0 = cs_mix(l, (float)(t00 & 255), (float)(t10 & 255), (float)(t01 & 255), (float)(t11 & 255));
+        const float q1 = cs_mix(l, (float)((t00 >> 8) & 255), (float)((t10 >> 8) & 255), (float)((t01 >> 8) & 255), (float)((t11 >> 8) & 255));
+        const float q2 = cs_mix(l, (float)((t00 >> 16) & 255), (float)((t10 >> 16) & 255), (float)((t01 >> 16) & 255), (float)((t11 >> 16) & 255));
+        const float q3 = cs_mix(l, (float)(t00 >> 24), (float)(t10 >> 24), (float)(t01 >> 24), (float)(t11 >> 24));
+        uint32_t py, pu, pv;
+        rgb_to_yuv_int(k, (int)to_code_raw(L.swizzle ? q2 : q0), (int)to_code_raw(q1), (int)to_code_raw(L.swizzle ? q0 : q2), py, pu, pv);
+        const float a = q3 * (U[U_OPACITY] * kInv255), ia = 1.f - a;
+        r0 = __builtin_fmaf((float)py, a, r0 * ia);
+        r1 = __builtin_fmaf((float)pu, a, r1 * ia);
+        r2 = __builtin_fmaf((float)pv, a, r2 * ia);
+    }
+    cy = to_code_raw(r0);
+    if (owner) { cu = to_code_raw(r1); cv = to_code_raw(r2); }
+}
+
 // RGB source: kernels.cl.swift:495-530 (img_bgra_nv12) and its three siblings
 CHV_DEV void apply_yuv_from_rgb(const DLayer &L, int x, int y, float sx, float sy, bool owner,
                                 uint32_t &cy, uint32_t &cu, uint32_t &cv) {
+    if (L.kind == LK_YUV_FROM_RGB_INT) { apply_yuv_from_rgb_int(L, x, y, sx, sy, owner, cy, cu, cv); return; }
     const float *U = L.u;
     Geo g = geometry_for(L, x, y, sx, sy);
     if (!g.in_border || !g.in_tx) return;

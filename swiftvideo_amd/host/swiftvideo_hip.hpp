@@ -55,7 +55,10 @@ enum class ComputeKernel : int {
     img_clear_y420p = CHV_K_IMG_CLEAR_Y420P, img_clear_rgba = CHV_K_IMG_CLEAR_RGBA, img_rgba_y420p = CHV_K_IMG_RGBA_Y420P,
     img_bgra_y420p = CHV_K_IMG_BGRA_Y420P, snd_s16i_s16i = CHV_K_SND_S16I_S16I, me_fullsearch = CHV_K_ME_FULLSEARCH,
     img_nv12_bgra = CHV_K_IMG_NV12_BGRA, img_y420p_bgra = CHV_K_IMG_Y420P_BGRA,
-    img_bgra_bgra_tx = CHV_K_IMG_BGRA_BGRA_TX, img_rgba_bgra_tx = CHV_K_IMG_RGBA_BGRA_TX
+    img_bgra_bgra_tx = CHV_K_IMG_BGRA_BGRA_TX, img_rgba_bgra_tx = CHV_K_IMG_RGBA_BGRA_TX,
+    // integer BT.601/709 RGB -> YUV onto 4:2:0 canvases
+    img_bgra_nv12_int = CHV_K_IMG_BGRA_NV12_INT, img_rgba_nv12_int = CHV_K_IMG_RGBA_NV12_INT,
+    img_bgra_y420p_int = CHV_K_IMG_BGRA_Y420P_INT, img_rgba_y420p_int = CHV_K_IMG_RGBA_Y420P_INT
 };
 inline std::string describing(ComputeKernel k) {           // String(describing:)
     const char *n = chv_kernel_name((int)k);
@@ -665,8 +668,12 @@ public:
         std::string inp = lowercasedName(image.pixelFormat()), outp = lowercasedName(format_);
         std::string name = "img_" + inp + "_" + outp;
         if (outp == "bgra" && (inp == "bgra" || inp == "rgba")) name += "_tx";
+        // an RGB picture onto a 4:2:0 format: the integer BT.601/709 matrix of `colorspace` unless the
+        // reference's float full-range kernels are asked for
+        if (integerMatrix && (outp == "nv12" || outp == "y420p") && (inp == "bgra" || inp == "rgba")) name += "_int";
         return defaultComputeKernelFromString(name);
     }
+    bool integerMatrix = true;
 
     EventBox<PictureSample> operator()(const PictureSample &sample) {
         EventBox<PictureSample> r;

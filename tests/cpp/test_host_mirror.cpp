@@ -253,9 +253,19 @@ static void gpuTests() {
         sv::ImageUniforms u2 = sv::imageUniformsFor(f2, e2);
         auto tp2 = oraclePlanes(e2); auto ip2 = oraclePlanes(rgb);
         orc_run_kernel(ORC_IMG_CLEAR_NV12, tp2.data(), 2, nullptr, 0, nullptr, 0, 1);
-        orc_run_kernel(ORC_IMG_BGRA_NV12, tp2.data(), 2, ip2.data(), 1, (const orc_uniforms *)&u2, 0, 1);
+        // an RGB picture to a 4:2:0 format: the integer BT.601 matrix by default (img_bgra_nv12_int) ...
+        orc_run_kernel(ORC_IMG_BGRA_NV12_INT, tp2.data(), 2, ip2.data(), 1, (const orc_uniforms *)&u2, 0, 1);
         EXPECT(o2.kind == o2.just);
         if (o2.kind == o2.just) EXPECT(samePlanes(sv::downloadComputePicture(ctx, o2.value, true), e2));
+        // ... the reference's float full-range kernel on request
+        toNv12.integerMatrix = false;
+        auto o2f = toNv12(sv::uploadComputePicture(ctx, rgb));
+        sv::PictureSample e2f = sv::createPictureSample({ 96, 54 }, sv::PixelFormat::nv12);
+        auto tp2f = oraclePlanes(e2f);
+        orc_run_kernel(ORC_IMG_CLEAR_NV12, tp2f.data(), 2, nullptr, 0, nullptr, 0, 1);
+        orc_run_kernel(ORC_IMG_BGRA_NV12, tp2f.data(), 2, ip2.data(), 1, (const orc_uniforms *)&u2, 0, 1);
+        EXPECT(o2f.kind == o2f.just);
+        if (o2f.kind == o2f.just) EXPECT(samePlanes(sv::downloadComputePicture(ctx, o2f.value, true), e2f));
         // no kernel for the pair -> error event, not an exception
         sv::PictureFilter bad({ 96, 54 }, sv::PixelFormat::RGBA, ctx);
         auto o3 = bad(src);

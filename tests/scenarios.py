@@ -6,6 +6,8 @@ import util
 LAYER_KERNELS_REF = ["img_nv12_nv12", "img_y420p_nv12", "img_y420p_y420p", "img_bgra_y420p",
                      "img_rgba_y420p", "img_bgra_nv12", "img_rgba_nv12"]
 LAYER_KERNELS_OWN = ["img_nv12_bgra", "img_y420p_bgra", "img_bgra_bgra_tx", "img_rgba_bgra_tx"]
+# integer BT.601/709 RGB -> YUV; not part of the committed golden set (tests/golden/gen_golden.py)
+LAYER_KERNELS_INT = ["img_bgra_nv12_int", "img_rgba_nv12_int", "img_bgra_y420p_int", "img_rgba_y420p_int"]
 CLEAR_KERNELS = ["img_clear_nv12", "img_clear_y420p", "img_clear_bgra"]
 
 # name -> (canvas w, h, input w, h, make_uniforms kwargs)

@@ -71,6 +71,7 @@ def test_sample_from_own_asset_passes_through_and_errors_become_events(ctx):
 
 
 @pytest.mark.parametrize("src_fmt,dst_fmt,kernel", [("nv12", "bgra", "img_nv12_bgra"), ("y420p", "bgra", "img_y420p_bgra"),
+                                                    ("bgra", "nv12", "img_bgra_nv12_int"), ("rgba", "y420p", "img_rgba_y420p_int"),
                                                     ("bgra", "nv12", "img_bgra_nv12"), ("rgba", "y420p", "img_rgba_y420p"),
                                                     ("y420p", "nv12", "img_y420p_nv12"), ("bgra", "bgra", "img_bgra_bgra_tx")])
 def test_picture_filter_converts_and_scales(ctx, src_fmt, dst_fmt, kernel):
@@ -79,7 +80,8 @@ def test_picture_filter_converts_and_scales(ctx, src_fmt, dst_fmt, kernel):
     (W, H), (w, h) = (192, 108), (128, 72)
     planes = util.alloc_image(src_fmt, W, H, seed=91)
     cpu = sv.pictureFromArrays(G.FMT[src_fmt], (W, H), planes, assetId="cam", time=3.0, pts=3.5, zIndex=7)
-    filt = sv.PictureFilter((w, h), G.FMT[dst_fmt], computeContext=ctx)
+    # RGB -> 4:2:0: the integer BT.601/709 matrix by default, the reference's float kernels with integerMatrix=False
+    filt = sv.PictureFilter((w, h), G.FMT[dst_fmt], computeContext=ctx, integerMatrix=kernel.endswith("_int"))
     tag, out = filt(cpu)                                   # CPU sample: uploaded by the filter
     assert tag == "just", out
     assert out.bufferType() == "gpu" and out.size() == (w, h) and out.pixelFormat() == G.FMT[dst_fmt]

@@ -12,7 +12,7 @@ from swiftvideo_amd import compute as sv
 
 pytestmark = pytest.mark.gpu
 
-ALL_LAYER = S.LAYER_KERNELS_REF + S.LAYER_KERNELS_OWN
+ALL_LAYER = S.LAYER_KERNELS_REF + S.LAYER_KERNELS_OWN + S.LAYER_KERNELS_INT
 
 
 @pytest.mark.parametrize("scenario", list(S.SCENARIOS))
@@ -31,6 +31,15 @@ def test_yuv_to_bgra_colorspaces(ctx, kernel, csc):
     u = S.uniforms_for("downscale")
     got, exp = G.run_both(ctx, kernel, 64, 36, 96, 54, u, seed=77 + csc, csc=csc, clear_first=True)
     G.assert_same(got, exp, f"{kernel}/csc{csc}")
+
+
+@pytest.mark.parametrize("csc", [0, 1, 2, 3])
+@pytest.mark.parametrize("kernel", S.LAYER_KERNELS_INT)
+def test_rgb_to_yuv_int_colorspaces(ctx, kernel, csc):
+    for scenario in ("downscale", "rect_fill"):
+        cw, ch, iw, ih, _ = S.SCENARIOS[scenario]
+        got, exp = G.run_both(ctx, kernel, cw, ch, iw, ih, S.uniforms_for(scenario), seed=91 + csc, csc=csc)
+        G.assert_same(got, exp, f"{kernel}/{scenario}/csc{csc}")
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "y420p", "bgra"])

@@ -81,6 +81,12 @@ CASES = {
                                                   ("img_nv12_nv12", 128, 32, dict(rect=(-20, -6, 200, 50), opacity=0.3)),
                                                   ("img_y420p_nv12", 128, 32, dict(rect=(-20, -6, 200, 50), opacity=0.5)),
                                                   ("img_y420p_nv12", 128, 32, dict(rect=(-20, -6, 200, 50)))]),
+    # the integer-matrix RGB kind inside the strip kernel: per-pixel path, in z order with staged layers
+    "int_overlays":     ("y420p", 320, 180, True, [("img_y420p_y420p", 480, 270, dict()),
+                                                   ("img_bgra_y420p_int", 96, 54, dict(rect=(30, 20, 96, 54), opacity=0.8)),
+                                                   ("img_rgba_y420p_int", 96, 54, dict(rect=(150, 60, 120, 80), opacity=0.6, border=(4, 4, 4, 4), fill=(0.2, 0.9, 0.1, 0.5))),
+                                                   ("img_bgra_y420p", 64, 36, dict(rect=(200, 10, 64, 36)))]),
+    "int_encoder":      ("nv12", 256, 64, True, [("img_bgra_nv12_int", 256, 64, dict())]),
     "down_2.5":         ("nv12", 130, 50, True, [("img_nv12_nv12", 326, 124, dict()), ("img_bgra_nv12", 326, 124, dict(opacity=0.5))]),
 }
 

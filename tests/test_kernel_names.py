@@ -37,6 +37,13 @@ def test_names_findKernel_can_synthesise_for_bgra_canvases(built):
         assert str(sv.defaultComputeKernelFromString(name)) == name
 
 
+def test_integer_rgb_to_yuv_names(built):
+    # the encoder-side kernels: named like the reference's float family with an `_int` suffix
+    for name in ["img_bgra_nv12_int", "img_rgba_nv12_int", "img_bgra_y420p_int", "img_rgba_y420p_int"]:
+        assert str(sv.defaultComputeKernelFromString(name)) == name
+        assert cv.kernel_name(int(sv.ComputeKernel[name])) == name
+
+
 def test_enum_values_follow_reference_declaration_order(built):
     # compute.swift:49-74
     order = ["img_nv12_nv12", "img_bgra_nv12", "img_rgba_nv12", "img_bgra_bgra", "img_y420p_y420p", "img_y420p_nv12",

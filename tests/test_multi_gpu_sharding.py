@@ -124,7 +124,13 @@ def test_default_run_measures_its_hbm_traffic():
     import shutil
     d = _run_bench(["--steps", "2", "--warmup", "1", "--min-seconds", "0.1", "--min-seconds-other", "0.05", "--no-cpu-baseline"])
     assert set(d["workloads"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p"}
-    assert all(v["verified_vs_oracle"] is True for k, v in d["workloads"].items() if k != "cfg2_upload")
+    legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence")
+    assert all(v["verified_vs_oracle"] is True for k, v in d["workloads"].items() if k not in legs)
+    # the path a Swift VideoMixer takes — one tick at a time with a host wait — fused and as the unchanged 5-launch sequence
+    pt, seq = d["workloads"]["pipeline_per_tick"], d["workloads"]["pipeline_reference_sequence"]
+    assert pt["fused_equals_sequence"] is True and pt["launches_per_tick"] == 1 and seq["launches_per_tick"] == 5
+    assert 5 < pt["us_per_tick"] < seq["us_per_tick"] < 2000
+    assert d["config"]["build_flags"].startswith("arch=gfx950;") and "abl=0" in d["config"]["build_flags"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
     if shutil.which("rocprofv3"):
