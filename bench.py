@@ -47,6 +47,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0      # same guide: what a float4 copy kernel reaches
+H2D_LINK_GBS = 57.0        # what pinned copies of >= 32 MiB reach on this link (tools/h2d_probe.py; PCIe Gen5 x16)
 METRIC = "Gpix/s + achieved HBM GB/s, 1080p NV12→BGRA+scale+4-layer composite, 1/2/4/8 GPU"
 
 NV12_1080 = 3110400
@@ -110,6 +111,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the end-to-end (H2D-inclusive) cfg2 measurement")
+    ap.add_argument("--upload-group", type=int, default=8, help="frames per H2D copy in the upload-inclusive leg")
+    ap.add_argument("--upload-streams", type=int, default=2, help="upload streams (contexts) in the upload-inclusive leg")
     ap.add_argument("--no-per-tick", action="store_true", help="skip the one-tick-at-a-time legs (pipeline_per_tick, pipeline_reference_sequence)")
     ap.add_argument("--per-tick", action="store_true", help="run the one-tick-at-a-time legs even with --also none")
     ap.add_argument("--alias", default="none", choices=("none", "src", "dst", "both"),
@@ -631,25 +634,56 @@ def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
     return rep, cpu
 
 
-def run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=64):
-    """PCIe-inclusive pipeline for cfg2: two frame sets; while set A is converted on the compute
-    context's stream, set B's NV12 planes are uploaded (hipMemcpy2DAsync from pinned memory) on a
-    sharing context's stream.  Ordering: per-buffer upload events (kernel waits for its inputs) and a
-    per-set 'batch done' event (the next upload into the set waits for the kernel that read it)."""
+def bind_to_device_node(cv, lib, ctx):
+    """Bind this thread to the CPUs of the NUMA node the device hangs off (chv_context_numa_node) so that the pinned upload ring
+    is first-touched there; returns (node, previous affinity) — node -1 / None when the platform does not say."""
+    node = C.c_int(-1)
+    cv.check(lib.chv_context_numa_node(ctx.handle, C.byref(node)))
+    prev = None
+    if node.value >= 0:
+        try:
+            cpus = set()
+            for part in Path(f"/sys/devices/system/node/node{node.value}/cpulist").read_text().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            prev = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, cpus & prev or prev)
+        except OSError:
+            prev = None
+    return node.value, prev
+
+
+def run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=64, group=8, streams=2):
+    """PCIe-inclusive pipeline for cfg2: two frame sets; while set A is converted on the compute context's stream, set B's
+    decoded frames go up from a pinned host ring on `streams` sharing contexts' streams (one copy engine each).  Frames live
+    `group` to a device slab (PictureSlab) and `group` to a run of the host ring, so one LINEAR hipMemcpyAsync moves `group`
+    frames (8 x 3.1 MB = 25 MB: the link gives 55-57 GB/s at that size, 48 for one 3.1 MB frame — tools/h2d_probe.py).
+    Ordering: per-slab upload events (the kernel waits for its inputs on its own stream) and a per-set 'batch done' event (the
+    next upload into the set waits for the kernel that read it); no host waits inside the loop."""
     import util
+    from oracle import oracle as O
     wl = WORKLOADS["cfg2"]
-    up = sv.createComputeContext(sharing=ctx)
-    sw, sh = wl["sw"], wl["sh"]
-    ysz, csz = sw * sh, sw * sh // 2
+    sw, sh, dw, dh = wl["sw"], wl["sh"], wl["dw"], wl["dh"]
+    fbytes = sw * sh * 3 // 2
     distinct = 4
+    ups = [sv.createComputeContext(sharing=ctx) for _ in range(streams)]
+    node, prev_aff = bind_to_device_node(cv, lib, ctx)
     pinned = C.c_void_p()
-    cv.check(lib.chv_host_alloc(up.handle, distinct * (ysz + csz), C.byref(pinned)))
-    host = np.ctypeslib.as_array((C.c_uint8 * (distinct * (ysz + csz))).from_address(pinned.value))
-    for i in range(distinct):
-        img = util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 32 + i)
-        host[i * (ysz + csz): i * (ysz + csz) + ysz] = img[0].reshape(-1)
-        host[i * (ysz + csz) + ysz: (i + 1) * (ysz + csz)] = img[1].reshape(-1)
-    sets = [build_workload(sv, ctx, wl, frames, seed_base=0x5EED0000 + 32) for _ in range(2)]
+    cv.check(lib.chv_host_alloc(ups[0].handle, frames * fbytes, C.byref(pinned)))
+    host = np.ctypeslib.as_array((C.c_uint8 * (frames * fbytes)).from_address(pinned.value))
+    imgs = [util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 32 + i) for i in range(distinct)]
+    for f in range(frames):                 # the host ring: frame f of a set = distinct frame f % 4, packed Y then UV (first touch here)
+        img = imgs[f % distinct]
+        host[f * fbytes: f * fbytes + sw * sh] = img[0].reshape(-1)
+        host[f * fbytes + sw * sh: (f + 1) * fbytes] = img[1].reshape(-1)
+    u = util.full_canvas_uniforms((dw, dh), (sw, sh))
+    k = sv.defaultComputeKernelFromString("img_nv12_bgra")
+    sets = []
+    for _ in range(2):
+        slabs = [sv.PictureSlab(ctx, (sw, sh), sv.PixelFormat.nv12, group) for _ in range(frames // group)]
+        canvases = [sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False) for _ in range(frames)]
+        ticks = [(canvases[f], True, [(k, slabs[f // group].pictures[f % group], u, cv.CSC_BT601_LIMITED)]) for f in range(frames)]
+        sets.append(dict(slabs=slabs, canvases=canvases, batch=sv.TickBatch(ctx, ticks)))
     done = []
     for _ in sets:
         e = C.c_void_p()
@@ -657,50 +691,60 @@ def run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=64):
         cv.check(lib.chv_event_record(ctx.handle, e))
         done.append(e)
 
-    def upload_set(k):
-        cv.check(lib.chv_event_wait(up.handle, done[k]))          # the kernel that last read this set is finished
-        keep = sets[k]["keep"]
-        for f in range(frames):
-            src = keep[2 * f].imageBuffer()
-            base = pinned.value + (f % distinct) * (ysz + csz)
-            # luma + interleaved chroma are adjacent with equal pitch on both sides: one pitched copy per frame
-            # (3.1 MB copies reach ~48 GB/s on this link, separate 2 MB + 1 MB copies ~37 GB/s; tools/h2d_probe.py)
-            assert src.gpuPitches[0] == src.gpuPitches[1] and src.gpuOffsets[1] == src.gpuPitches[0] * sh
-            cv.check(lib.chv_upload(up.handle, src.computeTextures[0]._h, src.gpuOffsets[0], src.gpuPitches[0], base, sw, sw, sh + sh // 2, 2))
+    def upload_set(s):
+        for upc in ups:
+            cv.check(lib.chv_event_wait(upc.handle, done[s]))       # the kernel that last read this set is finished
+        for g, slab in enumerate(sets[s]["slabs"]):
+            slab.upload(ups[g % streams], 0, group, pinned.value + g * group * fbytes, mode=2)
 
-    def convert_set(k):
-        cv.check(lib.chv_batch_run(ctx.handle, sets[k]["batch"]))  # waits for the set's upload events on its stream
-        cv.check(lib.chv_event_record(ctx.handle, done[k]))
+    def convert_set(s):
+        sets[s]["batch"].run(ctx)                                   # waits for the slabs' upload events on its stream
+        cv.check(lib.chv_event_record(ctx.handle, done[s]))
 
     state = [0]
 
     def launch():
-        k = state[0] & 1
+        s = state[0] & 1
         state[0] += 1
-        upload_set(k)
-        convert_set(k)
+        upload_set(s)
+        convert_set(s)
 
     for _ in range(max(args.warmup, 2)):
         launch()
     tm.sync()
+    # frame 5 of the set converted last == oracle on the host ring's bytes (uploaded, not pre-resident)
+    verified = None
+    if not args.no_verify and rank == 0:
+        f = 5
+        exp = util.alloc_image("bgra", dw, dh)
+        assert O.run_kernel("img_clear_bgra", exp, threads=os.cpu_count() or 1) == 0
+        assert O.run_kernel("img_nv12_bgra", exp, imgs[f % distinct], u, threads=os.cpu_count() or 1) == 0
+        got = sv.downloadComputePicture(ctx, sets[(state[0] - 1) & 1]["canvases"][f], retainGpuBuffer=True).imageBuffer().buffers[0]
+        verified = bool(np.array_equal(got[:dh, : dw * 4].reshape(dh, dw, 4), exp[0]))
     per_step = tm.calibrate(launch, args.steps, args.min_seconds_other, args.launches_per_step)
     elapsed, local, launch_ms = tm.run(launch, args.steps, per_step)
-    px = frames * wl["dw"] * wl["dh"]
+    px = frames * dw * dh
+    h2d = frames * fbytes * per_step * args.steps / local / 1e9
     rep = {
-        "workload": "cfg2_upload: cfg2 END-TO-END incl. H2D upload of every 1080p NV12 source frame from pinned host memory on a "
-                    "side stream (PCIe-bound; never the headline value)",
+        "workload": f"cfg2_upload: cfg2 END-TO-END incl. H2D upload of every 1080p NV12 source frame from a pinned host ring, {group} frames "
+                    f"({group * fbytes / 1e6:.1f} MB) per copy on {streams} side streams (PCIe-bound; never the headline value)",
         "value": whole_job_gpix(n_gpus, px * per_step, args.steps, elapsed), "unit": "Gpix/s",
         "ms_per_step": elapsed / args.steps * 1e3, "launches_per_step": per_step, "timed_seconds": elapsed,
-        "frames_per_launch_per_gpu": frames, "kernel": sets[0]["kernel"],
-        "h2d_GBps_per_gpu": frames * (ysz + csz) * per_step * args.steps / local / 1e9,
-        "per_stream_ticks_per_s": 1e3 / launch_ms,
+        "frames_per_launch_per_gpu": frames, "kernel": sets[0]["batch"].kernelName,
+        "h2d_GBps_per_gpu": h2d, "h2d_frac_of_link": h2d / H2D_LINK_GBS, "h2d_link_GBps": H2D_LINK_GBS,
+        "upload_copy_MB": group * fbytes / 1e6, "upload_streams": streams, "pinned_numa_node": node,
+        "per_stream_ticks_per_s": 1e3 / launch_ms, "verified_vs_oracle": verified,
     }
     for e in done:
         cv.check(lib.chv_event_destroy(e))
-    for s in sets:
-        free_workload(s)
-    cv.check(lib.chv_host_free(up.handle, pinned))
-    sv.destroyComputeContext(up)
+    for st in sets:
+        st["batch"].destroy()
+        st["slabs"].clear(); st["canvases"].clear()
+    cv.check(lib.chv_host_free(ups[0].handle, pinned))
+    for upc in ups:
+        sv.destroyComputeContext(upc)
+    if prev_aff is not None:
+        os.sched_setaffinity(0, prev_aff)
     return rep
 
 
@@ -840,13 +884,15 @@ def main(argv=None):
          (lambda name, headline: measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline))
 
     if args.with_upload and not args.stub_device:
-        rep = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus)
+        rep = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": rep["value"], "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": rep["workload"], "mode": "END-TO-END (not the headline mode)",
                                          "launches_per_step": rep["launches_per_step"], "h2d_GBps_per_gpu": rep["h2d_GBps_per_gpu"],
+                                         "h2d_frac_of_link": rep["h2d_frac_of_link"], "upload_copy_MB": rep["upload_copy_MB"], "upload_streams": rep["upload_streams"],
+                                         "pinned_numa_node": rep["pinned_numa_node"], "verified_vs_oracle": rep["verified_vs_oracle"],
                                          "frames_per_step_per_gpu": rep["frames_per_launch_per_gpu"] * rep["launches_per_step"],
                                          "kernel": rep["kernel"]}}), flush=True)
         tm.barrier()
@@ -863,7 +909,7 @@ def main(argv=None):
     for name in others:
         reports[name], _ = do(name, False)
     if others and not args.no_upload_leg and not args.stub_device:
-        reports["cfg2_upload"] = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus)
+        reports["cfg2_upload"] = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
     if (others or args.per_tick) and not args.stub_device and not args.no_per_tick and n_gpus == 1:
         reports.update(run_per_tick(args, sv, cv, lib, ctx))
 

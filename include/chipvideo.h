@@ -149,6 +149,8 @@ int chv_context_destroy(chv_context *ctx);
 int chv_context_device(chv_context *ctx, int *device);
 /* Raw hipStream_t of the context, for callers that interleave their own work. */
 int chv_context_stream(chv_context *ctx, void **hip_stream);
+/* NUMA node of the device's PCIe root complex (sysfs), -1 if unknown: where a host should pin its upload ring. */
+int chv_context_numa_node(chv_context *ctx, int *node);
 
 /* ---- device memory: ComputeBuffer, compute.cl.swift:46-58 ---------------- */
 typedef struct chv_buffer chv_buffer;

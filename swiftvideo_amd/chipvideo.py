@@ -97,6 +97,7 @@ _SIGNATURES = {
     "chv_context_destroy": (C.c_int, [C.c_void_p]),
     "chv_context_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "chv_context_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "chv_context_numa_node": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "chv_buffer_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "chv_buffer_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "chv_buffer_free": (C.c_int, [C.c_void_p]),

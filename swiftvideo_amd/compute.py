@@ -369,6 +369,38 @@ def uploadComputePicture(ctx, pict, maxPlanes=3, retainCpuBuffer=True, asynchron
     return pict.derive(img=img)
 
 
+class PictureSlab:
+    """`count` device pictures of one size and format in ONE allocation, frame after frame — the device side of an upload ring.
+    A decoder that writes its frames back to back into pinned host memory (same plane order, rows packed: the layout of
+    sample.pict.linux.swift:296-311) gets `frames` of them onto the device with ONE linear copy (`upload`): on this link a
+    3 MiB copy reaches 48 GB/s, copies of 8 MiB and more 55-57 (tools/h2d_probe.py).  `pictures[i]` are ordinary GPU
+    PictureSamples (views with plane offsets); packed rows need width x components to be a multiple of 128 bytes."""
+
+    def __init__(self, ctx, size, fmt, count):
+        proto = createPictureSample(size, fmt).imageBuffer()
+        pitches, offsets, total = [], [], 0
+        for p in proto.planes:
+            pitch = p.size[0] * _plane_comps(p)
+            if pitch % 128:
+                raise ComputeError(1, f"PictureSlab needs packed rows of a multiple of 128 bytes, got {pitch}")
+            pitches.append(pitch); offsets.append(total); total += pitch * p.size[1]
+        self.frameBytes, self.count = total, count
+        h = C.c_void_p()
+        cv.check(cv.load().chv_buffer_alloc(ctx.handle, total * count, C.byref(h)))
+        self.buffer = ComputeBuffer(h.value, total * count)
+        self.pictures = []
+        for i in range(count):
+            img = proto.withChanges(computeTextures=[self.buffer] * len(pitches), gpuPitches=pitches,
+                                    gpuOffsets=[i * total + o for o in offsets], buffers=[], bufferType="gpu")
+            self.pictures.append(PictureSample(img))
+
+    def upload(self, ctx, first, frames, host_address, mode=2):
+        """frames [first, first + frames) from `frames` packed host frames at host_address, one linear copy on ctx's stream
+        (mode 2: caller-pinned memory, chv_host_alloc; 1: staged; 0: synchronous)"""
+        n = self.frameBytes * frames
+        cv.check(cv.load().chv_upload(ctx.handle, self.buffer._h, first * self.frameBytes, n, host_address, n, n, 1, mode))
+
+
 def downloadComputePicture(ctx, pict, retainGpuBuffer=False):
     """compute.cl.swift:461-498"""
     if pict.bufferType() != "gpu":

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cstdarg>
 #include <cmath>
 #include <cstdio>
@@ -429,6 +430,22 @@ extern "C" int chv_context_destroy(chv_context *c) {
 extern "C" int chv_context_device(chv_context *c, int *device) {
     if (!ctx_ok(c) || !device) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
     *device = c->device;
+    return CHV_OK;
+}
+// NUMA node of the device's PCIe root (sysfs), -1 when the platform does not say: a host that pins its upload ring on that
+// node (first touch from a thread bound there) keeps H2D copies off the inter-socket link
+extern "C" int chv_context_numa_node(chv_context *c, int *node) {
+    if (!ctx_ok(c) || !node) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    *node = -1;
+    char bus[64] = { 0 };
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) != hipSuccess) { (void)hipGetLastError(); return CHV_OK; }
+    for (char *p = bus; *p; p++) *p = (char)tolower((unsigned char)*p);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    if (FILE *f = fopen(path.c_str(), "r")) {
+        int n = -1;
+        if (fscanf(f, "%d", &n) == 1) *node = n;
+        fclose(f);
+    }
     return CHV_OK;
 }
 extern "C" int chv_context_stream(chv_context *c, void **s) {

@@ -87,8 +87,21 @@ CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float 
 #ifndef CHV_WAVEY_CARRY
 #define CHV_WAVEY_CARRY 1
 #endif
+// (bit 2: narrow interior YUV rectangles through the shift-and-mask slot map, wstage_load_p2)
 #ifndef CHV_WAVEY_INTERIOR
-#define CHV_WAVEY_INTERIOR 1
+#define CHV_WAVEY_INTERIOR 5
+#endif
+#ifndef CHV_WAVEY_WIDE_STORES
+#define CHV_WAVEY_WIDE_STORES 1
+#endif
+#ifndef CHV_WAVEY_INTERIOR_OWN
+#define CHV_WAVEY_INTERIOR_OWN 4
+#endif
+// The instantiations that also carry the RGB-overlay rows run 5 waves per SIMD (96 VGPRs, nothing in scratch): at 6 waves they
+// kept five or six registers in scratch, which showed as 1.5x write traffic (profiles/r02_mixer_y420p_rocprofv3.txt) and was no
+// faster (mixer_nv12 0.741 -> 0.690 ms, mixer_y420p 0.787 -> 0.767 with 5; the own-format instantiation stays at 6: 0.410 vs 0.430)
+#ifndef CHV_WAVEY_MINW_MIXED
+#define CHV_WAVEY_MINW_MIXED 5
 #endif
 #ifndef CHV_WAVEY_MINW
 #define CHV_WAVEY_MINW 6
@@ -104,7 +117,7 @@ CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float 
 // KINDS: source classes in the launch (wave_common.hip.h): 1 / 2 = pictures of the canvas' own format only (NV12 / y420p), 5 / 6 = those
 // plus RGB overlays (the reference's usual mixer), 7 = any
 template <int TF, bool CLEAR, int YTH, int KINDS>
-__global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(const DTick *__restrict__ ticks,
+__global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY_MINW : CHV_WAVEY_MINW_MIXED)) void tick_yuv_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
@@ -116,12 +129,12 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
     __syncthreads();                      // the only block barrier, before any wave leaves
 #endif
     // (compact staging of interior rectangles: measured better for the mixed-class instantiations, worse for the own-format one)
-    using Strip = WaveStrip<YTH, (KINDS == 1 || KINDS == 2) ? 0 : CHV_WAVEY_INTERIOR, KINDS>;
+    using Strip = WaveStrip<YTH, (KINDS == 1 || KINDS == 2) ? CHV_WAVEY_INTERIOR_OWN : CHV_WAVEY_INTERIOR, KINDS>;
     Strip S;
     if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all + UNORM_TAB_BYTES, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;
     const DTick &T = *S.T;
     const DLayer *L = S.L;
-    const int nl = S.nl, x = S.x, y0 = S.y0;
+    const int nl = S.nl, x = S.x, x0 = S.x0, y0 = S.y0;
     const bool col_in = S.col_in;
     const uint8_t *smem = S.smem;
     const uint4 *rowtab = S.rowtab;
@@ -391,18 +404,65 @@ __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVEY_MINW) void tick_yuv_wave(cons
 #pragma unroll
         for (int k = 0; k < YLW; k++) asm volatile("" :: "v"(ly[k]));
         asm volatile("" :: "v"(nu), "v"(nv));
-    } else if (col_in) {
+    } else {
+        // Stores.  A vector memory instruction occupies the CU's address unit for 16 cycles whatever it moves (tools/ubench_vmem.cpp),
+        // and a strip written byte by byte is 16 + 8 of them — a quarter of this kernel's time (profiles/r03_notes.md).  Strips that
+        // lie entirely inside the canvas (uniform test) transpose their codes inside the wave first — luma: a 4 x 4 byte transpose in
+        // every quad of lanes turns "4 rows of one column" into "4 columns of one row"; chroma: the two lanes of a column pair
+        // regroup their 8 rows into rows 0-3 / 4-7, one ds_bpermute packs the columns, then the same transpose — and store dwords:
+        // YTH / 4 instructions for luma, one per chroma plane (one 8-byte store for NV12's interleaved plane).
+        const bool wide = CHV_WAVEY_WIDE_STORES && x0 + WTW <= T.W && y0 + YTH <= TH &&
+                          ((((uintptr_t)PY.ptr | (uintptr_t)PC.ptr | (uintptr_t)PV.ptr) & 3u) == 0) && (((PY.pitch | PC.pitch | PV.pitch) & 3) == 0);
+        const int lane = S.lane;
+        if (wide) {
+            const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+            auto quad_transpose = [&](uint32_t v) {
+                const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+                const uint32_t a = __builtin_amdgcn_perm(p1, v, sel1);
+                const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
+                return __builtin_amdgcn_perm(p2, a, sel2);
+            };
+            const uint32_t loff = (uint32_t)(lane & 3) * (uint32_t)PY.pitch + (uint32_t)(x0 + (lane & ~3));
 #pragma unroll
-        for (int j = 0; j < YTH; j++)
-            if (y0 + j < TH) gst_at<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch, (uint32_t)x, (uint8_t)((ly[j >> 2] >> (8 * (j & 3))) & 255u));
+            for (int k = 0; k < YLW; k++) gst_at<uint32_t>(PY.ptr + (size_t)(y0 + 4 * k) * PY.pitch, loff, quad_transpose(ly[k]));
+        } else if (col_in) {
 #pragma unroll
-        for (int m = 0; m < YCM; m++) {
-            if (y0 + 4 * m + 2 * par < TH) {
-                const uint32_t ub = (nu >> (8 * m)) & 255u, vb = (nv >> (8 * m)) & 255u;
-                if (TF == TF_NV12) gst_at<uint16_t>(PC.ptr + (size_t)(qy0 + 2 * m) * PC.pitch, coff_c, (uint16_t)(ub | (vb << 8)));
-                else {
-                    gst_at<uint8_t>(PC.ptr + (size_t)(qy0 + 2 * m) * PC.pitch, coff_c, (uint8_t)ub);
-                    gst_at<uint8_t>(PV.ptr + (size_t)(qy0 + 2 * m) * PV.pitch, coff_v, (uint8_t)vb);
+            for (int j = 0; j < YTH; j++)
+                if (y0 + j < TH) gst_at<uint8_t>(PY.ptr + (size_t)(y0 + j) * PY.pitch, (uint32_t)x, (uint8_t)((ly[j >> 2] >> (8 * (j & 3))) & 255u));
+        }
+        if (wide && YTH == 16) {
+            // lane 2k: rows 0, 2, 4, 6 of chroma column k; lane 2k + 1: rows 1, 3, 5, 7  ->  lane 2k: rows 0-3, lane 2k + 1: rows 4-7
+            const uint32_t selp = (lane & 1) ? 0x03070206u : 0x05010400u;
+            const int src = ((lane & ~7) + 2 * (lane & 3) + ((lane >> 2) & 1)) * 4;         // ds_bpermute: lane 8c + i <- column 4c + i (rows 0-3), lane 8c + 4 + i <- the same column (rows 4-7)
+            const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+            auto regroup = [&](uint32_t v) {
+                const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+                uint32_t a = __builtin_amdgcn_perm(p, v, selp);
+                a = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)a);
+                const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xf, 0xf, false);
+                const uint32_t b = __builtin_amdgcn_perm(p1, a, sel1);
+                const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xf, 0xf, false);
+                return __builtin_amdgcn_perm(p2, b, sel2);                                   // lane 8c + i: row i (+ 4 for lanes 8c + 4 ..), columns 4c .. 4c + 3
+            };
+            const uint32_t tu = regroup(nu), tv = regroup(nv);
+            const uint32_t crow = (uint32_t)((lane & 3) + 4 * ((lane >> 2) & 1)), ccol = (uint32_t)((x0 >> 1) + 4 * (lane >> 3));
+            if (TF == TF_NV12) {
+                const uint2 w = make_uint2(__builtin_amdgcn_perm(tv, tu, 0x05010400u), __builtin_amdgcn_perm(tv, tu, 0x07030602u));     // u0 v0 u1 v1 | u2 v2 u3 v3
+                gst_at<chv_u32x2>(PC.ptr + (size_t)qy0 * PC.pitch, crow * (uint32_t)PC.pitch + ccol * 2u, chv_u32x2{ w.x, w.y });
+            } else {
+                gst_at<uint32_t>(PC.ptr + (size_t)qy0 * PC.pitch, crow * (uint32_t)PC.pitch + ccol, tu);
+                gst_at<uint32_t>(PV.ptr + (size_t)qy0 * PV.pitch, crow * (uint32_t)PV.pitch + ccol, tv);
+            }
+        } else if (col_in) {
+#pragma unroll
+            for (int m = 0; m < YCM; m++) {
+                if (y0 + 4 * m + 2 * par < TH) {
+                    const uint32_t ub = (nu >> (8 * m)) & 255u, vb = (nv >> (8 * m)) & 255u;
+                    if (TF == TF_NV12) gst_at<uint16_t>(PC.ptr + (size_t)(qy0 + 2 * m) * PC.pitch, coff_c, (uint16_t)(ub | (vb << 8)));
+                    else {
+                        gst_at<uint8_t>(PC.ptr + (size_t)(qy0 + 2 * m) * PC.pitch, coff_c, (uint8_t)ub);
+                        gst_at<uint8_t>(PV.ptr + (size_t)(qy0 + 2 * m) * PV.pitch, coff_v, (uint8_t)vb);
+                    }
                 }
             }
         }

@@ -202,6 +202,9 @@ CHV_DEV void wstage_load_p2(uint4 (&regs)[NR], const DPlane &P, const StageGeom 
     const uint8_t *base = P.ptr + (size_t)g.r_lo * P.pitch + g.b0;          // (uniform: scalar unit)
 #pragma unroll
     for (int n = 0; n < N; n++) {
+        // (rounds past the rectangle's last row are skipped — uniform: a vector memory instruction costs the CU's address unit 16
+        // cycles whatever it moves, tools/ubench_vmem.cpp, and the 4:2:0 kernels are short of exactly that)
+        if (n > 0 && n * m.rstep >= g.rows) break;
         const int r = min(m.rsub + n * m.rstep, g.rows - 1);
         regs[OFF + n] = gld_at<uint4>(base, __umul24((uint32_t)r, (uint32_t)P.pitch) + (uint32_t)m.vcol);       // (24-bit multiply: v_mul_lo_u32 issues at a quarter of the rate; pitches < 2^24 on this path, host-checked)
     }
@@ -210,6 +213,7 @@ template <int OFF, int N, int NR>
 CHV_DEV void wstage_store_p2(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, const StageGeom &g, const P2Map &m) {
 #pragma unroll
     for (int n = 0; n < N; n++) {
+        if (n > 0 && n * m.rstep >= g.rows) break;
         const int r = min(m.rsub + n * m.rstep, g.rows - 1);
         *(uint4 *)(lds + (__umul24((uint32_t)r, (uint32_t)lds_pitch) + 16u + (uint32_t)m.vcol)) = regs[OFF + n];
     }
