@@ -87,7 +87,8 @@ CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float 
 #ifndef CHV_WAVEY_CARRY
 #define CHV_WAVEY_CARRY 1
 #endif
-// (bit 2: narrow interior YUV rectangles through the shift-and-mask slot map, wstage_load_p2)
+// (bit 2: narrow interior YUV rectangles through the shift-and-mask slot map, wstage_load_p2; bit 3 — skip its unneeded rounds —
+// measured and left off: mixer_y420p 0.649 -> 0.663 ms, mixer_nv12 0.637 -> 0.664 with it)
 #ifndef CHV_WAVEY_INTERIOR
 #define CHV_WAVEY_INTERIOR 5
 #endif

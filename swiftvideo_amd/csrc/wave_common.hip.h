@@ -197,23 +197,23 @@ CHV_DEV P2Map p2_map(const StageGeom &g, int lane) {
     m.vcol = min(lane & ((1 << sh) - 1), g.nvec - 1) * 16;
     return m;
 }
-template <int OFF, int N, int NR>
+template <int OFF, int N, int NR, bool SKIP>
 CHV_DEV void wstage_load_p2(uint4 (&regs)[NR], const DPlane &P, const StageGeom &g, const P2Map &m) {
     const uint8_t *base = P.ptr + (size_t)g.r_lo * P.pitch + g.b0;          // (uniform: scalar unit)
 #pragma unroll
     for (int n = 0; n < N; n++) {
-        // (rounds past the rectangle's last row are skipped — uniform: a vector memory instruction costs the CU's address unit 16
-        // cycles whatever it moves, tools/ubench_vmem.cpp, and the 4:2:0 kernels are short of exactly that)
-        if (n > 0 && n * m.rstep >= g.rows) break;
+        // (SKIP — INTERIOR bit 3, off everywhere: rounds past the rectangle's last row skipped by a uniform branch.  The branches cost
+        // more than the duplicate loads they save: pipeline 1.514 -> 1.546 ms, mixed 0.743 -> 0.783, mixer_nv12 0.637 -> 0.664)
+        if (SKIP && n > 0 && n * m.rstep >= g.rows) break;
         const int r = min(m.rsub + n * m.rstep, g.rows - 1);
         regs[OFF + n] = gld_at<uint4>(base, __umul24((uint32_t)r, (uint32_t)P.pitch) + (uint32_t)m.vcol);       // (24-bit multiply: v_mul_lo_u32 issues at a quarter of the rate; pitches < 2^24 on this path, host-checked)
     }
 }
-template <int OFF, int N, int NR>
+template <int OFF, int N, int NR, bool SKIP>
 CHV_DEV void wstage_store_p2(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, const StageGeom &g, const P2Map &m) {
 #pragma unroll
     for (int n = 0; n < N; n++) {
-        if (n > 0 && n * m.rstep >= g.rows) break;
+        if (SKIP && n > 0 && n * m.rstep >= g.rows) break;
         const int r = min(m.rsub + n * m.rstep, g.rows - 1);
         *(uint4 *)(lds + (__umul24((uint32_t)r, (uint32_t)lds_pitch) + 16u + (uint32_t)m.vcol)) = regs[OFF + n];
     }
@@ -427,13 +427,13 @@ struct WaveStrip {
         if (!(m0.ok && m1.ok)) return false;
         uint4 regs[WNR];
         const bool planar = is_planar(Ly.kind);
-        wstage_load_p2<0, WN_Y, WNR>(regs, Ly.src.pl[0], w.g0, m0);
-        wstage_load_p2<WN_Y, WN_C, WNR>(regs, Ly.src.pl[1], w.g1, m1);
-        if (planar) wstage_load_p2<WN_Y + WN_C, WN_C, WNR>(regs, Ly.src.pl[2], w.g1, m1);
+        wstage_load_p2<0, WN_Y, WNR, (INTERIOR & 8) != 0>(regs, Ly.src.pl[0], w.g0, m0);
+        wstage_load_p2<WN_Y, WN_C, WNR, (INTERIOR & 8) != 0>(regs, Ly.src.pl[1], w.g1, m1);
+        if (planar) wstage_load_p2<WN_Y + WN_C, WN_C, WNR, (INTERIOR & 8) != 0>(regs, Ly.src.pl[2], w.g1, m1);
         touch_regs(regs);                 // one wait for all of the layer's loads
-        wstage_store_p2<0, WN_Y, WNR>(regs, smem + base0, p0pitch, w.g0, m0);
-        wstage_store_p2<WN_Y, WN_C, WNR>(regs, smem + base1, p1pitch, w.g1, m1);
-        if (planar) wstage_store_p2<WN_Y + WN_C, WN_C, WNR>(regs, smem + base1 + voff, p1pitch, w.g1, m1);
+        wstage_store_p2<0, WN_Y, WNR, (INTERIOR & 8) != 0>(regs, smem + base0, p0pitch, w.g0, m0);
+        wstage_store_p2<WN_Y, WN_C, WNR, (INTERIOR & 8) != 0>(regs, smem + base1, p1pitch, w.g1, m1);
+        if (planar) wstage_store_p2<WN_Y + WN_C, WN_C, WNR, (INTERIOR & 8) != 0>(regs, smem + base1 + voff, p1pitch, w.g1, m1);
         return true;
     }
     // (rectangles that touch no picture edge — most strips — take the instantiation without clamping and patching code)
