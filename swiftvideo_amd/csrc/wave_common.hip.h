@@ -268,7 +268,7 @@ struct WaveStrip {
                       uint8_t *smem_all, int p0pitch_, int p0rows_, int p1pitch_, int p1rows_, int planar_any) {
         const int tid = threadIdx.x;
         lane = tid & 63;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);      // (one wave per block: no per-wave LDS offset arithmetic)
         p0pitch = p0pitch_; p0rows = p0rows_; p1pitch = p1pitch_; p1rows = p1rows_;
         voff = p1rows * p1pitch;
         const int wbytes = ROWTAB_BYTES + p0rows * p0pitch + voff * (planar_any ? 2 : 1);
