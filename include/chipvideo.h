@@ -60,7 +60,7 @@ int chv_version(void);
  * build whose pixels are wrong by design (profiles/r02_notes.md section 6); tests/test_abi.py asserts 0, bench.py prints it. */
 const char *chv_build_flags(void);
 /* Measurement / test hook: path-selection switches.  Names and values are those of the environment variables read once at
- * first use (CHV_FORCE_GENERAL=1, CHV_BGRA_PATH=wave|tiled, CHV_WAVE_ROWS=8|16, CHV_TILE_ROWS=16|32, CHV_SAME_GEOM=0);
+ * first use (CHV_FORCE_GENERAL=1, CHV_BGRA_PATH=wave|tiled, CHV_WAVE_ROWS=8|16, CHV_TILE_ROWS=16|32, CHV_SAME_GEOM=0, CHV_DESC=host);
  * NULL or "" restores the default.  Process-wide, atomic; not part of the Swift-facing contract. */
 int chv_debug_set_switch(const char *name, const char *value);
 

@@ -60,17 +60,18 @@ static int parse_switch(const char *name, const char *value, int *out) {
     if (n == "CHV_WAVE_ROWS") { *out = v == "8" ? 8 : v == "16" ? 16 : 0; return 2; }
     if (n == "CHV_TILE_ROWS") { *out = v == "16" ? 16 : v == "32" ? 32 : 0; return 3; }
     if (n == "CHV_SAME_GEOM") { *out = v == "0" ? 0 : 1; return 4; }
+    if (n == "CHV_DESC") { *out = v == "host" ? 1 : 0; return 5; }
     return -1;
 }
 static void store_switch(Switches &s, int which, int val) {
-    std::atomic<int> *slots[5] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom };
+    std::atomic<int> *slots[6] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom, &s.desc_host };
     slots[which]->store(val, std::memory_order_relaxed);
 }
 Switches &chv::switches() {
     static Switches s;
     static std::once_flag once;
     std::call_once(once, [] {
-        static const char *const names[5] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM" };
+        static const char *const names[6] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC" };
         for (const char *n : names) {
             const char *v = getenv(n);
             int val = 0, which = v ? parse_switch(n, v, &val) : -1;
@@ -283,6 +284,7 @@ struct chv_context {
     int next_staging = 0;
     // descriptor ring in pinned, device-mapped host memory
     uint8_t *desc_host = nullptr;
+    uint8_t *desc_dev = nullptr;       // the same ring in device memory: a transient launch's descriptors are copied there on the stream
     DescSlot desc[kDescSlots];
     int next_desc = 0;
     // `library` of the reference's ComputeContext (compute.cl.swift:66-73): name -> built kernel
@@ -384,6 +386,8 @@ static int context_new(int device, std::shared_ptr<DeviceShared> shared, chv_con
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     hipError_t e = hipHostMalloc((void **)&c->desc_host, kDescSlots * kDescSlotBytes, hipHostMallocMapped);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); return hip_fail(e, "hipHostMalloc(descriptors)"); }
+    e = hipMalloc((void **)&c->desc_dev, kDescSlots * kDescSlotBytes);
+    if (e != hipSuccess) { (void)hipHostFree(c->desc_host); (void)hipStreamDestroy(c->stream); return hip_fail(e, "hipMalloc(descriptors)"); }
     *out = c.release();
     return CHV_OK;
 }
@@ -420,6 +424,7 @@ extern "C" int chv_context_destroy(chv_context *c) {
     }
     for (auto &d : c->desc) if (d.done) (void)hipEventDestroy(d.done);
     if (c->desc_host) (void)hipHostFree(c->desc_host);
+    if (c->desc_dev) (void)hipFree(c->desc_dev);
     (void)hipStreamDestroy(c->stream);
     c->magic = 0;
     c->stream = nullptr;
@@ -897,8 +902,19 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     *ht = tick_in;
     ht->first_layer = 0;
     if (!layers.empty()) memcpy(hl, layers.data(), layers.size() * sizeof(DLayer));
+    // Where the kernel reads the descriptors from.  Every wave of the launch fetches its tick and, layer by layer, that layer's
+    // planes, uniforms and flags with scalar loads — a handful of dependent loads per layer.  From the pinned host ring each of them
+    // is a trip across PCIe (~1.5 us, uncached): a 4-layer 720p tick took 31 us of kernel time, 5 us per layer, whatever was done on
+    // the chip (tools/tick_latency.py).  So the slot is copied to its twin in device memory on the launch's own stream first
+    // (one small asynchronous copy), and the waves read L2 / scalar-cache resident descriptors.  CHV_DESC=host keeps the old way (A/B).
     DTick *dt = nullptr;
-    HIP_TRY(hipHostGetDevicePointer((void **)&dt, ht, 0));
+    const size_t used = sizeof(DTick) + layers.size() * sizeof(DLayer);
+    if (switches().desc_host.load(std::memory_order_relaxed)) {
+        HIP_TRY(hipHostGetDevicePointer((void **)&dt, ht, 0));
+    } else {
+        dt = (DTick *)(c->desc_dev + (size_t)slot * kDescSlotBytes);
+        HIP_TRY(hipMemcpyAsync(dt, ht, used, hipMemcpyHostToDevice, c->stream));
+    }
     DLayer *dl = (DLayer *)((uint8_t *)dt + sizeof(DTick));
     int path = select_fast_path(tf, ht, hl, 1);
     (void)hipGetLastError();   // the launchers report through hipGetLastError(): drop whatever an earlier, unrelated call left there

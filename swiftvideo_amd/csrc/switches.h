@@ -15,6 +15,7 @@ struct Switches {
     std::atomic<int> wave_rows{0};       // 8 | 16: strip height of the wave kernels
     std::atomic<int> tile_rows{0};       // 16 | 32: tile height of the tiled YUV -> BGRA kernel
     std::atomic<int> same_geom{1};       // 0: do not share a layer's geometry with its predecessor (A/B of LF_SAME_GEOM)
+    std::atomic<int> desc_host{0};       // 1: transient launches read their descriptors from the pinned host ring (A/B; default: device copy)
 };
 Switches &switches();                    // (chipvideo.cpp; initialised from the environment on first use)
 

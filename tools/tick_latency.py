@@ -38,9 +38,30 @@ def probe(label, layers, n=400):
     dev.sort()
     print(f"{label:42s} wall {wall:6.1f} us/tick   device (events) median {dev[len(dev)//2]:6.1f} us  min {dev[0]:6.1f}", flush=True)
 
-for rows in (None, "8", "16"):
+ydst = G.to_gpu(ctx, "y420p", 1920, 1080, util.alloc_image("y420p", 1920, 1080))
+ysrc = G.to_gpu(ctx, "y420p", 1920, 1080, util.alloc_image("y420p", 1920, 1080, seed=9))
+yov = [G.to_gpu(ctx, "bgra", 640, 360, util.alloc_image("bgra", 640, 360, seed=10 + i)) for i in range(2)]
+ydesc = sv._image_desc(ydst)
+
+
+def probe_yuv(n=300):
+    """the reference-default mixer tick: 1080p y420p canvas <- 1080p y420p layer + two 640x360 BGRA overlays"""
+    global tdesc
+    f0 = ysrc.derive(matrix=sv._unit_quad_to_ndc(), borderMatrix=sv._unit_quad_to_ndc())
+    layers = [(sv.ComputeKernel.img_y420p_y420p, f0, sv.imageUniformsFor(f0, ydst), 0)]
+    for o, (px, py) in zip(yov, ((64, 64), (1200, 640))):
+        layers.append((sv.ComputeKernel.img_bgra_y420p, o, util.make_uniforms((1920, 1080), rect=(px, py, 640, 360), opacity=0.8, in_size=(640, 360)), 0))
+    keep, tdesc = tdesc, ydesc
+    try:
+        probe("mixer_y420p tick (1080p, 3 layers)", layers, n)
+    finally:
+        tdesc = keep
+
+
+for rows, desc in ((None, None), (None, "host"), ("16", None)):
     cv.set_switch("CHV_WAVE_ROWS", rows)
-    print(f"-- CHV_WAVE_ROWS={rows}")
+    cv.set_switch("CHV_DESC", desc)
+    print(f"-- CHV_WAVE_ROWS={rows} CHV_DESC={desc} (descriptors of a transient launch: copied to device memory | read from the pinned host ring)")
     probe("empty tick (clear only)", [])
     probe("cfg2 tick (1 NV12 layer)", four[:1])
     cv.set_switch("CHV_BGRA_PATH", "wave")
@@ -48,6 +69,7 @@ for rows in (None, "8", "16"):
     cv.set_switch("CHV_BGRA_PATH", None)
     probe("2 NV12 layers", four[:2])
     probe("pipeline tick (4 NV12 layers)", four)
+    probe_yuv()
     cv.set_switch("CHV_SAME_GEOM", "0")
     probe("pipeline tick, no geometry sharing", four)
     cv.set_switch("CHV_SAME_GEOM", None)
