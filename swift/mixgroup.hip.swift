@@ -9,7 +9,7 @@
    (composer.swift:203-224) leaves the device idle most of the time.  With the two hunks of INTEGRATION.md section 1
    a mixer (a) issues its tick as one chv_composite launch, or (b) — when it belongs to a VideoMixerGroup — hands the
    tick to the group, which composes the ticks of all its members with ONE chv_batch launch per canvas format and ONE
-   host wait (measured: 256 ticks per launch = 5.9 us per tick, bench.py; one tick at a time: 38 us fused, 105 us as the
+   host wait (measured: 256 ticks per launch = 5.8 us per tick, bench.py; one tick at a time: 34 us fused, 91 us as the
    unchanged clear + 4 launches sequence, bench.py legs pipeline_per_tick / pipeline_reference_sequence).
 */
 #if GPGPU_HIP
