@@ -34,13 +34,21 @@ class Plane(C.Structure):
 
 def build(force=False):
     """Compile the restatement (and the clref cross-check when /root/reference exists)."""
+    did = {"liboracle": "reused", "clref": "absent"}
     so = HERE / "liboracle.so"
     if force or not so.exists() or so.stat().st_mtime < (HERE / "ref_kernels.c").stat().st_mtime:
         subprocess.check_call(["make", "-C", str(HERE), "liboracle.so"], stdout=subprocess.DEVNULL)
+        did["liboracle"] = "compiled"
+    ref = HERE / "_ref" / "libclref.so"
     if os.path.exists("/root/reference/Sources/SwiftVideo/kernels.cl.swift"):
-        ref = HERE / "_ref" / "libclref.so"
         if force or not ref.exists():
             subprocess.check_call(["make", "-C", str(HERE), "clref"], stdout=subprocess.DEVNULL)
+            did["clref"] = "compiled"
+        else:
+            did["clref"] = "reused"
+    elif ref.exists():
+        did["clref"] = "prebuilt (no reference tree here)"
+    return did
 
 
 _lib = None

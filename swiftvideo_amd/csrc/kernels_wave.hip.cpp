@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
             // Layers the strip machinery cannot stage (rotation, shear, unbounded matrices — the launch has some: KINDS bit 3)
             // are applied pixel by pixel with the general kernel's code, in z order with everything else: one rotated logo does
             // not send the whole tick to the general kernel.
-            if ((Ly.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) {
+            if (Ly.kind == LK_BGRA_METAL || (Ly.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) {
                 const float gsx = (float)T.W, gsy = (float)TH;
 #pragma unroll 1
                 for (int j = 0; j < WTH; j++) {

@@ -526,6 +526,10 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
         for (int l = 0; l < T.n_layers; l++) {
             const DLayer &L = layers[T.first_layer + l];
             const bool rgb = host_src_rgb(L.kind), nv12 = host_src_nv12(L.kind), planar = host_src_planar(L.kind);
+            // img_bgra_bgra (kernels.metal:52-62 — what an unchanged VideoMixer.findKernel resolves a BGRA layer on a BGRA canvas to):
+            // nearest sampling, nothing to stage; applied per pixel inside the wave kernel like a rotated layer, so that a
+            // reference-default tick of video layers + a BGRA overlay keeps the strip path for its video layers
+            if (L.kind == LK_BGRA_METAL && target_format == TF_BGRA) { any_general = true; continue; }
             if (!(rgb || nv12 || planar)) return false;
             // layers that cannot be staged (rotation, shear, unbounded matrices) are applied per pixel inside the kernel: nothing to check
             if ((L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) { any_general = true; continue; }
@@ -580,7 +584,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
         for (int i = 0; i < n_ticks; i++) {
             for (int l = 0; l < ticks_host[i].n_layers; l++) {
                 const DLayer &L = layers_host[ticks_host[i].first_layer + l];
-                if ((L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) { kinds |= 8; continue; }     // not staged
+                if (L.kind == LK_BGRA_METAL || (L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) { kinds |= 8; continue; }     // not staged
                 WaveDims d = wave_dims(ticks_host[i], L, rows);
                 m.p0pitch = std::max(m.p0pitch, d.p0pitch); m.p0rows = std::max(m.p0rows, d.p0rows);
                 m.p1pitch = std::max(m.p1pitch, d.p1pitch); m.p1rows = std::max(m.p1rows, d.p1rows);

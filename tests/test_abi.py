@@ -121,6 +121,17 @@ def test_build_flags_report_a_product_build(built):
     assert "unorm_table=0" in flags
 
 
+def test_build_reports_whether_it_compiled(built, capsys):
+    """__graft_entry__.build() prints one `chipvideo build_mode=…` line; a second call over an up-to-date tree is "reused"."""
+    import __graft_entry__ as entry
+    from swiftvideo_amd import build as B
+    entry.build()
+    entry.build()
+    assert B.last_build["mode"] == "reused" and B.last_build["objects_rebuilt"] == [] and not B.last_build["relinked"]
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("chipvideo build_mode=")]
+    assert len(lines) == 2 and "build_mode=reused" in lines[-1] and "flags=arch=gfx950;" in lines[-1]
+
+
 def test_switch_hook_validates_names(built):
     lib = cv.load()
     assert lib.chv_debug_set_switch(b"CHV_NO_SUCH_SWITCH", b"1") == 1

@@ -77,6 +77,45 @@ def test_cfg3_four_1080p_bgra_layers(ctx):
     G.assert_same(G.from_gpu(ctx, out2, "bgra", w, h), exp, "cfg3 sequential mixer tick")
 
 
+def test_default_kernel_family_tick_with_a_bgra_overlay(ctx):
+    """What an UNCHANGED VideoMixer issues on a 1080p BGRA canvas (findKernel, mix.video.swift:167-182; no `bgraKernelFamily` opt-in):
+    two 1080p NV12 videos through img_nv12_bgra and a 1080p BGRA overlay through img_bgra_bgra (kernels.metal:52-62).  The video layers
+    keep the strip kernel (the overlay is applied per pixel inside it); fused tick == the reference's call sequence == the oracle."""
+    w, h = 1920, 1080
+    vids = [util.alloc_image("nv12", w, h, seed=0x5EED0000 + 112 + i) for i in range(2)]
+    logo = util.alloc_image("bgra", w, h, seed=0x5EED0000 + 120)
+    M = util.ortho(w, h) @ util._mat_scale(w, h)
+    exp = util.alloc_image("bgra", w, h)
+    assert O.run_kernel("img_clear_bgra", exp, threads=CORES) == 0
+    for v, o in zip(vids, (1.0, 0.5)):
+        assert O.run_kernel("img_nv12_bgra", exp, v, util.full_canvas_uniforms((w, h), (w, h), opacity=o), threads=CORES) == 0
+    assert O.run_kernel("img_bgra_bgra", exp, logo, util.full_canvas_uniforms((w, h), (w, h)), threads=CORES) == 0
+    up = sv.GPUBarrierUpload(ctx)
+    for fused in (True, False):
+        mixer = sv.VideoMixer("ws", 1 / 30, (w, h), outputFormat=sv.PixelFormat.BGRA, computeContext=ctx, fused=fused)
+        pics = [sv.pictureFromArrays(sv.PixelFormat.nv12, (w, h), v, matrix=M, opacity=o, zIndex=z, assetId=f"v{z}")
+                for z, (v, o) in enumerate(zip(vids, (1.0, 0.5)))]
+        pics.append(sv.pictureFromArrays(sv.PixelFormat.BGRA, (w, h), logo, matrix=M, zIndex=2, assetId="logo"))
+        for p in pics:
+            assert mixer.push(up(p)[1])[0] == "nothing"
+        out = mixer.mix(at=0.0)
+        assert out is not None, mixer.result
+        G.assert_same(G.from_gpu(ctx, out, "bgra", w, h), exp, f"default family, fused={fused}")
+    # and the launch the fused tick is: the strip kernel, not the general one
+    gv = [G.to_gpu(ctx, "nv12", w, h, v) for v in vids]
+    gl = G.to_gpu(ctx, "bgra", w, h, logo)
+    gd = G.to_gpu(ctx, "bgra", w, h, util.alloc_image("bgra", w, h, seed=3))
+    u = util.full_canvas_uniforms((w, h), (w, h))
+    layers = [(sv.ComputeKernel.img_nv12_bgra, gv[0], u, 0),
+              (sv.ComputeKernel.img_nv12_bgra, gv[1], util.full_canvas_uniforms((w, h), (w, h), opacity=0.5), 0),
+              (sv.ComputeKernel.img_bgra_bgra, gl, u, 0)]
+    hb, name, keep = G.make_batch(ctx, [(gd, True, layers)])
+    assert name == "tick_bgra_wave"
+    G.run_batch(ctx, hb)
+    G.destroy_batch(hb)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", w, h), exp, "default family as one batch")
+
+
 def test_cfg4_streams_are_independent(ctx):
     """configs[3] on one device: 8 streams in one launch; every stream's output equals that stream's
     single-tick output (no cross-talk between ticks of a batch)."""

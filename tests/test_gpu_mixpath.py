@@ -179,6 +179,29 @@ def test_rotated_layers_inside_wave_ticks(ctx, path, case):
     assert run_tick_case(ctx, cw, ch, clear, specs, expect=None) == WAVE
 
 
+METAL_CASES = {
+    # what an UNCHANGED VideoMixer.findKernel issues on a BGRA canvas (mix.video.swift:167-182): video layers through img_<fmt>_bgra and
+    # every BGRA layer through img_bgra_bgra (kernels.metal:52-62: nearest, whole canvas, per-pixel source alpha, no transform / opacity)
+    "overlay_over_videos": (320, 180, True, [("img_nv12_bgra", 480, 270, dict()), ("img_y420p_bgra", 480, 270, dict(opacity=0.5)),
+                                             ("img_bgra_bgra", 64, 36, dict())]),
+    "overlay_between": (260, 70, False, [("img_nv12_bgra", 96, 54, dict(rect=(20, 5, 200, 60))), ("img_bgra_bgra", 260, 70, dict()),
+                                         ("img_y420p_bgra", 96, 54, dict(rect=(100, 0, 150, 70), opacity=0.9, fill=(0.3, 0.3, 0.9, 0.5)))]),
+    "overlay_first_odd": (203, 117, True, [("img_bgra_bgra", 77, 41, dict()), ("img_nv12_bgra", 64, 36, dict(rect=(12, 8, 90, 50), opacity=0.7)),
+                                           ("img_bgra_bgra", 203, 117, dict()), ("img_nv12_bgra", 64, 36, dict(rect=(60, 40, 90, 50)))]),
+}
+
+
+@pytest.mark.parametrize("case", list(METAL_CASES))
+def test_reference_default_bgra_overlays_inside_wave_ticks(ctx, path, case):
+    cw, ch, clear, specs = METAL_CASES[case]
+    assert run_tick_case(ctx, cw, ch, clear, specs, expect=None) == WAVE
+
+
+def test_only_reference_default_bgra_layers_take_the_general_kernel(ctx):
+    specs = [("img_bgra_bgra", 96, 54, dict()), ("img_bgra_bgra", 40, 30, dict())]
+    assert run_tick_case(ctx, 96, 54, True, specs, expect=None) == "tick_general_bgra"
+
+
 @pytest.mark.parametrize("seed", range(32))
 def test_random_mixed_ticks(ctx, path, seed):
     """Seeded random ticks: 1..8 layers of random kinds with random axis-aligned geometry (placement, crop, flips, borders,
