@@ -605,6 +605,11 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
         m.p0rows = std::min(m.p0rows, rows); m.p1rows = std::min(m.p1rows, rows);
         lds = wave_lds(m, planar, target_format, WTH);
     }
+#ifdef CHV_EXP_LDS_PAD
+    // measurement-only variant (tools/build_variant.sh … -DCHV_EXP_LDS_PAD): extra LDS per block caps the waves per SIMD — how much
+    // occupancy the strip kernels need (profiles/r03_notes.md section 7)
+    if (const char *pad = getenv("CHV_LDS_PAD")) { fprintf(stderr, "[chv] lds %zu + pad %d, rows %d\n", lds, atoi(pad), WTH); lds += (size_t)atoi(pad); }
+#endif
     int strips_x = (maxW + WTW - 1) / WTW, strips_y = (maxH + WTH - 1) / WTH;
     // floor(2^32 / d) for the kernels' scalar divisions by the strips per tick and per row (WaveStrip::udivmod)
     auto magic = [](uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); };
