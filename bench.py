@@ -82,6 +82,10 @@ WORKLOADS = {
     "mixer_nv12": dict(desc="1080p NV12 canvas <- full-canvas 1080p NV12 layer + two 640x360 BGRA overlays (opacity .8/.6)",
                        kind="mixer420", mixer="nv12", sw=1920, sh=1080, dw=1920, dh=1080, layers=3, frames=128,
                        bytes=NV12_1080 + NV12_1080 + 2 * 921600),
+    "encode_nv12": dict(desc="the encoder side: 1080p BGRA canvas -> 1080p NV12, integer BT.601 limited-range matrix (img_bgra_nv12_int, what "
+                             "PictureFilter(.nv12) issues per mixed frame in front of an H.264 encoder)",
+                        kind="mixer420", mixer="nv12", main_src="bgra", main_kernel="img_bgra_nv12_int", overlays=0,
+                        sw=1920, sh=1080, dw=1920, dh=1080, layers=1, frames=128, bytes=BGRA_1080 + NV12_1080),
     "cfg5": dict(desc="8 x 3840x2160 BGRA layers composited onto a 2160p canvas, then Lanczos-3 down to 1920x1080",
                  kind="rgb_layers", sw=3840, sh=2160, dw=3840, dh=2160, layers=8, frames=24,
                  bytes=8 * BGRA_2160 + BGRA_1080, lanczos=(1920, 1080)),
@@ -90,7 +94,7 @@ WORKLOADS = {
                   bytes=2 * NV12_1080 + 2 * 921600 + BGRA_720),
 }
 HEADLINE = "pipeline"
-DEFAULT_SET = ["pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p"]
+DEFAULT_SET = ["pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12"]
 
 
 def parse_args(argv=None):
@@ -288,18 +292,19 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
 
     if wl["kind"] == "mixer420":
         fmt = wl["mixer"]
+        sfmt, kmain = wl.get("main_src", fmt), wl.get("main_kernel", f"img_{fmt}_{fmt}")
         for i in range(distinct):
-            host_src.append(util.alloc_image(fmt, sw, sh, seed=seed_base + i))
+            host_src.append(util.alloc_image(sfmt, sw, sh, seed=seed_base + i))
         ov = [util.alloc_image("bgra", 640, 360, seed=seed_base + 100 + i) for i in range(2)]
         us = [util.full_canvas_uniforms((dw, dh), (sw, sh)),
               util.make_uniforms((dw, dh), rect=(64, 64, 640, 360), opacity=0.8, in_size=(640, 360)),
               util.make_uniforms((dw, dh), rect=(1200, 640, 640, 360), opacity=0.6, in_size=(640, 360))]
-        k_main = sv.defaultComputeKernelFromString(f"img_{fmt}_{fmt}")
+        k_main = sv.defaultComputeKernelFromString(kmain)
         k_ov = sv.defaultComputeKernelFromString(f"img_bgra_{fmt}")
         govs = [up(sv.PixelFormat.BGRA, (640, 360), o) for o in ov]
         keep += govs
         for f in range(frames):
-            src = up(PF[fmt], (sw, sh), host_src[f % distinct])
+            src = up(PF[sfmt], (sw, sh), host_src[f % distinct])
             dst = blank(PF[fmt], (dw, dh))
             keep += [src, dst]
             if f > 0 and alias in ("src", "both"):
@@ -309,7 +314,7 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
             canvases.append(dst)
             nov = wl.get("overlays", 2)
             finish_tick(f, dst, [(k_main, src, us[0], 0)] + [(k_ov, govs[i], us[1 + i], 0) for i in range(nov)])
-        verify = dict(target=fmt, layers=lambda f: [(f"img_{fmt}_{fmt}", host_src[f % distinct], us[0])] +
+        verify = dict(target=fmt, layers=lambda f: [(kmain, host_src[f % distinct], us[0])] +
                                                    [(f"img_bgra_{fmt}", ov[i], us[1 + i]) for i in range(wl.get("overlays", 2))])
     elif wl["kind"] == "yuv_layers":
         sfmt, nl = wl["src"], wl["layers"]

@@ -80,6 +80,17 @@ CHV_DEV void for_each_row_impl(F &f, std::integer_sequence<int, J...>) { (f(std:
 template <int N, typename F>
 CHV_DEV void for_rows(F &f) { for_each_row_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// code-scale variants (the integer-matrix RGB kind): byte K of a word as a float; to_code_raw of a code-scale value into byte K
+template <int K>
+CHV_DEV float ubk(uint32_t w) { return K == 0 ? ub0(w) : K == 1 ? ub1(w) : K == 2 ? ub2(w) : ub3(w); }
+template <int K>
+CHV_DEV uint32_t put_code_raw(uint32_t w, float v) {
+    if (K == 0) asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(w) : "v"(v));
+    if (K == 1) asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(w) : "v"(v));
+    if (K == 2) asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(w) : "v"(v));
+    if (K == 3) asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(w) : "v"(v));
+    return w;
+}
 CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float t10, float t01, float t11) {
     return ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;      // lin_mix's order (OpenCL 1.2 section 8.2)
 }
@@ -215,8 +226,10 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
 #ifndef CHV_WAVEY_MASKED
 #define CHV_WAVEY_MASKED 1
 #endif
-        // (the integer-matrix RGB kind, DESIGN.md 4.5, has no branch-free row loop here: per pixel below, taps from global memory)
-        const bool fast = !general_layer && cur.staged && (cur.all_inside || (CHV_WAVEY_MASKED && nofill)) && Ly.kind != LK_YUV_FROM_RGB_INT;
+#ifndef CHV_WAVEY_INT_ROWS
+#define CHV_WAVEY_INT_ROWS 1        // A/B: 0 sends the integer-matrix RGB kind through the per-pixel path (taps from global memory)
+#endif
+        const bool fast = !general_layer && cur.staged && (cur.all_inside || (CHV_WAVEY_MASKED && nofill)) && (CHV_WAVEY_INT_ROWS || Ly.kind != LK_YUV_FROM_RGB_INT);
         const bool lane_pic = cur.cfl == AX_ALL;
         // a pixel takes a row's result if its column and the row are inside the picture (row flags: uniform, from the row table);
         // every row is computed (branch-free: a branch per row keeps the rows' LDS reads from overlapping), row offsets are
@@ -296,6 +309,95 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
             const bool planar = Strip::is_planar(Ly.kind), opaque = (Ly.flags & LF_OPAQUE) != 0;
             if (planar) { if (opaque) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
             else        { if (opaque) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+        } else if (fast && Ly.kind == LK_YUV_FROM_RGB_INT) {
+            // ---- RGB picture, integer BT.601 / 709 matrix (img_*_int; statement of record: yuv_pixel.hip.h::
+            //      apply_yuv_from_rgb_int = oracle px_rgb_to_yuv_int): everything on the 0..255 code scale — bilinear sample with
+            //      fused multiply-adds, the sample rounded to codes, the 16.16 matrix on the codes, canvas blended by alpha x opacity,
+            //      fill painted first.  The encoder side's full-frame BGRA -> NV12 / y420p conversion runs here. ----
+            const R2Y &k = kR2Y[Ly.csc & 3];
+            const float opacity = U[U_OPACITY];
+            const float ka = opacity * kInv255;
+            const float af = opacity * U[U_FILL + 3], iaf = 1.f - af;
+            uint32_t fyc, fuc, fvc;
+            rgb_to_yuv_int(k, (int)to_code_raw(U[U_FILL + 0] * 255.0f), (int)to_code_raw(U[U_FILL + 1] * 255.0f), (int)to_code_raw(U[U_FILL + 2] * 255.0f), fyc, fuc, fvc);
+            const float fyf = (float)fyc, fuf = (float)fuc, fvf = (float)fvc;
+            const float a = cur.cya, ia = 1.0f - a;
+            // native-resolution pictures (source rows advance one per canvas row: the encoder-side conversion): a pixel's lower tap row
+            // is the upper tap row of the pixel below — its eight conversions and two LDS reads are carried down the lane
+            // (measured: encode_nv12 0.638 -> 0.622 ms per 128 frames, but the eight carried registers put 2-6 registers of the 16-row
+            // mixed-class instantiations in scratch and the mixer workloads lose 2 %: off)
+#ifndef CHV_WAVEY_INT_CARRY
+#define CHV_WAVEY_INT_CARRY 0
+#endif
+            const bool carry = CHV_WAVEY_INT_CARRY && cur.unit_rows;
+            float t00 = 0.f, t01 = 0.f, t02 = 0.f, t03 = 0.f, t10 = 0.f, t11 = 0.f, t12 = 0.f, t13 = 0.f;
+            if (carry) {
+                const uint8_t *p0 = smem + (row_fast<YTH, false>(rowtab, 0).yoff + cur.cyo);
+                const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
+                t00 = ub0(u00); t01 = ub1(u00); t02 = ub2(u00); t03 = ub3(u00);
+                t10 = ub0(u10); t11 = ub1(u10); t12 = ub2(u10); t13 = ub3(u10);
+            }
+            auto int_rows = [&](auto fill_c, auto carry_c) {
+                constexpr bool FILL = decltype(fill_c)::value;      // !FILL: clamp(fma(f, 0, c * 1), 0, 255) = c for a code c
+                constexpr bool CARRY = decltype(carry_c)::value;
+                auto row = [&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const RowFast rw = row_fast<YTH, false>(rowtab, j);
+                    const bool tk = take(row_fast_flags<YTH>(rowtab, j));
+                    const float b = rw.yb, ib = rw.iyb;
+                    const uint8_t *p0 = smem + (rw.yoff + cur.cyo);
+                    const uint32_t u01 = ((const uint32_t *)(p0 + p0pitch))[0], u11 = ((const uint32_t *)(p0 + p0pitch))[1];
+                    const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
+                    // staged texels are R, G, B, A whatever the source order
+                    const float b00 = ub0(u01), b01 = ub1(u01), b02 = ub2(u01), b03 = ub3(u01);
+                    const float b10 = ub0(u11), b11 = ub1(u11), b12 = ub2(u11), b13 = ub3(u11);
+                    if constexpr (!CARRY) {
+                        const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
+                        t00 = ub0(u00); t01 = ub1(u00); t02 = ub2(u00); t03 = ub3(u00);
+                        t10 = ub0(u10); t11 = ub1(u10); t12 = ub2(u10); t13 = ub3(u10);
+                    }
+                    const float q0 = cs_mix(w00, w10, w01, w11, t00, t10, b00, b10);
+                    const float q1 = cs_mix(w00, w10, w01, w11, t01, t11, b01, b11);
+                    const float q2 = cs_mix(w00, w10, w01, w11, t02, t12, b02, b12);
+                    const float q3 = cs_mix(w00, w10, w01, w11, t03, t13, b03, b13);
+                    if constexpr (CARRY) { t00 = b00; t01 = b01; t02 = b02; t03 = b03; t10 = b10; t11 = b11; t12 = b12; t13 = b13; }
+                    // to_code_raw of a convex combination of codes: no clamp can trigger; rint through the float adder
+                    const int cr = (int)(code_biased(q0) & 255u), cg = (int)(code_biased(q1) & 255u), cb = (int)(code_biased(q2) & 255u);
+                    const float a2 = q3 * ka, ia2 = 1.f - a2;
+                    const int py = clip8((k.y[0] * cr + k.y[1] * cg + k.y[2] * cb + (k.yoff << 16) + 32768) >> 16);
+                    uint32_t &lw = ly[j >> 2];
+                    const float cyf = ubk<j & 3>(lw);
+                    const float r0 = FILL ? clampf(__builtin_fmaf(fyf, af, cyf * iaf), 0.f, 255.f) : cyf;
+                    const uint32_t nlw = put_code_raw<j & 3>(lw, __builtin_fmaf((float)py, a2, r0 * ia2));
+                    lw = tk ? nlw : lw;
+                    if constexpr ((j & 1) == 0) {
+                        // chroma of the quad: the even lane's pixel of this (even) row; chroma row jj = j / 2 lives in the even lane
+                        // (jj even) or in its odd neighbour (jj odd: the values travel one lane up, quad_perm [0, 0, 2, 2])
+                        constexpr int jj = j >> 1, m = jj >> 1;
+                        int pu = clip8((k.u[0] * cr + k.u[1] * cg + k.u[2] * cb + (128 << 16) + 32768) >> 16);
+                        int pv = clip8((k.v[0] * cr + k.v[1] * cg + k.v[2] * cb + (128 << 16) + 32768) >> 16);
+                        float sa = a2, sia = ia2;
+                        int stk = (tk && owner_lane) ? 1 : 0;
+                        if constexpr ((jj & 1) != 0) {
+                            pu = __builtin_amdgcn_update_dpp(pu, pu, 0xA0, 0xf, 0xf, false);
+                            pv = __builtin_amdgcn_update_dpp(pv, pv, 0xA0, 0xf, 0xf, false);
+                            sa = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a2), __float_as_int(a2), 0xA0, 0xf, 0xf, false));
+                            sia = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ia2), __float_as_int(ia2), 0xA0, 0xf, 0xf, false));
+                            stk = __builtin_amdgcn_update_dpp(stk, stk, 0xA0, 0xf, 0xf, false);
+                        }
+                        const bool mine = stk != 0 && par == (jj & 1);
+                        const float cuf = ubk<m>(nu), cvf = ubk<m>(nv);
+                        const float r1 = FILL ? clampf(__builtin_fmaf(fuf, af, cuf * iaf), 0.f, 255.f) : cuf;
+                        const float r2 = FILL ? clampf(__builtin_fmaf(fvf, af, cvf * iaf), 0.f, 255.f) : cvf;
+                        const uint32_t nnu = put_code_raw<m>(nu, __builtin_fmaf((float)pu, sa, r1 * sia));
+                        const uint32_t nnv = put_code_raw<m>(nv, __builtin_fmaf((float)pv, sa, r2 * sia));
+                        nu = mine ? nnu : nu; nv = mine ? nnv : nv;
+                    }
+                };
+                for_rows<YTH>(row);
+            };
+            if (carry) { if (nofill) int_rows(std::false_type{}, std::true_type{}); else int_rows(std::true_type{}, std::true_type{}); }
+            else { if (nofill) int_rows(std::false_type{}, std::false_type{}); else int_rows(std::true_type{}, std::false_type{}); }
         } else if (fast) {
             // ---- RGB picture over the whole strip (kernels.cl.swift:509-529): fill pre-blend, sample, rgb2yuv of the
             //      pre-multiplied pixel, blend by alpha x opacity; staged texels are R,G,B,A whatever the source order ----

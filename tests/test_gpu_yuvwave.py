@@ -21,7 +21,7 @@ def rows(request, switch):
     return request.param
 
 
-def run_yuv_tick(ctx, d, cw, ch, clear, specs, seed=81, expect="wave"):
+def run_yuv_tick(ctx, d, cw, ch, clear, specs, seed=81, expect="wave", csc=0):
     canvas0 = util.alloc_image(d, cw, ch, seed=seed)
     exp = util.copy_image(canvas0)
     if clear:
@@ -31,8 +31,8 @@ def run_yuv_tick(ctx, d, cw, ch, clear, specs, seed=81, expect="wave"):
         u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
         s = k.split("_")[1]
         src = util.alloc_image(s, sw, sh, seed=seed + 9 + i)
-        assert O.run_kernel(k, exp, src, u, threads=4) == 0
-        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, 0))
+        assert O.run_kernel(k, exp, src, u, csc=csc, threads=4) == 0
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, csc))
     gd = G.to_gpu(ctx, d, cw, ch, canvas0)
     h, name, keep = G.make_batch(ctx, [(gd, clear, layers)])
     if expect == "wave":
@@ -87,6 +87,20 @@ CASES = {
                                                    ("img_rgba_y420p_int", 96, 54, dict(rect=(150, 60, 120, 80), opacity=0.6, border=(4, 4, 4, 4), fill=(0.2, 0.9, 0.1, 0.5))),
                                                    ("img_bgra_y420p", 64, 36, dict(rect=(200, 10, 64, 36)))]),
     "int_encoder":      ("nv12", 256, 64, True, [("img_bgra_nv12_int", 256, 64, dict())]),
+    # its branch-free row loop: whole strips inside the picture with and without fill paint, scaled, flipped, on a canvas that is not
+    # cleared (source alpha blends with what is there), strips crossed by the picture's edge (no fill: masked rows; with fill: per pixel)
+    "int_full_fill":    ("y420p", 192, 64, True, [("img_rgba_y420p_int", 192, 64, dict(opacity=0.8, fill=(0.3, 0.8, 0.1, 0.6)))]),
+    "int_scaled":       ("y420p", 192, 64, True, [("img_rgba_y420p_int", 300, 100, dict(opacity=0.9))]),
+    "int_up":           ("nv12", 300, 90, False, [("img_bgra_nv12_int", 100, 30, dict(opacity=0.5))]),
+    "int_noclear":      ("nv12", 192, 64, False, [("img_nv12_nv12", 192, 64, dict(opacity=0.4)), ("img_rgba_nv12_int", 192, 64, dict(opacity=0.5)),
+                                                  ("img_bgra_nv12_int", 192, 64, dict(opacity=0.7, fill=(0.9, 0.1, 0.4, 0.3)))]),
+    "int_flips":        ("nv12", 192, 40, True, [("img_rgba_nv12_int", 96, 54, dict(tex=(0.2, 1.0, 0.5, -0.7), opacity=0.5)),
+                                                 ("img_bgra_nv12_int", 96, 54, dict(tex=(1.0, 0.0, -1.0, 1.0), opacity=0.5))]),
+    "int_edges":        ("y420p", 260, 70, True, [("img_y420p_y420p", 260, 70, dict()), ("img_bgra_y420p_int", 50, 40, dict(rect=(-20, -10, 120, 60), opacity=0.6)),
+                                                  ("img_rgba_y420p_int", 64, 36, dict(rect=(131, 33, 101, 31)))]),
+    "int_edges_fill":   ("nv12", 260, 70, True, [("img_bgra_nv12_int", 50, 40, dict(rect=(-20, -10, 120, 60), fill=(0.1, 0.5, 0.9, 1.0), opacity=0.35)),
+                                                 ("img_rgba_nv12_int", 96, 54, dict(rect=(33, 9, 180, 40), border=(5, 3, 7, 2), fill=(0.9, 0.2, 0.1, 0.6), opacity=0.8))]),
+    "int_opacity_gt_1": ("y420p", 128, 32, True, [("img_bgra_y420p_int", 128, 32, dict(opacity=1.7)), ("img_rgba_y420p_int", 128, 32, dict(opacity=-0.3, fill=(0.5, 0.5, 0.5, 1.0)))]),
     "down_2.5":         ("nv12", 130, 50, True, [("img_nv12_nv12", 326, 124, dict()), ("img_bgra_nv12", 326, 124, dict(opacity=0.5))]),
 }
 
@@ -98,7 +112,15 @@ def test_yuv_wave_matches_oracle(ctx, rows, case):
     run_yuv_tick(ctx, d, cw, ch, clear, specs, expect=None if case == "down_2.5" else "wave")
 
 
-@pytest.mark.parametrize("case", ["mixer", "rect_border_fill", "noclear", "flips", "same_geom"])
+@pytest.mark.parametrize("csc", [1, 2, 3])
+@pytest.mark.parametrize("case", ["int_full_fill", "int_noclear", "int_edges"])
+def test_integer_matrix_rows_in_every_colourspace(ctx, rows, case, csc):
+    """BT.601 limited is csc 0 (every other case); BT.709 limited, BT.601 full, BT.709 full here"""
+    d, cw, ch, clear, specs = CASES[case]
+    run_yuv_tick(ctx, d, cw, ch, clear, specs, csc=csc)
+
+
+@pytest.mark.parametrize("case", ["mixer", "rect_border_fill", "noclear", "flips", "same_geom", "int_noclear", "int_edges", "int_scaled"])
 def test_yuv_wave_equals_general_kernel(ctx, switch, case):
     """the same tick through CHV_FORCE_GENERAL=1: both device paths are held to the same oracle bytes"""
     switch("CHV_FORCE_GENERAL", "1")
@@ -124,15 +146,19 @@ def test_rotated_overlay_stays_in_the_wave_kernel(ctx, rows, d):
     assert run_yuv_tick(ctx, d, 384, 216, True, specs, expect=None) == f"tick_yuv_wave<{d}>"
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", list(range(32)) + [f"int{i}" for i in range(16)])
 def test_random_yuv_ticks(ctx, rows, seed):
     """Seeded random ticks on 4:2:0 canvases: 1..8 layers of random source kinds with random axis-aligned geometry, three ticks
-    of different (even) sizes per launch."""
+    of different (even) sizes per launch.  Seeds `int<n>`: the RGB layers through the integer-matrix kernels, a random colourspace each."""
+    integer = isinstance(seed, str)
+    seed = int(seed[3:]) + 100 if integer else seed
     rng = np.random.default_rng(11000 + seed)
     d = "nv12" if seed % 2 == 0 else "y420p"
     clear = bool(rng.integers(0, 2))
     kinds = {"nv12": ["img_nv12_nv12", "img_y420p_nv12", "img_bgra_nv12", "img_rgba_nv12"],
              "y420p": ["img_y420p_y420p", "img_bgra_y420p", "img_rgba_y420p"]}[d]
+    if integer:
+        kinds = [k + "_int" if k.split("_")[1] in ("bgra", "rgba") else k for k in kinds] + [f"img_bgra_{d}_int"]
     ticks, exps, gds = [], [], []
     for t in range(3):
         cw, ch = int(rng.integers(4, 165)) * 2, int(rng.integers(2, 70)) * 2
@@ -161,8 +187,9 @@ def test_random_yuv_ticks(ctx, rows, seed):
                 kw["rotation"] = float(rng.uniform(-0.8, 0.8))
             u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
             src = util.alloc_image(s, sw, sh, seed=int(rng.integers(1, 1 << 20)))
-            assert O.run_kernel(k, exp, src, u, threads=4) == 0
-            layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, 0))
+            csc = int(rng.integers(0, 4)) if integer else 0
+            assert O.run_kernel(k, exp, src, u, csc=csc, threads=4) == 0
+            layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, csc))
         gd = G.to_gpu(ctx, d, cw, ch, canvas0)
         ticks.append((gd, clear, layers))
         exps.append(exp)

@@ -123,7 +123,7 @@ def test_default_run_measures_its_hbm_traffic():
     which)."""
     import shutil
     d = _run_bench(["--steps", "2", "--warmup", "1", "--min-seconds", "0.1", "--min-seconds-other", "0.05", "--no-cpu-baseline"])
-    assert set(d["workloads"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p"}
+    assert set(d["workloads"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12"}
     legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence")
     assert all(v["verified_vs_oracle"] is True for k, v in d["workloads"].items() if k not in legs)
     # the path a Swift VideoMixer takes — one tick at a time with a host wait — fused and as the unchanged 5-launch sequence
