@@ -33,11 +33,13 @@ def run_tick_case(ctx, cw, ch, clear, specs, seed=61, expect=WAVE, csc=0):
         assert O.run_kernel("img_clear_bgra", exp) == 0
     layers = []
     for i, (k, sw, sh, kw) in enumerate(specs):
+        kw = dict(kw)
+        lcsc = kw.pop("csc", csc)               # (a layer may name its own colourspace)
         u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
         s = k.split("_")[1]
         src = util.alloc_image(s, sw, sh, seed=seed + 9 + i)
-        assert O.run_kernel(k, exp, src, u, csc=csc, threads=4) == 0
-        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, csc))
+        assert O.run_kernel(k, exp, src, u, csc=lcsc, threads=4) == 0
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, lcsc))
     gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
     h, name, keep = G.make_batch(ctx, [(gd, clear, layers)])
     if expect is not None:
@@ -111,6 +113,37 @@ def test_layers_sharing_geometry_match_oracle(ctx, path, switch, case, share):
     switch("CHV_SAME_GEOM", share)
     cw, ch, clear, specs = SAME_GEOM_CASES[case]
     run_tick_case(ctx, cw, ch, clear, specs, expect=path, seed=131)
+
+
+def _stack(kernel, sw, sh, base, ops):
+    return [(kernel, sw, sh, dict(base, opacity=o)) for o in ops]
+
+
+PAIR_CASES = {
+    # launches of ONE YUV source class (the single-class instantiations of the kernel), same-geometry runs of 2-5 layers
+    "pipeline_small":  (320, 180, True, _stack("img_nv12_bgra", 480, 270, A, (1.0, 0.75, 0.5, 0.25))),
+    "translucent_first_uncleared": (320, 180, False, _stack("img_nv12_bgra", 480, 270, A, (0.6, 0.3))),
+    "three_and_five":  (320, 180, True, _stack("img_nv12_bgra", 480, 270, A, (1.0, 0.5, 0.25)) + _stack("img_nv12_bgra", 200, 110, R, (0.9, 0.7, 0.5, 0.3, 0.1))),
+    "edges_masked":    (320, 180, False, _stack("img_nv12_bgra", 300, 170, OFF, (0.8, 0.6, 1.0, 0.4))),
+    "planar":          (320, 180, True, _stack("img_y420p_bgra", 480, 270, A, (1.0, 0.5)) + _stack("img_y420p_bgra", 200, 110, R, (0.5, 1.0, 0.25))),
+    "planar_edges":    (260, 70, True, _stack("img_y420p_bgra", 300, 170, OFF, (1.0, 0.35))),
+    "opaque_on_top":   (192, 64, True, _stack("img_nv12_bgra", 288, 96, A, (0.5, 1.0, 1.0, 0.5))),
+    "upscaled":        (300, 90, True, _stack("img_nv12_bgra", 100, 30, A, (1.0, 0.5, 0.5))),
+    "own_colourspaces": (192, 64, True, [("img_nv12_bgra", 288, 96, dict(A, csc=c, opacity=o)) for c, o in ((0, 1.0), (1, 0.5), (2, 0.5), (3, 0.25))]),
+    # fill paint and opacities outside [0, 1] between layers of one geometry
+    "unpairable":      (320, 180, True, [("img_nv12_bgra", 200, 110, dict(BF, opacity=0.8)), ("img_nv12_bgra", 200, 110, dict(BF, opacity=0.5)),
+                                         ("img_nv12_bgra", 480, 270, dict(A, opacity=1.5)), ("img_nv12_bgra", 480, 270, dict(A, opacity=0.5)),
+                                         ("img_nv12_bgra", 480, 270, dict(A, opacity=-0.25)), ("img_nv12_bgra", 480, 270, dict(A, opacity=0.5)),
+                                         ("img_nv12_bgra", 480, 270, dict(A, opacity=0.5, fill=(0.2, 0.4, 0.6, 0.5)))]),
+}
+
+
+@pytest.mark.parametrize("case", list(PAIR_CASES))
+def test_single_class_stacks_match_oracle(ctx, path, case):
+    """stacks of same-geometry layers of ONE YUV class (the shape of the headline tick), per-layer colourspaces, opaque layers on top,
+    layers that paint fill or have opacities outside [0, 1] in between"""
+    cw, ch, clear, specs = PAIR_CASES[case]
+    run_tick_case(ctx, cw, ch, clear, specs, expect=path, seed=151)
 
 
 @pytest.mark.parametrize("case", list(MIXED_CASES))
