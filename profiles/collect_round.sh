@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 # 1. the default line, exactly as the driver runs it
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 # 2. kernel-trace stats of every workload's kernel (shorter timed regions: the profiler keeps every dispatch)
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_all/stats -o stats -- python $ROOT/bench.py --no-cpu-baseline --no-verify --no-live-pmc --min-seconds 0.3 --min-seconds-other 0.15 --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> /dev/null)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_all/stats -o stats -- python $ROOT/bench.py --no-cpu-baseline --no-verify --no-live-pmc --no-per-tick --no-upload-leg --min-seconds 0.3 --min-seconds-other 0.15 --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> /dev/null)
 python profiles/summarize.py gpurun_out/prof_${R}_all > $OUT/all_workloads_rocprofv3.txt 2>&1
 # 3a. the headline workload alone under kernel-trace, long enough (hundreds of launches) for the average to be comparable with the
 #     HIP-event figure of the default line
@@ -27,5 +27,5 @@ python profiles/summarize.py gpurun_out/prof_${R}_mixer --kernel tick_yuv_wave >
 # 5. A/B lines: general kernels, wave kernel on the single-purpose workloads
 for w in pipeline mixer_y420p cfg2; do CHV_FORCE_GENERAL=1 python bench.py --workload $w --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_${w}_general_kernel.json 2>/dev/null; done
 for w in cfg2 cfg3; do CHV_BGRA_PATH=wave python bench.py --workload $w --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_${w}_wave_kernel.json 2>/dev/null; done
-python bench.py --workload mixed --also y420p_main,mixer_nv12,cfg2_y420p --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_more_workloads.json 2>/dev/null
+python bench.py --workload mixed --also y420p_main,mixer_nv12,cfg2_y420p,encode_nv12,pipeline_logo --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_more_workloads.json 2>/dev/null
 tail -c 400 $OUT/bench_default.json; echo; tail -5 $OUT/pipeline_rocprofv3.txt
