@@ -43,7 +43,7 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
 // kernels_lanczos.hip.cpp
 hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *fx, const float *wx,
                           int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream,
-                          const DPlane *batch, int n_batch);
+                          const DPlane *batch, int n_batch, int stride_x, int first_x, int stride_y);
 }  // namespace chv
 
 using namespace chv;
@@ -222,6 +222,8 @@ struct LanczosTable {
     int taps = 0;
     int32_t *first = nullptr;  // device
     float *weights = nullptr;  // device
+    int stride = 0;            // first[o + 1] - first[o] when that is the same for every o (2 for the 2:1 class), else 0
+    int first0 = 0;            // first[0]
     LanczosTable() = default;
     LanczosTable(const LanczosTable &) = delete;
     LanczosTable &operator=(const LanczosTable &) = delete;
@@ -1312,6 +1314,9 @@ static int lanczos_table(chv_context *c, int in_size, int out_size, LanczosRef *
     t->device = c->device;
     int rc = lanczos_host_table(in_size, out_size, &t->taps, &first, &weights);
     if (rc) return rc;
+    t->first0 = first[0];
+    t->stride = first.size() > 1 ? first[1] - first[0] : 0;
+    for (size_t o = 1; o + 1 < first.size() && t->stride; o++) if (first[o + 1] - first[o] != t->stride) t->stride = 0;
     HIP_TRY(hipMalloc((void **)&t->first, first.size() * sizeof(int32_t)));
     hipError_t e = hipMalloc((void **)&t->weights, weights.size() * sizeof(float));
     if (e != hipSuccess) t->weights = nullptr;
@@ -1373,7 +1378,7 @@ extern "C" int chv_scale_lanczos(chv_context *c, const chv_image *dst, const chv
     rc = lanczos_table(c, s.h, d.h, &ty);
     if (rc) return rc;
     (void)hipGetLastError();
-    hipError_t e = launch_lanczos(d, s, tx->first, tx->weights, tx->taps, ty->first, ty->weights, ty->taps, c->stream, nullptr, 0);
+    hipError_t e = launch_lanczos(d, s, tx->first, tx->weights, tx->taps, ty->first, ty->weights, ty->taps, c->stream, nullptr, 0, tx->stride, tx->first0, ty->stride);
     if (e != hipSuccess) return hip_fail(e, "lanczos launch");
     return CHV_OK;
 }
@@ -1420,7 +1425,7 @@ extern "C" int chv_scale_lanczos_batch(chv_context *c, const chv_image *dsts, co
         DPlane *dev = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&dev, host, 0));
         (void)hipGetLastError();
-        hipError_t e = launch_lanczos(pairs[0], pairs[1], tx->first, tx->weights, tx->taps, ty->first, ty->weights, ty->taps, c->stream, dev, m);
+        hipError_t e = launch_lanczos(pairs[0], pairs[1], tx->first, tx->weights, tx->taps, ty->first, ty->weights, ty->taps, c->stream, dev, m, tx->stride, tx->first0, ty->stride);
         if (e != hipSuccess) return hip_fail(e, "lanczos launch");
         HIP_TRY(hipEventRecord(ds.done, c->stream));
         ds.pending = true;

@@ -22,6 +22,9 @@ namespace chv {
 // (tile * scale + taps in each direction) would not fit the LDS otherwise.
 constexpr int LZ_MAXT = 24;      // taps held in registers (scale <= 4); more taps use the slow loop
 // `ks` tiles per block, side by side (the host's choice, see launch_lanczos): tile t+1's source rectangle is prefetched into
+#ifndef CHV_LZ_STRIP
+#define CHV_LZ_STRIP 1
+#endif
 constexpr int LZ_NPRE = 6;       // registers (one 16-byte vector per row rg + 8n, n < LZ_NPRE) while tile t is filtered
 
 // EXACT: tx == ty == TAPS_IN_REGS, the tap loops are straight-line code.  Otherwise taps beyond the table's count
@@ -245,9 +248,167 @@ __global__ __launch_bounds__(256, (TAPS_IN_REGS > 12 ? 2 : EXACT ? 4 : 3)) void 
     }   // tiles of the strip
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// lanczos3_strip2 — reductions of the 2:1 class (12 taps on both axes, every output advancing by exactly two source texels:
+// 2160p -> 1080p, 1440p -> 720p, ...), ONE WAVE per strip of 64 output columns x `rows_per_wave` output rows, no block barrier.
+//
+// A lane owns an output column for BOTH passes: the horizontal results of its column for the 12 source rows a vertical
+// filter needs are a window of 12 float4 in the lane's registers (a source row enters, the oldest leaves; indices are static
+// in a loop unrolled over the window), so the float intermediate never goes through LDS and nothing has to wait for another
+// wave.  Per source row: lanes 0..35 write the row's 144 staged texels (16-byte vectors prefetched four rows ahead into
+// registers; CLAMP_TO_EDGE resolved here) to a two-row LDS ring, every lane reads its 12 taps as 6 or 7 aligned pairs
+// (the tap offset 2 * lane + c has the parity of c for the whole launch: ODD) and runs the same fused chain as
+// lanczos3_bgra; every second source row one output row is finished: the vertical chain over the window, packed store.
+// The tile kernel above recomputes 12 halo rows per 16 output rows (2.75 horizontally filtered rows per output row) and
+// synchronises four waves twice per tile; here it is 2 + 10 / rows_per_wave, and the SIMDs never idle at a barrier.
+constexpr int LS_NV = 36;          // 16-byte vectors of one staged source row: 2 * 63 + 3 + 12 = 141 texels at most
+#ifndef CHV_LS_PRE
+#define CHV_LS_PRE 4
+#endif
+#ifndef CHV_LS_WAVES
+#define CHV_LS_WAVES 4     // waves per SIMD the register allocation leaves room for
+#endif
+#ifndef CHV_LS_ABL
+#define CHV_LS_ABL 0      // timing-only ablations (wrong pixels): 1 no staging at all, 2 no global loads, 4 taps from registers instead of LDS
+#endif
+constexpr int LS_PRE = CHV_LS_PRE;   // source rows in flight (registers) ahead of the row being filtered (a divisor of 12)
+
+template <bool ODD>
+__global__ __launch_bounds__(64, CHV_LS_WAVES) void lanczos3_strip2(DPlane dst, DPlane src, const int32_t *__restrict__ fx, const float *__restrict__ wx,
+                                                         const int32_t *__restrict__ fy, const float *__restrict__ wy, int rows_per_wave,
+                                                         int strips, int chunks, int total, const DPlane *__restrict__ batch) {
+    // XCD-aware numbering (as in the strip kernels of the composite): block b runs on XCD b % 8, and every XCD gets one contiguous
+    // range of (image, row chunk, strip) — neighbouring strips and chunks share their halo columns and rows through that XCD's L2
+    // instead of fetching them once per XCD (the staged rows start 32 bytes before a 512-byte boundary: with strips dealt round-robin
+    // FETCH_SIZE was 1.67x the source bytes)
+    const int b = blockIdx.x, per_xcd = (total + 7) >> 3;
+    const int idx = (b & 7) * per_xcd + (b >> 3);
+    if ((b >> 3) >= per_xcd || idx >= total) return;
+    const int image = idx / (strips * chunks), rem = idx - image * (strips * chunks);
+    const int chunk = rem / strips, strip = rem - chunk * strips;
+    if (batch) { dst = batch[2 * image]; src = batch[2 * image + 1]; }
+    __shared__ __attribute__((aligned(16))) uint4 ring[2][LS_NV];
+    const int lane = threadIdx.x;
+    const int ox0 = strip * 64, j0 = chunk * rows_per_wave;
+    if (ox0 >= dst.w || j0 >= dst.h) return;
+    const int nrows = min(rows_per_wave, dst.h - j0);
+    const int x = ox0 + lane, xe = min(x, dst.w - 1);
+    const int col0 = __builtin_amdgcn_readfirstlane(fx[ox0]);
+    const int col0a = col0 & ~3;                                  // (rounds towards -inf: the staged row starts on a 16-byte vector)
+    const int cb = fx[xe] - col0a;                                // tap 0 of this lane, in texels from the start of the staged row
+    float wr[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) wr[k] = wx[(size_t)xe * 12 + k];
+    const int row0 = __builtin_amdgcn_readfirstlane(fy[j0]);
+    const bool edge = col0a < 0 || col0a + 4 * LS_NV > src.w;     // (uniform) some staged vector sticks out of the picture
+    const int S = 2 * nrows + 10;                                 // source rows this strip filters
+    const int vc = col0a + 4 * lane, vcc = min(max(vc, 0), src.w - 4);
+    const bool loader = lane < LS_NV;
+    // The row loads are issued and awaited by hand.  gfx950 counts loads and stores in ONE counter (vmcnt) and completes them out of
+    // order with respect to each other, so with the output stores in the loop hipcc has to drain the counter (`s_waitcnt vmcnt(0)`)
+    // before every use of a prefetched row: the prefetch depth collapses to nothing and the kernel runs at VALU time PLUS memory time
+    // (0.49 ms per 24 images, 0.34 without the loads).  Loads complete in order among themselves: once at most LS_PRE - 1 operations
+    // are outstanding, the oldest of LS_PRE loads has arrived whatever the stores did — that is the wait below.
+    auto issue = [&](int s) {
+        const int sy = min(max(row0 + s, 0), src.h - 1);
+        const uint8_t *p = src.ptr + (size_t)sy * src.pitch + (size_t)vcc * 4;
+        chv_u32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+        return v;
+    };
+    auto arrived = [&](chv_u32x4 &v) {            // (the "+v" ties the wait to the row's registers: no use can move above it)
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(LS_PRE - 1) : "memory");
+    };
+    auto fix = [&](chv_u32x4 L) {                                  // texel k of the vector = texel clamp(vc + k) of the row
+        auto pick = [&](int k) {
+            const int idx = min(max(vc + k, 0), src.w - 1) - vcc;
+            return idx == 0 ? L.x : idx == 1 ? L.y : idx == 2 ? L.z : L.w;
+        };
+        chv_u32x4 r = { pick(0), pick(1), pick(2), pick(3) };
+        return r;
+    };
+    chv_u32x4 pre[LS_PRE];
+#pragma unroll
+    for (int p = 0; p < LS_PRE; p++) pre[p] = chv_u32x4{ 0u, 0u, 0u, 0u };
+    if (loader) {
+#pragma unroll
+        for (int p = 0; p < LS_PRE; p++) pre[p] = issue(p);
+    }
+    float4 h[12];
+#pragma unroll
+    for (int t = 0; t < 12; t++) h[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t taps_off = (uint32_t)(cb >> 1) * 8u;
+    for (int g = 0; 12 * g < S; g++) {
+#pragma unroll
+        for (int t = 0; t < 12; t++) {
+            const int s = 12 * g + t;
+            if (s >= S) break;                                    // (uniform)
+            // stage source row s, request row s + LS_PRE
+            if (loader && !(CHV_LS_ABL & 1)) {
+                if (!(CHV_LS_ABL & 2)) arrived(pre[t % LS_PRE]);
+                const chv_u32x4 v = edge ? fix(pre[t % LS_PRE]) : pre[t % LS_PRE];
+                *(chv_u32x4 *)&ring[t & 1][lane] = v;
+                if (!(CHV_LS_ABL & 2)) pre[t % LS_PRE] = issue(s + LS_PRE);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            // horizontal pass of this lane's column
+            const uint2 *q = (const uint2 *)((const uint8_t *)ring[t & 1] + taps_off);
+            uint32_t e[14];
+#pragma unroll
+            for (int i = 0; i < 6 + (ODD ? 1 : 0); i++) {
+                if (CHV_LS_ABL & 4) { e[2 * i] = (uint32_t)(s * 77 + lane + i); e[2 * i + 1] = (uint32_t)(s * 31 + lane * 3 + i); continue; }
+                const uint2 pr = q[i]; e[2 * i] = pr.x; e[2 * i + 1] = pr.y;
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const uint32_t p = e[k + (ODD ? 1 : 0)];
+                acc.x = __builtin_fmaf(wr[k], (float)(p & 255), acc.x);
+                acc.y = __builtin_fmaf(wr[k], (float)((p >> 8) & 255), acc.y);
+                acc.z = __builtin_fmaf(wr[k], (float)((p >> 16) & 255), acc.z);
+                acc.w = __builtin_fmaf(wr[k], (float)(p >> 24), acc.w);
+            }
+            h[t] = acc;
+            if (t & 1) {
+                // source rows up to s = 2 j + 11 are in the window: output row j, rows (t + 1 + k) % 12 of the window in tap order
+                const int j = (s - 11) >> 1;
+                if (j >= 0 && j < nrows) {                        // (uniform)
+                    const float *wrow = wy + (size_t)(j0 + j) * 12;
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < 12; k++) {
+                        const float4 hk = h[(t + 1 + k) % 12];
+                        const float wk = wrow[k];
+                        o.x = __builtin_fmaf(wk, hk.x, o.x);
+                        o.y = __builtin_fmaf(wk, hk.y, o.y);
+                        o.z = __builtin_fmaf(wk, hk.z, o.z);
+                        o.w = __builtin_fmaf(wk, hk.w, o.w);
+                    }
+                    if (x < dst.w) gst<uint32_t>(dst.ptr + (size_t)(j0 + j) * dst.pitch + (size_t)x * 4, pack_codes(o.x, o.y, o.z, o.w));
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the rows requested past the strip's last one: nothing leaves in flight)
+}
+
 hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *fx, const float *wx,
                           int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream,
-                          const DPlane *batch, int n_batch) {
+                          const DPlane *batch, int n_batch, int stride_x, int first_x, int stride_y) {
+    // uniform tap stride 2 on both axes, 12 taps: the wave-per-strip kernel (CHV_LZ_STRIP=0 builds keep the tile kernel: A/B)
+    if (CHV_LZ_STRIP && tx == 12 && ty == 12 && stride_x == 2 && stride_y == 2 && src.w >= 4 * LS_NV) {
+        const int strips = (dst.w + 63) / 64;
+        const long want = 4L * 1024 * 4;                       // waves: four rounds of four per SIMD
+        long r = ((long)dst.h * strips * (batch ? n_batch : 1) + want - 1) / want;
+        r = std::min<long>(std::max<long>(r, 24), 180);
+        const int rows = (int)((r + 5) / 6 * 6);
+        const int chunks = (dst.h + rows - 1) / rows, total = strips * chunks * (batch ? n_batch : 1);
+        dim3 grid((unsigned)(((total + 7) / 8) * 8));
+        if (first_x & 1) hipLaunchKernelGGL(lanczos3_strip2<true>, grid, dim3(64), 0, stream, dst, src, fx, wx, fy, wy, rows, strips, chunks, total, batch);
+        else hipLaunchKernelGGL(lanczos3_strip2<false>, grid, dim3(64), 0, stream, dst, src, fx, wx, fy, wy, rows, strips, chunks, total, batch);
+        return hipGetLastError();
+    }
     // rows / columns of source one tile can need: first[] advances by at most ceil(scale) per output
     const double sy = (double)src.h / (double)dst.h, sxs = (double)src.w / (double)dst.w;
     auto dims = [&](int tw, int th, int *max_rows, int *max_cols) -> size_t {

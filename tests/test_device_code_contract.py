@@ -79,6 +79,24 @@ def test_lanczos_exact_tap_kernels_do_not_spill(tmp_path):
             assert m["vgpr_count"] <= 128 and m["vgpr_spill_count"] == 0, (name, m)   # 4 blocks of 4 waves per CU (LDS-limited)
 
 
+def test_lanczos_strip_kernel_keeps_its_prefetch_in_flight(tmp_path):
+    """lanczos3_strip2 (2:1 reductions, one wave per strip): 4 waves per SIMD without scratch, and the prefetched source rows are
+    awaited with `s_waitcnt vmcnt(3)` (three younger loads stay in flight).  Left to the compiler every row waited with vmcnt(0) —
+    gfx950 has one counter for loads and stores and completes them out of order with respect to each other, and the loop stores its
+    output rows — which cost a third of the kernel's time (profiles/r03_notes.md section 8)."""
+    co = _code_object(tmp_path, "kernels_lanczos")
+    for name, m in _find(_kernels(co), "lanczos3_strip2").items():
+        assert m["vgpr_count"] <= 128 and m["vgpr_spill_count"] == 0 and m.get("private_segment_fixed_size", 0) == 0, (name, m)
+    asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    bodies = re.split(r"\n[0-9a-f]+ <(_ZN3chv15lanczos3_strip2[^>]*)>:\n", asm)
+    assert len(bodies) >= 5, "two instantiations expected"
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        body = re.split(r"\n[0-9a-f]+ <_Z", body)[0]
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)
+        assert waits.count("3") >= 12 and waits.count("0") <= 3, (name, waits)
+        assert len(re.findall(r"global_load_dwordx4", body)) >= 16, name
+
+
 @pytest.mark.parametrize("stem", ["kernels_wave", "kernels_wave_yuv"])
 def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem):
     """One wave per strip: <= 80 VGPRs = 6 waves per SIMD (5 measured 8 % slower on the 4 x NV12

@@ -305,7 +305,15 @@ def test_wrapped_decoder_surface_with_plane_offsets(ctx):
                                          (200, 120, 20, 12),    # 10:1, 60 taps: weights from memory, no register prefetch
                                          (130, 70, 40, 22),     # 3.25:1, 20 taps in registers, rectangle too tall to prefetch
                                          (257, 131, 129, 66),   # ~2:1 with odd sizes: prefetch path, edge vectors re-ordered
-                                         (16, 16, 16, 16)])     # identity size
+                                         (16, 16, 16, 16),      # identity size
+                                         # exact 2:1 (12 taps, every output two source texels on): the wave-per-strip kernel
+                                         (256, 128, 128, 64),   # two full strips, one row chunk
+                                         (146, 20, 73, 10),     # narrowest source it takes; second strip partial, both strips on a picture edge
+                                         (640, 360, 320, 180),  # interior strips + edge strips, several row chunks
+                                         (1000, 200, 500, 100), # 8 strips, the last one partial
+                                         (160, 1000, 80, 500),  # tall: many row chunks, tail chunk shorter than the others
+                                         (200, 8, 100, 4),      # fewer output rows than one window
+                                         (256, 90, 128, 60)])   # 2:1 across only (10 taps down): stays on the tile kernel
 def test_lanczos_paths_match_oracle(ctx, iw, ih, ow, oh):
     src = util.alloc_image("bgra", iw, ih, seed=iw * 7 + oh)
     exp = util.alloc_image("bgra", ow, oh)
@@ -316,7 +324,7 @@ def test_lanczos_paths_match_oracle(ctx, iw, ih, ow, oh):
     G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"lanczos {iw}x{ih} -> {ow}x{oh}")
 
 
-@pytest.mark.parametrize("iw,ih,ow,oh,n", [(96, 54, 48, 27, 5), (64, 36, 128, 72, 3), (200, 120, 75, 45, 70), (33, 17, 20, 10, 2), (40, 24, 20, 12, 130)])
+@pytest.mark.parametrize("iw,ih,ow,oh,n", [(96, 54, 48, 27, 5), (64, 36, 128, 72, 3), (200, 120, 75, 45, 70), (33, 17, 20, 10, 2), (40, 24, 20, 12, 130), (288, 96, 144, 48, 9)])
 def test_lanczos_batch_equals_single_calls(ctx, iw, ih, ow, oh, n):
     """chv_scale_lanczos_batch: n resizes of one geometry in one launch per 64 pairs == the oracle, image by image"""
     srcs = [util.alloc_image("bgra", iw, ih, seed=900 + i) for i in range(n)]
