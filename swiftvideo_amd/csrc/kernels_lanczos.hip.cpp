@@ -13,6 +13,7 @@
 #include "pixel_math.hip.h"
 
 #include <algorithm>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -22,6 +23,12 @@ namespace chv {
 // (tile * scale + taps in each direction) would not fit the LDS otherwise.
 constexpr int LZ_MAXT = 24;      // taps held in registers (scale <= 4); more taps use the slow loop
 // `ks` tiles per block, side by side (the host's choice, see launch_lanczos): tile t+1's source rectangle is prefetched into
+#ifndef CHV_LZ_MIN_ROWS
+#define CHV_LZ_MIN_ROWS 8        // (measured: 4, 8, 16 -> 27.5 / 23.3 / 30.8 us for one 1080p -> 720p resize, wall time with the host wait)
+#endif
+#ifndef CHV_LZ_STRIP_ANY
+#define CHV_LZ_STRIP_ANY 1   // A/B: 0 keeps every ratio outside the 2:1 class on the tile kernel
+#endif
 #ifndef CHV_LZ_STRIP
 #define CHV_LZ_STRIP 1
 #endif
@@ -393,6 +400,130 @@ __global__ __launch_bounds__(64, CHV_LS_WAVES) void lanczos3_strip2(DPlane dst, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the rows requested past the strip's last one: nothing leaves in flight)
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// lanczos3_strip<T> — any ratio whose two axes have the same tap count T <= 24 and whose staged source row fits 64 vectors
+// (reductions up to about 3.5:1, every enlargement): the wave-per-strip structure of lanczos3_strip2 with the window of
+// horizontal results in LDS instead of registers, because the number of new source rows per output row varies from row to row
+// (3:2 alternates 1 and 2) and a register window needs static indices.  The window is a ring of exactly T rows x 64 lanes x
+// float4 (a lane reads and writes its own column only: no conflicts, nothing crosses lanes), T KB per wave; the source rows
+// arrive through a rotating three-deep register prefetch awaited by hand (vmcnt(2): see lanczos3_strip2).
+// Same chains, same bytes as lanczos3_bgra.
+constexpr int LG_PRE = 3;
+
+template <int T>
+__global__ __launch_bounds__(64, (T >= 20 ? 3 : 4)) void lanczos3_strip(DPlane dst, DPlane src, const int32_t *__restrict__ fx, const float *__restrict__ wx,
+                                                        const int32_t *__restrict__ fy, const float *__restrict__ wy, int rows_per_wave,
+                                                        int strips, int chunks, int total, int nv, const DPlane *__restrict__ batch) {
+    const int b = blockIdx.x, per_xcd = (total + 7) >> 3;         // XCD-aware numbering, as in lanczos3_strip2
+    const int idx = (b & 7) * per_xcd + (b >> 3);
+    if ((b >> 3) >= per_xcd || idx >= total) return;
+    const int image = idx / (strips * chunks), rem = idx - image * (strips * chunks);
+    const int chunk = rem / strips, strip = rem - chunk * strips;
+    if (batch) { dst = batch[2 * image]; src = batch[2 * image + 1]; }
+    extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
+    float4 *window = (float4 *)lsm;                               // [T][64]
+    chv_u32x4 *stage = (chv_u32x4 *)(lsm + (size_t)T * 64 * sizeof(float4));      // [2][nv]
+    const int lane = threadIdx.x;
+    const int ox0 = strip * 64, j0 = chunk * rows_per_wave;
+    if (ox0 >= dst.w || j0 >= dst.h) return;
+    const int nrows = min(rows_per_wave, dst.h - j0);
+    const int x = ox0 + lane, xe = min(x, dst.w - 1);
+    const int col0 = __builtin_amdgcn_readfirstlane(fx[ox0]);
+    const int col0a = col0 & ~3;
+    const int cb = fx[xe] - col0a;
+    float wr[T];
+#pragma unroll
+    for (int k = 0; k < T; k++) wr[k] = wx[(size_t)xe * T + k];
+    const int row0 = __builtin_amdgcn_readfirstlane(fy[j0]);
+    const bool edge = col0a < 0 || col0a + 4 * nv > src.w;
+    const int vc = col0a + 4 * lane, vcc = min(max(vc, 0), src.w - 4);
+    const bool loader = lane < nv;
+    // (the load writes its destination registers some time AFTER the statement: the asm names the prefetch slot itself as its output,
+    // with no temporary in between that the compiler could copy from before the data has landed; tests/test_device_code_contract.py
+    // checks on the built code that nothing touches a slot's registers between its load and its wait)
+#define LG_ISSUE(SLOT, S) do { const int sy_ = min(max(row0 + (S), 0), src.h - 1); \
+                               const uint8_t *p_ = src.ptr + (size_t)sy_ * src.pitch + (size_t)vcc * 4; \
+                               asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(SLOT) : "v"(p_) : "memory"); } while (0)
+    auto fix = [&](chv_u32x4 L) {
+        auto pick = [&](int k) {
+            const int i2 = min(max(vc + k, 0), src.w - 1) - vcc;
+            return i2 == 0 ? L.x : i2 == 1 ? L.y : i2 == 2 ? L.z : L.w;
+        };
+        chv_u32x4 r = { pick(0), pick(1), pick(2), pick(3) };
+        return r;
+    };
+    chv_u32x4 pre0 = { 0u, 0u, 0u, 0u }, pre1 = pre0, pre2 = pre0;
+    if (loader) { LG_ISSUE(pre0, 0); LG_ISSUE(pre1, 1); LG_ISSUE(pre2, 2); }
+    const uint32_t tap0 = (uint32_t)cb * 4u;
+    static_assert(LG_PRE == 3, "three prefetch slots");
+    // The loop runs over SOURCE rows, three per trip, so that every copy of the body names its prefetch slot statically: a slot chosen
+    // at run time (a switch, or registers moved along a queue) makes the compiler copy slot registers at the joins, and a register
+    // whose load is still in flight cannot be copied — the copy holds whatever was there before the data lands.  After every source
+    // row the output rows that have just become complete (none, one, or several when enlarging) are finished.
+    const int S = __builtin_amdgcn_readfirstlane(fy[j0 + nrows - 1]) - row0 + T;       // source rows this strip filters
+    int jcur = 0;                                                                       // next output row to finish
+    int fcur = 0;                                                                       // its first source row (fy[j0] - row0 = 0)
+    int wslot = 0;                                                                      // ring slot of source row `s`: s % T
+#define LG_ROW(SLOT, S_) do { \
+        const int s_ = (S_); \
+        if (loader) { \
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(SLOT) :: "memory"); \
+            stage[(s_ & 1) * nv + lane] = edge ? fix(SLOT) : SLOT; \
+            LG_ISSUE(SLOT, s_ + LG_PRE); \
+        } \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local"); \
+        __builtin_amdgcn_wave_barrier(); \
+        filter_row(s_); \
+    } while (0)
+    auto filter_row = [&](int s_) {
+        const uint32_t *row = (const uint32_t *)((const uint8_t *)(stage + (s_ & 1) * nv) + tap0);
+        uint32_t e[T];
+#pragma unroll
+        for (int k = 0; k < T; k++) e[k] = row[k];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < T; k++) {
+            acc.x = __builtin_fmaf(wr[k], (float)(e[k] & 255), acc.x);
+            acc.y = __builtin_fmaf(wr[k], (float)((e[k] >> 8) & 255), acc.y);
+            acc.z = __builtin_fmaf(wr[k], (float)((e[k] >> 16) & 255), acc.z);
+            acc.w = __builtin_fmaf(wr[k], (float)(e[k] >> 24), acc.w);
+        }
+        window[wslot * 64 + lane] = acc;
+        wslot = wslot + 1 == T ? 0 : wslot + 1;
+        // output rows whose last source row this was: rows fcur .. fcur + T - 1 = s_ - T + 1 .. s_ are in the ring, oldest in `wslot`
+        while (jcur < nrows && fcur + T - 1 == s_) {              // (uniform)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            const float *wrow = wy + (size_t)(j0 + jcur) * T;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            int sl = wslot;
+#pragma unroll
+            for (int k = 0; k < T; k++) {
+                const float4 hk = window[sl * 64 + lane];
+                const float wk = wrow[k];
+                o.x = __builtin_fmaf(wk, hk.x, o.x);
+                o.y = __builtin_fmaf(wk, hk.y, o.y);
+                o.z = __builtin_fmaf(wk, hk.z, o.z);
+                o.w = __builtin_fmaf(wk, hk.w, o.w);
+                sl = sl + 1 == T ? 0 : sl + 1;
+            }
+            if (x < dst.w) gst<uint32_t>(dst.ptr + (size_t)(j0 + jcur) * dst.pitch + (size_t)x * 4, pack_codes(o.x, o.y, o.z, o.w));
+            jcur++;
+            if (jcur < nrows) fcur = __builtin_amdgcn_readfirstlane(fy[j0 + jcur]) - row0;
+        }
+    };
+    for (int s3 = 0; s3 < S; s3 += 3) {
+        LG_ROW(pre0, s3);
+        if (s3 + 1 >= S) break;
+        LG_ROW(pre1, s3 + 1);
+        if (s3 + 2 >= S) break;
+        LG_ROW(pre2, s3 + 2);
+    }
+#undef LG_ROW
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre0), "+v"(pre1), "+v"(pre2) :: "memory");
+#undef LG_ISSUE
+}
+
 hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *fx, const float *wx,
                           int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream,
                           const DPlane *batch, int n_batch, int stride_x, int first_x, int stride_y) {
@@ -411,6 +542,29 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
     }
     // rows / columns of source one tile can need: first[] advances by at most ceil(scale) per output
     const double sy = (double)src.h / (double)dst.h, sxs = (double)src.w / (double)dst.w;
+    // equal tap counts on both axes, a staged row of at most 64 vectors: the general wave-per-strip kernel
+    if (CHV_LZ_STRIP_ANY && tx == ty && tx <= 24 && (tx & 1) == 0 && src.w >= 4) {
+        const int nv = ((int)(63 * sxs) + 1 + 3 + tx + 3) / 4 + 1;          // fx[x + 63] - fx[x] <= floor(63 scale) + 1; 3 texels of alignment
+        if (nv <= 64) {
+            const int strips = (dst.w + 63) / 64;
+            // rows per wave: enough waves for three rounds of four per SIMD when the launch is large; a small launch (one picture) gets
+            // short chunks instead — every chunk re-filters tx - 2 warm-up rows, but a wave's serial chain is what a lone resize waits for
+            const long want = 4L * 1024 * 3;
+            long r = ((long)dst.h * strips * (batch ? n_batch : 1) + want - 1) / want;
+            const int rows = (int)std::min<long>(std::max<long>(r, CHV_LZ_MIN_ROWS), 256);
+            const int chunks = (dst.h + rows - 1) / rows, total = strips * chunks * (batch ? n_batch : 1);
+            dim3 grid((unsigned)(((total + 7) / 8) * 8));
+            const size_t lds = (size_t)tx * 64 * sizeof(float4) + (size_t)2 * nv * 16;
+#define CHV_LZ_GO(TT) hipLaunchKernelGGL(lanczos3_strip<TT>, grid, dim3(64), lds, stream, dst, src, fx, wx, fy, wy, rows, strips, chunks, total, nv, batch)
+            switch (tx) {
+            case 6: CHV_LZ_GO(6); break;   case 8: CHV_LZ_GO(8); break;   case 10: CHV_LZ_GO(10); break; case 12: CHV_LZ_GO(12); break;
+            case 14: CHV_LZ_GO(14); break; case 16: CHV_LZ_GO(16); break; case 18: CHV_LZ_GO(18); break; case 20: CHV_LZ_GO(20); break;
+            case 22: CHV_LZ_GO(22); break; default: CHV_LZ_GO(24); break;
+            }
+#undef CHV_LZ_GO
+            return hipGetLastError();
+        }
+    }
     auto dims = [&](int tw, int th, int *max_rows, int *max_cols) -> size_t {
         *max_rows = (int)((th - 1) * sy + 2) + ty;
         *max_cols = ((int)((tw - 1) * sxs + 2) + tx + 3) & ~3;

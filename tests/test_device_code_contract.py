@@ -97,6 +97,21 @@ def test_lanczos_strip_kernel_keeps_its_prefetch_in_flight(tmp_path):
         assert len(re.findall(r"global_load_dwordx4", body)) >= 16, name
 
 
+def test_hand_awaited_loads_are_not_touched_while_in_flight(tmp_path):
+    """The strip Lanczos kernels issue their row loads from inline asm and wait for them with a hand-written s_waitcnt: the compiler does
+    not know the destination registers are still being written.  Two earlier versions of lanczos3_strip<T> let it copy such registers at
+    control-flow joins (garbage pixels, then a memory fault); tools/check_inflight.py walks the built code and rejects any instruction
+    that names a prefetch quad between its load and its wait, any spill of one, any reload of one still in flight."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import check_inflight
+    co = _code_object(tmp_path, "kernels_lanczos")
+    asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", "--demangle", co], check=True, capture_output=True, text=True).stdout
+    seen, bad = check_inflight.check(asm, "lanczos3_strip")
+    assert seen == 12, seen                       # lanczos3_strip2<odd|even> + lanczos3_strip<6 .. 24>
+    assert not bad, bad[:5]
+
+
 @pytest.mark.parametrize("stem", ["kernels_wave", "kernels_wave_yuv"])
 def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem):
     """One wave per strip: <= 80 VGPRs = 6 waves per SIMD (5 measured 8 % slower on the 4 x NV12

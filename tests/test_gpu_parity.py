@@ -313,7 +313,18 @@ def test_wrapped_decoder_surface_with_plane_offsets(ctx):
                                          (1000, 200, 500, 100), # 8 strips, the last one partial
                                          (160, 1000, 80, 500),  # tall: many row chunks, tail chunk shorter than the others
                                          (200, 8, 100, 4),      # fewer output rows than one window
-                                         (256, 90, 128, 60)])   # 2:1 across only (10 taps down): stays on the tile kernel
+                                         (256, 90, 128, 60),    # 2:1 across only (10 taps down): stays on the tile kernel
+                                         # equal tap counts on both axes, staged row of at most 64 vectors: the general wave-per-strip kernel,
+                                         # one case per tap count it is instantiated for (6 and 12 and 20 are above: 16x16, 257x131, 130x70)
+                                         (240, 120, 200, 100),  # 1.2:1, 8 taps
+                                         (300, 150, 200, 100),  # 3:2, 10 taps: one or two new source rows per output row
+                                         (440, 220, 200, 100),  # 2.2:1, 14 taps
+                                         (500, 250, 200, 100),  # 2.5:1, 16 taps
+                                         (600, 300, 200, 100),  # 3:1, 18 taps
+                                         (700, 140, 200, 40),   # 3.5:1, 22 taps: 63 staged vectors
+                                         (100, 50, 333, 171),   # enlargement by 3.33 / 3.42, odd sizes: output rows sharing all their source rows
+                                         (8, 8, 5, 5),          # narrower than one strip, every vector on an edge
+                                         (1920, 1080, 1280, 720)])   # a real 3:2 size: many strips, row chunks with and without a tail
 def test_lanczos_paths_match_oracle(ctx, iw, ih, ow, oh):
     src = util.alloc_image("bgra", iw, ih, seed=iw * 7 + oh)
     exp = util.alloc_image("bgra", ow, oh)
@@ -324,7 +335,7 @@ def test_lanczos_paths_match_oracle(ctx, iw, ih, ow, oh):
     G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"lanczos {iw}x{ih} -> {ow}x{oh}")
 
 
-@pytest.mark.parametrize("iw,ih,ow,oh,n", [(96, 54, 48, 27, 5), (64, 36, 128, 72, 3), (200, 120, 75, 45, 70), (33, 17, 20, 10, 2), (40, 24, 20, 12, 130), (288, 96, 144, 48, 9)])
+@pytest.mark.parametrize("iw,ih,ow,oh,n", [(96, 54, 48, 27, 5), (64, 36, 128, 72, 3), (200, 120, 75, 45, 70), (33, 17, 20, 10, 2), (40, 24, 20, 12, 130), (288, 96, 144, 48, 9), (300, 150, 200, 100, 7)])
 def test_lanczos_batch_equals_single_calls(ctx, iw, ih, ow, oh, n):
     """chv_scale_lanczos_batch: n resizes of one geometry in one launch per 64 pairs == the oracle, image by image"""
     srcs = [util.alloc_image("bgra", iw, ih, seed=900 + i) for i in range(n)]
