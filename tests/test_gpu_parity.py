@@ -335,6 +335,34 @@ def test_lanczos_paths_match_oracle(ctx, iw, ih, ow, oh):
     G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"lanczos {iw}x{ih} -> {ow}x{oh}")
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_lanczos_random_geometries(ctx, seed):
+    """Seeded random sizes: every kernel of the family (2:1 strip, general strip for each tap count, tiles) with strips and row chunks
+    that end anywhere, enlargements and reductions mixed across the axes."""
+    rng = np.random.default_rng(5200 + seed)
+    iw, ih = int(rng.integers(4, 700)), int(rng.integers(1, 260))
+    if seed % 3 == 0:                                   # same ratio on both axes: the strip kernels
+        r = float(rng.uniform(0.3, 3.4))
+        ow, oh = max(1, int(round(iw / r))), max(1, int(round(ih / r)))
+    elif seed % 3 == 1:                                 # exact 2:1
+        iw, ih = 2 * int(rng.integers(2, 350)), 2 * int(rng.integers(1, 130))
+        ow, oh = iw // 2, ih // 2
+    else:                                               # anything
+        ow, oh = int(rng.integers(1, 400)), int(rng.integers(1, 200))
+    src = util.alloc_image("bgra", iw, ih, seed=seed + 1)
+    exp = util.alloc_image("bgra", ow, oh)
+    if O.lanczos_bgra(exp[0], src[0]) != 0:
+        pytest.skip("ratio beyond the oracle's tap limit")
+    gs = G.to_gpu(ctx, "bgra", iw, ih, src)
+    gd = G.to_gpu(ctx, "bgra", ow, oh, util.alloc_image("bgra", ow, oh, seed=9))
+    try:
+        sv.usingContext(ctx, lambda c: sv.scaleLanczos(c, gd, gs))
+    except sv.ComputeError:
+        assert max(iw / ow, ih / oh) > 20               # beyond about 24:1 the library refuses (LDS): nothing else may fail
+        return
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"lanczos {iw}x{ih} -> {ow}x{oh}")
+
+
 @pytest.mark.parametrize("iw,ih,ow,oh,n", [(96, 54, 48, 27, 5), (64, 36, 128, 72, 3), (200, 120, 75, 45, 70), (33, 17, 20, 10, 2), (40, 24, 20, 12, 130), (288, 96, 144, 48, 9), (300, 150, 200, 100, 7)])
 def test_lanczos_batch_equals_single_calls(ctx, iw, ih, ow, oh, n):
     """chv_scale_lanczos_batch: n resizes of one geometry in one launch per 64 pairs == the oracle, image by image"""
