@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 #pragma clang fp contract(off)
 
@@ -401,19 +402,24 @@ __global__ __launch_bounds__(64, CHV_LS_WAVES) void lanczos3_strip2(DPlane dst, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// lanczos3_strip<T> — any ratio whose two axes have the same tap count T <= 24 and whose staged source row fits 64 vectors
-// (reductions up to about 3.5:1, every enlargement): the wave-per-strip structure of lanczos3_strip2 with the window of
-// horizontal results in LDS instead of registers, because the number of new source rows per output row varies from row to row
-// (3:2 alternates 1 and 2) and a register window needs static indices.  The window is a ring of exactly T rows x 64 lanes x
-// float4 (a lane reads and writes its own column only: no conflicts, nothing crosses lanes), T KB per wave; the source rows
-// arrive through a rotating three-deep register prefetch awaited by hand (vmcnt(2): see lanczos3_strip2).
+// lanczos3_strip<T> — any ratio whose two axes have the same tap count T <= 22 and whose staged source row fits 64 vectors
+// (reductions up to 3.5:1, every enlargement): the structure of lanczos3_strip2 — one wave per strip, a lane owns an output
+// column for both passes, the horizontal results of the last T source rows in a window of T float4 in the lane's REGISTERS —
+// for ratios where the number of new source rows per output row varies (3:2 alternates one and two; enlargements finish
+// several output rows per source row).  The loop runs over SOURCE rows, T per trip, so that window indices and prefetch slots
+// are static in every copy of the body (a slot or a window row chosen at run time would make the compiler copy registers at
+// the joins, and a prefetch register whose load is in flight must not be copied: tools/check_inflight.py); after each source
+// row a uniform test finishes the output rows whose last source row it was — their window starts at row (t + 1) % T.
 // Same chains, same bytes as lanczos3_bgra.
-constexpr int LG_PRE = 3;
+template <typename F, int... Is>
+CHV_DEV bool lg_all_of(F &&f, std::integer_sequence<int, Is...>) { return (... && f(std::integral_constant<int, Is>{})); }
+template <int T> struct LgPre { static constexpr int value = T % 4 == 0 ? 4 : T % 3 == 0 ? 3 : 2; };      // prefetch depth: a divisor of T
 
 template <int T>
-__global__ __launch_bounds__(64, (T >= 20 ? 3 : 4)) void lanczos3_strip(DPlane dst, DPlane src, const int32_t *__restrict__ fx, const float *__restrict__ wx,
-                                                        const int32_t *__restrict__ fy, const float *__restrict__ wy, int rows_per_wave,
-                                                        int strips, int chunks, int total, int nv, const DPlane *__restrict__ batch) {
+__global__ __launch_bounds__(64, (T >= 14 ? 3 : 4)) void lanczos3_strip(DPlane dst, DPlane src, const int32_t *__restrict__ fx, const float *__restrict__ wx,
+                                                                        const int32_t *__restrict__ fy, const float *__restrict__ wy, int rows_per_wave,
+                                                                        int strips, int chunks, int total, int nv, const DPlane *__restrict__ batch) {
+    constexpr int PRE = LgPre<T>::value;
     const int b = blockIdx.x, per_xcd = (total + 7) >> 3;         // XCD-aware numbering, as in lanczos3_strip2
     const int idx = (b & 7) * per_xcd + (b >> 3);
     if ((b >> 3) >= per_xcd || idx >= total) return;
@@ -421,8 +427,7 @@ __global__ __launch_bounds__(64, (T >= 20 ? 3 : 4)) void lanczos3_strip(DPlane d
     const int chunk = rem / strips, strip = rem - chunk * strips;
     if (batch) { dst = batch[2 * image]; src = batch[2 * image + 1]; }
     extern __shared__ __attribute__((aligned(16))) uint8_t lsm[];
-    float4 *window = (float4 *)lsm;                               // [T][64]
-    chv_u32x4 *stage = (chv_u32x4 *)(lsm + (size_t)T * 64 * sizeof(float4));      // [2][nv]
+    chv_u32x4 *stage = (chv_u32x4 *)lsm;                          // [2][nv]
     const int lane = threadIdx.x;
     const int ox0 = strip * 64, j0 = chunk * rows_per_wave;
     if (ox0 >= dst.w || j0 >= dst.h) return;
@@ -438,12 +443,6 @@ __global__ __launch_bounds__(64, (T >= 20 ? 3 : 4)) void lanczos3_strip(DPlane d
     const bool edge = col0a < 0 || col0a + 4 * nv > src.w;
     const int vc = col0a + 4 * lane, vcc = min(max(vc, 0), src.w - 4);
     const bool loader = lane < nv;
-    // (the load writes its destination registers some time AFTER the statement: the asm names the prefetch slot itself as its output,
-    // with no temporary in between that the compiler could copy from before the data has landed; tests/test_device_code_contract.py
-    // checks on the built code that nothing touches a slot's registers between its load and its wait)
-#define LG_ISSUE(SLOT, S) do { const int sy_ = min(max(row0 + (S), 0), src.h - 1); \
-                               const uint8_t *p_ = src.ptr + (size_t)sy_ * src.pitch + (size_t)vcc * 4; \
-                               asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(SLOT) : "v"(p_) : "memory"); } while (0)
     auto fix = [&](chv_u32x4 L) {
         auto pick = [&](int k) {
             const int i2 = min(max(vc + k, 0), src.w - 1) - vcc;
@@ -452,75 +451,74 @@ __global__ __launch_bounds__(64, (T >= 20 ? 3 : 4)) void lanczos3_strip(DPlane d
         chv_u32x4 r = { pick(0), pick(1), pick(2), pick(3) };
         return r;
     };
-    chv_u32x4 pre0 = { 0u, 0u, 0u, 0u }, pre1 = pre0, pre2 = pre0;
-    if (loader) { LG_ISSUE(pre0, 0); LG_ISSUE(pre1, 1); LG_ISSUE(pre2, 2); }
+    // (the load writes its destination registers some time AFTER the statement: the asm names the prefetch slot itself as its output,
+    // with no temporary in between that the compiler could copy from before the data has landed)
+#define LG_ISSUE(SLOT, S) do { const int sy_ = min(max(row0 + (S), 0), src.h - 1); \
+                               const uint8_t *p_ = src.ptr + (size_t)sy_ * src.pitch + (size_t)vcc * 4; \
+                               asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(SLOT) : "v"(p_) : "memory"); } while (0)
+    chv_u32x4 pre[PRE];
+#pragma unroll
+    for (int p = 0; p < PRE; p++) pre[p] = chv_u32x4{ 0u, 0u, 0u, 0u };
+    if (loader) {
+#pragma unroll
+        for (int p = 0; p < PRE; p++) LG_ISSUE(pre[p], p);
+    }
+    float4 h[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) h[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     const uint32_t tap0 = (uint32_t)cb * 4u;
-    static_assert(LG_PRE == 3, "three prefetch slots");
-    // The loop runs over SOURCE rows, three per trip, so that every copy of the body names its prefetch slot statically: a slot chosen
-    // at run time (a switch, or registers moved along a queue) makes the compiler copy slot registers at the joins, and a register
-    // whose load is still in flight cannot be copied — the copy holds whatever was there before the data lands.  After every source
-    // row the output rows that have just become complete (none, one, or several when enlarging) are finished.
     const int S = __builtin_amdgcn_readfirstlane(fy[j0 + nrows - 1]) - row0 + T;       // source rows this strip filters
-    int jcur = 0;                                                                       // next output row to finish
-    int fcur = 0;                                                                       // its first source row (fy[j0] - row0 = 0)
-    int wslot = 0;                                                                      // ring slot of source row `s`: s % T
-#define LG_ROW(SLOT, S_) do { \
-        const int s_ = (S_); \
-        if (loader) { \
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(SLOT) :: "memory"); \
-            stage[(s_ & 1) * nv + lane] = edge ? fix(SLOT) : SLOT; \
-            LG_ISSUE(SLOT, s_ + LG_PRE); \
-        } \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local"); \
-        __builtin_amdgcn_wave_barrier(); \
-        filter_row(s_); \
-    } while (0)
-    auto filter_row = [&](int s_) {
-        const uint32_t *row = (const uint32_t *)((const uint8_t *)(stage + (s_ & 1) * nv) + tap0);
-        uint32_t e[T];
-#pragma unroll
-        for (int k = 0; k < T; k++) e[k] = row[k];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < T; k++) {
-            acc.x = __builtin_fmaf(wr[k], (float)(e[k] & 255), acc.x);
-            acc.y = __builtin_fmaf(wr[k], (float)((e[k] >> 8) & 255), acc.y);
-            acc.z = __builtin_fmaf(wr[k], (float)((e[k] >> 16) & 255), acc.z);
-            acc.w = __builtin_fmaf(wr[k], (float)(e[k] >> 24), acc.w);
-        }
-        window[wslot * 64 + lane] = acc;
-        wslot = wslot + 1 == T ? 0 : wslot + 1;
-        // output rows whose last source row this was: rows fcur .. fcur + T - 1 = s_ - T + 1 .. s_ are in the ring, oldest in `wslot`
-        while (jcur < nrows && fcur + T - 1 == s_) {              // (uniform)
+    int jcur = 0, fcur = 0;                                       // next output row to finish, its first source row (fy[j0] - row0 = 0)
+    for (int g = 0; g * T < S; g++) {
+        // (expanded through a fold expression, not `#pragma unroll`: with the early exit and the inner loop the unroller gives up from
+        // 10 taps on, and a window indexed at run time lives in scratch memory)
+        auto body = [&](auto tc) -> bool {
+            constexpr int t = decltype(tc)::value;
+            const int s = g * T + t;
+            if (s >= S) return false;                             // (uniform)
+            if (loader) {
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pre[t % PRE]) : "n"(PRE - 1) : "memory");
+                stage[(t & 1) * nv + lane] = edge ? fix(pre[t % PRE]) : pre[t % PRE];
+                LG_ISSUE(pre[t % PRE], s + PRE);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
             __builtin_amdgcn_wave_barrier();
-            const float *wrow = wy + (size_t)(j0 + jcur) * T;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            int sl = wslot;
+            const uint32_t *row = (const uint32_t *)((const uint8_t *)(stage + (t & 1) * nv) + tap0);
+            uint32_t e[T];
+#pragma unroll
+            for (int k = 0; k < T; k++) e[k] = row[k];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int k = 0; k < T; k++) {
-                const float4 hk = window[sl * 64 + lane];
-                const float wk = wrow[k];
-                o.x = __builtin_fmaf(wk, hk.x, o.x);
-                o.y = __builtin_fmaf(wk, hk.y, o.y);
-                o.z = __builtin_fmaf(wk, hk.z, o.z);
-                o.w = __builtin_fmaf(wk, hk.w, o.w);
-                sl = sl + 1 == T ? 0 : sl + 1;
+                acc.x = __builtin_fmaf(wr[k], (float)(e[k] & 255), acc.x);
+                acc.y = __builtin_fmaf(wr[k], (float)((e[k] >> 8) & 255), acc.y);
+                acc.z = __builtin_fmaf(wr[k], (float)((e[k] >> 16) & 255), acc.z);
+                acc.w = __builtin_fmaf(wr[k], (float)(e[k] >> 24), acc.w);
             }
-            if (x < dst.w) gst<uint32_t>(dst.ptr + (size_t)(j0 + jcur) * dst.pitch + (size_t)x * 4, pack_codes(o.x, o.y, o.z, o.w));
-            jcur++;
-            if (jcur < nrows) fcur = __builtin_amdgcn_readfirstlane(fy[j0 + jcur]) - row0;
-        }
-    };
-    for (int s3 = 0; s3 < S; s3 += 3) {
-        LG_ROW(pre0, s3);
-        if (s3 + 1 >= S) break;
-        LG_ROW(pre1, s3 + 1);
-        if (s3 + 2 >= S) break;
-        LG_ROW(pre2, s3 + 2);
+            h[t] = acc;
+            // output rows whose last source row this was: source rows s - T + 1 .. s are window rows (t + 1) % T, (t + 2) % T, ...
+            while (jcur < nrows && fcur + T - 1 == s) {           // (uniform; at most once per source row when reducing)
+                const float *wrow = wy + (size_t)(j0 + jcur) * T;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < T; k++) {
+                    const float4 hk = h[(t + 1 + k) % T];
+                    const float wk = wrow[k];
+                    o.x = __builtin_fmaf(wk, hk.x, o.x);
+                    o.y = __builtin_fmaf(wk, hk.y, o.y);
+                    o.z = __builtin_fmaf(wk, hk.z, o.z);
+                    o.w = __builtin_fmaf(wk, hk.w, o.w);
+                }
+                if (x < dst.w) gst<uint32_t>(dst.ptr + (size_t)(j0 + jcur) * dst.pitch + (size_t)x * 4, pack_codes(o.x, o.y, o.z, o.w));
+                jcur++;
+                if (jcur < nrows) fcur = __builtin_amdgcn_readfirstlane(fy[j0 + jcur]) - row0;
+            }
+            return true;
+        };
+        lg_all_of(body, std::make_integer_sequence<int, T>{});
     }
-#undef LG_ROW
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre0), "+v"(pre1), "+v"(pre2) :: "memory");
+#pragma unroll
+    for (int p = 0; p < PRE; p++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pre[p]) :: "memory");
 #undef LG_ISSUE
 }
 
@@ -543,7 +541,7 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
     // rows / columns of source one tile can need: first[] advances by at most ceil(scale) per output
     const double sy = (double)src.h / (double)dst.h, sxs = (double)src.w / (double)dst.w;
     // equal tap counts on both axes, a staged row of at most 64 vectors: the general wave-per-strip kernel
-    if (CHV_LZ_STRIP_ANY && tx == ty && tx <= 24 && (tx & 1) == 0 && src.w >= 4) {
+    if (CHV_LZ_STRIP_ANY && tx == ty && tx <= 22 && (tx & 1) == 0 && src.w >= 4) {
         const int nv = ((int)(63 * sxs) + 1 + 3 + tx + 3) / 4 + 1;          // fx[x + 63] - fx[x] <= floor(63 scale) + 1; 3 texels of alignment
         if (nv <= 64) {
             const int strips = (dst.w + 63) / 64;
@@ -554,12 +552,12 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
             const int rows = (int)std::min<long>(std::max<long>(r, CHV_LZ_MIN_ROWS), 256);
             const int chunks = (dst.h + rows - 1) / rows, total = strips * chunks * (batch ? n_batch : 1);
             dim3 grid((unsigned)(((total + 7) / 8) * 8));
-            const size_t lds = (size_t)tx * 64 * sizeof(float4) + (size_t)2 * nv * 16;
+            const size_t lds = (size_t)2 * nv * 16;                       // the two-row staging ring; the window is in registers
 #define CHV_LZ_GO(TT) hipLaunchKernelGGL(lanczos3_strip<TT>, grid, dim3(64), lds, stream, dst, src, fx, wx, fy, wy, rows, strips, chunks, total, nv, batch)
             switch (tx) {
             case 6: CHV_LZ_GO(6); break;   case 8: CHV_LZ_GO(8); break;   case 10: CHV_LZ_GO(10); break; case 12: CHV_LZ_GO(12); break;
             case 14: CHV_LZ_GO(14); break; case 16: CHV_LZ_GO(16); break; case 18: CHV_LZ_GO(18); break; case 20: CHV_LZ_GO(20); break;
-            case 22: CHV_LZ_GO(22); break; default: CHV_LZ_GO(24); break;
+            default: CHV_LZ_GO(22); break;
             }
 #undef CHV_LZ_GO
             return hipGetLastError();

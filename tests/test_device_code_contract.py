@@ -108,7 +108,7 @@ def test_hand_awaited_loads_are_not_touched_while_in_flight(tmp_path):
     co = _code_object(tmp_path, "kernels_lanczos")
     asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", "--demangle", co], check=True, capture_output=True, text=True).stdout
     seen, bad = check_inflight.check(asm, "lanczos3_strip")
-    assert seen == 12, seen                       # lanczos3_strip2<odd|even> + lanczos3_strip<6 .. 24>
+    assert seen == 11, seen                       # lanczos3_strip2<odd|even> + lanczos3_strip<6 .. 22>
     assert not bad, bad[:5]
 
 
