@@ -56,22 +56,23 @@ static void g_detail_set(const char *msg);
 static int parse_switch(const char *name, const char *value, int *out) {
     const std::string n = name ? name : "", v = value ? value : "";
     if (n == "CHV_FORCE_GENERAL") { *out = v == "1" ? 1 : 0; return 0; }
-    if (n == "CHV_BGRA_PATH") { *out = v == "wave" ? 1 : v == "tiled" ? 2 : 0; return 1; }
+    if (n == "CHV_BGRA_PATH") { *out = v == "wave" ? 1 : v == "tiled" ? 2 : v == "stream" ? 3 : 0; return 1; }
     if (n == "CHV_WAVE_ROWS") { *out = v == "8" ? 8 : v == "16" ? 16 : 0; return 2; }
     if (n == "CHV_TILE_ROWS") { *out = v == "16" ? 16 : v == "32" ? 32 : 0; return 3; }
     if (n == "CHV_SAME_GEOM") { *out = v == "0" ? 0 : 1; return 4; }
     if (n == "CHV_DESC") { *out = v == "host" ? 1 : 0; return 5; }
+    if (n == "CHV_STREAM") { *out = v == "0" ? 0 : 1; return 6; }
     return -1;
 }
 static void store_switch(Switches &s, int which, int val) {
-    std::atomic<int> *slots[6] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom, &s.desc_host };
+    std::atomic<int> *slots[7] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom, &s.desc_host, &s.stream };
     slots[which]->store(val, std::memory_order_relaxed);
 }
 Switches &chv::switches() {
     static Switches s;
     static std::once_flag once;
     std::call_once(once, [] {
-        static const char *const names[6] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC" };
+        static const char *const names[7] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC", "CHV_STREAM" };
         for (const char *n : names) {
             const char *v = getenv(n);
             int val = 0, which = v ? parse_switch(n, v, &val) : -1;
@@ -85,7 +86,7 @@ extern "C" int chv_debug_set_switch(const char *name, const char *value) {
     Switches &s = switches();                     // (environment first, so that a later first use cannot overwrite this)
     const int which = parse_switch(name, value, &val);
     if (which < 0) { g_detail_set("unknown switch"); return CHV_ERR_INVALID_VALUE; }
-    if (!value || !*value) val = which == 4 ? 1 : 0;      // empty / NULL: back to "the library decides"
+    if (!value || !*value) val = (which == 4 || which == 6) ? 1 : 0;      // empty / NULL: back to "the library decides"
     store_switch(s, which, val);
     return CHV_OK;
 }

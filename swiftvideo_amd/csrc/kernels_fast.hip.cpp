@@ -33,10 +33,13 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_Y420P_BGRA_TILED = 1, FP_WAVE_LAYERS = 2, FP_WAVE_NV12 = 3, FP_WAVE_Y420P = 4, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_Y420P_BGRA_TILED = 1, FP_WAVE_LAYERS = 2, FP_WAVE_NV12 = 3, FP_WAVE_Y420P = 4, FP_STREAM = 5, FP_COUNT };
 
 // kernels_wave.hip.cpp / kernels_wave_yuv.hip.cpp
 bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
+// kernels_stream.hip.cpp
+bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
+hipError_t launch_bgra_stream(const DTick *ticks_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream);
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream);
 
@@ -396,6 +399,7 @@ const char *fast_path_name(int path) {
     case FP_NV12_BGRA_TILED: return "tick_nv12_bgra_tiled";
     case FP_Y420P_BGRA_TILED: return "tick_y420p_bgra_tiled";
     case FP_WAVE_LAYERS: return "tick_bgra_wave";
+    case FP_STREAM: return "tick_bgra_stream";
     case FP_WAVE_NV12: return "tick_yuv_wave<nv12>";
     case FP_WAVE_Y420P: return "tick_yuv_wave<y420p>";
     default: return "none";
@@ -431,6 +435,14 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     // 4:2:0 canvases (the reference's own kernels): one wave per strip, or the general quad kernel
     if (target_format != TF_BGRA)
         return wave_layers_eligible(target_format, ticks, layers, n_ticks) ? (target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P) : FP_NONE;
+    // ticks of 2..4 full-frame NV12 layers of one geometry on a cleared canvas: rows outermost, layers innermost (kernels_stream.hip.cpp);
+    // one-layer ticks only on request (CHV_BGRA_PATH=stream)
+    // (a lone tick keeps the strip kernel: 33.3 against 35.3 us with the host wait — its waves are shorter)
+    if ((bp == 0 || bp == 3) && bgra_stream_eligible(ticks, layers, n_ticks)) {
+        long strips = 0;
+        for (int i = 0; i < n_ticks; i++) strips += (long)((ticks[i].W + 63) / 64) * ((ticks[i].H + 15) / 16);
+        if (bp == 3 || (ticks[0].n_layers >= 2 && strips >= 4096)) return FP_STREAM;
+    }
     if (bp != 1) {
         int p = select_single_purpose(ticks, layers, n_ticks);
         // planar sources in launches that fill the chip: the y420p-only instantiation of the wave kernel is the faster one
@@ -449,6 +461,7 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
+    if (path == FP_STREAM) return launch_bgra_stream(ticks_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_LAYERS) return launch_wave_layers(TF_BGRA, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_NV12) return launch_wave_layers(TF_NV12, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_Y420P) return launch_wave_layers(TF_Y420P, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);

@@ -1,0 +1,341 @@
+// kernels_stream.hip.cpp — tick_bgra_stream: ticks of 1..4 full-frame NV12 video layers of ONE geometry onto a cleared BGRA canvas
+// (the bench headline's tick, cfg2's tick; VideoMixer.mix of N camera feeds scaled to the canvas, mix.video.swift:114-124), rows
+// outermost and the layers innermost.
+//
+// tick_bgra_wave (kernels_wave.hip.cpp) stages one layer's rectangle for a 64 x 16 strip (6.7 KB), runs the rows of that layer,
+// stages the next one: the eight weight products of a pixel row, its row-table reads and the canvas pixel's trip through packed
+// codes are paid once per row AND layer, because four rectangles do not fit beside each other at five waves per SIMD
+// (profiles/r03_notes.md section 7).  Here nothing is staged as a rectangle.  A wave owns a 64-column strip of the canvas over a
+// chunk of rows and streams every layer's source rows through a small LDS ring per plane — 8 luma rows and 4 chroma rows of 128
+// bytes, 1.5 KB per layer — filled four (two) rows at a time by `global_load_lds_dwordx4`: a lane's 16 bytes go straight from its own
+// global address to LDS at M0 + lane * 16 (tools/probe_lds_dma.cpp), no registers, no LDS write instruction.  With every layer's
+// rows resident the loop runs over canvas rows: row entry, weights, tap addresses once, then per layer 12 taps, the integer
+// matrix and one blend on float codes, one pack and one store at the end.  Same operations per pixel and layer as
+// apply_layer_bgra / tick_bgra_wave (the blend result of a layer is rounded to codes exactly as its store would round it), so the
+// same bytes.
+//
+// Eligibility is decided on the host (launch_bgra_stream_eligible): cleared BGRA canvas, every tick the same number (<= 4) of NV12
+// layers, layers 1.. flagged LF_SAME_GEOM, axis-aligned bounded matrices without flips, no fill paint, opacities in [0, 1],
+// horizontal reduction <= 1.7 (a strip's source bytes fit the ring's 128-byte rows), plane rows a multiple of 16 bytes.
+#include "wave_common.hip.h"
+#include "switches.h"
+
+#include <algorithm>
+#include <cmath>
+
+#pragma clang fp contract(off)
+
+namespace chv {
+
+#ifndef CHV_ST_ABL
+#define CHV_ST_ABL 0        // timing-only (wrong pixels): 1 no ring fills, 2 no canvas stores
+#endif
+#ifndef CHV_STREAM_MIN_ROWS
+#define CHV_STREAM_MIN_ROWS 16
+#endif
+#ifndef CHV_STREAM_ROUNDS
+#define CHV_STREAM_ROUNDS 48      // chunk height: enough chunks for this many rounds of waves (measured 2 .. 48: 1.59 .. 1.34 ms, flat from 24 on;
+                                  // HBM traffic falls with the height — neighbouring strips drift apart over a tall chunk and re-fetch shared lines)
+#endif
+#ifndef CHV_STREAM_WAVES
+#define CHV_STREAM_WAVES 5
+#endif
+
+constexpr int ST_PITCH = 128;                 // bytes per ring row (8 vectors)
+constexpr int ST_YROWS = 8, ST_CROWS = 4;     // ring rows: luma (batches of 4), chroma (batches of 2)
+constexpr int ST_LAYER = ST_PITCH * (ST_YROWS + ST_CROWS);      // 1536 bytes per layer
+// LDS layout (NL layers): luma [2 batch slots][NL layers][4 rows][128], then chroma [2 batch slots][NL layers][2 rows][128] — the layers of one
+// batch slot lie next to each other so that ONE load instruction fills the rows of two layers (luma: 2 x 4 rows x 8 vectors = 64 lanes) or of
+// all four (chroma: 4 x 2 x 8): a vector memory instruction occupies the CU's address unit for 16 cycles whatever it moves
+// (tools/ubench_vmem.cpp), and with one instruction per layer and plane that unit was a fifth of the kernel's time.
+constexpr int ST_YL = 4 * ST_PITCH, ST_CL = 2 * ST_PITCH;       // bytes of one layer inside a batch slot: 512, 256
+constexpr int ST_TAB = 32;                    // row entries computed at a time (lane = row)
+#ifndef CHV_STREAM_BLOCK
+#define CHV_STREAM_BLOCK 4
+#endif
+constexpr int ST_WAVES = CHV_STREAM_BLOCK;    // waves (neighbouring strips) per block
+
+// integer colour matrix on biased codes -> float codes (kernels_wave.hip.cpp::yuv_to_bgr_floats)
+CHV_DEV void st_yuv_to_bgr(const CscFolded &k, int y, int u, int v, float &fb, float &fg, float &fr) {
+    int32_t t = __mul24(y, k.cy);
+    int32_t r = mad24_uniform(v, k.crv, t) + k.kr;
+    int32_t g = mad24_uniform(v, k.ncgv, mad24_uniform(u, k.ncgu, t)) + k.kg;
+    int32_t b = mad24_uniform(u, k.cbu, t) + k.kb;
+    const int32_t cb = min(max(b, 0), 0xFFFFFF), cg = min(max(g, 0), 0xFFFFFF), cr = min(max(r, 0), 0xFFFFFF);
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fb) : "v"(cb));
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fg) : "v"(cg));
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fr) : "v"(cr));
+}
+
+// One load instruction: lane -> (layer li, row rr of the batch, vector vec); `p` is the lane's own 16-byte source address, its LDS
+// destination is m0 + lane * 16 (tools/probe_lds_dma.cpp).
+CHV_DEV void st_dma(const uint8_t *p, bool active, uint32_t m0) {
+    if (active && !(CHV_ST_ABL & 1))
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0), "v"(p) : "memory");
+}
+
+template <int NL>
+__global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_stream(const DTick *__restrict__ ticks, const DLayer *__restrict__ layers, int n_ticks,
+                                                                          int strips_x, int chunks_y, int rows_per_chunk) {
+    // ST_WAVES independent waves per block, on neighbouring strips (no barrier anywhere): their source windows overlap by a vector or two,
+    // and waves of one block start together on one CU — the shared lines are fetched once (HBM traffic 1.47x -> see profiles/r03_notes.md)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+    constexpr int WBYTES = NL * ST_LAYER + ST_TAB * (int)(sizeof(uint4) + sizeof(uint32_t));
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    uint8_t *lds = lds_all + wave * WBYTES;
+    uint4 *rowtab = (uint4 *)(lds + NL * ST_LAYER);               // [ST_TAB]
+    uint32_t *rowfl = (uint32_t *)(rowtab + ST_TAB);              // [ST_TAB] row flags
+    const uint32_t lds0 = (uint32_t)(size_t)lds;                  // LDS byte address of the rings (the DMA's M0)
+    const int lane = threadIdx.x & 63;
+    // XCD-aware numbering: block b runs on XCD b % 8; an XCD owns a contiguous range of (tick, chunk, group of ST_WAVES strips)
+    const int groups_x = (strips_x + ST_WAVES - 1) / ST_WAVES;
+    const int total = n_ticks * chunks_y * groups_x;
+    const int b = blockIdx.x, per_xcd = (total + 7) >> 3;
+    const int idx = (b & 7) * per_xcd + (b >> 3);
+    if ((b >> 3) >= per_xcd || idx >= total) return;
+    const int tick = idx / (chunks_y * groups_x), rem = idx - tick * (chunks_y * groups_x);
+    const int chunk = rem / groups_x, strip = (rem - chunk * groups_x) * ST_WAVES + wave;
+    if (strip >= strips_x) return;
+    const DTick &T = ticks[tick];
+    const DLayer *L = layers + T.first_layer;
+    const int x0 = strip * 64, y0 = chunk * rows_per_chunk;
+    if (x0 >= T.W || y0 >= T.H) return;
+    const int nrows = min(rows_per_chunk, T.H - y0);
+    const DPlane D = T.dst.pl[0];
+    const float sx = (float)T.W, sy = (float)T.H;
+    const float *U = L[0].u;                                       // (layers 1.. : LF_SAME_GEOM — the same 48 geometry inputs, plane shapes, bounding box)
+    const DPlane SY = L[0].src.pl[0], SC = L[0].src.pl[1];
+
+    // ---- this lane's column: tap positions and weights (WaveStrip::setup, wave_common.hip.h) ---------------------------------
+    const int x = x0 + lane, xe = min(x, T.W - 1);
+    const float nx = ((float)xe / sx) * 2.f - 1.f;
+    const float t3 = U[U_TRANSFORM + 15];
+    const float t0 = nx * U[U_TRANSFORM + 0] + U[U_TRANSFORM + 3];
+    const float b0 = nx * U[U_BORDER + 0] + U[U_BORDER + 3];
+    const float u = t0 * U[U_TEXTURE + 0] + t3 * U[U_TEXTURE + 3];
+    const int cfl = ((b0 >= 0.f && b0 <= 1.f) ? AX_BORDER : 0) | ((t0 >= 0.f && t0 <= 1.f) ? AX_TX : 0) | ((u >= 0.f && u <= 1.f) ? AX_UV : 0);
+    int cy, cc;
+    float cya, cca;
+    lin_axis_raw(u, SY.w, cy, cya); lin_axis_raw(u, SC.w, cc, cca);
+    // first source column of the strip (no flips: lane 0 has the smallest positions), as the start of the staged 128 bytes
+    const int cy_first = __builtin_amdgcn_readfirstlane(cy), cc_first = __builtin_amdgcn_readfirstlane(cc);
+    const int ycol0 = min(max(cy_first, 0), SY.w - 1) & ~15;
+    const int ccol0 = (min(max(cc_first, 0), SC.w - 1) * 2) & ~15;                      // bytes: a chroma texel is a (U, V) pair
+    // byte offsets of the two tap columns inside a ring row, CLAMP_TO_EDGE in x; lanes past the staged bytes (columns outside the canvas
+    // or outside the picture, never stored / never taken) read whatever is there
+    const int oy0 = min(max(min(max(cy, 0), SY.w - 1) - ycol0, 0), ST_PITCH - 1), oy1 = min(max(min(max(cy + 1, 0), SY.w - 1) - ycol0, 0), ST_PITCH - 1);
+    const int oc0 = min(max(min(max(cc, 0), SC.w - 1) * 2 - ccol0, 0), ST_PITCH - 2), oc1 = min(max(min(max(cc + 1, 0), SC.w - 1) * 2 - ccol0, 0), ST_PITCH - 2);
+    // (the chroma offsets are even, and a compiler that knows it fuses a pair's U and V byte reads into one 16-bit read and splits it
+    // again with two more vector instructions per tap pair: every tap its own byte read is the cheaper form here, r03_notes.md section 2)
+    int oc0v = oc0, oc1v = oc1;
+    asm("" : "+v"(oc0v), "+v"(oc1v));
+    const float iya = (1.0f - cya) * kTapScale, ya = cya * kTapScale, ica = (1.0f - cca) * kTapScale, ca = cca * kTapScale;
+    const bool lane_pic = cfl == AX_ALL && x < T.W;
+    // 16-byte vectors of a ring row that some tap of the strip can read (the last lane has the largest offsets): the rest is not requested
+    const int nvecY = (__builtin_amdgcn_readlane(oy1, 63) >> 4) + 1, nvecC = ((__builtin_amdgcn_readlane(oc1, 63) + 1) >> 4) + 1;
+
+    // per-layer constants (wave-uniform)
+    CscFolded csc[NL];
+    float al[NL], ial[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        csc[l] = csc_fold_biased(kCsc[L[l].csc & 3]);
+        al[l] = 1.0f * L[l].u[U_OPACITY]; ial[l] = 1.f - al[l];
+    }
+
+    // the chunk's last tap rows: nothing past them is requested (a chunk's overshoot is another wave's first rows: fetched twice)
+    int lastY, lastC;
+    {
+        const int ye = min(y0 + nrows - 1, T.H - 1);
+        const float ny = ((float)ye / sy) * 2.f - 1.f;
+        const float t1 = ny * U[U_TRANSFORM + 5] + U[U_TRANSFORM + 7];
+        const float v = t1 * U[U_TEXTURE + 5] + t3 * U[U_TEXTURE + 7];
+        int ry, rc;
+        float a_;
+        lin_axis_raw(v, SY.h, ry, a_); lin_axis_raw(v, SC.h, rc, a_);
+        lastY = __builtin_amdgcn_readfirstlane(ry) + 1; lastC = __builtin_amdgcn_readfirstlane(rc) + 1;
+    }
+    uint32_t pending = 0u;                                        // the previous row's pixel, stored after this row's wait
+    int issued = 0, seqY = 0, seqC = 0;                           // load instructions issued so far; the count right after the newest luma / chroma batch
+    int nextY = 0, nextC = 0, landY = 0, landC = 0, baseY = 0, baseC = 0;      // ring state: rows below next* are requested, below land* have arrived
+    for (int j = 0; j < nrows; j++) {
+        // ---- row entries, ST_TAB at a time: lane = row (WaveStrip::setup) ------------------------------------------------
+        if ((j & (ST_TAB - 1)) == 0) {
+            wave_lds_fence();
+            const int ye = min(y0 + j + min(lane, ST_TAB - 1), T.H - 1);
+            const float ny = ((float)ye / sy) * 2.f - 1.f;
+            const float t1 = ny * U[U_TRANSFORM + 5] + U[U_TRANSFORM + 7];
+            const float b1 = ny * U[U_BORDER + 5] + U[U_BORDER + 7];
+            const float v = t1 * U[U_TEXTURE + 5] + t3 * U[U_TEXTURE + 7];
+            const int rfl = ((b1 >= 0.f && b1 <= 1.f) ? AX_BORDER : 0) | ((t1 >= 0.f && t1 <= 1.f) ? AX_TX : 0) | ((v >= 0.f && v <= 1.f) ? AX_UV : 0);
+            int ry, rc;
+            float rya, rca;
+            lin_axis_raw(v, SY.h, ry, rya); lin_axis_raw(v, SC.h, rc, rca);
+            if (lane < ST_TAB) {
+                rowtab[lane] = make_uint4((uint32_t)ry, (uint32_t)rc, __float_as_uint(rya), __float_as_uint(rca));
+                rowfl[lane] = (uint32_t)rfl;
+            }
+            wave_lds_fence();
+        }
+        const uint4 re = rowtab[j & (ST_TAB - 1)];
+        const int ry = __builtin_amdgcn_readfirstlane((int)re.x);
+        const int rc = __builtin_amdgcn_readfirstlane((int)re.y);
+        const int rfl = __builtin_amdgcn_readfirstlane((int)rowfl[j & (ST_TAB - 1)]);
+        const float yb = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)re.z));
+        const float cbw = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)re.w));
+        // ---- residency: source rows ry, ry + 1 (luma) and rc, rc + 1 (chroma) of every layer ------------------------------
+        // A ring holds two batches.  The next batch is REQUESTED as soon as the taps have left the older of the two (ry has entered the
+        // newer one) and AWAITED only when a tap row reaches it — about two canvas rows later at a 1.5 : 1 reduction, time the other waves
+        // of the SIMD fill; waiting right after the request put every wave to sleep for a memory latency every 1.3 rows (pipeline 1.57 ms).
+        if (j == 0) {
+            baseY = ry; baseC = rc; nextY = ry; nextC = rc; landY = ry; landC = rc;       // the rings start at the chunk's first tap rows
+        }
+        {
+            // Requests are awaited by COUNT: loads complete in order among themselves, so once at most n vector-memory operations are
+            // outstanding, where n is the number of loads issued after the batch a tap row needs, that batch has landed — whatever the
+            // canvas stores in between did (they share the counter and complete out of order; they can only make the wait longer).
+            // A full drain instead would also wait for the other plane's request of a row ago.
+            auto await = [&](int younger) {                        // (uniform)
+                if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                wave_lds_fence();
+            };
+            const bool needY = ry + 1 >= landY, needC = rc + 1 >= landC;
+            const bool wantY = ry + ST_YROWS / 2 >= nextY && nextY <= lastY, wantC = rc + ST_CROWS / 2 >= nextC && nextC <= lastC;     // (uniform)
+            // (one test for the rows on which nothing happens — two in five at a 1.5 : 1 reduction: a row's nine uniform branches were a
+            // tenth of its time)
+            if (needY | needC | wantY | wantC) {
+            if (needY) { await(issued - seqY); landY = nextY; }
+            if (needC) { await(issued - seqC); landC = nextC; }
+            if (wantY || wantC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the taps of the rows being overwritten have been read)
+            // (a while: the first row fills both batches; strong vertical reductions skip rows)
+            while (ry + ST_YROWS / 2 >= nextY && nextY <= lastY) {
+                // four luma rows of every layer, two layers per instruction; the planes of all layers have one shape (LF_SAME_GEOM)
+                const uint32_t slot = (uint32_t)((((nextY - baseY) >> 2) & 1) * (NL * ST_YL));
+                const int r = min(max(nextY + ((lane >> 3) & 3), 0), SY.h - 1);
+                const size_t roff = (size_t)r * SY.pitch + (size_t)min(ycol0 + 16 * (lane & 7), SY.w - 16);
+#pragma unroll
+                for (int l0 = 0; l0 < NL; l0 += 2) {
+                    const uint8_t *pa = L[l0].src.pl[0].ptr, *pb = L[l0 + 1 < NL ? l0 + 1 : l0].src.pl[0].ptr;
+                    st_dma((lane < 32 ? pa : pb) + roff, (lane < 32 || l0 + 1 < NL) && (lane & 7) < nvecY && nextY + ((lane >> 3) & 3) <= lastY, lds0 + slot + (uint32_t)(l0 * ST_YL));
+                }
+                nextY += 4; issued += (NL + 1) / 2; seqY = issued;
+            }
+            while (rc + ST_CROWS / 2 >= nextC && nextC <= lastC) {
+                // two chroma rows of every layer in one instruction
+                const uint32_t slot = (uint32_t)(2 * NL * ST_YL + (((nextC - baseC) >> 1) & 1) * (NL * ST_CL));
+                const int r = min(max(nextC + ((lane >> 3) & 1), 0), SC.h - 1);
+                const size_t roff = (size_t)r * SC.pitch + (size_t)min(ccol0 + 16 * (lane & 7), SC.w * 2 - 16);
+                const int li = lane >> 4;
+                const uint8_t *p0 = L[0].src.pl[1].ptr, *p1 = L[NL > 1 ? 1 : 0].src.pl[1].ptr, *p2 = L[NL > 2 ? 2 : 0].src.pl[1].ptr, *p3 = L[NL > 3 ? 3 : 0].src.pl[1].ptr;
+                const uint8_t *pl = li == 0 ? p0 : li == 1 ? p1 : li == 2 ? p2 : p3;
+                st_dma(pl + roff, li < NL && (lane & 7) < nvecC && nextC + ((lane >> 3) & 1) <= lastC, lds0 + slot);
+                nextC += 2; issued += 1; seqC = issued;
+            }
+            // (first row of a chunk, rows skipped by a strong reduction: what was just requested is needed now)
+            if (ry + 1 >= landY || rc + 1 >= landC) { await(0); landY = nextY; landC = nextC; }
+            }
+        }
+        // The previous row's pixels are stored HERE, right after this row's wait: gfx950 has one counter for loads and stores, the wait above
+        // drains it, and a store issued just before it would be waited for every time (a write latency per wait); issued now it has
+        // until the next wait, a row or two away.
+        if (j > 0 && x < T.W && !(CHV_ST_ABL & 2)) gst_at<uint32_t>(D.ptr + (size_t)(y0 + j - 1) * D.pitch, (uint32_t)x * 4u, pending);
+        // ---- tap addresses and weights, once for all layers -----------------------------------------------------------------
+        auto yoff = [&](int q) { return ((q >> 2) & 1) * (NL * ST_YL) + (q & 3) * ST_PITCH; };                       // layer 0's copy of luma row baseY + q
+        auto coff = [&](int q) { return 2 * NL * ST_YL + ((q >> 1) & 1) * (NL * ST_CL) + (q & 1) * ST_PITCH; };
+        const int sY0 = yoff(ry - baseY), sY1 = yoff(ry + 1 - baseY), sC0 = coff(rc - baseC), sC1 = coff(rc + 1 - baseC);
+        const uint8_t *pY00 = lds + (oy0 + sY0), *pY10 = lds + (oy1 + sY0), *pY01 = lds + (oy0 + sY1), *pY11 = lds + (oy1 + sY1);
+        const uint8_t *pC00 = lds + (oc0v + sC0), *pC10 = lds + (oc1v + sC0), *pC01 = lds + (oc0v + sC1), *pC11 = lds + (oc1v + sC1);
+        const float iyb = 1.0f - yb, icb = 1.0f - cbw;
+        const float w00 = iya * iyb, w10 = ya * iyb, w01 = iya * yb, w11 = ya * yb;
+        const float c00 = ica * icb, c10 = ca * icb, c01 = ica * cbw, c11 = ca * cbw;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;                          // img_clear_bgra: (0, 0, 0, 1) — the canvas pixel as float codes
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int lo = l * ST_YL, lc = l * ST_CL;
+            const float fy = cs_mix_h(w00, w10, w01, w11, tap_h(pY00 + lo), tap_h(pY10 + lo), tap_h(pY01 + lo), tap_h(pY11 + lo));
+            const float fu = cs_mix_h(c00, c10, c01, c11, tap_h(pC00 + lc), tap_h(pC10 + lc), tap_h(pC01 + lc), tap_h(pC11 + lc));
+            const float fv = cs_mix_h(c00, c10, c01, c11, tap_h(pC00 + lc + 1), tap_h(pC10 + lc + 1), tap_h(pC01 + lc + 1), tap_h(pC11 + lc + 1));
+            float pb, pg, pr;
+            st_yuv_to_bgr(csc[l], (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv), pb, pg, pr);
+            if (l == 0) {                // the cleared canvas: fma(p, a, 0 * (1 - a)) = RN(p * a) for a in [0, 1]
+                r0 = pb * al[0]; r1 = pg * al[0]; r2 = pr * al[0];
+            } else {
+                r0 = __builtin_fmaf(pb, al[l], r0 * ial[l]);
+                r1 = __builtin_fmaf(pg, al[l], r1 * ial[l]);
+                r2 = __builtin_fmaf(pr, al[l], r2 * ial[l]);
+            }
+            if (l + 1 < NL) { r0 = code_rintf(r0); r1 = code_rintf(r1); r2 = code_rintf(r2); }      // what the layer's store would have kept
+        }
+        const uint32_t out = pack_codes(r0, r1, r2, 0xFF000000u);
+        // a pixel outside the picture keeps the cleared canvas (inside the border quad its alpha is forced: the same word)
+        const uint32_t res = (lane_pic && rfl == AX_ALL) ? out : 0xFF000000u;
+        pending = res;
+    }
+    if (nrows > 0 && x < T.W && !(CHV_ST_ABL & 2)) gst_at<uint32_t>(D.ptr + (size_t)(y0 + nrows - 1) * D.pitch, (uint32_t)x * 4u, pending);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static bool stream_plane_ok(const DPlane &p) {
+    return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0 && ((p.w * p.comps) & 15) == 0 && p.w * p.comps >= 16 && p.h >= 1;
+}
+
+// every tick: cleared canvas, the same number (1..4) of NV12 -> BGRA layers of one geometry, axis-aligned and bounded, no flips, no fill,
+// opacities in [0, 1], a strip's source columns within one 128-byte ring row
+bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks) {
+    if (n_ticks < 1 || !switches().stream.load(std::memory_order_relaxed)) return false;
+    const int nl = ticks[0].n_layers;
+    if (nl < 1 || nl > 4) return false;
+    for (int i = 0; i < n_ticks; i++) {
+        const DTick &T = ticks[i];
+        if (T.n_layers != nl || !T.clear_first) return false;
+        if ((((uintptr_t)T.dst.pl[0].ptr) & 3) != 0 || (T.dst.pl[0].pitch & 3) != 0) return false;
+        for (int l = 0; l < nl; l++) {
+            const DLayer &Y = layers[T.first_layer + l];
+            if (Y.kind != LK_BGRA_FROM_NV12) return false;
+            const int need = LF_AXIS_ALIGNED | LF_BOUNDED | LF_NO_FILL | (l ? LF_SAME_GEOM : 0);
+            if ((Y.flags & need) != need) return false;
+            const float op = Y.u[U_OPACITY];
+            if (!(op >= 0.f && op <= 1.f)) return false;
+            if (!stream_plane_ok(Y.src.pl[0]) || !stream_plane_ok(Y.src.pl[1])) return false;
+            if (Y.src.pl[1].comps != 2 || Y.src.pl[0].comps != 1) return false;
+            if (l == 0) {
+                // source texels per canvas pixel: u = (x / W * 2 - 1) * T0 * X0 + ...  =>  du/dx * w = 2 T0 X0 w / W
+                const double kx = 2.0 * (double)Y.u[U_TRANSFORM + 0] * (double)Y.u[U_TEXTURE + 0], ky = 2.0 * (double)Y.u[U_TRANSFORM + 5] * (double)Y.u[U_TEXTURE + 5];
+                if (!(kx > 0.0) || !(ky > 0.0)) return false;                                   // flips: the rings assume rising positions
+                const double sx = kx * Y.src.pl[0].w / (double)T.W;
+                if (!(63.0 * sx + 2.0 + 15.0 + 1.0 <= 128.0)) return false;                     // luma bytes of a strip (chroma: the same count)
+                if (!std::isfinite(ky * Y.src.pl[0].h / (double)T.H)) return false;
+            }
+        }
+    }
+    return true;
+}
+
+hipError_t launch_bgra_stream(const DTick *ticks_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream) {
+    const int nl = ticks_host[0].n_layers;
+    const int strips_x = (maxW + 63) / 64;
+    // rows per chunk: tall chunks amortise the per-chunk geometry and the first ring fill; enough chunks to fill the chip a few times
+    const long want = 1024L * CHV_STREAM_WAVES * CHV_STREAM_ROUNDS;
+    long chunks = std::max<long>(1, want / std::max<long>(1, (long)n_ticks * strips_x));
+    int rows = (int)std::max<long>(CHV_STREAM_MIN_ROWS, (maxH + chunks - 1) / chunks);
+    rows = std::min(rows, maxH);
+    const int chunks_y = (maxH + rows - 1) / rows;
+    const long total = (long)n_ticks * chunks_y * ((strips_x + ST_WAVES - 1) / ST_WAVES);
+    dim3 grid((unsigned)(((total + 7) / 8) * 8));
+    const size_t lds = (size_t)ST_WAVES * ((size_t)nl * ST_LAYER + ST_TAB * (sizeof(uint4) + sizeof(uint32_t)));
+    switch (nl) {
+    case 1: hipLaunchKernelGGL(tick_bgra_stream<1>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;
+    case 2: hipLaunchKernelGGL(tick_bgra_stream<2>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;
+    case 3: hipLaunchKernelGGL(tick_bgra_stream<3>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;
+    default: hipLaunchKernelGGL(tick_bgra_stream<4>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace chv

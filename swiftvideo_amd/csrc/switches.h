@@ -2,7 +2,7 @@
 //
 // The environment is read ONCE, at the first use in the process (getenv on a hot path is undefined behaviour next to a
 // setenv in another thread, and the mixer and uploader threads run concurrently): CHV_FORCE_GENERAL, CHV_BGRA_PATH,
-// CHV_WAVE_ROWS, CHV_TILE_ROWS.  Tests and A/B tools change them afterwards through chv_debug_set_switch (include/chipvideo.h),
+// CHV_WAVE_ROWS, CHV_TILE_ROWS, CHV_SAME_GEOM, CHV_DESC, CHV_STREAM.  Tests and A/B tools change them afterwards through chv_debug_set_switch (include/chipvideo.h),
 // never through the environment.  Every value is an atomic int; 0 = "the library decides".
 #pragma once
 #include <atomic>
@@ -16,6 +16,7 @@ struct Switches {
     std::atomic<int> tile_rows{0};       // 16 | 32: tile height of the tiled YUV -> BGRA kernel
     std::atomic<int> same_geom{1};       // 0: do not share a layer's geometry with its predecessor (A/B of LF_SAME_GEOM)
     std::atomic<int> desc_host{0};       // 1: transient launches read their descriptors from the pinned host ring (A/B; default: device copy)
+    std::atomic<int> stream{1};          // 0: never tick_bgra_stream (A/B; CHV_BGRA_PATH=stream: also for one-layer ticks)
 };
 Switches &switches();                    // (chipvideo.cpp; initialised from the environment on first use)
 

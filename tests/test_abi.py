@@ -136,6 +136,6 @@ def test_switch_hook_validates_names(built):
     lib = cv.load()
     assert lib.chv_debug_set_switch(b"CHV_NO_SUCH_SWITCH", b"1") == 1
     assert lib.chv_debug_set_switch(None, b"1") == 1
-    for name in ("CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC"):
+    for name in ("CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC", "CHV_STREAM"):
         assert lib.chv_debug_set_switch(name.encode(), b"") == 0
         assert lib.chv_debug_set_switch(name.encode(), None) == 0

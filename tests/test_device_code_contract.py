@@ -12,7 +12,7 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "swiftvideo_amd" / "csrc"
 LLVM = Path("/opt/rocm/lib/llvm/bin")
-OBJECTS = ["kernels_general", "kernels_fast", "kernels_wave", "kernels_wave_yuv", "kernels_lanczos"]
+OBJECTS = ["kernels_general", "kernels_fast", "kernels_wave", "kernels_wave_yuv", "kernels_lanczos", "kernels_stream"]
 
 
 def _code_object(tmp_path, stem):

@@ -146,6 +146,111 @@ def test_single_class_stacks_match_oracle(ctx, path, case):
     run_tick_case(ctx, cw, ch, clear, specs, expect=path, seed=151)
 
 
+STREAM = "tick_bgra_stream"
+STREAM_CASES = {
+    # ticks of 1..4 full-frame NV12 layers of ONE geometry on a cleared canvas: rows outermost, layers innermost (kernels_stream.hip.cpp);
+    # plane rows are multiples of 16 bytes, the horizontal reduction is at most 1.7
+    "pipeline_small":   (320, 180, _stack("img_nv12_bgra", 480, 272, A, (1.0, 0.75, 0.5, 0.25))),
+    "two_layers":       (320, 180, _stack("img_nv12_bgra", 480, 272, A, (0.6, 0.3))),
+    "three_opaque_top": (192, 64, _stack("img_nv12_bgra", 288, 96, A, (0.5, 1.0, 1.0))),
+    "one_layer":        (320, 180, _stack("img_nv12_bgra", 480, 272, A, (1.0,))),
+    "native_size":      (320, 192, _stack("img_nv12_bgra", 320, 192, A, (1.0, 0.5, 0.5, 0.5))),
+    "enlarged":         (322, 182, _stack("img_nv12_bgra", 160, 96, A, (1.0, 0.5))),
+    "inside_canvas":    (320, 180, _stack("img_nv12_bgra", 304, 176, R, (0.9, 0.7, 0.5, 0.3))),
+    "across_edges":     (320, 180, _stack("img_nv12_bgra", 304, 176, OFF, (0.8, 0.6, 1.0, 0.4))),
+    "tall":             (192, 700, _stack("img_nv12_bgra", 288, 1056, A, (1.0, 0.5, 0.25))),
+    "wide":             (1280, 40, _stack("img_nv12_bgra", 1920, 64, A, (1.0, 0.75, 0.5, 0.25))),
+    "own_colourspaces": (192, 64, [("img_nv12_bgra", 288, 96, dict(A, csc=c, opacity=o)) for c, o in ((0, 1.0), (1, 0.5), (2, 0.5), (3, 0.25))]),
+    "tex_window":       (320, 180, _stack("img_nv12_bgra", 480, 272, dict(tex=(0.05, 0.1, 0.95, 0.9)), (1.0, 0.5))),
+}
+
+
+@pytest.mark.parametrize("case", list(STREAM_CASES))
+def test_stream_kernel_matches_oracle(ctx, switch, case):
+    switch("CHV_BGRA_PATH", "stream")
+    cw, ch, specs = STREAM_CASES[case]
+    run_tick_case(ctx, cw, ch, True, specs, expect=STREAM, seed=171)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_stream_ticks(ctx, seed):
+    """Seeded random ticks of the streaming kernel's class: three ticks of different canvas sizes per launch, 2..4 NV12 layers of one
+    geometry each — full canvas or a rectangle anywhere (also across the canvas edges), enlargements and reductions up to 1.7 across
+    and anything down, a texture window now and then, per-layer colourspaces and opacities."""
+    rng = np.random.default_rng(7100 + seed)
+    nl = int(rng.integers(2, 5))
+    ticks, exps, gds = [], [], []
+    for t in range(3):
+        cw, ch = int(rng.integers(20, 330)) * 2, int(rng.integers(8, 200)) * 2
+        sw, sh = int(rng.integers(2, 40)) * 16, int(rng.integers(4, 150)) * 2
+        kw = {}
+        if rng.random() < 0.6:
+            rw = float(rng.uniform(0.62, 3.0)) * sw                 # the picture's width on the canvas: source texels per pixel <= 1.6
+            kw["rect"] = (float(rng.uniform(-0.3, 0.5) * cw), float(rng.uniform(-0.3, 0.5) * ch), rw, float(rng.uniform(0.2, 2.5)) * sh)
+        else:
+            if sw / cw > 1.6:
+                sw = max(16, int(cw * 1.5) // 16 * 16)
+        if rng.random() < 0.25:
+            kw["tex"] = (0.0, 0.0, float(rng.uniform(1.0, 1.5)), float(rng.uniform(0.6, 1.4)))
+        canvas0 = util.alloc_image("bgra", cw, ch, seed=int(rng.integers(1, 1 << 20)))
+        exp = util.copy_image(canvas0)
+        assert O.run_kernel("img_clear_bgra", exp) == 0
+        layers = []
+        for l in range(nl):
+            op = float(rng.choice([1.0, rng.uniform(0, 1)]))
+            csc = int(rng.integers(0, 4))
+            u = util.make_uniforms((cw, ch), in_size=(sw, sh), opacity=op, **kw)
+            src = util.alloc_image("nv12", sw, sh, seed=int(rng.integers(1, 1 << 20)))
+            assert O.run_kernel("img_nv12_bgra", exp, src, u, csc=csc, threads=4) == 0
+            layers.append((sv.ComputeKernel.img_nv12_bgra, G.to_gpu(ctx, "nv12", sw, sh, src), u, csc))
+        gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+        ticks.append((gd, True, layers)); exps.append(exp); gds.append((gd, cw, ch))
+    h, name, keep = G.make_batch(ctx, ticks)
+    assert name in (STREAM, WAVE), name                  # (a rectangle wider than 1.7 source texels per pixel: the strip kernel)
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    for i, ((gd, cw, ch), exp) in enumerate(zip(gds, exps)):
+        G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed} tick {i} via {name}")
+
+
+def test_stream_kernel_eligibility(ctx, switch):
+    """what it must leave to the other kernels: an un-cleared canvas, a layer of another geometry or class, fill paint, opacity
+    outside [0, 1], a flip, a strong reduction, plane rows that are not a multiple of 16 bytes, more than four layers"""
+    base = _stack("img_nv12_bgra", 480, 272, A, (1.0, 0.5))
+    assert run_tick_case(ctx, 320, 180, True, base, expect=None) == WAVE                    # a lone small tick: the strip kernel
+    switch("CHV_BGRA_PATH", "stream")
+    assert run_tick_case(ctx, 320, 180, True, base, expect=None) == STREAM
+    assert run_tick_case(ctx, 320, 180, False, base, expect=None) != STREAM
+    for bad in ([("img_nv12_bgra", 480, 272, dict(A)), ("img_nv12_bgra", 480, 272, dict(R, opacity=0.5))],
+                [("img_nv12_bgra", 480, 272, dict(A)), ("img_y420p_bgra", 480, 272, dict(A, opacity=0.5))],
+                _stack("img_nv12_bgra", 480, 272, dict(A, fill=(0.1, 0.2, 0.3, 0.5)), (1.0, 0.5)),
+                _stack("img_nv12_bgra", 480, 272, A, (1.0, 1.5)),
+                _stack("img_nv12_bgra", 480, 272, dict(tex=(1.0, 0.0, -1.0, 1.0)), (1.0, 0.5)),
+                _stack("img_nv12_bgra", 640, 360, dict(A), (1.0, 0.5)),                      # 2:1 reduction onto 320 columns
+                _stack("img_nv12_bgra", 300, 170, A, (1.0, 0.5)),
+                _stack("img_nv12_bgra", 480, 272, A, (1.0, 0.5, 0.5, 0.5, 0.5))):
+        assert run_tick_case(ctx, 320, 180, True, bad, expect=None) != STREAM
+    switch("CHV_STREAM", "0")
+    assert run_tick_case(ctx, 320, 180, True, base, expect=None) != STREAM
+    switch("CHV_STREAM", "1")
+    switch("CHV_BGRA_PATH", "")
+    # the default route of a launch that fills the chip: 64 two-layer ticks
+    u = [util.make_uniforms((320, 192), in_size=(480, 288), opacity=o) for o in (1.0, 0.5)]
+    srcs = [util.alloc_image("nv12", 480, 288, seed=50 + i) for i in range(2)]
+    exp = util.alloc_image("bgra", 320, 192)
+    assert O.run_kernel("img_clear_bgra", exp) == 0
+    for s_, u_ in zip(srcs, u):
+        assert O.run_kernel("img_nv12_bgra", exp, s_, u_) == 0
+    gs = [G.to_gpu(ctx, "nv12", 480, 288, s_) for s_ in srcs]
+    gds = [G.to_gpu(ctx, "bgra", 320, 192, util.alloc_image("bgra", 320, 192, seed=7)) for _ in range(80)]
+    h, name, keep = G.make_batch(ctx, [(gd, True, [(sv.ComputeKernel.img_nv12_bgra, g, uu, 0) for g, uu in zip(gs, u)]) for gd in gds])
+    assert name == STREAM
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    for gd in (gds[0], gds[41], gds[79]):
+        G.assert_same(G.from_gpu(ctx, gd, "bgra", 320, 192), exp, "80-tick launch through the streaming kernel")
+
+
 @pytest.mark.parametrize("case", list(MIXED_CASES))
 @pytest.mark.parametrize("csc", [0, 1])
 def test_mixed_layers_match_oracle(ctx, path, case, csc):
@@ -284,9 +389,13 @@ def test_random_mixed_ticks(ctx, path, seed):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed} tick {i} ({len(ticks[i][2])} layers) via {name}")
 
 
-def test_pipeline_full_size(ctx):
+@pytest.mark.parametrize("kernel", ["tick_bgra_stream", WAVE])
+def test_pipeline_full_size(ctx, switch, kernel):
     """The headline tick at full size: 4 x 1080p NV12 -> 720p BGRA canvas, opacities 1/.75/.5/.25 == oracle's clear + 4 kernel calls;
-    fused == the sequence of chv_run_kernel launches the reference would issue; replay is idempotent."""
+    fused == the sequence of chv_run_kernel launches the reference would issue; replay is idempotent.  Through the streaming kernel (the
+    route of this tick in a launch that fills the chip; forced here for one tick) and through the strip kernel (a lone tick's route)."""
+    if kernel != WAVE:
+        switch("CHV_BGRA_PATH", "stream")
     sw, sh, dw, dh = 1920, 1080, 1280, 720
     srcs = [util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 48 + i) for i in range(4)]
     us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in (1.0, 0.75, 0.5, 0.25)]
@@ -298,7 +407,7 @@ def test_pipeline_full_size(ctx):
     gd = G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=5))
     layers = [(sv.ComputeKernel.img_nv12_bgra, g, u, 0) for g, u in zip(gs, us)]
     h, name, keep = G.make_batch(ctx, [(gd, True, layers)])
-    assert name == WAVE
+    assert name == kernel
     G.run_batch(ctx, h)
     G.run_batch(ctx, h)
     G.destroy_batch(h)

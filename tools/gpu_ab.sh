@@ -7,7 +7,7 @@ while IFS= read -r line; do
   [ -z "$line" ] && continue
   label=${line%% *}; rest=${line#* }; envs=${rest%%--*}; wls=${rest#*--}
   for wl in $wls; do
-    env $envs timeout 600 python bench.py --workload $wl --also none --no-cpu-baseline --min-seconds 0.5 --steps 10 --warmup 3 $AB_ARGS 2>&1 | tail -1 | \
+    env $envs timeout 600 python bench.py --workload $wl --also none --no-cpu-baseline --min-seconds ${AB_SECONDS:-0.5} --steps 10 --warmup 3 $AB_ARGS 2>&1 | tail -1 | \
     python -c "import sys,json
 try:
     d=json.loads(sys.stdin.read()); print('$label $wl', d['config']['kernel'], 'launch_ms', round(d['roofline']['launch_ms'],4), 'frac', round(d['roofline']['frac'],4), 'verified', d['config']['verified_vs_oracle'])
