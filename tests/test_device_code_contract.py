@@ -97,6 +97,24 @@ def test_lanczos_strip_kernel_keeps_its_prefetch_in_flight(tmp_path):
         assert len(re.findall(r"global_load_dwordx4", body)) >= 16, name
 
 
+def test_stream_kernel_owns_m0_and_keeps_six_waves(tmp_path):
+    """tick_bgra_stream fills its LDS rings with global_load_lds_dwordx4, whose LDS address is M0: set by hand (s_mov_b32 m0) right in
+    front of every such load, and nothing else in the object may touch M0 (the compiler is not told).  Four layers: <= 80 VGPRs
+    (6 waves per SIMD; the rings allow 6), nothing in scratch."""
+    co = _code_object(tmp_path, "kernels_stream")
+    for name, m in _find(_kernels(co), "tick_bgra_stream").items():
+        assert m["vgpr_count"] <= 80 and m["vgpr_spill_count"] == 0 and m.get("private_segment_fixed_size", 0) == 0, (name, m)
+    asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    lines = [l.split("//")[0].strip() for l in asm.splitlines()]
+    lines = [l for l in lines if l and not l.endswith(":")]
+    dma = [i for i, l in enumerate(lines) if l.startswith("global_load_lds_dwordx4")]
+    assert len(dma) >= 8
+    for i in dma:
+        assert any(l.startswith("s_mov_b32 m0") for l in lines[max(0, i - 3):i]), lines[max(0, i - 3):i + 1]
+    others = [l for l in lines if re.search(r"\bm0\b", l) and not l.startswith("s_mov_b32 m0")]
+    assert not others, others[:3]
+
+
 def test_hand_awaited_loads_are_not_touched_while_in_flight(tmp_path):
     """The strip Lanczos kernels issue their row loads from inline asm and wait for them with a hand-written s_waitcnt: the compiler does
     not know the destination registers are still being written.  Two earlier versions of lanczos3_strip<T> let it copy such registers at
