@@ -34,11 +34,13 @@ namespace chv {
 #define CHV_STREAM_MIN_ROWS 16
 #endif
 #ifndef CHV_STREAM_ROUNDS
-#define CHV_STREAM_ROUNDS 48      // chunk height: enough chunks for this many rounds of waves (measured 2 .. 48: 1.59 .. 1.34 ms, flat from 24 on;
-                                  // HBM traffic falls with the height — neighbouring strips drift apart over a tall chunk and re-fetch shared lines)
+#define CHV_STREAM_ROUNDS 12      // chunk height: enough chunks for this many rounds of waves.  With one strip per block and untrimmed requests
+                                  // short chunks won (neighbouring strips drift apart over a tall chunk and fetch shared lines twice: 240 rows 1.59 ms
+                                  // and 1.75x the algorithmic bytes, 30 rows 1.34 ms); with four strips per block and trimmed requests: 3 / 6 / 12 /
+                                  // 18 / 24 / 48 rounds (240 .. 16 rows) = 1.294 / 1.256 / 1.250 / 1.276 / 1.282 / 1.347 ms, traffic 1.00x at 60 rows
 #endif
 #ifndef CHV_STREAM_WAVES
-#define CHV_STREAM_WAVES 5
+#define CHV_STREAM_WAVES 6
 #endif
 
 constexpr int ST_PITCH = 128;                 // bytes per ring row (8 vectors)
@@ -134,14 +136,20 @@ __global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_str
     // 16-byte vectors of a ring row that some tap of the strip can read (the last lane has the largest offsets): the rest is not requested
     const int nvecY = (__builtin_amdgcn_readlane(oy1, 63) >> 4) + 1, nvecC = ((__builtin_amdgcn_readlane(oc1, 63) + 1) >> 4) + 1;
 
-    // per-layer constants (wave-uniform)
+    // per-layer constants (wave-uniform), read once: the asm statements below clobber "memory", and every descriptor read after one of
+    // them would be a fresh scalar load with its latency in the middle of the ring logic
     CscFolded csc[NL];
     float al[NL], ial[NL];
+    const uint8_t *planeY[NL], *planeC[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) {
         csc[l] = csc_fold_biased(kCsc[L[l].csc & 3]);
         al[l] = 1.0f * L[l].u[U_OPACITY]; ial[l] = 1.f - al[l];
+        planeY[l] = L[l].src.pl[0].ptr; planeC[l] = L[l].src.pl[1].ptr;
     }
+    // this lane's place in a batch: (row, vector) and its byte column, luma and chroma
+    const int rrY = (lane >> 3) & 3, rrC = (lane >> 3) & 1;
+    const int colY = min(ycol0 + 16 * (lane & 7), SY.w - 16), colC = min(ccol0 + 16 * (lane & 7), SC.w * 2 - 16);
 
     // the chunk's last tap rows: nothing past them is requested (a chunk's overshoot is another wave's first rows: fetched twice)
     int lastY, lastC;
@@ -214,24 +222,23 @@ __global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_str
             while (ry + ST_YROWS / 2 >= nextY && nextY <= lastY) {
                 // four luma rows of every layer, two layers per instruction; the planes of all layers have one shape (LF_SAME_GEOM)
                 const uint32_t slot = (uint32_t)((((nextY - baseY) >> 2) & 1) * (NL * ST_YL));
-                const int r = min(max(nextY + ((lane >> 3) & 3), 0), SY.h - 1);
-                const size_t roff = (size_t)r * SY.pitch + (size_t)min(ycol0 + 16 * (lane & 7), SY.w - 16);
+                const int r = min(max(nextY + rrY, 0), SY.h - 1);
+                const size_t roff = (size_t)r * SY.pitch + (size_t)colY;
 #pragma unroll
                 for (int l0 = 0; l0 < NL; l0 += 2) {
-                    const uint8_t *pa = L[l0].src.pl[0].ptr, *pb = L[l0 + 1 < NL ? l0 + 1 : l0].src.pl[0].ptr;
-                    st_dma((lane < 32 ? pa : pb) + roff, (lane < 32 || l0 + 1 < NL) && (lane & 7) < nvecY && nextY + ((lane >> 3) & 3) <= lastY, lds0 + slot + (uint32_t)(l0 * ST_YL));
+                    const uint8_t *pa = planeY[l0], *pb = planeY[l0 + 1 < NL ? l0 + 1 : l0];
+                    st_dma((lane < 32 ? pa : pb) + roff, (lane < 32 || l0 + 1 < NL) && (lane & 7) < nvecY && nextY + rrY <= lastY, lds0 + slot + (uint32_t)(l0 * ST_YL));
                 }
                 nextY += 4; issued += (NL + 1) / 2; seqY = issued;
             }
             while (rc + ST_CROWS / 2 >= nextC && nextC <= lastC) {
                 // two chroma rows of every layer in one instruction
                 const uint32_t slot = (uint32_t)(2 * NL * ST_YL + (((nextC - baseC) >> 1) & 1) * (NL * ST_CL));
-                const int r = min(max(nextC + ((lane >> 3) & 1), 0), SC.h - 1);
-                const size_t roff = (size_t)r * SC.pitch + (size_t)min(ccol0 + 16 * (lane & 7), SC.w * 2 - 16);
+                const int r = min(max(nextC + rrC, 0), SC.h - 1);
+                const size_t roff = (size_t)r * SC.pitch + (size_t)colC;
                 const int li = lane >> 4;
-                const uint8_t *p0 = L[0].src.pl[1].ptr, *p1 = L[NL > 1 ? 1 : 0].src.pl[1].ptr, *p2 = L[NL > 2 ? 2 : 0].src.pl[1].ptr, *p3 = L[NL > 3 ? 3 : 0].src.pl[1].ptr;
-                const uint8_t *pl = li == 0 ? p0 : li == 1 ? p1 : li == 2 ? p2 : p3;
-                st_dma(pl + roff, li < NL && (lane & 7) < nvecC && nextC + ((lane >> 3) & 1) <= lastC, lds0 + slot);
+                const uint8_t *pl = li == 0 ? planeC[0] : li == 1 ? planeC[NL > 1 ? 1 : 0] : li == 2 ? planeC[NL > 2 ? 2 : 0] : planeC[NL > 3 ? 3 : 0];
+                st_dma(pl + roff, li < NL && (lane & 7) < nvecC && nextC + rrC <= lastC, lds0 + slot);
                 nextC += 2; issued += 1; seqC = issued;
             }
             // (first row of a chunk, rows skipped by a strong reduction: what was just requested is needed now)
