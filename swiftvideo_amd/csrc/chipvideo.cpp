@@ -28,6 +28,7 @@
 namespace chv {
 const char *bgra_wave_build_flags();      // kernels_wave.hip.cpp
 const char *yuv_wave_build_flags();       // kernels_wave_yuv.hip.cpp
+const char *bgra_stream_build_flags();   // kernels_stream.hip.cpp
 hipError_t launch_tick_general(int target_format, const DTick *ticks, const DLayer *layers,
                                int n_ticks, int maxW, int maxH, hipStream_t stream);
 hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
@@ -91,7 +92,7 @@ extern "C" int chv_debug_set_switch(const char *name, const char *value) {
     return CHV_OK;
 }
 extern "C" const char *chv_build_flags(void) {
-    static const std::string flags = std::string("arch=gfx950;fp_contract=off;") + bgra_wave_build_flags() + ";" + yuv_wave_build_flags();
+    static const std::string flags = std::string("arch=gfx950;fp_contract=off;") + bgra_wave_build_flags() + ";" + yuv_wave_build_flags() + ";" + bgra_stream_build_flags();
     return flags.c_str();
 }
 

@@ -294,6 +294,11 @@ static bool stream_plane_ok(const DPlane &p) {
 
 // every tick: cleared canvas, the same number (1..4) of NV12 -> BGRA layers of one geometry, axis-aligned and bounded, no flips, no fill,
 // opacities in [0, 1], a strip's source columns within one 128-byte ring row
+#define CHV_STR2(x) #x
+#define CHV_STR(x) CHV_STR2(x)
+// what this translation unit was built with (chv_build_flags; a timing-only CHV_ST_ABL build must never ship)
+const char *bgra_stream_build_flags() { return "tick_bgra_stream:abl=" CHV_STR(CHV_ST_ABL) ",strips_per_block=" CHV_STR(CHV_STREAM_BLOCK) ",rounds=" CHV_STR(CHV_STREAM_ROUNDS); }
+
 bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks) {
     if (n_ticks < 1 || !switches().stream.load(std::memory_order_relaxed)) return false;
     const int nl = ticks[0].n_layers;
