@@ -173,10 +173,11 @@ def test_stream_kernel_matches_oracle(ctx, switch, case):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_random_stream_ticks(ctx, seed):
+def test_random_stream_ticks(ctx, switch, seed):
     """Seeded random ticks of the streaming kernel's class: three ticks of different canvas sizes per launch, 2..4 NV12 layers of one
     geometry each — full canvas or a rectangle anywhere (also across the canvas edges), enlargements and reductions up to 1.7 across
     and anything down, a texture window now and then, per-layer colourspaces and opacities."""
+    switch("CHV_BGRA_PATH", "stream")                   # (three small ticks: the default route would be the strip kernel)
     rng = np.random.default_rng(7100 + seed)
     nl = int(rng.integers(2, 5))
     ticks, exps, gds = [], [], []
