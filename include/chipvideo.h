@@ -326,7 +326,8 @@ int chv_run_custom(chv_context *ctx, const char *name, const chv_image *target,
 
 /* ---- resampling --------------------------------------------------------- */
 /* Separable Lanczos-3 resize of a 4-component image (BGRA or RGBA) from `src`
- * to `dst` size.  No reference counterpart; DESIGN.md section 4.4. */
+ * to `dst` size.  No reference counterpart; DESIGN.md section 4.4.  Reductions whose 8 x 4 output tile needs more than 160 KB of staged
+ * source (about 24:1 on one axis, about 17:1 on both at once) are refused with CHV_ERR_INVALID_VALUE: nothing is written. */
 int chv_scale_lanczos(chv_context *ctx, const chv_image *dst, const chv_image *src);
 /* n resizes of one geometry (every src of one size, every dst of one size) in one launch per CHV_LANCZOS_BATCH_CHUNK pairs;
  * same bytes as n calls of chv_scale_lanczos.  Other geometries in the list -> CHV_ERR_INVALID_VALUE, nothing is launched. */

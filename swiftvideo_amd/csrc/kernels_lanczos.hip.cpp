@@ -574,7 +574,7 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
     size_t lds = dims(32, 16, &max_rows, &max_cols);
     const bool small_tiles = lds > 64 * 1024;                 // reduction factors beyond about 4
     if (small_tiles) lds = dims(8, 4, &max_rows, &max_cols);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;        // beyond about 24:1
+    if (lds > 160 * 1024) return hipErrorInvalidValue;        // beyond about 24:1 on one axis, about 17:1 on both
     const int tw = small_tiles ? 8 : 32, th = small_tiles ? 4 : 16;
     // Tiles per block: a block lives for `ks` tile times and the chip holds 256 CUs x floor(160 KB / lds) blocks at once,
     // so the launch takes about ceil(blocks / resident) * ks tile times; pick the ks in 2..8 that minimises it (ties: the

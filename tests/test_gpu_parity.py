@@ -358,7 +358,9 @@ def test_lanczos_random_geometries(ctx, seed):
     try:
         sv.usingContext(ctx, lambda c: sv.scaleLanczos(c, gd, gs))
     except sv.ComputeError:
-        assert max(iw / ow, ih / oh) > 20               # beyond about 24:1 the library refuses (LDS): nothing else may fail
+        # the library refuses reductions whose 8 x 4 tile needs more than 160 KB of staged source (about 24:1 on one axis, about 17:1 on
+        # both at once: include/chipvideo.h); nothing else may fail
+        assert max(iw / ow, ih / oh) > 20 or min(iw / ow, ih / oh) > 14
         return
     G.assert_same(G.from_gpu(ctx, gd, "bgra", ow, oh), exp, f"lanczos {iw}x{ih} -> {ow}x{oh}")
 
