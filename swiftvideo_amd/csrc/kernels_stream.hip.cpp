@@ -71,6 +71,8 @@ CHV_DEV void st_yuv_to_bgr(const CscFolded &k, int y, int u, int v, float &fb, f
 
 // One load instruction: lane -> (layer li, row rr of the batch, vector vec); `p` is the lane's own 16-byte source address, its LDS
 // destination is m0 + lane * 16 (tools/probe_lds_dma.cpp).
+// (M0 is a reserved register to hipcc: it cannot be named as a clobber — "may lead to undefined behaviour" — so the statement sets it itself
+// every time, and tests/test_device_code_contract.py checks on the built code that nothing else in this kernel reads or writes M0.)
 CHV_DEV void st_dma(const uint8_t *p, bool active, uint32_t m0) {
     if (active && !(CHV_ST_ABL & 1))
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0), "v"(p) : "memory");
