@@ -437,11 +437,13 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
         return wave_layers_eligible(target_format, ticks, layers, n_ticks) ? (target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P) : FP_NONE;
     // ticks of 2..4 full-frame NV12 layers of one geometry on a cleared canvas: rows outermost, layers innermost (kernels_stream.hip.cpp);
     // one-layer ticks only on request (CHV_BGRA_PATH=stream)
-    // (a lone tick keeps the strip kernel: 33.3 against 35.3 us with the host wait — its waves are shorter)
+    // (one or two 720p ticks per launch keep the strip kernel: 22.8 against 24.2 us for two, 33.3 against 35.3 us for one with the host
+    // wait; from three ticks on the streaming kernel is level or ahead — 4 / 8 / 16 / 64 ticks: 33.1 / 55.0 / 93.3 / 340 us against
+    // 35.7 / 58.1 / 109.6 / 393, tools/stream_threshold_sweep.sh)
     if ((bp == 0 || bp == 3) && bgra_stream_eligible(ticks, layers, n_ticks)) {
         long strips = 0;
         for (int i = 0; i < n_ticks; i++) strips += (long)((ticks[i].W + 63) / 64) * ((ticks[i].H + 15) / 16);
-        if (bp == 3 || (ticks[0].n_layers >= 2 && strips >= 4096)) return FP_STREAM;
+        if (bp == 3 || (ticks[0].n_layers >= 2 && strips >= 2560)) return FP_STREAM;
     }
     if (bp != 1) {
         int p = select_single_purpose(ticks, layers, n_ticks);
