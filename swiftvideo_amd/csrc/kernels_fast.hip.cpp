@@ -436,14 +436,11 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     if (target_format != TF_BGRA)
         return wave_layers_eligible(target_format, ticks, layers, n_ticks) ? (target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P) : FP_NONE;
     // ticks of 2..4 full-frame NV12 layers of one geometry on a cleared canvas: rows outermost, layers innermost (kernels_stream.hip.cpp);
-    // one-layer ticks only on request (CHV_BGRA_PATH=stream)
-    // (one or two 720p ticks per launch keep the strip kernel: 22.8 against 24.2 us for two, 33.3 against 35.3 us for one with the host
-    // wait; from three ticks on the streaming kernel is level or ahead — 4 / 8 / 16 / 64 ticks: 33.1 / 55.0 / 93.3 / 340 us against
-    // 35.7 / 58.1 / 109.6 / 393, tools/stream_threshold_sweep.sh)
+    // one-layer ticks only on request (CHV_BGRA_PATH=stream).  Launches of every size: the streaming kernel takes its chunk height as an
+    // argument, and with 4-row chunks a lone 720p tick is 10.9 us on the chip against ~17 through 8-row strips of the strip kernel
+    // (26.4 against 33.7 us per tick with the host wait; tools/tick_rows_sweep.sh, tools/stream_threshold_sweep.sh).
     if ((bp == 0 || bp == 3) && bgra_stream_eligible(ticks, layers, n_ticks)) {
-        long strips = 0;
-        for (int i = 0; i < n_ticks; i++) strips += (long)((ticks[i].W + 63) / 64) * ((ticks[i].H + 15) / 16);
-        if (bp == 3 || (ticks[0].n_layers >= 2 && strips >= 2560)) return FP_STREAM;
+        if (bp == 3 || ticks[0].n_layers >= 2) return FP_STREAM;
     }
     if (bp != 1) {
         int p = select_single_purpose(ticks, layers, n_ticks);

@@ -30,8 +30,17 @@ namespace chv {
 #ifndef CHV_ST_ABL
 #define CHV_ST_ABL 0        // timing-only (wrong pixels): 1 no ring fills, 2 no canvas stores
 #endif
+#ifndef CHV_STREAM_ROWS_FIXED
+#define CHV_STREAM_ROWS_FIXED 0
+#endif
+#ifndef CHV_STREAM_SMALL_WAVES
+#define CHV_STREAM_SMALL_WAVES 4800       // waves a small launch is cut into (launch_bgra_stream)
+#endif
+#ifndef CHV_STREAM_SMALL_ROWS_MAX
+#define CHV_STREAM_SMALL_ROWS_MAX 12
+#endif
 #ifndef CHV_STREAM_MIN_ROWS
-#define CHV_STREAM_MIN_ROWS 16
+#define CHV_STREAM_MIN_ROWS 4
 #endif
 #ifndef CHV_STREAM_ROUNDS
 #define CHV_STREAM_ROUNDS 12      // chunk height: enough chunks for this many rounds of waves.  With one strip per block and untrimmed requests
@@ -334,11 +343,19 @@ bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks)
 hipError_t launch_bgra_stream(const DTick *ticks_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream) {
     const int nl = ticks_host[0].n_layers;
     const int strips_x = (maxW + 63) / 64;
-    // rows per chunk: tall chunks amortise the per-chunk geometry and the first ring fill; enough chunks to fill the chip a few times
+    // rows per chunk.  Launches that fill the chip: tall chunks amortise the per-chunk geometry and the first ring fill — enough chunks for
+    // CHV_STREAM_ROUNDS rounds of waves.  Small launches (a Swift VideoMixer issues ONE tick and waits): a wave's rows are a serial chain — a lone
+    // wave issues an instruction every ~2.3 ns and sits out every memory round trip itself — so the chain is cut short, down to 4 rows,
+    // until about 4 800 waves share the launch (tools/stream_rows_sweep.sh, 720p ticks, us per launch at 4 / 6 / 8 / 12 / 16 / 24 rows:
+    // one tick 10.9 / 12.4 / 13.2 / 18.0 / 20.0 / 28.2; two 18.9 / 17.6 / 18.8 / 21.9 / 24.0 / 33.7; eight 54.2 / 51.2 / 51.8 / 51.0 / 54.6 / 52.3;
+    // sixteen 104.5 / 97.2 / 95.7 / 91.6 / 93.8 / 94.3).
     const long want = 1024L * CHV_STREAM_WAVES * CHV_STREAM_ROUNDS;
-    long chunks = std::max<long>(1, want / std::max<long>(1, (long)n_ticks * strips_x));
-    int rows = (int)std::max<long>(CHV_STREAM_MIN_ROWS, (maxH + chunks - 1) / chunks);
-    rows = std::min(rows, maxH);
+    const long chunks = std::max<long>(1, want / std::max<long>(1, (long)n_ticks * strips_x));
+    const long wave_rows = (long)n_ticks * strips_x * maxH;
+    const long rows_small = std::min<long>(CHV_STREAM_SMALL_ROWS_MAX, std::max<long>(CHV_STREAM_MIN_ROWS, (wave_rows + CHV_STREAM_SMALL_WAVES - 1) / CHV_STREAM_SMALL_WAVES));
+    int rows = (int)std::max<long>(rows_small, (maxH + chunks - 1) / chunks);
+    if (CHV_STREAM_ROWS_FIXED > 0) rows = CHV_STREAM_ROWS_FIXED;      // (sweeps: tools/build_variant.sh ... -DCHV_STREAM_ROWS_FIXED=n)
+    rows = std::max(1, std::min(rows, maxH));
     const int chunks_y = (maxH + rows - 1) / rows;
     const long total = (long)n_ticks * chunks_y * ((strips_x + ST_WAVES - 1) / ST_WAVES);
     dim3 grid((unsigned)(((total + 7) / 8) * 8));

@@ -218,9 +218,11 @@ def test_stream_kernel_eligibility(ctx, switch):
     """what it must leave to the other kernels: an un-cleared canvas, a layer of another geometry or class, fill paint, opacity
     outside [0, 1], a flip, a strong reduction, plane rows that are not a multiple of 16 bytes, more than four layers"""
     base = _stack("img_nv12_bgra", 480, 272, A, (1.0, 0.5))
-    assert run_tick_case(ctx, 320, 180, True, base, expect=None) == WAVE                    # a lone small tick: the strip kernel
+    assert run_tick_case(ctx, 320, 180, True, base, expect=None) == STREAM                  # launches of every size (short chunks for small ones)
+    assert run_tick_case(ctx, 320, 180, True, base[:1], expect=None) != STREAM              # one-layer ticks: only on request
     switch("CHV_BGRA_PATH", "stream")
     assert run_tick_case(ctx, 320, 180, True, base, expect=None) == STREAM
+    assert run_tick_case(ctx, 320, 180, True, base[:1], expect=None) == STREAM
     assert run_tick_case(ctx, 320, 180, False, base, expect=None) != STREAM
     for bad in ([("img_nv12_bgra", 480, 272, dict(A)), ("img_nv12_bgra", 480, 272, dict(R, opacity=0.5))],
                 [("img_nv12_bgra", 480, 272, dict(A)), ("img_y420p_bgra", 480, 272, dict(A, opacity=0.5))],
@@ -260,10 +262,14 @@ def test_mixed_layers_match_oracle(ctx, path, case, csc):
     run_tick_case(ctx, cw, ch, clear, specs, csc=csc, expect=None if case == "down_4x" else path)
 
 
-def test_default_route_of_a_mixed_tick(ctx):
-    """without any switch: several YUV layers / mixed kinds -> the wave kernel; one YUV layer, RGB layers only -> single-purpose kernels"""
+def test_default_route_of_a_mixed_tick(ctx, switch):
+    """without any switch: a stack of NV12 videos of one geometry on a cleared canvas -> the streaming kernel (the strip kernel with
+    CHV_STREAM=0); mixed kinds -> the strip kernel; one YUV layer, RGB layers only -> single-purpose kernels"""
     cw, ch, clear, specs = MIXED_CASES["pipeline_small"]
+    assert run_tick_case(ctx, cw, ch, clear, specs, expect=None) == STREAM
+    switch("CHV_STREAM", "0")
     assert run_tick_case(ctx, cw, ch, clear, specs, expect=None) == WAVE
+    switch("CHV_STREAM", "1")
     cw, ch, clear, specs = MIXED_CASES["video_overlays"]
     assert run_tick_case(ctx, cw, ch, clear, specs, expect=None) == WAVE
 
@@ -394,9 +400,10 @@ def test_random_mixed_ticks(ctx, path, seed):
 def test_pipeline_full_size(ctx, switch, kernel):
     """The headline tick at full size: 4 x 1080p NV12 -> 720p BGRA canvas, opacities 1/.75/.5/.25 == oracle's clear + 4 kernel calls;
     fused == the sequence of chv_run_kernel launches the reference would issue; replay is idempotent.  Through the streaming kernel (the
-    route of this tick in a launch that fills the chip; forced here for one tick) and through the strip kernel (a lone tick's route)."""
-    if kernel != WAVE:
-        switch("CHV_BGRA_PATH", "stream")
+    default route of this tick in launches of every size) and through the strip kernel (CHV_STREAM=0; the route of every stack the
+    streaming kernel does not take)."""
+    if kernel == WAVE:
+        switch("CHV_STREAM", "0")
     sw, sh, dw, dh = 1920, 1080, 1280, 720
     srcs = [util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 48 + i) for i in range(4)]
     us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in (1.0, 0.75, 0.5, 0.25)]
