@@ -37,6 +37,7 @@ hipError_t launch_selftest_pack(const int *b, const int *g, const int *r, uint32
 hipError_t launch_selftest_pack_codes(const float *in, uint32_t *out, int n, hipStream_t stream);
 // kernels_fast.hip.cpp
 const char *fast_path_name(int path);
+bool fast_path_by_value(int path);      // a lone tick's descriptors can travel as kernel arguments (ticks == layers == nullptr)
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
@@ -61,7 +62,7 @@ static int parse_switch(const char *name, const char *value, int *out) {
     if (n == "CHV_WAVE_ROWS") { *out = v == "8" ? 8 : v == "16" ? 16 : 0; return 2; }
     if (n == "CHV_TILE_ROWS") { *out = v == "16" ? 16 : v == "32" ? 32 : 0; return 3; }
     if (n == "CHV_SAME_GEOM") { *out = v == "0" ? 0 : 1; return 4; }
-    if (n == "CHV_DESC") { *out = v == "host" ? 1 : 0; return 5; }
+    if (n == "CHV_DESC") { *out = v == "host" ? 1 : v == "device" ? 2 : 0; return 5; }
     if (n == "CHV_STREAM") { *out = v == "0" ? 0 : 1; return 6; }
     return -1;
 }
@@ -911,16 +912,23 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     // is a trip across PCIe (~1.5 us, uncached): a 4-layer 720p tick took 31 us of kernel time, 5 us per layer, whatever was done on
     // the chip (tools/tick_latency.py).  So the slot is copied to its twin in device memory on the launch's own stream first
     // (one small asynchronous copy), and the waves read L2 / scalar-cache resident descriptors.  CHV_DESC=host keeps the old way (A/B).
+    // The streaming kernel goes one better for a lone tick: its descriptors travel as kernel ARGUMENTS (tick_bgra_stream_one) — no copy
+    // in front of the launch, and every field a scalar load from one base instead of the tick -> layer chain.  CHV_DESC=device keeps the
+    // copy for it too (A/B).
     DTick *dt = nullptr;
     const size_t used = sizeof(DTick) + layers.size() * sizeof(DLayer);
-    if (switches().desc_host.load(std::memory_order_relaxed)) {
+    int path = select_fast_path(tf, ht, hl, 1);
+    const int desc_mode = switches().desc_host.load(std::memory_order_relaxed);       // 0 default, 1 host ring, 2 device twin always
+    const bool by_value = fast_path_by_value(path) && desc_mode == 0;
+    if (by_value) {
+        dt = nullptr;
+    } else if (desc_mode == 1) {
         HIP_TRY(hipHostGetDevicePointer((void **)&dt, ht, 0));
     } else {
         dt = (DTick *)(c->desc_dev + (size_t)slot * kDescSlotBytes);
         HIP_TRY(hipMemcpyAsync(dt, ht, used, hipMemcpyHostToDevice, c->stream));
     }
-    DLayer *dl = (DLayer *)((uint8_t *)dt + sizeof(DTick));
-    int path = select_fast_path(tf, ht, hl, 1);
+    DLayer *dl = by_value ? nullptr : (DLayer *)((uint8_t *)dt + sizeof(DTick));
     (void)hipGetLastError();   // the launchers report through hipGetLastError(): drop whatever an earlier, unrelated call left there
     hipError_t e = path >= 0 ? launch_tick_fast(path, ht, hl, dt, dl, 1, ht->W, ht->H, c->stream)
                              : launch_tick_general(tf, dt, dl, 1, ht->W, ht->H, c->stream);

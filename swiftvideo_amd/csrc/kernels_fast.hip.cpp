@@ -39,7 +39,7 @@ enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_Y420P_BGRA_TILED 
 bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
 // kernels_stream.hip.cpp
 bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
-hipError_t launch_bgra_stream(const DTick *ticks_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream);
+hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream);
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream);
 
@@ -457,10 +457,12 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     return wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks) ? FP_WAVE_LAYERS : FP_NONE;
 }
 
+bool fast_path_by_value(int path) { return path == FP_STREAM; }
+
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
-    if (path == FP_STREAM) return launch_bgra_stream(ticks_host, ticks, layers, n_ticks, maxW, maxH, stream);
+    if (path == FP_STREAM) return launch_bgra_stream(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_LAYERS) return launch_wave_layers(TF_BGRA, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_NV12) return launch_wave_layers(TF_NV12, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_Y420P) return launch_wave_layers(TF_Y420P, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);

@@ -21,6 +21,7 @@
 #include "switches.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 
 #pragma clang fp contract(off)
@@ -87,9 +88,11 @@ CHV_DEV void st_dma(const uint8_t *p, bool active, uint32_t m0) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0), "v"(p) : "memory");
 }
 
-template <int NL>
-__global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_stream(const DTick *__restrict__ ticks, const DLayer *__restrict__ layers, int n_ticks,
-                                                                          int strips_x, int chunks_y, int rows_per_chunk) {
+// ONE: a launch of one tick whose descriptors are kernel ARGUMENTS (tick_bgra_stream_one below) — `ticks` / `layers` point into the kernarg
+// segment, every field is a scalar load at a constant offset from one base, issued together: no tick -> first_layer -> layer chain of
+// dependent loads in front of a lone tick's waves, and no descriptor copy in front of the launch.
+template <int NL, bool ONE>
+CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restrict__ layers, int n_ticks, int strips_x, int chunks_y, int rows_per_chunk) {
     // ST_WAVES independent waves per block, on neighbouring strips (no barrier anywhere): their source windows overlap by a vector or two,
     // and waves of one block start together on one CU — the shared lines are fetched once (HBM traffic 1.47x -> see profiles/r03_notes.md)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_str
     const int tick = idx / (chunks_y * groups_x), rem = idx - tick * (chunks_y * groups_x);
     const int chunk = rem / groups_x, strip = (rem - chunk * groups_x) * ST_WAVES + wave;
     if (strip >= strips_x) return;
-    const DTick &T = ticks[tick];
-    const DLayer *L = layers + T.first_layer;
+    const DTick &T = ticks[ONE ? 0 : tick];
+    const DLayer *L = layers + (ONE ? 0 : T.first_layer);
     const int x0 = strip * 64, y0 = chunk * rows_per_chunk;
     if (x0 >= T.W || y0 >= T.H) return;
     const int nrows = min(rows_per_chunk, T.H - y0);
@@ -296,6 +299,23 @@ __global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_str
     if (nrows > 0 && x < T.W && !(CHV_ST_ABL & 2)) gst_at<uint32_t>(D.ptr + (size_t)(y0 + nrows - 1) * D.pitch, (uint32_t)x * 4u, pending);
 }
 
+template <int NL>
+__global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_stream(const DTick *__restrict__ ticks, const DLayer *__restrict__ layers, int n_ticks,
+                                                                          int strips_x, int chunks_y, int rows_per_chunk) {
+    stream_body<NL, false>(ticks, layers, n_ticks, strips_x, chunks_y, rows_per_chunk);
+}
+
+// one tick, descriptors by value (96 + NL x 344 bytes of kernel arguments)
+template <int NL>
+struct StreamOne {
+    DTick t;
+    DLayer l[NL];
+};
+template <int NL>
+__global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_stream_one(const StreamOne<NL> a, int strips_x, int chunks_y, int rows_per_chunk) {
+    stream_body<NL, true>(&a.t, a.l, 1, strips_x, chunks_y, rows_per_chunk);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -340,7 +360,8 @@ bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks)
     return true;
 }
 
-hipError_t launch_bgra_stream(const DTick *ticks_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream) {
+// ticks == nullptr: one tick, launched with its descriptors (ticks_host[0], layers_host) as kernel arguments
+hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream) {
     const int nl = ticks_host[0].n_layers;
     const int strips_x = (maxW + 63) / 64;
     // rows per chunk.  Launches that fill the chip: tall chunks amortise the per-chunk geometry and the first ring fill — enough chunks for
@@ -360,6 +381,24 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DTick *ticks, const
     const long total = (long)n_ticks * chunks_y * ((strips_x + ST_WAVES - 1) / ST_WAVES);
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     const size_t lds = (size_t)ST_WAVES * ((size_t)nl * ST_LAYER + ST_TAB * (sizeof(uint4) + sizeof(uint32_t)));
+    if (!ticks) {
+        // one tick, descriptors as kernel arguments (launch_transient)
+        auto go = [&](auto tag) {
+            constexpr int NL = decltype(tag)::value;
+            StreamOne<NL> a;
+            a.t = ticks_host[0];
+            a.t.first_layer = 0;
+            for (int l = 0; l < NL; l++) a.l[l] = layers_host[ticks_host[0].first_layer + l];
+            hipLaunchKernelGGL(tick_bgra_stream_one<NL>, grid, dim3(64 * ST_WAVES), lds, stream, a, strips_x, chunks_y, rows);
+        };
+        switch (nl) {
+        case 1: go(std::integral_constant<int, 1>{}); break;
+        case 2: go(std::integral_constant<int, 2>{}); break;
+        case 3: go(std::integral_constant<int, 3>{}); break;
+        default: go(std::integral_constant<int, 4>{}); break;
+        }
+        return hipGetLastError();
+    }
     switch (nl) {
     case 1: hipLaunchKernelGGL(tick_bgra_stream<1>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;
     case 2: hipLaunchKernelGGL(tick_bgra_stream<2>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;

@@ -15,7 +15,8 @@ struct Switches {
     std::atomic<int> wave_rows{0};       // 8 | 16: strip height of the wave kernels
     std::atomic<int> tile_rows{0};       // 16 | 32: tile height of the tiled YUV -> BGRA kernel
     std::atomic<int> same_geom{1};       // 0: do not share a layer's geometry with its predecessor (A/B of LF_SAME_GEOM)
-    std::atomic<int> desc_host{0};       // 1: transient launches read their descriptors from the pinned host ring (A/B; default: device copy)
+    std::atomic<int> desc_host{0};       // CHV_DESC, a transient launch's descriptors: 0 kernel arguments where the kernel takes them (tick_bgra_stream_one), else a device
+                                         // copy; 1 (host) read from the pinned host ring; 2 (device) the device copy always (A/Bs)
     std::atomic<int> stream{1};          // 0: never tick_bgra_stream (A/B; CHV_BGRA_PATH=stream: also for one-layer ticks)
 };
 Switches &switches();                    // (chipvideo.cpp; initialised from the environment on first use)

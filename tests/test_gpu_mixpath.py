@@ -172,6 +172,33 @@ def test_stream_kernel_matches_oracle(ctx, switch, case):
     run_tick_case(ctx, cw, ch, True, specs, expect=STREAM, seed=171)
 
 
+@pytest.mark.parametrize("desc", ["arguments", "device", "host"])
+@pytest.mark.parametrize("case", list(STREAM_CASES))
+def test_lone_stream_tick_matches_oracle(ctx, switch, case, desc):
+    """One tick at a time (chv_composite, what a Swift VideoMixer issues): the streaming kernel takes the tick's descriptors as kernel
+    arguments (tick_bgra_stream_one); CHV_DESC=device / host: the copy in device memory / the pinned host ring, through the pointer kernel."""
+    if desc != "arguments":
+        switch("CHV_DESC", desc)
+    cw, ch, specs = STREAM_CASES[case]
+    if len(specs) == 1:
+        switch("CHV_BGRA_PATH", "stream")
+    canvas0 = util.alloc_image("bgra", cw, ch, seed=333)
+    exp = util.copy_image(canvas0)
+    assert O.run_kernel("img_clear_bgra", exp) == 0
+    layers = []
+    for i, (k, sw, sh, kw) in enumerate(specs):
+        kw = dict(kw)
+        lcsc = kw.pop("csc", 0)
+        u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+        src = util.alloc_image("nv12", sw, sh, seed=340 + i)
+        assert O.run_kernel(k, exp, src, u, csc=lcsc, threads=4) == 0
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, "nv12", sw, sh, src), u, lcsc))
+    gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+    for _ in range(2):                                   # (twice: the second tick finds the first one's canvas)
+        sv.usingContext(ctx, lambda c: sv.compositeTick(c, gd, layers, True))
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"lone tick, descriptors: {desc}")
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_stream_ticks(ctx, switch, seed):
     """Seeded random ticks of the streaming kernel's class: three ticks of different canvas sizes per launch, 2..4 NV12 layers of one
