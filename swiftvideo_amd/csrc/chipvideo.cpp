@@ -38,7 +38,7 @@ hipError_t launch_selftest_pack_codes(const float *in, uint32_t *out, int n, hip
 // kernels_fast.hip.cpp
 const char *fast_path_name(int path);
 bool fast_path_by_value(int path);      // a lone tick's descriptors can travel as kernel arguments (ticks == layers == nullptr)
-int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
+int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks, bool transient = false);   // transient: one tick, launched once
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream);
@@ -917,8 +917,8 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     // copy for it too (A/B).
     DTick *dt = nullptr;
     const size_t used = sizeof(DTick) + layers.size() * sizeof(DLayer);
-    int path = select_fast_path(tf, ht, hl, 1);
     const int desc_mode = switches().desc_host.load(std::memory_order_relaxed);       // 0 default, 1 host ring, 2 device twin always
+    int path = select_fast_path(tf, ht, hl, 1, desc_mode == 0);
     const bool by_value = fast_path_by_value(path) && desc_mode == 0;
     if (by_value) {
         dt = nullptr;

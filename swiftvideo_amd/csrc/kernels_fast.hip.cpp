@@ -424,7 +424,7 @@ static int select_single_purpose(const DTick *ticks, const DLayer *layers, int n
     return layers[ticks[0].first_layer].kind == LK_BGRA_FROM_Y420P ? FP_Y420P_BGRA_TILED : FP_NV12_BGRA_TILED;
 }
 
-int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
+int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks, bool transient) {
     if (n_ticks <= 0) return FP_NONE;
     // A/B switches for measurements and tests (switches.h: environment read once, chv_debug_set_switch afterwards):
     //   force_general (CHV_FORCE_GENERAL=1)  everything through the general kernels
@@ -436,11 +436,14 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     if (target_format != TF_BGRA)
         return wave_layers_eligible(target_format, ticks, layers, n_ticks) ? (target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P) : FP_NONE;
     // ticks of 2..4 full-frame NV12 layers of one geometry on a cleared canvas: rows outermost, layers innermost (kernels_stream.hip.cpp);
-    // one-layer ticks only on request (CHV_BGRA_PATH=stream).  Launches of every size: the streaming kernel takes its chunk height as an
+    // one-layer ticks: a transient launch (chv_composite / chv_run_kernel: 19.7 against 22.6 us with the host wait through the tiled kernel —
+    // its descriptors travel as kernel arguments, tools/tick_rows_sweep.sh; a one-tick BATCH reads them through pointers and is level with
+    // the tiled kernel, which keeps it), otherwise on request (CHV_BGRA_PATH=stream; cfg2's 256-tick launches: 0.55 against 0.44 ms).
+    // Launches of every size: the streaming kernel takes its chunk height as an
     // argument, and with 4-row chunks a lone 720p tick is 10.9 us on the chip against ~17 through 8-row strips of the strip kernel
     // (26.4 against 33.7 us per tick with the host wait; tools/tick_rows_sweep.sh, tools/stream_threshold_sweep.sh).
     if ((bp == 0 || bp == 3) && bgra_stream_eligible(ticks, layers, n_ticks)) {
-        if (bp == 3 || ticks[0].n_layers >= 2) return FP_STREAM;
+        if (bp == 3 || ticks[0].n_layers >= 2 || transient) return FP_STREAM;
     }
     if (bp != 1) {
         int p = select_single_purpose(ticks, layers, n_ticks);

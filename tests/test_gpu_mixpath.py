@@ -180,8 +180,8 @@ def test_lone_stream_tick_matches_oracle(ctx, switch, case, desc):
     if desc != "arguments":
         switch("CHV_DESC", desc)
     cw, ch, specs = STREAM_CASES[case]
-    if len(specs) == 1:
-        switch("CHV_BGRA_PATH", "stream")
+    if len(specs) == 1 and desc != "arguments":
+        switch("CHV_BGRA_PATH", "stream")                # (a lone one-layer tick takes the streaming kernel only with by-value descriptors)
     canvas0 = util.alloc_image("bgra", cw, ch, seed=333)
     exp = util.copy_image(canvas0)
     assert O.run_kernel("img_clear_bgra", exp) == 0
@@ -246,7 +246,7 @@ def test_stream_kernel_eligibility(ctx, switch):
     outside [0, 1], a flip, a strong reduction, plane rows that are not a multiple of 16 bytes, more than four layers"""
     base = _stack("img_nv12_bgra", 480, 272, A, (1.0, 0.5))
     assert run_tick_case(ctx, 320, 180, True, base, expect=None) == STREAM                  # launches of every size (short chunks for small ones)
-    assert run_tick_case(ctx, 320, 180, True, base[:1], expect=None) != STREAM              # one-layer ticks: only on request
+    assert run_tick_case(ctx, 320, 180, True, base[:1], expect=None) != STREAM              # one-layer ticks in a batch: only on request
     switch("CHV_BGRA_PATH", "stream")
     assert run_tick_case(ctx, 320, 180, True, base, expect=None) == STREAM
     assert run_tick_case(ctx, 320, 180, True, base[:1], expect=None) == STREAM
