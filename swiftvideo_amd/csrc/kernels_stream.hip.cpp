@@ -383,6 +383,7 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
     const size_t lds = (size_t)ST_WAVES * ((size_t)nl * ST_LAYER + ST_TAB * (sizeof(uint4) + sizeof(uint32_t)));
     if (!ticks) {
         // one tick, descriptors as kernel arguments (launch_transient)
+        if (n_ticks != 1 || !layers_host) return hipErrorInvalidValue;
         auto go = [&](auto tag) {
             constexpr int NL = decltype(tag)::value;
             StreamOne<NL> a;
