@@ -199,14 +199,10 @@ def test_lone_stream_tick_matches_oracle(ctx, switch, case, desc):
     G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"lone tick, descriptors: {desc}")
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_random_stream_ticks(ctx, switch, seed):
-    """Seeded random ticks of the streaming kernel's class: three ticks of different canvas sizes per launch, 2..4 NV12 layers of one
-    geometry each — full canvas or a rectangle anywhere (also across the canvas edges), enlargements and reductions up to 1.7 across
-    and anything down, a texture window now and then, per-layer colourspaces and opacities."""
-    switch("CHV_BGRA_PATH", "stream")                   # (three small ticks: the default route would be the strip kernel)
+def _random_stream_ticks(ctx, seed, nl_low=2):
+    """three ticks of different canvas sizes, nl_low..4 NV12 layers of one geometry each -> (ticks, expected canvases, (canvas, w, h))"""
     rng = np.random.default_rng(7100 + seed)
-    nl = int(rng.integers(2, 5))
+    nl = int(rng.integers(nl_low, 5))
     ticks, exps, gds = [], [], []
     for t in range(3):
         cw, ch = int(rng.integers(20, 330)) * 2, int(rng.integers(8, 200)) * 2
@@ -233,12 +229,31 @@ def test_random_stream_ticks(ctx, switch, seed):
             layers.append((sv.ComputeKernel.img_nv12_bgra, G.to_gpu(ctx, "nv12", sw, sh, src), u, csc))
         gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
         ticks.append((gd, True, layers)); exps.append(exp); gds.append((gd, cw, ch))
+    return ticks, exps, gds
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_stream_ticks(ctx, switch, seed):
+    """Seeded random ticks of the streaming kernel's class: three ticks of different canvas sizes per launch, 2..4 NV12 layers of one
+    geometry each — full canvas or a rectangle anywhere (also across the canvas edges), enlargements and reductions up to 1.7 across
+    and anything down, a texture window now and then, per-layer colourspaces and opacities."""
+    switch("CHV_BGRA_PATH", "stream")
+    ticks, exps, gds = _random_stream_ticks(ctx, seed)
     h, name, keep = G.make_batch(ctx, ticks)
     assert name in (STREAM, WAVE), name                  # (a rectangle wider than 1.7 source texels per pixel: the strip kernel)
     G.run_batch(ctx, h)
     G.destroy_batch(h)
     for i, ((gd, cw, ch), exp) in enumerate(zip(gds, exps)):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed} tick {i} via {name}")
+
+
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_random_lone_stream_ticks(ctx, seed):
+    """the same random ticks (1..4 layers), one at a time through chv_composite: descriptors as kernel arguments (tick_bgra_stream_one)"""
+    ticks, exps, gds = _random_stream_ticks(ctx, seed, nl_low=1)
+    for (gd, clear, layers), exp, (_, cw, ch) in zip(ticks, exps, gds):
+        sv.usingContext(ctx, lambda c: sv.compositeTick(c, gd, layers, True))
+        G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed}, lone tick of {len(layers)} layer(s)")
 
 
 def test_stream_kernel_eligibility(ctx, switch):

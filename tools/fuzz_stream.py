@@ -1,4 +1,5 @@
-"""tools/fuzz_stream.py [first [count]] — tests/test_gpu_mixpath.py::test_random_stream_ticks over many more seeds (run on the GPU box)."""
+"""tools/fuzz_stream.py [first [count]] — tests/test_gpu_mixpath.py::test_random_stream_ticks and ::test_random_lone_stream_ticks over many
+more seeds (run on the GPU box)."""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -19,6 +20,8 @@ T.G.make_batch = _mb
 for seed in range(first, first + count):
     try:
         T.test_random_stream_ticks(ctx, lambda n, v: chipvideo.set_switch(n, v), seed)
+        chipvideo.set_switch("CHV_BGRA_PATH", None)
+        T.test_random_lone_stream_ticks(ctx, seed)        # the same ticks one at a time (descriptors as kernel arguments)
     except AssertionError as e:
         bad += 1
         print("seed", seed, "FAILED:", str(e)[:300])
