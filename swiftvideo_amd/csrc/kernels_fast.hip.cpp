@@ -33,7 +33,7 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_Y420P_BGRA_TILED = 1, FP_WAVE_LAYERS = 2, FP_WAVE_NV12 = 3, FP_WAVE_Y420P = 4, FP_STREAM = 5, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_Y420P_BGRA_TILED = 1, FP_WAVE_LAYERS = 2, FP_WAVE_NV12 = 3, FP_WAVE_Y420P = 4, FP_STREAM = 5, FP_CLEAR_BGRA = 6, FP_COUNT };
 
 // kernels_wave.hip.cpp / kernels_wave_yuv.hip.cpp
 bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
@@ -101,11 +101,10 @@ struct TileTablesT {
 #ifndef CHV_MINW
 #define CHV_MINW ((!PLANAR && (NYV == 2 || THV == 32)) ? 6 : (NYV == 3 && PLANAR) ? 4 : 5)
 #endif
-template <bool CLEAR, bool PLANAR, int NYV, int NCV, int THV>
-__global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const DTick *__restrict__ ticks,
-                                                                  const DLayer *__restrict__ layers,
-                                                                  int n_ticks, int tiles_x, int strips_y, int kt,
-                                                                  int ypitch, int yrows, int cpitch, int crows) {
+// ONE: a launch of one tick whose descriptors are kernel arguments (tick_yuv_bgra_tiled_one below; see tick_bgra_stream_one)
+template <bool CLEAR, bool PLANAR, int NYV, int NCV, int THV, bool ONE>
+CHV_DEV void tiled_body(const DTick *__restrict__ ticks, const DLayer *__restrict__ layers,
+                        int n_ticks, int tiles_x, int strips_y, int kt, int ypitch, int yrows, int cpitch, int crows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int TH = THV, RPT = TH / TYT;
     using TileTables = TileTablesT<THV>;
@@ -123,11 +122,11 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     if (slot >= per_xcd || index >= total) return;
     const int tick = index / strips;
     const int strip = index - tick * strips;
-    const DTick &T = ticks[tick];
+    const DTick &T = ticks[ONE ? 0 : tick];
     const int x0 = (strip % tiles_x) * TW, ys0 = (strip / tiles_x) * (kt * TH);   // kt <= KT tiles per strip (host's choice)
     if (x0 >= T.W || ys0 >= T.H) return;
     const int ntiles = min(kt, (T.H - ys0 + TH - 1) / TH);
-    const DLayer &L = layers[T.first_layer];
+    const DLayer &L = layers[ONE ? 0 : T.first_layer];
     const float *U = L.u;
     const DPlane &SY = L.src.pl[0];
     const DPlane &SC = L.src.pl[1];
@@ -361,6 +360,26 @@ __global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const 
     }
 }
 
+template <bool CLEAR, bool PLANAR, int NYV, int NCV, int THV>
+__global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled(const DTick *__restrict__ ticks,
+                                                                  const DLayer *__restrict__ layers,
+                                                                  int n_ticks, int tiles_x, int strips_y, int kt,
+                                                                  int ypitch, int yrows, int cpitch, int crows) {
+    tiled_body<CLEAR, PLANAR, NYV, NCV, THV, false>(ticks, layers, n_ticks, tiles_x, strips_y, kt, ypitch, yrows, cpitch, crows);
+}
+
+// one tick, its descriptors by value (440 bytes of kernel arguments): a transient launch — chv_run_kernel as an unchanged mix.video.swift
+// issues it, layer by layer — has no descriptor copy in front of it and no tick -> layer chain of dependent loads in its waves
+struct TiledOne {
+    DTick t;
+    DLayer l;
+};
+template <bool CLEAR, bool PLANAR, int NYV, int NCV, int THV>
+__global__ __launch_bounds__(NTHREADS, CHV_MINW) void tick_yuv_bgra_tiled_one(const TiledOne a, int tiles_x, int strips_y, int kt,
+                                                                      int ypitch, int yrows, int cpitch, int crows) {
+    tiled_body<CLEAR, PLANAR, NYV, NCV, THV, true>(&a.t, &a.l, 1, tiles_x, strips_y, kt, ypitch, yrows, cpitch, crows);
+}
+
 // ---------------------------------------------------------------------------
 // host side: path selection and launch geometry
 // ---------------------------------------------------------------------------
@@ -394,12 +413,27 @@ static TileDims tile_dims(const DTick &T, const DLayer &L, int TH) {
 // what the staged loads need: 16-byte aligned base and pitch, rows of at least one 16-byte vector
 static bool aligned16(const DPlane &p) { return (((uintptr_t)p.ptr) & 15) == 0 && (p.pitch & 15) == 0 && p.w * p.comps >= 16; }
 
+// img_clear_bgra on its own (the first launch of an unchanged mix.video.swift tick): every canvas pixel becomes (0, 0, 0, 1).  The plane
+// travels by value — a transient launch, no descriptor copy in front of it.
+__global__ __launch_bounds__(256) void canvas_clear_bgra(const DPlane D, int W, int H) {
+    const int y = blockIdx.y, x = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    const int w = min(W, D.w);
+    if (y >= min(H, D.h) || x >= w) return;
+    uint8_t *row = D.ptr + (size_t)y * D.pitch;
+    if (x + 4 <= w && ((((uintptr_t)row) + (size_t)x * 4) & 15) == 0) {
+        *(uint4 *)(row + (size_t)x * 4) = make_uint4(0xFF000000u, 0xFF000000u, 0xFF000000u, 0xFF000000u);
+    } else {
+        for (int i = x; i < min(x + 4, w); i++) *(uint32_t *)(row + (size_t)i * 4) = 0xFF000000u;
+    }
+}
+
 const char *fast_path_name(int path) {
     switch (path) {
     case FP_NV12_BGRA_TILED: return "tick_nv12_bgra_tiled";
     case FP_Y420P_BGRA_TILED: return "tick_y420p_bgra_tiled";
     case FP_WAVE_LAYERS: return "tick_bgra_wave";
     case FP_STREAM: return "tick_bgra_stream";
+    case FP_CLEAR_BGRA: return "canvas_clear_bgra";
     case FP_WAVE_NV12: return "tick_yuv_wave<nv12>";
     case FP_WAVE_Y420P: return "tick_yuv_wave<y420p>";
     default: return "none";
@@ -442,6 +476,9 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     // Launches of every size: the streaming kernel takes its chunk height as an
     // argument, and with 4-row chunks a lone 720p tick is 10.9 us on the chip against ~17 through 8-row strips of the strip kernel
     // (26.4 against 33.7 us per tick with the host wait; tools/tick_rows_sweep.sh, tools/stream_threshold_sweep.sh).
+    if (transient && n_ticks == 1 && ticks[0].n_layers == 0 && ticks[0].clear_first && (((uintptr_t)ticks[0].dst.pl[0].ptr) & 3) == 0 &&
+        (ticks[0].dst.pl[0].pitch & 3) == 0)
+        return FP_CLEAR_BGRA;
     if ((bp == 0 || bp == 3) && bgra_stream_eligible(ticks, layers, n_ticks)) {
         if (bp == 3 || ticks[0].n_layers >= 2 || transient) return FP_STREAM;
     }
@@ -460,11 +497,17 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     return wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks) ? FP_WAVE_LAYERS : FP_NONE;
 }
 
-bool fast_path_by_value(int path) { return path == FP_STREAM; }
+bool fast_path_by_value(int path) { return path == FP_STREAM || path == FP_NV12_BGRA_TILED || path == FP_Y420P_BGRA_TILED || path == FP_CLEAR_BGRA; }
 
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream) {
+    if (path == FP_CLEAR_BGRA) {
+        const DTick &T = ticks_host[0];
+        if (T.W <= 0 || T.H <= 0) return hipSuccess;
+        hipLaunchKernelGGL(canvas_clear_bgra, dim3((unsigned)((T.W + 1023) / 1024), (unsigned)T.H), dim3(256), 0, stream, T.dst.pl[0], T.W, T.H);
+        return hipGetLastError();
+    }
     if (path == FP_STREAM) return launch_bgra_stream(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_LAYERS) return launch_wave_layers(TF_BGRA, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_NV12) return launch_wave_layers(TF_NV12, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
@@ -516,8 +559,19 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
     int tiles_y = (maxH + kt * th - 1) / (kt * th);
     int per_xcd = (n_ticks * tiles_x * tiles_y + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8));
-#define CHV_LAUNCH(C, P, NY, NC, H) hipLaunchKernelGGL((tick_yuv_bgra_tiled<C, P, NY, NC, H>), grid, dim3(NTHREADS), lds, stream, ticks, layers, \
-                                                       n_ticks, tiles_x, tiles_y, kt, m.ypitch, m.yrows, m.cpitch, m.crows)
+    TiledOne one;
+    if (!ticks) {
+        // one tick, descriptors as kernel arguments (launch_transient)
+        if (n_ticks != 1) return hipErrorInvalidValue;
+        one.t = ticks_host[0];
+        one.l = layers_host[ticks_host[0].first_layer];
+        one.t.first_layer = 0;
+    }
+#define CHV_LAUNCH(C, P, NY, NC, H) do { \
+        if (ticks) hipLaunchKernelGGL((tick_yuv_bgra_tiled<C, P, NY, NC, H>), grid, dim3(NTHREADS), lds, stream, ticks, layers, \
+                                      n_ticks, tiles_x, tiles_y, kt, m.ypitch, m.yrows, m.cpitch, m.crows); \
+        else hipLaunchKernelGGL((tick_yuv_bgra_tiled_one<C, P, NY, NC, H>), grid, dim3(NTHREADS), lds, stream, one, \
+                                tiles_x, tiles_y, kt, m.ypitch, m.yrows, m.cpitch, m.crows); } while (0)
 #define CHV_LAUNCH_N(C, P) do { if (th == TH_LARGE) { if (small) CHV_LAUNCH(C, P, 2, 1, TH_LARGE); else CHV_LAUNCH(C, P, 3, 2, TH_LARGE); } \
                                 else { if (small) CHV_LAUNCH(C, P, 2, 1, TH_SMALL); else CHV_LAUNCH(C, P, 3, 2, TH_SMALL); } } while (0)
     const bool small = slots_fit(m, 2, 1, 2);

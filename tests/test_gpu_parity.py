@@ -43,7 +43,7 @@ def test_rgb_to_yuv_int_colorspaces(ctx, kernel, csc):
 
 
 @pytest.mark.parametrize("fmt", ["nv12", "y420p", "bgra"])
-@pytest.mark.parametrize("size", [(64, 36), (7, 5), (1, 1), (130, 3)])
+@pytest.mark.parametrize("size", [(64, 36), (7, 5), (1, 1), (130, 3), (1030, 9), (2050, 2)])
 def test_clear_kernels(ctx, fmt, size):
     w, h = size
     if fmt != "bgra" and min(w, h) < 2:
