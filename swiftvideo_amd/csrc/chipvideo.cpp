@@ -270,13 +270,18 @@ struct StagingSlot {
     bool pending = false;
 };
 
-struct DescSlot {
+// The descriptor ring is walked slot by slot, and its slots are guarded in GROUPS of kDescGroup: one event after the launch that used a
+// group's last slot stands for every launch of the group (a stream runs in order), and it is waited for when the walk enters the group
+// again, kDescSlots launches later.  An event per launch — what this was until round 3 — put a marker between every two kernels of a
+// tick issued layer by layer: an unchanged mix.video.swift tick (clear + 4 launches + wait) took 77-84 us with them and 55 without.
+struct DescGroup {
     hipEvent_t done = nullptr;
-    bool pending = false;
+    bool pending = false;     // `done` has been recorded and not yet waited for
+    bool dirty = false;       // a launch of this pass over the group reads one of its slots
 };
 
 static constexpr int kStagingSlots = 4;
-static constexpr int kDescSlots = 64;
+static constexpr int kDescSlots = 64, kDescGroup = 8;
 static constexpr size_t kDescSlotBytes = sizeof(DTick) + CHV_MAX_LAYERS * sizeof(DLayer);
 
 struct chv_context {
@@ -290,7 +295,7 @@ struct chv_context {
     // descriptor ring in pinned, device-mapped host memory
     uint8_t *desc_host = nullptr;
     uint8_t *desc_dev = nullptr;       // the same ring in device memory: a transient launch's descriptors are copied there on the stream
-    DescSlot desc[kDescSlots];
+    DescGroup desc_group[kDescSlots / kDescGroup];
     int next_desc = 0;
     // `library` of the reference's ComputeContext (compute.cl.swift:66-73): name -> built kernel
     std::map<std::string, std::shared_ptr<CustomKernel>> library;
@@ -427,7 +432,7 @@ extern "C" int chv_context_destroy(chv_context *c) {
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.host) (void)hipHostFree(s.host);
     }
-    for (auto &d : c->desc) if (d.done) (void)hipEventDestroy(d.done);
+    for (auto &d : c->desc_group) if (d.done) (void)hipEventDestroy(d.done);
     if (c->desc_host) (void)hipHostFree(c->desc_host);
     if (c->desc_dev) (void)hipFree(c->desc_dev);
     (void)hipStreamDestroy(c->stream);
@@ -893,20 +898,35 @@ static int tick_to_device(const chv_tick &t, int device, int forced_target_forma
     return CHV_OK;
 }
 
+// the next slot of the descriptor ring, once the device is done with what it held (see DescGroup)
+static int desc_acquire(chv_context *c, int *slot_out) {
+    const int slot = c->next_desc;
+    c->next_desc = (c->next_desc + 1) % kDescSlots;
+    DescGroup &g = c->desc_group[slot / kDescGroup];
+    if (slot % kDescGroup == 0 && g.pending) { HIP_TRY(hipEventSynchronize(g.done)); g.pending = false; }
+    g.dirty = true;
+    *slot_out = slot;
+    return CHV_OK;
+}
+
+// after the launch that reads `slot` has been issued on the context's stream
+static int desc_release(chv_context *c, int slot) {
+    DescGroup &g = c->desc_group[slot / kDescGroup];
+    if (slot % kDescGroup != kDescGroup - 1 || !g.dirty) return CHV_OK;
+    if (!g.done) HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(g.done, c->stream));
+    g.pending = true; g.dirty = false;
+    return CHV_OK;
+}
+
 // launch one transient tick through the pinned descriptor ring
 static int launch_transient(chv_context *c, const DTick &tick_in, const std::vector<DLayer> &layers, int tf) {
     HIP_TRY(hipSetDevice(c->device));
-    int slot = c->next_desc;
-    c->next_desc = (c->next_desc + 1) % kDescSlots;
-    DescSlot &ds = c->desc[slot];
-    if (ds.pending) { HIP_TRY(hipEventSynchronize(ds.done)); ds.pending = false; }
-    if (!ds.done) HIP_TRY(hipEventCreateWithFlags(&ds.done, hipEventDisableTiming));
-    uint8_t *base = c->desc_host + (size_t)slot * kDescSlotBytes;
-    DTick *ht = (DTick *)base;
-    DLayer *hl = (DLayer *)(base + sizeof(DTick));
-    *ht = tick_in;
-    ht->first_layer = 0;
-    if (!layers.empty()) memcpy(hl, layers.data(), layers.size() * sizeof(DLayer));
+    // the tick as the kernels see it: first_layer = 0, its layers behind it
+    DTick tick = tick_in;
+    tick.first_layer = 0;
+    const DTick *ht = &tick;
+    const DLayer *hl = layers.data();
     // Where the kernel reads the descriptors from.  Every wave of the launch fetches its tick and, layer by layer, that layer's
     // planes, uniforms and flags with scalar loads — a handful of dependent loads per layer.  From the pinned host ring each of them
     // is a trip across PCIe (~1.5 us, uncached): a 4-layer 720p tick took 31 us of kernel time, 5 us per layer, whatever was done on
@@ -915,27 +935,35 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     // The streaming kernel goes one better for a lone tick: its descriptors travel as kernel ARGUMENTS (tick_bgra_stream_one) — no copy
     // in front of the launch, and every field a scalar load from one base instead of the tick -> layer chain.  CHV_DESC=device keeps the
     // copy for it too (A/B).
-    DTick *dt = nullptr;
     const size_t used = sizeof(DTick) + layers.size() * sizeof(DLayer);
     const int desc_mode = switches().desc_host.load(std::memory_order_relaxed);       // 0 default, 1 host ring, 2 device twin always
     int path = select_fast_path(tf, ht, hl, 1, desc_mode == 0);
-    const bool by_value = fast_path_by_value(path) && desc_mode == 0;
-    if (by_value) {
-        dt = nullptr;
-    } else if (desc_mode == 1) {
-        HIP_TRY(hipHostGetDevicePointer((void **)&dt, ht, 0));
+    (void)hipGetLastError();   // the launchers report through hipGetLastError(): drop whatever an earlier, unrelated call left there
+    if (fast_path_by_value(path) && desc_mode == 0) {
+        // descriptors as kernel arguments: the ring is not involved
+        hipError_t e = launch_tick_fast(path, ht, hl, nullptr, nullptr, 1, ht->W, ht->H, c->stream);
+        return e == hipSuccess ? CHV_OK : hip_fail(e, "kernel launch");
+    }
+    int slot = 0;
+    int rc = desc_acquire(c, &slot);
+    if (rc) return rc;
+    uint8_t *base = c->desc_host + (size_t)slot * kDescSlotBytes;
+    DTick *st = (DTick *)base;
+    DLayer *sl = (DLayer *)(base + sizeof(DTick));
+    *st = tick;
+    if (!layers.empty()) memcpy(sl, layers.data(), layers.size() * sizeof(DLayer));
+    DTick *dt = nullptr;
+    if (desc_mode == 1) {
+        HIP_TRY(hipHostGetDevicePointer((void **)&dt, st, 0));
     } else {
         dt = (DTick *)(c->desc_dev + (size_t)slot * kDescSlotBytes);
-        HIP_TRY(hipMemcpyAsync(dt, ht, used, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(dt, st, used, hipMemcpyHostToDevice, c->stream));
     }
-    DLayer *dl = by_value ? nullptr : (DLayer *)((uint8_t *)dt + sizeof(DTick));
-    (void)hipGetLastError();   // the launchers report through hipGetLastError(): drop whatever an earlier, unrelated call left there
-    hipError_t e = path >= 0 ? launch_tick_fast(path, ht, hl, dt, dl, 1, ht->W, ht->H, c->stream)
-                             : launch_tick_general(tf, dt, dl, 1, ht->W, ht->H, c->stream);
+    DLayer *dl = (DLayer *)((uint8_t *)dt + sizeof(DTick));
+    hipError_t e = path >= 0 ? launch_tick_fast(path, st, sl, dt, dl, 1, st->W, st->H, c->stream)
+                             : launch_tick_general(tf, dt, dl, 1, st->W, st->H, c->stream);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    HIP_TRY(hipEventRecord(ds.done, c->stream));
-    ds.pending = true;
-    return CHV_OK;
+    return desc_release(c, slot);
 }
 
 // ---------------------------------------------------------------------------
@@ -1425,11 +1453,9 @@ extern "C" int chv_scale_lanczos_batch(chv_context *c, const chv_image *dsts, co
     static_assert((size_t)CHV_LANCZOS_BATCH_CHUNK * 2 * sizeof(DPlane) <= kDescSlotBytes, "a chunk's plane pairs must fit one descriptor slot");
     for (int first = 0; first < n; first += per_slot) {
         const int m = std::min(per_slot, n - first);
-        int slot = c->next_desc;
-        c->next_desc = (c->next_desc + 1) % kDescSlots;
-        DescSlot &ds = c->desc[slot];
-        if (ds.pending) { HIP_TRY(hipEventSynchronize(ds.done)); ds.pending = false; }
-        if (!ds.done) HIP_TRY(hipEventCreateWithFlags(&ds.done, hipEventDisableTiming));
+        int slot = 0;
+        rc = desc_acquire(c, &slot);
+        if (rc) return rc;
         DPlane *host = (DPlane *)(c->desc_host + (size_t)slot * kDescSlotBytes);
         memcpy(host, pairs.data() + 2 * (size_t)first, sizeof(DPlane) * 2 * (size_t)m);
         DPlane *dev = nullptr;
@@ -1437,8 +1463,8 @@ extern "C" int chv_scale_lanczos_batch(chv_context *c, const chv_image *dsts, co
         (void)hipGetLastError();
         hipError_t e = launch_lanczos(pairs[0], pairs[1], tx->first, tx->weights, tx->taps, ty->first, ty->weights, ty->taps, c->stream, dev, m, tx->stride, tx->first0, ty->stride);
         if (e != hipSuccess) return hip_fail(e, "lanczos launch");
-        HIP_TRY(hipEventRecord(ds.done, c->stream));
-        ds.pending = true;
+        rc = desc_release(c, slot);
+        if (rc) return rc;
     }
     return CHV_OK;
 }
