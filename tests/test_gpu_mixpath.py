@@ -256,6 +256,33 @@ def test_random_lone_stream_ticks(ctx, seed):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed}, lone tick of {len(layers)} layer(s)")
 
 
+@pytest.mark.parametrize("desc", ["device", "host"])
+def test_descriptor_ring_wraps_under_back_to_back_launches(ctx, switch, desc):
+    """200 transient launches without a host wait in between, each with its own descriptors (a 16 x 16 picture somewhere else on the
+    canvas), through a kernel that reads them from the ring (the strip kernel; the ring has 64 slots guarded by one event per eight):
+    a slot rewritten before its launch had read it would misplace a picture."""
+    switch("CHV_DESC", desc)
+    cw, ch, n = 256, 64, 200
+    canvas0 = util.alloc_image("bgra", cw, ch, seed=901)
+    exp = util.copy_image(canvas0)
+    srcs = [util.alloc_image("bgra", 16, 16, seed=910 + i) for i in range(5)]
+    gsrc = [G.to_gpu(ctx, "bgra", 16, 16, s) for s in srcs]
+    k = sv.defaultComputeKernelFromString("img_bgra_bgra_tx")
+    layers = []
+    for i in range(n):
+        u = util.make_uniforms((cw, ch), rect=((i * 37) % 236 + 0.5 * (i % 2), (i * 11) % 46, 16, 16), opacity=0.5 + 0.5 * ((i * 7) % 10) / 10.0, in_size=(16, 16))
+        assert O.run_kernel("img_bgra_bgra_tx", exp, srcs[i % 5], u) == 0
+        layers.append((k, gsrc[i % 5], u, 0))
+    gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+
+    def burst(c):
+        for l in layers:
+            sv.compositeTick(c, gd, [l], False)
+        return c
+    sv.usingContext(ctx, burst)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"200 back-to-back transient launches, descriptors: {desc}")
+
+
 def test_stream_kernel_eligibility(ctx, switch):
     """what it must leave to the other kernels: an un-cleared canvas, a layer of another geometry or class, fill paint, opacity
     outside [0, 1], a flip, a strong reduction, plane rows that are not a multiple of 16 bytes, more than four layers"""
