@@ -865,6 +865,84 @@ def run_per_tick(args, sv, cv, lib, ctx, seconds=0.35, ring=10, distinct=4, mixe
     }
 
 
+def run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p", seconds=0.3, ring=10, distinct=4):
+    """The reference-default mixer tick (1080p 4:2:0 canvas <- full-canvas video + two 640x360 BGRA overlays: the `mixer_<fmt>` workload) issued
+    ONE AT A TIME with the reference's host wait after it: fused (one chv_composite) and as the unchanged 1 + 3 launch sequence
+    (img_clear_<fmt> + 3 x chv_run_kernel, mix.video.swift:116-124)."""
+    import util
+    dw, dh = 1920, 1080
+    us = [util.full_canvas_uniforms((dw, dh), (dw, dh)),
+          util.make_uniforms((dw, dh), rect=(64, 64, 640, 360), opacity=0.8, in_size=(640, 360)),
+          util.make_uniforms((dw, dh), rect=(1200, 640, 640, 360), opacity=0.6, in_size=(640, 360))]
+    PF = {"nv12": sv.PixelFormat.nv12, "y420p": sv.PixelFormat.y420p}[fmt]
+    host = [util.alloc_image(fmt, dw, dh, seed=0x5EED0000 + 64 + i) for i in range(distinct)]
+    ov = [util.alloc_image("bgra", 640, 360, seed=0x5EED0000 + 80 + i) for i in range(2)]
+    K = sv.defaultComputeKernelFromString
+    k_main, k_ov, k_clear = K(f"img_{fmt}_{fmt}"), K(f"img_bgra_{fmt}"), K(f"img_clear_{fmt}")
+    src = [sv.uploadComputePicture(ctx, sv.pictureFromArrays(PF, (dw, dh), h), retainCpuBuffer=False) for h in host]
+    gov = [sv.uploadComputePicture(ctx, sv.pictureFromArrays(sv.PixelFormat.BGRA, (640, 360), o), retainCpuBuffer=False) for o in ov]
+    canvas = [sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), PF), retainCpuBuffer=False) for _ in range(ring)]
+    tdesc = [sv._image_desc(cn) for cn in canvas]
+    layer_arr = [sv._layer_array([(k_main, src[t], us[0], 0), (k_ov, gov[0], us[1], 0), (k_ov, gov[1], us[2], 0)]) for t in range(distinct)]
+    sdesc = [sv._image_desc(x) for x in src] + [sv._image_desc(x) for x in gov]
+    uni = [(cv.Uniforms).from_buffer_copy(np.asarray(u, dtype=np.float32).tobytes()) for u in us]
+    opts = cv.KernelOpts(0)
+    h = ctx.handle
+    state = {"n": 0}
+
+    def tick_fused():
+        t = state["n"]; state["n"] += 1
+        lib.chv_pass_begin(h)
+        rc = lib.chv_composite(h, C.byref(tdesc[t % ring]), 1, layer_arr[t % distinct], 3)
+        rc |= lib.chv_pass_end(h, 1)
+        if rc:
+            cv.check(rc)
+
+    def tick_sequence():
+        t = state["n"]; state["n"] += 1
+        td = C.byref(tdesc[t % ring])
+        lib.chv_pass_begin(h)
+        rc = lib.chv_run_kernel(h, int(k_clear), td, None, 0, None, 0, 0, None)
+        rc |= lib.chv_run_kernel(h, int(k_main), td, C.byref(sdesc[t % distinct]), 1, C.byref(uni[0]), 236, 1, C.byref(opts))
+        for i in (0, 1):
+            rc |= lib.chv_run_kernel(h, int(k_ov), td, C.byref(sdesc[distinct + i]), 1, C.byref(uni[1 + i]), 236, 1, C.byref(opts))
+        rc |= lib.chv_pass_end(h, 1)
+        if rc:
+            cv.check(rc)
+
+    def timed(fn, secs):
+        for _ in range(20):
+            fn()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(20):
+                fn()
+            n += 20
+            el = time.perf_counter() - t0
+            if el >= secs:
+                return el / n * 1e6, n
+
+    out = {}
+    for mode, fn in (("fused", tick_fused), ("sequence", tick_sequence)):
+        us_tick, n = timed(fn, seconds)
+        out[mode] = {"us_per_tick": us_tick, "ticks": n}
+    # fused == sequence on one tick, byte for byte (both against the same sources)
+    state["n"] = 0; tick_fused()
+    ga = [b.copy() for b in sv.downloadComputePicture(ctx, canvas[0], retainGpuBuffer=True).imageBuffer().buffers]
+    state["n"] = 0; tick_sequence()
+    gb = sv.downloadComputePicture(ctx, canvas[0], retainGpuBuffer=True).imageBuffer().buffers
+    same = all(bool(np.array_equal(a, b)) for a, b in zip(ga, gb))
+    desc = ("the reference-default mixer tick (1080p %s canvas <- 1080p %s video + two 640x360 BGRA overlays) issued ONE AT A TIME with a host "
+            "wait after every tick: {}; Python host (ctypes), canvas ring of %d" % (fmt, fmt, ring))
+    return {
+        f"mixer_{fmt}_per_tick": dict(out["fused"], workload=desc.format("one chv_composite + chv_pass_end(wait)"), launches_per_tick=1,
+                                      fused_equals_sequence=same, gpix_per_s=dw * dh / out["fused"]["us_per_tick"] / 1e3),
+        f"mixer_{fmt}_reference_sequence": dict(out["sequence"], workload=desc.format(f"img_clear_{fmt} + 3 x chv_run_kernel + chv_pass_end(wait): an unchanged "
+                                                                                      "mix.video.swift:116-124"),
+                                                launches_per_tick=4, fused_equals_sequence=same, gpix_per_s=dw * dh / out["sequence"]["us_per_tick"] / 1e3),
+    }
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -917,6 +995,7 @@ def main(argv=None):
         reports["cfg2_upload"] = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
     if (others or args.per_tick) and not args.stub_device and not args.no_per_tick and n_gpus == 1:
         reports.update(run_per_tick(args, sv, cv, lib, ctx))
+        reports.update(run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p"))
 
     if rank == 0:
         wl = WORKLOADS[args.workload]

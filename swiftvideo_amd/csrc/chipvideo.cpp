@@ -29,6 +29,8 @@ namespace chv {
 const char *bgra_wave_build_flags();      // kernels_wave.hip.cpp
 const char *yuv_wave_build_flags();       // kernels_wave_yuv.hip.cpp
 const char *bgra_stream_build_flags();   // kernels_stream.hip.cpp
+const char *yuv_stream_build_flags();    // kernels_stream_yuv.hip.cpp
+const char *lanczos_build_flags();       // kernels_lanczos.hip.cpp
 hipError_t launch_tick_general(int target_format, const DTick *ticks, const DLayer *layers,
                                int n_ticks, int maxW, int maxH, hipStream_t stream);
 hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
@@ -64,17 +66,18 @@ static int parse_switch(const char *name, const char *value, int *out) {
     if (n == "CHV_SAME_GEOM") { *out = v == "0" ? 0 : 1; return 4; }
     if (n == "CHV_DESC") { *out = v == "host" ? 1 : v == "device" ? 2 : 0; return 5; }
     if (n == "CHV_STREAM") { *out = v == "0" ? 0 : 1; return 6; }
+    if (n == "CHV_YUV_STREAM") { *out = v == "0" ? 0 : (v == "force" || v == "2") ? 2 : 1; return 7; }
     return -1;
 }
 static void store_switch(Switches &s, int which, int val) {
-    std::atomic<int> *slots[7] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom, &s.desc_host, &s.stream };
+    std::atomic<int> *slots[8] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom, &s.desc_host, &s.stream, &s.yuv_stream };
     slots[which]->store(val, std::memory_order_relaxed);
 }
 Switches &chv::switches() {
     static Switches s;
     static std::once_flag once;
     std::call_once(once, [] {
-        static const char *const names[7] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC", "CHV_STREAM" };
+        static const char *const names[8] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC", "CHV_STREAM", "CHV_YUV_STREAM" };
         for (const char *n : names) {
             const char *v = getenv(n);
             int val = 0, which = v ? parse_switch(n, v, &val) : -1;
@@ -88,12 +91,17 @@ extern "C" int chv_debug_set_switch(const char *name, const char *value) {
     Switches &s = switches();                     // (environment first, so that a later first use cannot overwrite this)
     const int which = parse_switch(name, value, &val);
     if (which < 0) { g_detail_set("unknown switch"); return CHV_ERR_INVALID_VALUE; }
-    if (!value || !*value) val = (which == 4 || which == 6) ? 1 : 0;      // empty / NULL: back to "the library decides"
+    if (!value || !*value) val = (which == 4 || which == 6 || which == 7) ? 1 : 0;      // empty / NULL: back to "the library decides"
     store_switch(s, which, val);
     return CHV_OK;
 }
 extern "C" const char *chv_build_flags(void) {
-    static const std::string flags = std::string("arch=gfx950;fp_contract=off;") + bgra_wave_build_flags() + ";" + yuv_wave_build_flags() + ";" + bgra_stream_build_flags();
+    // what the library was built with: the architecture the Makefile compiled for, the compiler (the hand-scheduled kernels — LDS-DMA through
+    // M0, counted vmcnt waits, prefetch registers in flight — were validated against THIS hipcc; tests/test_device_code_contract.py refuses
+    // another major version until tools/check_inflight.py and the GPU suite have been re-run with it), every timing-only ablation macro
+    static const std::string flags = std::string("arch=" CHV_ARCH ";hipcc=" CHV_HIPCC_VERSION ";clang=") + std::to_string(__clang_major__) + "." + std::to_string(__clang_minor__) +
+                                     ";fp_contract=off;" + bgra_wave_build_flags() + ";" + yuv_wave_build_flags() + ";" + bgra_stream_build_flags() + ";" +
+                                     yuv_stream_build_flags() + ";" + lanczos_build_flags();
     return flags.c_str();
 }
 

@@ -33,13 +33,15 @@
 
 namespace chv {
 
-enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_Y420P_BGRA_TILED = 1, FP_WAVE_LAYERS = 2, FP_WAVE_NV12 = 3, FP_WAVE_Y420P = 4, FP_STREAM = 5, FP_CLEAR_BGRA = 6, FP_COUNT };
+enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_Y420P_BGRA_TILED = 1, FP_WAVE_LAYERS = 2, FP_WAVE_NV12 = 3, FP_WAVE_Y420P = 4, FP_STREAM = 5, FP_CLEAR_BGRA = 6, FP_STREAM_NV12 = 7, FP_STREAM_Y420P = 8, FP_COUNT };
 
 // kernels_wave.hip.cpp / kernels_wave_yuv.hip.cpp
 bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
 // kernels_stream.hip.cpp
 bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
 hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream);
+bool yuv_stream_eligible(int tf, const DTick *ticks, const DLayer *layers, int n_ticks, bool transient);
+hipError_t launch_yuv_stream(int tf, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream);
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream);
 
@@ -436,6 +438,8 @@ const char *fast_path_name(int path) {
     case FP_CLEAR_BGRA: return "canvas_clear_bgra";
     case FP_WAVE_NV12: return "tick_yuv_wave<nv12>";
     case FP_WAVE_Y420P: return "tick_yuv_wave<y420p>";
+    case FP_STREAM_NV12: return "tick_yuv_stream<nv12>";
+    case FP_STREAM_Y420P: return "tick_yuv_stream<y420p>";
     default: return "none";
     }
 }
@@ -467,6 +471,9 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     const int bp = switches().bgra_path.load(std::memory_order_relaxed);
     if (switches().force_general.load(std::memory_order_relaxed)) return FP_NONE;
     // 4:2:0 canvases (the reference's own kernels): one wave per strip, or the general quad kernel
+    // 4:2:0 canvases: cleared ticks of 1..4 axis-aligned layers without fill paint can stream their source rows (kernels_stream_yuv.hip.cpp: rows
+    // outermost, a ring per layer, launches of every size); by default where that measured faster, everything else keeps the strip kernel
+    if (target_format != TF_BGRA && yuv_stream_eligible(target_format, ticks, layers, n_ticks, transient)) return target_format == TF_NV12 ? FP_STREAM_NV12 : FP_STREAM_Y420P;
     if (target_format != TF_BGRA)
         return wave_layers_eligible(target_format, ticks, layers, n_ticks) ? (target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P) : FP_NONE;
     // ticks of 2..4 full-frame NV12 layers of one geometry on a cleared canvas: rows outermost, layers innermost (kernels_stream.hip.cpp);
@@ -497,7 +504,7 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     return wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks) ? FP_WAVE_LAYERS : FP_NONE;
 }
 
-bool fast_path_by_value(int path) { return path == FP_STREAM || path == FP_NV12_BGRA_TILED || path == FP_Y420P_BGRA_TILED || path == FP_CLEAR_BGRA; }
+bool fast_path_by_value(int path) { return path == FP_STREAM || path == FP_STREAM_NV12 || path == FP_STREAM_Y420P || path == FP_NV12_BGRA_TILED || path == FP_Y420P_BGRA_TILED || path == FP_CLEAR_BGRA; }
 
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
@@ -509,6 +516,8 @@ hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *lay
         return hipGetLastError();
     }
     if (path == FP_STREAM) return launch_bgra_stream(ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
+    if (path == FP_STREAM_NV12) return launch_yuv_stream(TF_NV12, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
+    if (path == FP_STREAM_Y420P) return launch_yuv_stream(TF_Y420P, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_LAYERS) return launch_wave_layers(TF_BGRA, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_NV12) return launch_wave_layers(TF_NV12, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);
     if (path == FP_WAVE_Y420P) return launch_wave_layers(TF_Y420P, ticks_host, layers_host, ticks, layers, n_ticks, maxW, maxH, stream);

@@ -608,4 +608,9 @@ hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *f
     return launch(lanczos3_bgra<0, false, false, 32, 16>);
 }
 
+#define CHV_LSTR2(x) #x
+#define CHV_LSTR(x) CHV_LSTR2(x)
+// what this translation unit was built with (chv_build_flags; a timing-only CHV_LS_ABL build must never ship)
+const char *lanczos_build_flags() { return "lanczos3:abl=" CHV_LSTR(CHV_LS_ABL); }
+
 }  // namespace chv

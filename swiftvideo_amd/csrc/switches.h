@@ -2,7 +2,7 @@
 //
 // The environment is read ONCE, at the first use in the process (getenv on a hot path is undefined behaviour next to a
 // setenv in another thread, and the mixer and uploader threads run concurrently): CHV_FORCE_GENERAL, CHV_BGRA_PATH,
-// CHV_WAVE_ROWS, CHV_TILE_ROWS, CHV_SAME_GEOM, CHV_DESC, CHV_STREAM.  Tests and A/B tools change them afterwards through chv_debug_set_switch (include/chipvideo.h),
+// CHV_WAVE_ROWS, CHV_TILE_ROWS, CHV_SAME_GEOM, CHV_DESC, CHV_STREAM, CHV_YUV_STREAM.  Tests and A/B tools change them afterwards through chv_debug_set_switch (include/chipvideo.h),
 // never through the environment.  Every value is an atomic int; 0 = "the library decides".
 #pragma once
 #include <atomic>
@@ -18,6 +18,8 @@ struct Switches {
     std::atomic<int> desc_host{0};       // CHV_DESC, a transient launch's descriptors: 0 kernel arguments where the kernel takes them (tick_bgra_stream_one), else a device
                                          // copy; 1 (host) read from the pinned host ring; 2 (device) the device copy always (A/Bs)
     std::atomic<int> stream{1};          // 0: never tick_bgra_stream (A/B; CHV_BGRA_PATH=stream: also for one-layer ticks)
+    std::atomic<int> yuv_stream{1};      // CHV_YUV_STREAM: 0 never tick_yuv_stream (4:2:0 canvases keep tick_yuv_wave); 1 (default) where it measured faster
+                                         // (kernels_stream_yuv.hip.cpp::yuv_stream_eligible); force: every eligible launch (A/Bs and tests)
 };
 Switches &switches();                    // (chipvideo.cpp; initialised from the environment on first use)
 

@@ -12,7 +12,8 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "swiftvideo_amd" / "csrc"
 LLVM = Path("/opt/rocm/lib/llvm/bin")
-OBJECTS = ["kernels_general", "kernels_fast", "kernels_wave", "kernels_wave_yuv", "kernels_lanczos", "kernels_stream"]
+OBJECTS = ["kernels_general", "kernels_fast", "kernels_wave", "kernels_wave_yuv", "kernels_lanczos", "kernels_stream", "kernels_stream_yuv"]
+VALIDATED_HIPCC_MAJOR_MINOR = "7.2"       # the hipcc the hand-scheduled kernels were validated with (GPU suite + tools/check_inflight.py)
 
 
 def _code_object(tmp_path, stem):
@@ -121,6 +122,53 @@ def test_stream_kernel_owns_m0_and_keeps_six_waves(tmp_path):
         assert any(l.startswith("s_mov_b32 m0") for l in lines[max(0, i - 3):i]), lines[max(0, i - 3):i + 1]
     others = [l for l in lines if re.search(r"\bm0\b", l) and not l.startswith("s_mov_b32 m0")]
     assert not others, others[:3]
+
+
+def _lds_dma_contract(co, min_loads):
+    asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    lines = [l.split("//")[0].strip() for l in asm.splitlines()]
+    lines = [l for l in lines if l and not l.endswith(":")]
+    dma = [i for i, l in enumerate(lines) if l.startswith("global_load_lds_dwordx4")]
+    assert len(dma) >= min_loads
+    for i in dma:
+        assert any(l.startswith("s_mov_b32 m0") for l in lines[max(0, i - 3):i]), lines[max(0, i - 3):i + 1]
+    others = [l for l in lines if re.search(r"\bm0\b", l) and not l.startswith("s_mov_b32 m0")]
+    assert not others, others[:3]
+
+
+def test_yuv_stream_kernel_owns_m0_and_keeps_its_waves(tmp_path):
+    """tick_yuv_stream: the same M0 contract as tick_bgra_stream.  Registers (what the measurements of profiles/r04_notes.md were taken with):
+    one video layer slot — 80 VGPRs (6 waves per SIMD) with at most a few registers in scratch (88 registers and 5 waves measured 3 % slower); the
+    encoder-side integer instantiation: nothing in scratch; two video layers 96; the mixer instantiations (video + RGB overlays, three or four
+    layer slots) 128 — their rings leave the LDS to four waves per SIMD anyway."""
+    co = _code_object(tmp_path, "kernels_stream_yuv")
+    kernels = _find(_kernels(co), "tick_yuv_stream")
+    assert len(kernels) >= 20
+    for name, m in kernels.items():
+        nl, kinds = [int(x) for x in re.search(r"ILi\d+ELi(\d+)ELi(\d+)E", name).groups()]
+        scratch = m.get("private_segment_fixed_size", 0)
+        if kinds == 8:
+            assert m["vgpr_count"] <= 64 and scratch == 0, (name, m)
+        elif kinds in (1, 2) and nl == 1:
+            assert m["vgpr_count"] <= 80 and scratch <= 48, (name, m)
+        elif kinds in (1, 2):
+            assert m["vgpr_count"] <= 96, (name, m)
+        else:
+            assert m["vgpr_count"] <= 128, (name, m)
+    _lds_dma_contract(co, 16)
+
+
+def test_compiler_is_the_one_the_hand_scheduled_kernels_were_validated_with(built):
+    """The streaming and Lanczos strip kernels rely on behaviours of gfx950 AND of the compiler that nothing in the language promises: loads
+    return in order and share `vmcnt` with stores, hipcc never touches M0 by itself, inline-asm loads stay where they are written.  They were
+    checked on the built code (this file, tools/check_inflight.py) and on the GPU with one hipcc; chv_build_flags() carries the version the
+    library was built with, and another major.minor has to be re-validated (run the GPU suite and tools/check_inflight.py, then move the pin)."""
+    from swiftvideo_amd import chipvideo as cv
+    flags = dict(f.split("=", 1) for f in cv.build_flags().split(";") if "=" in f and ":" not in f.split("=", 1)[0])
+    assert "hipcc" in flags and "clang" in flags, cv.build_flags()
+    assert flags["hipcc"].startswith(VALIDATED_HIPCC_MAJOR_MINOR + "."), (
+        f"libchipvideo.so was built with hipcc {flags['hipcc']}; the hand-scheduled kernels were validated with {VALIDATED_HIPCC_MAJOR_MINOR}.x — "
+        "re-run `pytest -m gpu` and tools/check_inflight.py with this compiler, then update VALIDATED_HIPCC_MAJOR_MINOR")
 
 
 def test_hand_awaited_loads_are_not_touched_while_in_flight(tmp_path):

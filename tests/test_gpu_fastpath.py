@@ -293,7 +293,8 @@ def test_yuv_layer_ticks_match_oracle(ctx, case):
     h, name, keep = G.make_batch(ctx, [(gd, clear, layers)])
     # sources with rows shorter than one 16-byte vector cannot be staged -> general quad kernel; everything else here is
     # axis-aligned on an even canvas -> one wave per strip (tests/test_gpu_yuvwave.py covers that kernel in depth)
-    assert name == (f"tick_general_yuv<{d}>" if case in ("y420p_tiny",) else f"tick_yuv_wave<{d}>"), name
+    # — or, for cleared ticks of at most four layers inside the rings' limits, streamed rows (tests/test_gpu_yuvstream.py)
+    assert name == f"tick_general_yuv<{d}>" if case in ("y420p_tiny",) else name in (f"tick_yuv_wave<{d}>", f"tick_yuv_stream<{d}>"), name
     G.run_batch(ctx, h)
     G.destroy_batch(h)
     G.assert_same(G.from_gpu(ctx, gd, d, cw, ch), exp, f"{case} via {name}")

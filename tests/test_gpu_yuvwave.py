@@ -13,6 +13,12 @@ from swiftvideo_amd import compute as sv
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def strip_kernel_only(switch):
+    """this file is about the strip kernel: cleared ticks the streaming kernel would take (tests/test_gpu_yuvstream.py) stay here"""
+    switch("CHV_YUV_STREAM", "0")
+
+
 @pytest.fixture(params=["8", "16"])
 def rows(request, switch):
     """both strip heights of tick_yuv_wave (the host picks per launch: 16 rows for launches of >= 8192 strips; CHV_WAVE_ROWS

@@ -7,7 +7,7 @@ NAME=$1; FILE=$2; shift 2
 cd "$(dirname "$0")/../swiftvideo_amd/csrc"
 OBJ=../../variants/obj_$NAME
 mkdir -p $OBJ
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -w"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -w -DCHV_ARCH=\"gfx950\" -DCHV_HIPCC_VERSION=\"variant\""
 for f in chipvideo.cpp kernels_*.hip.cpp; do
   if [ "$FILE" = all ] || [ "$FILE" = "$f" ]; then /opt/rocm/bin/hipcc $FLAGS "$@" -x hip -c $f -o $OBJ/${f%.cpp}.o &
   else cp ${f%.cpp}.o $OBJ/; fi
