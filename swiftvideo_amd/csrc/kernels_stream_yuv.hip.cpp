@@ -1020,7 +1020,8 @@ bool yuv_stream_eligible(int tf, const DTick *ticks, const DLayer *layers, int n
     }
     YsPlan p = ys_plan(ticks, layers, n_ticks);
     ys_round(tf, p);
-    return (size_t)YS_WAVES * (size_t)ys_wave_bytes(p, ticks, layers, n_ticks) <= (size_t)LDS_BUDGET;
+    // (a wave's rings and tables: beyond 16 KB the LDS holds fewer than ten waves per CU, and the strip kernel is the better choice)
+    return ys_wave_bytes(p, ticks, layers, n_ticks) <= 16 * 1024;
 }
 
 template <int TF, int NL, int KINDS>

@@ -124,12 +124,16 @@ def test_default_run_measures_its_hbm_traffic():
     import shutil
     d = _run_bench(["--steps", "2", "--warmup", "1", "--min-seconds", "0.1", "--min-seconds-other", "0.05", "--no-cpu-baseline"])
     assert set(d["workloads"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12"}
-    legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence")
+    legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence", "mixer_y420p_per_tick", "mixer_y420p_reference_sequence")
     assert all(v["verified_vs_oracle"] is True for k, v in d["workloads"].items() if k not in legs)
     # the path a Swift VideoMixer takes — one tick at a time with a host wait — fused and as the unchanged 5-launch sequence
     pt, seq = d["workloads"]["pipeline_per_tick"], d["workloads"]["pipeline_reference_sequence"]
     assert pt["fused_equals_sequence"] is True and pt["launches_per_tick"] == 1 and seq["launches_per_tick"] == 5
     assert 5 < pt["us_per_tick"] < seq["us_per_tick"] < 2000
+    # the same for the reference-default 4:2:0 mixer tick (video + two overlays; 1 + 3 launches unchanged)
+    mt, mseq = d["workloads"]["mixer_y420p_per_tick"], d["workloads"]["mixer_y420p_reference_sequence"]
+    assert mt["fused_equals_sequence"] is True and mt["launches_per_tick"] == 1 and mseq["launches_per_tick"] == 4
+    assert 5 < mt["us_per_tick"] < mseq["us_per_tick"] < 2000
     assert d["config"]["build_flags"].startswith("arch=gfx950;") and "abl=0" in d["config"]["build_flags"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
