@@ -56,11 +56,14 @@ const char *chv_error_string(int status);
 /* Thread-local detail text of the last failing call on this thread ("" if none). */
 const char *chv_last_error_detail(void);
 int chv_version(void);
-/* What the library was built with: "arch=gfx950;...;tick_bgra_wave:abl=0,...".  `abl` != 0 marks a timing-only ablation
- * build whose pixels are wrong by design (profiles/r02_notes.md section 6); tests/test_abi.py asserts 0, bench.py prints it. */
+/* What the library was built with: "arch=<the Makefile's ARCH>;hipcc=<HIP version>;clang=<major.minor>;fp_contract=off;tick_bgra_wave:abl=0,...;
+ * ...;lanczos3:abl=0".  `abl` != 0 marks a timing-only ablation build whose pixels are wrong by design (profiles/r02_notes.md section 6):
+ * tests/test_abi.py asserts 0 for every kernel family, bench.py prints the string.  The compiler version is there because the streaming and
+ * Lanczos strip kernels are scheduled by hand against one hipcc (tests/test_device_code_contract.py pins major.minor). */
 const char *chv_build_flags(void);
 /* Measurement / test hook: path-selection switches.  Names and values are those of the environment variables read once at
- * first use (CHV_FORCE_GENERAL=1, CHV_BGRA_PATH=wave|tiled, CHV_WAVE_ROWS=8|16, CHV_TILE_ROWS=16|32, CHV_SAME_GEOM=0, CHV_DESC=host);
+ * first use (CHV_FORCE_GENERAL=1, CHV_BGRA_PATH=wave|tiled|stream, CHV_WAVE_ROWS=8|16, CHV_TILE_ROWS=16|32, CHV_SAME_GEOM=0,
+ * CHV_DESC=host|device, CHV_STREAM=0, CHV_YUV_STREAM=0|force);
  * NULL or "" restores the default.  Process-wide, atomic; not part of the Swift-facing contract. */
 int chv_debug_set_switch(const char *name, const char *value);
 

@@ -25,11 +25,13 @@ public class PictureFilter: Tx<PictureSample, PictureSample> {
                 outputSize: Vector2,
                 outputFormat: PixelFormat = .BGRA,
                 scaler: PictureScaler = .bilinear,
+                integerMatrix: Bool = true,
                 computeContext: ComputeContext? = nil) {
         self.clock = clock
         self.outputSize = outputSize
         self.outputFormat = outputFormat
         self.scaler = scaler
+        self.integerMatrix = integerMatrix
         do {
             if let context = computeContext {
                 self.context = createComputeContext(sharing: context)
@@ -82,8 +84,11 @@ public class PictureFilter: Tx<PictureSample, PictureSample> {
         let outp = String(describing: outputFormat).lowercased()
         let rgbIn = image != nil && (inp == "bgra" || inp == "rgba")
         // BGRA targets: the transform-aware kernels; 4:2:0 targets from RGB pictures: the integer BT.601/709 matrix
-        // (img_*_int, what an encoder expects) instead of the reference's float full-range rows (kernels.cl.swift:96-99)
-        let suffix = (rgbIn && outp == "bgra") ? "_tx" : (rgbIn && (outp == "nv12" || outp == "y420p")) ? "_int" : ""
+        // (img_*_int, what an encoder expects; the default, as in swiftvideo_amd/compute.py::PictureFilter and
+        // host/swiftvideo_hip.hpp) — or, with integerMatrix: false, the reference's own float full-range rows
+        // (kernels.cl.swift:96-99), byte for byte what its OpenCL family writes
+        let to420 = outp == "nv12" || outp == "y420p"
+        let suffix = (rgbIn && outp == "bgra") ? "_tx" : (rgbIn && to420 && integerMatrix) ? "_int" : ""
         return try defaultComputeKernelFromString("img_\(inp)_\(outp)\(suffix)")
     }
 
@@ -108,6 +113,7 @@ public class PictureFilter: Tx<PictureSample, PictureSample> {
     let outputSize: Vector2
     let outputFormat: PixelFormat
     let scaler: PictureScaler
+    let integerMatrix: Bool
     var context: ComputeContext?
 }
 #endif

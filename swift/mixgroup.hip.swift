@@ -5,12 +5,16 @@
 
    Why it exists.  VideoMixer.mix (mix.video.swift:95-140) issues, per mixer and per tick, a clear, one kernel per layer
    and one blocking wait (usingContext, compute.swift:131-134).  On an MI355X one 720p tick is ~7 us of device work behind
-   a ~17 us launch + wait floor (tools/tick_latency.py): a composer with many mixers on one device
+   a ~14 us launch + wait floor (tools/tick_latency.py): a composer with many mixers on one device
    (composer.swift:203-224) leaves the device idle most of the time.  With the two hunks of INTEGRATION.md section 1
    a mixer (a) issues its tick as one chv_composite launch, or (b) — when it belongs to a VideoMixerGroup — hands the
    tick to the group, which composes the ticks of all its members with ONE chv_batch launch per canvas format and ONE
-   host wait (measured: 256 ticks per launch = 5.8 us per tick, bench.py; one tick at a time: 34 us fused, 91 us as the
-   unchanged clear + 4 launches sequence, bench.py legs pipeline_per_tick / pipeline_reference_sequence).
+   host wait.  Current figures: INTEGRATION.md section 1 and the `workloads` of the default bench.py line (round 3: 256
+   ticks per launch = 4.9 us of device time per tick; one tick at a time 23-25 us fused, 54-56 us as the unchanged
+   clear + 4 launches sequence: legs pipeline_per_tick / pipeline_reference_sequence).  The per-tick figure of a group does
+   not include building the TickBatch: VideoMixerGroup.flush below makes a new one every tick (a device allocation and a
+   descriptor copy, ~10 us); a group whose members and canvas rings recur should keep its batches, keyed by the
+   (canvas, sources) tuple, as swiftvideo_amd/compute.py::LanczosBatch does for resizes.
 */
 #if GPGPU_HIP
 import Foundation

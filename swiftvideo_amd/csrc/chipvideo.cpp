@@ -285,7 +285,7 @@ struct StagingSlot {
 struct DescGroup {
     hipEvent_t done = nullptr;
     bool pending = false;     // `done` has been recorded and not yet waited for
-    bool dirty = false;       // a launch of this pass over the group reads one of its slots
+    bool unguarded = false;   // the event behind the group's last slot could not be recorded: the walk drains the stream before it enters the group again
 };
 
 static constexpr int kStagingSlots = 4;
@@ -906,26 +906,38 @@ static int tick_to_device(const chv_tick &t, int device, int forced_target_forma
     return CHV_OK;
 }
 
-// the next slot of the descriptor ring, once the device is done with what it held (see DescGroup)
-static int desc_acquire(chv_context *c, int *slot_out) {
-    const int slot = c->next_desc;
-    c->next_desc = (c->next_desc + 1) % kDescSlots;
-    DescGroup &g = c->desc_group[slot / kDescGroup];
-    if (slot % kDescGroup == 0 && g.pending) { HIP_TRY(hipEventSynchronize(g.done)); g.pending = false; }
-    g.dirty = true;
-    *slot_out = slot;
-    return CHV_OK;
-}
-
-// after the launch that reads `slot` has been issued on the context's stream
-static int desc_release(chv_context *c, int slot) {
-    DescGroup &g = c->desc_group[slot / kDescGroup];
-    if (slot % kDescGroup != kDescGroup - 1 || !g.dirty) return CHV_OK;
-    if (!g.done) HIP_TRY(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(g.done, c->stream));
-    g.pending = true; g.dirty = false;
-    return CHV_OK;
-}
+// One slot of the descriptor ring for the lifetime of the object: taken once the device is done with what the slot's group held (see
+// DescGroup), given back on EVERY path out of the scope — a launch that fails after taking the group's last slot still leaves the event
+// (or the `unguarded` mark) behind the launches of the group that were queued before it.  The walk advances only when the wait succeeded.
+struct DescSlot {
+    chv_context *c;
+    int slot = -1;
+    int rc = CHV_OK;
+    explicit DescSlot(chv_context *ctx) : c(ctx) {
+        const int s = c->next_desc;
+        DescGroup &g = c->desc_group[s / kDescGroup];
+        if (s % kDescGroup == 0) {
+            hipError_t e = hipSuccess;
+            if (g.unguarded) e = hipStreamSynchronize(c->stream);
+            else if (g.pending) e = hipEventSynchronize(g.done);
+            if (e != hipSuccess) { rc = hip_fail(e, "waiting for a descriptor slot"); return; }
+            g.pending = false; g.unguarded = false;
+        }
+        c->next_desc = (s + 1) % kDescSlots;
+        slot = s;
+    }
+    ~DescSlot() {
+        if (slot < 0 || slot % kDescGroup != kDescGroup - 1) return;
+        DescGroup &g = c->desc_group[slot / kDescGroup];
+        hipError_t e = hipSuccess;
+        if (!g.done) e = hipEventCreateWithFlags(&g.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(g.done, c->stream);
+        if (e == hipSuccess) g.pending = true;
+        else { g.pending = false; g.unguarded = true; (void)hipGetLastError(); }
+    }
+    DescSlot(const DescSlot &) = delete;
+    DescSlot &operator=(const DescSlot &) = delete;
+};
 
 // launch one transient tick through the pinned descriptor ring
 static int launch_transient(chv_context *c, const DTick &tick_in, const std::vector<DLayer> &layers, int tf) {
@@ -952,9 +964,9 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
         hipError_t e = launch_tick_fast(path, ht, hl, nullptr, nullptr, 1, ht->W, ht->H, c->stream);
         return e == hipSuccess ? CHV_OK : hip_fail(e, "kernel launch");
     }
-    int slot = 0;
-    int rc = desc_acquire(c, &slot);
-    if (rc) return rc;
+    DescSlot ds(c);
+    if (ds.rc) return ds.rc;
+    const int slot = ds.slot;
     uint8_t *base = c->desc_host + (size_t)slot * kDescSlotBytes;
     DTick *st = (DTick *)base;
     DLayer *sl = (DLayer *)(base + sizeof(DTick));
@@ -971,7 +983,7 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     hipError_t e = path >= 0 ? launch_tick_fast(path, st, sl, dt, dl, 1, st->W, st->H, c->stream)
                              : launch_tick_general(tf, dt, dl, 1, st->W, st->H, c->stream);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
-    return desc_release(c, slot);
+    return CHV_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1461,18 +1473,15 @@ extern "C" int chv_scale_lanczos_batch(chv_context *c, const chv_image *dsts, co
     static_assert((size_t)CHV_LANCZOS_BATCH_CHUNK * 2 * sizeof(DPlane) <= kDescSlotBytes, "a chunk's plane pairs must fit one descriptor slot");
     for (int first = 0; first < n; first += per_slot) {
         const int m = std::min(per_slot, n - first);
-        int slot = 0;
-        rc = desc_acquire(c, &slot);
-        if (rc) return rc;
-        DPlane *host = (DPlane *)(c->desc_host + (size_t)slot * kDescSlotBytes);
+        DescSlot ds(c);
+        if (ds.rc) return ds.rc;
+        DPlane *host = (DPlane *)(c->desc_host + (size_t)ds.slot * kDescSlotBytes);
         memcpy(host, pairs.data() + 2 * (size_t)first, sizeof(DPlane) * 2 * (size_t)m);
         DPlane *dev = nullptr;
         HIP_TRY(hipHostGetDevicePointer((void **)&dev, host, 0));
         (void)hipGetLastError();
         hipError_t e = launch_lanczos(pairs[0], pairs[1], tx->first, tx->weights, tx->taps, ty->first, ty->weights, ty->taps, c->stream, dev, m, tx->stride, tx->first0, ty->stride);
         if (e != hipSuccess) return hip_fail(e, "lanczos launch");
-        rc = desc_release(c, slot);
-        if (rc) return rc;
     }
     return CHV_OK;
 }

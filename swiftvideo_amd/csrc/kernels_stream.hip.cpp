@@ -353,7 +353,11 @@ bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks)
                 if (!(kx > 0.0) || !(ky > 0.0)) return false;                                   // flips: the rings assume rising positions
                 const double sx = kx * Y.src.pl[0].w / (double)T.W;
                 if (!(63.0 * sx + 2.0 + 15.0 + 1.0 <= 128.0)) return false;                     // luma bytes of a strip (chroma: the same count)
-                if (!std::isfinite(ky * Y.src.pl[0].h / (double)T.H)) return false;
+                // source rows per canvas row: the rings are advanced batch by batch (four luma rows per load), so the work per canvas row grows
+                // with the vertical reduction — a picture squeezed into a few canvas rows (a zoom animation's first frames) would issue
+                // hundreds of loads of rows nobody taps per canvas row, and tick_bgra_wave culls by bounding box instead
+                const double sy = ky * Y.src.pl[0].h / (double)T.H;
+                if (!std::isfinite(sy) || sy > 4.0) return false;
             }
         }
     }

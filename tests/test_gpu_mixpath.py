@@ -300,6 +300,10 @@ def test_stream_kernel_eligibility(ctx, switch):
                 _stack("img_nv12_bgra", 480, 272, dict(tex=(1.0, 0.0, -1.0, 1.0)), (1.0, 0.5)),
                 _stack("img_nv12_bgra", 640, 360, dict(A), (1.0, 0.5)),                      # 2:1 reduction onto 320 columns
                 _stack("img_nv12_bgra", 300, 170, A, (1.0, 0.5)),
+                # a picture squeezed into a few canvas rows (a zoom animation's first frames): the rings would be advanced through dozens
+                # of source rows per canvas row, the strip kernels cull by bounding box instead — and the bytes still match the oracle
+                _stack("img_nv12_bgra", 480, 272, dict(rect=(0, 60, 320, 6)), (1.0, 0.5)),
+                _stack("img_nv12_bgra", 480, 272, dict(rect=(0, 90, 320, 0.01)), (1.0, 0.5)),
                 _stack("img_nv12_bgra", 480, 272, A, (1.0, 0.5, 0.5, 0.5, 0.5))):
         assert run_tick_case(ctx, 320, 180, True, bad, expect=None) != STREAM
     switch("CHV_STREAM", "0")
