@@ -37,6 +37,7 @@ hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, cons
                            const float *den, float *out_q, int n, hipStream_t stream);
 hipError_t launch_selftest_pack(const int *b, const int *g, const int *r, uint32_t *out, int n, hipStream_t stream);
 hipError_t launch_selftest_pack_codes(const float *in, uint32_t *out, int n, hipStream_t stream);
+hipError_t launch_selftest_matrices(int dir, int csc, uint32_t *out, uint32_t *mism, hipStream_t stream);
 // kernels_fast.hip.cpp
 const char *fast_path_name(int path);
 bool fast_path_by_value(int path);      // a lone tick's descriptors can travel as kernel arguments (ticks == layers == nullptr)
@@ -1593,6 +1594,26 @@ extern "C" int chv_selftest_pack(chv_context *c, const int *b, const int *g, con
     HIP_TRY(hipMemcpy(out, d_o, n * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d_b); (void)hipFree(d_g); (void)hipFree(d_r); (void)hipFree(d_o);
     return CHV_OK;
+}
+
+// Exhaustive device self-test of the integer BT.601 / 709 matrices (tests/test_gpu_matrices.py): direction 0 YUV -> RGB (out[Y << 16 | U << 8 | V]
+// = the BGRA word), 1 RGB -> YUV (out[R << 16 | G << 8 | B] = Y | U << 8 | V << 16), all 2^24 triples of colourspace `csc`; *mismatches = triples
+// on which the forms of the YUV -> RGB matrix the kernels use disagree among themselves (direction 0).
+extern "C" int chv_selftest_matrices(chv_context *c, int direction, int csc, uint32_t *out /* 1 << 24 */, uint32_t *mismatches) {
+    if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    if (!out || !mismatches || direction < 0 || direction > 1 || csc < 0 || csc > 3) return fail(CHV_ERR_INVALID_VALUE, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t *d_o = nullptr, *d_m = nullptr;
+    const size_t bytes = sizeof(uint32_t) << 24;
+    HIP_TRY(hipMalloc((void **)&d_o, bytes));
+    hipError_t e = hipMalloc((void **)&d_m, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(d_m, 0, sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = launch_selftest_matrices(direction, csc, d_o, d_m, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_o, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(mismatches, d_m, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_o); if (d_m) (void)hipFree(d_m);
+    return e == hipSuccess ? CHV_OK : hip_fail(e, "selftest matrices");
 }
 
 extern "C" int chv_selftest_pack_codes(chv_context *c, const float *in /*4n*/, uint32_t *out /*2n*/, int n) {

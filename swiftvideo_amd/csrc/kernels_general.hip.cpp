@@ -162,6 +162,41 @@ __global__ void selftest_pack_codes_kernel(const float *in, uint32_t *out, int n
         out[2 * i + 1] = pack_codes(c0, c1, c2, c3);
     }
 }
+// Exhaustive self-test of the integer colour matrices, all 2^24 code triples of one matrix in one launch.
+//   dir 0: i = Y << 16 | U << 8 | V  ->  out[i] = B | G << 8 | R << 16 | 255 << 24 through the plain form (yuv_to_bgra_word(Csc)); every OTHER
+//          form the kernels use — offsets folded into one constant per channel, operands carrying the float adder's bias 0x4B400000 + code
+//          (what code_biased hands the tiled / wave / stream kernels) packed by v_ashr_pk_u8_i32, and the float-code form of the blending
+//          kernels packed by v_cvt_pk_u8_f32 — is compared with it on the device: *mism counts the triples on which any of them differs
+//   dir 1: i = R << 16 | G << 8 | B  ->  out[i] = Y | U << 8 | V << 16 through rgb_to_yuv_int
+__global__ void selftest_matrices_kernel(int dir, int csc, uint32_t *out, uint32_t *mism) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = (int)(i >> 16), b = (int)((i >> 8) & 255u), c = (int)(i & 255u);
+    if (dir == 0) {
+        const Csc &k = kCsc[csc & 3];
+        const uint32_t w0 = yuv_to_bgra_word(k, a, b, c);
+        const CscFolded f = csc_fold(k), fb = csc_fold_biased(k);
+        const uint32_t w1 = yuv_to_bgra_word(f, a, b, c);
+        const int ya = (int)code_biased((float)a), ua = (int)code_biased((float)b), va = (int)code_biased((float)c);
+        const uint32_t w2 = yuv_to_bgra_word(fb, ya, ua, va);
+        float pb, pg, pr;
+        yuv_to_bgr_floats(fb, ya, ua, va, pb, pg, pr);
+        const uint32_t w3 = pack_codes(pb, pg, pr, 0xFF000000u);
+        out[i] = w0;
+        if (w1 != w0 || w2 != w0 || w3 != w0) atomicAdd(mism, 1u);
+    } else {
+        uint32_t y, u, v;
+        rgb_to_yuv_int(kR2Y[csc & 3], a, b, c, y, u, v);
+        // (the three codes leave as the kernels consume them — converted to floats — and are packed by v_cvt_pk_u8_f32: written as
+        // `y | u << 8 | v << 16`, hipcc 7.2 selects v_ashr_pk_u8_i32 for the clip8 pairs and ORs the third code into a register whose upper
+        // half that instruction does not leave zero — the defect pixel_math.hip.h::pack_bgra_fixed documents; it showed here as 15.5 M wrong
+        // V codes in the first version of this very test)
+        out[i] = pack_codes((float)y, (float)u, (float)v, 0u);
+    }
+}
+hipError_t launch_selftest_matrices(int dir, int csc, uint32_t *out, uint32_t *mism, hipStream_t stream) {
+    hipLaunchKernelGGL(selftest_matrices_kernel, dim3((1u << 24) / 256), dim3(256), 0, stream, dir, csc, out, mism);
+    return hipGetLastError();
+}
 hipError_t launch_selftest_pack_codes(const float *in, uint32_t *out, int n, hipStream_t stream) {
     hipLaunchKernelGGL(selftest_pack_codes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n);
     return hipGetLastError();

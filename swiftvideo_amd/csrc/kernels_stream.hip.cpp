@@ -67,17 +67,7 @@ constexpr int ST_TAB = 32;                    // row entries computed at a time 
 #endif
 constexpr int ST_WAVES = CHV_STREAM_BLOCK;    // waves (neighbouring strips) per block
 
-// integer colour matrix on biased codes -> float codes (kernels_wave.hip.cpp::yuv_to_bgr_floats)
-CHV_DEV void st_yuv_to_bgr(const CscFolded &k, int y, int u, int v, float &fb, float &fg, float &fr) {
-    int32_t t = __mul24(y, k.cy);
-    int32_t r = mad24_uniform(v, k.crv, t) + k.kr;
-    int32_t g = mad24_uniform(v, k.ncgv, mad24_uniform(u, k.ncgu, t)) + k.kg;
-    int32_t b = mad24_uniform(u, k.cbu, t) + k.kb;
-    const int32_t cb = min(max(b, 0), 0xFFFFFF), cg = min(max(g, 0), 0xFFFFFF), cr = min(max(r, 0), 0xFFFFFF);
-    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fb) : "v"(cb));
-    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fg) : "v"(cg));
-    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fr) : "v"(cr));
-}
+// integer colour matrix on biased codes -> float codes: yuv_to_bgr_floats (pixel_math.hip.h)
 
 // One load instruction: lane -> (layer li, row rr of the batch, vector vec); `p` is the lane's own 16-byte source address, its LDS
 // destination is m0 + lane * 16 (tools/probe_lds_dma.cpp).
@@ -281,7 +271,7 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
             const float fu = cs_mix_h(c00, c10, c01, c11, tap_h(pC00 + lc), tap_h(pC10 + lc), tap_h(pC01 + lc), tap_h(pC11 + lc));
             const float fv = cs_mix_h(c00, c10, c01, c11, tap_h(pC00 + lc + 1), tap_h(pC10 + lc + 1), tap_h(pC01 + lc + 1), tap_h(pC11 + lc + 1));
             float pb, pg, pr;
-            st_yuv_to_bgr(csc[l], (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv), pb, pg, pr);
+            yuv_to_bgr_floats(csc[l], (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv), pb, pg, pr);
             if (l == 0) {                // the cleared canvas: fma(p, a, 0 * (1 - a)) = RN(p * a) for a in [0, 1]
                 r0 = pb * al[0]; r1 = pg * al[0]; r2 = pr * al[0];
             } else {

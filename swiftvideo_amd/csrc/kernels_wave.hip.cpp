@@ -54,19 +54,7 @@ namespace chv {
 // clip8(x >> 16) = byte 2 of clamp(x, 0, 0xFFFFFF): v_med3_i32 + v_cvt_f32_ubyte2 per channel (two slow-class instructions,
 // 3.6 ns per wave) — v_ashr_pk_u8_i32 + v_cvt_f32_ubyteN measured 3.45 + 1.8 per channel pair / channel
 // (the packing instruction issues at a quarter of the rate, tools/ubench_tput.cpp).
-CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &fb, float &fg, float &fr) {
-    int32_t t = __mul24(y, k.cy);
-    int32_t r = mad24_uniform(v, k.crv, t) + k.kr;
-    int32_t g = mad24_uniform(v, k.ncgv, mad24_uniform(u, k.ncgu, t)) + k.kg;
-    int32_t b = mad24_uniform(u, k.cbu, t) + k.kb;
-    // (v_cvt_f32_ubyte2 spelled out: left alone hipcc picks v_cvt_f32_u32_sdwa src0_sel:WORD_1, and SDWA forms — like v_fma_mix_f32,
-    // the 24-bit multiplies and v_perm_b32 — do not pair with a neighbouring f32 instruction, while v_cvt_f32_ubyteN, v_med3_i32 and
-    // v_cvt_pk_u8_f32 do: tools/ubench_pair.cpp, profiles/r03_ubench_pair_gfx950.txt)
-    const int32_t cb = min(max(b, 0), 0xFFFFFF), cg = min(max(g, 0), 0xFFFFFF), cr = min(max(r, 0), 0xFFFFFF);
-    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fb) : "v"(cb));
-    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fg) : "v"(cg));
-    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fr) : "v"(cr));
-}
+// (yuv_to_bgr_floats: pixel_math.hip.h — shared with tick_bgra_stream and the exhaustive device self-test of the matrices)
 
 #ifndef CHV_WAVE_MINW
 #define CHV_WAVE_MINW 6

@@ -372,4 +372,20 @@ CHV_DEV uint32_t yuv_to_bgra_word(const CscFolded &k, int y, int u, int v) {
     return pack_bgra_fixed_pk(b, g, r);
 }
 
+// The same matrix on biased codes (csc_fold_biased), the channels returned as float codes 0..255 for a blend that follows (tick_bgra_wave,
+// tick_bgra_stream): clamp to 24 bits, then the integer byte of each 16.16 channel through v_cvt_f32_ubyte2.
+CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &fb, float &fg, float &fr) {
+    int32_t t = __mul24(y, k.cy);
+    int32_t r = mad24_uniform(v, k.crv, t) + k.kr;
+    int32_t g = mad24_uniform(v, k.ncgv, mad24_uniform(u, k.ncgu, t)) + k.kg;
+    int32_t b = mad24_uniform(u, k.cbu, t) + k.kb;
+    // (v_cvt_f32_ubyte2 spelled out: left alone hipcc picks v_cvt_f32_u32_sdwa src0_sel:WORD_1, and SDWA forms — like v_fma_mix_f32,
+    // the 24-bit multiplies and v_perm_b32 — do not pair with a neighbouring f32 instruction, while v_cvt_f32_ubyteN, v_med3_i32 and
+    // v_cvt_pk_u8_f32 do: tools/ubench_pair.cpp, profiles/r03_ubench_pair_gfx950.txt)
+    const int32_t cb = min(max(b, 0), 0xFFFFFF), cg = min(max(g, 0), 0xFFFFFF), cr = min(max(r, 0), 0xFFFFFF);
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fb) : "v"(cb));
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fg) : "v"(cg));
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fr) : "v"(cr));
+}
+
 }  // namespace chv
