@@ -753,6 +753,124 @@ def run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=64, group=8
     return rep
 
 
+def run_e2e(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=32, group=8, streams=2):
+    """The whole picture path END TO END, both directions over PCIe (never the headline value): per tick four decoded 1080p NV12 frames go
+    up from a pinned host ring (slabs of `group` frames per linear copy, `streams` upload contexts), the fused pipeline tick composes them
+    onto a 720p BGRA canvas, img_bgra_nv12_int converts the canvas for an encoder, and the NV12 result comes back into a pinned ring through
+    chv_download_async on a download context of its own.  Two sets of `frames` ticks are in flight; order comes from events only (upload ->
+    kernel by the per-buffer upload events, kernel -> next upload / kernel -> copy / copy -> next kernel by chv_event_wait), no host waits in
+    the loop.  Reports ticks/s and both link rates."""
+    import util
+    from oracle import oracle as O
+    wl = WORKLOADS["pipeline"]
+    sw, sh, dw, dh, nl = wl["sw"], wl["sh"], wl["dw"], wl["dh"], wl["layers"]
+    fbytes, obytes = sw * sh * 3 // 2, dw * dh * 3 // 2
+    distinct = 4
+    ups = [sv.createComputeContext(sharing=ctx) for _ in range(streams)]
+    dl = sv.createComputeContext(sharing=ctx)
+    node, prev_aff = bind_to_device_node(cv, lib, ctx)
+    n_in = frames * nl
+    pin_in, pin_out = C.c_void_p(), C.c_void_p()
+    cv.check(lib.chv_host_alloc(ups[0].handle, n_in * fbytes, C.byref(pin_in)))
+    cv.check(lib.chv_host_alloc(dl.handle, 2 * frames * obytes, C.byref(pin_out)))
+    host_in = np.ctypeslib.as_array((C.c_uint8 * (n_in * fbytes)).from_address(pin_in.value))
+    host_out = np.ctypeslib.as_array((C.c_uint8 * (2 * frames * obytes)).from_address(pin_out.value))
+    host_out[:] = 0
+    imgs = [util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 96 + i) for i in range(distinct)]
+    for f in range(n_in):                    # tick t, layer l reads ring frame t * nl + l = distinct frame (t + l) % 4
+        img = imgs[(f // nl + f % nl) % distinct]
+        host_in[f * fbytes: f * fbytes + sw * sh] = img[0].reshape(-1)
+        host_in[f * fbytes + sw * sh: (f + 1) * fbytes] = img[1].reshape(-1)
+    ops = (1.0, 0.75, 0.5, 0.25)
+    us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=ops[l]) for l in range(nl)]
+    u_enc = util.full_canvas_uniforms((dw, dh), (dw, dh))
+    k_in, k_enc = sv.defaultComputeKernelFromString("img_nv12_bgra"), sv.defaultComputeKernelFromString("img_bgra_nv12_int")
+    sets = []
+    for _ in range(2):
+        slabs = [sv.PictureSlab(ctx, (sw, sh), sv.PixelFormat.nv12, group) for _ in range(n_in // group)]
+        outs = [sv.PictureSlab(ctx, (dw, dh), sv.PixelFormat.nv12, group) for _ in range(frames // group)]
+        canvases = [sv.uploadComputePicture(ctx, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False) for _ in range(frames)]
+        pic = lambda i: slabs[i // group].pictures[i % group]      # noqa: E731
+        compose = [(canvases[t], True, [(k_in, pic(t * nl + l), us[l], cv.CSC_BT601_LIMITED) for l in range(nl)]) for t in range(frames)]
+        encode = [(outs[t // group].pictures[t % group], True, [(k_enc, canvases[t], u_enc, cv.CSC_BT601_LIMITED)]) for t in range(frames)]
+        sets.append(dict(slabs=slabs, outs=outs, canvases=canvases, compose=sv.TickBatch(ctx, compose), encode=sv.TickBatch(ctx, encode)))
+
+    def event(c):
+        e = C.c_void_p()
+        cv.check(lib.chv_event_create(c.handle, C.byref(e)))
+        cv.check(lib.chv_event_record(c.handle, e))
+        return e
+    composed = [event(ctx) for _ in sets]       # the kernel that read the set's source slabs has run
+    encoded = [event(ctx) for _ in sets]        # the set's output slabs hold the encoder frames
+    copied = [event(dl) for _ in sets]          # the copies that read the set's output slabs have run
+    state = [0]
+
+    def launch():
+        s = state[0] & 1
+        state[0] += 1
+        for upc in ups:
+            cv.check(lib.chv_event_wait(upc.handle, composed[s]))
+        for g, slab in enumerate(sets[s]["slabs"]):
+            slab.upload(ups[g % streams], 0, group, pin_in.value + g * group * fbytes, mode=2)
+        sets[s]["compose"].run(ctx)                                  # waits for the slabs' upload events on its stream
+        cv.check(lib.chv_event_record(ctx.handle, composed[s]))
+        cv.check(lib.chv_event_wait(ctx.handle, copied[s]))          # the previous read-back of these output slabs is through
+        sets[s]["encode"].run(ctx)
+        cv.check(lib.chv_event_record(ctx.handle, encoded[s]))
+        cv.check(lib.chv_event_wait(dl.handle, encoded[s]))
+        for g, out in enumerate(sets[s]["outs"]):
+            out.download(dl, 0, group, pin_out.value + (s * frames + g * group) * obytes)
+        cv.check(lib.chv_event_record(dl.handle, copied[s]))
+
+    for _ in range(max(args.warmup, 2)):
+        launch()
+    tm.sync()
+    sv.endComputePass(dl, True)
+    verified = None
+    if not args.no_verify and rank == 0:
+        # tick 5 of the set processed last, as it arrived in the pinned output ring == oracle (clear + 4 layers, then the integer matrix)
+        t, s = 5, (state[0] - 1) & 1
+        threads = os.cpu_count() or 1
+        cvs = util.alloc_image("bgra", dw, dh)
+        assert O.run_kernel("img_clear_bgra", cvs, threads=threads) == 0
+        for l in range(nl):
+            assert O.run_kernel("img_nv12_bgra", cvs, imgs[(t + l) % distinct], us[l], threads=threads) == 0
+        exp = util.alloc_image("nv12", dw, dh)
+        assert O.run_kernel("img_clear_nv12", exp, threads=threads) == 0
+        assert O.run_kernel("img_bgra_nv12_int", exp, cvs, u_enc, threads=threads) == 0
+        got = host_out[(s * frames + t) * obytes: (s * frames + t + 1) * obytes]
+        verified = bool(np.array_equal(got[:dw * dh].reshape(dh, dw), exp[0]) and np.array_equal(got[dw * dh:].reshape(dh // 2, dw // 2, 2), exp[1]))
+    per_step = tm.calibrate(launch, args.steps, args.min_seconds_other, args.launches_per_step)
+    elapsed, local, launch_ms = tm.run(launch, args.steps, per_step)
+    sv.endComputePass(dl, True)
+    n_sets = per_step * args.steps
+    h2d = n_in * fbytes * n_sets / local / 1e9
+    d2h = frames * obytes * n_sets / local / 1e9
+    rep = {
+        "workload": f"pipeline_e2e: the pipeline tick END TO END, both directions over PCIe: H2D of 4 x 1080p NV12 per tick ({group} frames = "
+                    f"{group * fbytes / 1e6:.1f} MB per copy, {streams} upload streams) -> fused 4-layer tick -> img_bgra_nv12_int -> D2H of the 720p "
+                    f"NV12 frame ({group} frames = {group * obytes / 1e6:.1f} MB per copy, chv_download_async on its own context); two sets of "
+                    f"{frames} ticks in flight, events only (PCIe-bound; never the headline value)",
+        "value": whole_job_gpix(n_gpus, frames * dw * dh * per_step, args.steps, elapsed), "unit": "Gpix/s",
+        "ticks_per_s": frames * n_sets / local, "ms_per_step": elapsed / args.steps * 1e3, "launches_per_step": per_step, "timed_seconds": elapsed,
+        "frames_per_launch_per_gpu": frames, "kernel": sets[0]["compose"].kernelName + " + " + sets[0]["encode"].kernelName,
+        "h2d_GBps_per_gpu": h2d, "h2d_frac_of_link": h2d / H2D_LINK_GBS, "d2h_GBps_per_gpu": d2h, "d2h_frac_of_link": d2h / H2D_LINK_GBS,
+        "link_GBps": H2D_LINK_GBS, "pinned_numa_node": node, "verified_vs_oracle": verified,
+    }
+    for e in composed + encoded + copied:
+        cv.check(lib.chv_event_destroy(e))
+    for st in sets:
+        st["compose"].destroy(); st["encode"].destroy()
+        st["slabs"].clear(); st["outs"].clear(); st["canvases"].clear()
+    cv.check(lib.chv_host_free(ups[0].handle, pin_in))
+    cv.check(lib.chv_host_free(dl.handle, pin_out))
+    for c in ups + [dl]:
+        sv.destroyComputeContext(c)
+    if prev_aff is not None:
+        os.sched_setaffinity(0, prev_aff)
+    return rep
+
+
 def run_per_tick(args, sv, cv, lib, ctx, seconds=0.35, ring=10, distinct=4, mixers=8):
     """The path a Swift VideoMixer takes: ONE tick at a time with the reference's host wait after it (usingContext,
     compute.swift:131-134).  Two ways of issuing the headline tick (4 x 1080p NV12 -> 720p BGRA canvas from a ring of 10):
@@ -993,6 +1111,7 @@ def main(argv=None):
         reports[name], _ = do(name, False)
     if others and not args.no_upload_leg and not args.stub_device:
         reports["cfg2_upload"] = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
+        reports["pipeline_e2e"] = run_e2e(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
     if (others or args.per_tick) and not args.stub_device and not args.no_per_tick and n_gpus == 1:
         reports.update(run_per_tick(args, sv, cv, lib, ctx))
         reports.update(run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p"))

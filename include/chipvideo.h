@@ -193,6 +193,14 @@ int chv_host_free(chv_context *ctx, void *ptr);
  * 461-498): pitched D2H copy, always complete on return. */
 int chv_download(chv_context *ctx, void *dst, size_t dst_pitch, chv_buffer *src,
                  size_t src_offset, size_t src_pitch, size_t width_bytes, size_t rows);
+/* The same copy without the wait (the D2H half of GPUBarrierDownload running on a context of its own, compute.swift:217-255, so that
+ * the read-back of tick t overlaps the kernels of tick t + 1): ordered on ctx's stream behind pending asynchronous uploads of `src`;
+ * `dst` is pinned memory from chv_host_alloc and holds the picture once ctx's stream has passed the copy (chv_event_record +
+ * chv_event_synchronize, or chv_pass_end(ctx, wait)).  Kernels of ANOTHER context that write `src` are ordered in front of the copy
+ * with chv_event_record (there) + chv_event_wait (here).  Adjacent planes / frames of one allocation travel as one linear copy when
+ * both pitches equal width_bytes. */
+int chv_download_async(chv_context *ctx, void *dst, size_t dst_pitch, chv_buffer *src,
+                       size_t src_offset, size_t src_pitch, size_t width_bytes, size_t rows);
 
 /* ---- images: POD view of ImageBuffer.planes + computeTextures,
  *      sample.pict.linux.swift:23-72 ------------------------------------- */

@@ -405,6 +405,27 @@ func downloadComputePicture(_ ctx: ComputeContext,
     return PictureSample(pict, img: image)
 }
 
+/// The D2H half of a download barrier that runs on a context of its own (GPUBarrierDownload, compute.swift:217-255) without the host
+/// wait: the planes of `pict` are copied into `pinned` (chv_host_alloc; plane after plane, rows packed) on `ctx`'s stream and the call
+/// returns.  The bytes are the picture's once that stream has passed the copy (`endComputePass(ctx, true)` on it, or an event).  Work of
+/// the mixer's context that writes `pict` is ordered in front of the copy by the caller: chv_event_record there, chv_event_wait here —
+/// the read-back of tick t then overlaps the kernels of tick t + 1 (bench.py leg pipeline_e2e).
+func downloadComputePictureAsync(_ ctx: ComputeContext, pict: PictureSample, pinned: UnsafeMutableRawPointer) throws {
+    guard pict.bufferType() == .gpu, let imageBuffer = pict.imageBuffer() else {
+        throw ComputeError.badInputData(description: "Missing device image")
+    }
+    var offset = 0
+    for idx in 0..<imageBuffer.computeTextures.count {
+        let plane = imageBuffer.planes[idx]
+        let comps = plane.components.count >= 3 ? 4 : plane.components.count
+        let rowBytes = Int(plane.size.x) * comps
+        let texture = imageBuffer.computeTextures[idx]
+        try check(chv_download_async(ctx.handle, pinned + offset, rowBytes, texture.handle, texture.offset, texture.pitch,
+                                     rowBytes, Int(plane.size.y)))
+        offset += rowBytes * Int(plane.size.y)
+    }
+}
+
 // MARK: - One mixer tick in one launch (optional fast path for VideoMixer.mix)
 
 /// Equivalent of `usingContext { clear; images.reduce { applyComputeImage } }` (mix.video.swift:116-124)

@@ -107,6 +107,7 @@ _SIGNATURES = {
     "chv_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "chv_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "chv_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "chv_download_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]),
     "chv_pass_begin": (C.c_int, [C.c_void_p]),
     "chv_run_kernel": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Image), C.POINTER(Image), C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(KernelOpts)]),
     "chv_pass_end": (C.c_int, [C.c_void_p, C.c_int]),

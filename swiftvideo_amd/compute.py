@@ -400,6 +400,12 @@ class PictureSlab:
         n = self.frameBytes * frames
         cv.check(cv.load().chv_upload(ctx.handle, self.buffer._h, first * self.frameBytes, n, host_address, n, n, 1, mode))
 
+    def download(self, ctx, first, frames, host_address):
+        """frames [first, first + frames) into `frames` packed host frames at host_address (pinned: chv_host_alloc), one linear copy on ctx's
+        stream, NOT waited for (chv_download_async): the bytes are there once ctx's stream has passed the copy"""
+        n = self.frameBytes * frames
+        cv.check(cv.load().chv_download_async(ctx.handle, host_address, n, self.buffer._h, first * self.frameBytes, n, n, 1))
+
 
 def downloadComputePicture(ctx, pict, retainGpuBuffer=False):
     """compute.cl.swift:461-498"""

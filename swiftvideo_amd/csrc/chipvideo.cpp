@@ -643,7 +643,7 @@ extern "C" int chv_host_free(chv_context *c, void *ptr) {
     return CHV_OK;
 }
 
-extern "C" int chv_download(chv_context *c, void *dst, size_t dst_pitch, chv_buffer *src,
+static int download_enqueue(chv_context *c, void *dst, size_t dst_pitch, chv_buffer *src,
                             size_t src_offset, size_t src_pitch, size_t width_bytes, size_t rows) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
     if (!dst) return fail(CHV_ERR_BAD_INPUT, "null destination");
@@ -655,10 +655,29 @@ extern "C" int chv_download(chv_context *c, void *dst, size_t dst_pitch, chv_buf
     // (GPUBarrierDownload's, compute.swift:175-255): order the read behind the upload
     rc = wait_for_buffer(src, c->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, (const uint8_t *)src->ptr + src_offset, src_pitch, width_bytes, rows,
-                             hipMemcpyDeviceToHost, c->stream));
+    const uint8_t *from = (const uint8_t *)src->ptr + src_offset;
+    // one contiguous block on both sides -> a linear copy (a slab of frames: the link gives its full rate to copies of 8 MB and more)
+    if (dst_pitch == width_bytes && src_pitch == width_bytes) HIP_TRY(hipMemcpyAsync(dst, from, width_bytes * rows, hipMemcpyDeviceToHost, c->stream));
+    else HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, from, src_pitch, width_bytes, rows, hipMemcpyDeviceToHost, c->stream));
+    return CHV_OK;
+}
+
+extern "C" int chv_download(chv_context *c, void *dst, size_t dst_pitch, chv_buffer *src,
+                            size_t src_offset, size_t src_pitch, size_t width_bytes, size_t rows) {
+    int rc = download_enqueue(c, dst, dst_pitch, src, src_offset, src_pitch, width_bytes, rows);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CHV_OK;
+}
+
+// The copy is ordered on the context's stream and the call returns at once: `dst` is pinned memory (chv_host_alloc) whose bytes are the
+// picture's once the stream has passed the copy — chv_event_record + chv_event_synchronize, or chv_pass_end(wait) on this context.  Work of
+// OTHER contexts that writes `src` (the mixer's tick) is ordered in front of it with chv_event_record there and chv_event_wait here, as
+// between any two contexts: a download barrier running on a context of its own (GPUBarrierDownload, compute.swift:217-255) then overlaps the
+// D2H copy of tick t with the kernels of tick t + 1.
+extern "C" int chv_download_async(chv_context *c, void *dst, size_t dst_pitch, chv_buffer *src,
+                                  size_t src_offset, size_t src_pitch, size_t width_bytes, size_t rows) {
+    return download_enqueue(c, dst, dst_pitch, src, src_offset, src_pitch, width_bytes, rows);
 }
 
 // ---------------------------------------------------------------------------

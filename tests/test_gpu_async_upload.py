@@ -79,3 +79,53 @@ def test_pinned_uploads_overlap_with_kernels_and_stay_ordered(ctx):
     # argument checks
     assert lib.chv_event_elapsed_ms(None, None, C.byref(ms)) != 0
     assert lib.chv_host_alloc(ctx.handle, 0, C.byref(pinned)) != 0
+
+
+def test_async_downloads_overlap_with_kernels_and_stay_ordered(ctx):
+    """chv_download_async on a download context of its own (GPUBarrierDownload's, compute.swift:217-255): tick t's canvas is read back into a
+    pinned ring while tick t + 1 is composed; order comes from events only (kernel -> copy, copy -> reuse of the canvas and of the pinned slot),
+    the host waits once at the end — and every frame in the ring is the oracle's"""
+    lib = cv.load()
+    dl = sv.createComputeContext(sharing=ctx)
+    (W, H), (w, h) = (256, 88), (256, 88)                # (PictureSlab: packed rows of a multiple of 128 bytes)
+    n_ticks, ring = 10, 3
+    slab = sv.PictureSlab(ctx, (w, h), sv.PixelFormat.nv12, ring)           # the canvases: NV12 frames, one allocation
+    fb = slab.frameBytes
+    pinned = C.c_void_p()
+    cv.check(lib.chv_host_alloc(dl.handle, n_ticks * fb, C.byref(pinned)))
+    host = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_uint8)), shape=(n_ticks * fb,))
+    host[:] = 0xA5
+    u = util.full_canvas_uniforms((w, h), (W, H))
+    k = sv.defaultComputeKernelFromString("img_bgra_nv12_int")
+    composed = [C.c_void_p() for _ in range(ring)]       # "the tick that wrote canvas k has run"
+    copied = [C.c_void_p() for _ in range(ring)]         # "the copy that read canvas k has run"
+    for e in composed + copied:
+        cv.check(lib.chv_event_create(ctx.handle, C.byref(e)))
+    for e in copied:
+        cv.check(lib.chv_event_record(dl.handle, e))
+    expected, keep = [], []
+    for t in range(n_ticks):
+        c = t % ring
+        src = util.alloc_image("bgra", W, H, seed=500 + t)
+        exp = util.alloc_image("nv12", w, h)
+        assert O.run_kernel("img_clear_nv12", exp) == 0 and O.run_kernel("img_bgra_nv12_int", exp, src, u) == 0
+        expected.append(exp)
+        g = G.to_gpu(ctx, "bgra", W, H, src)
+        keep.append(g)
+        cv.check(lib.chv_event_wait(ctx.handle, copied[c]))                  # the canvas is free again
+        sv.beginComputePass(ctx)
+        sv.compositeTick(ctx, slab.pictures[c], [(k, g, u, 0)], True)
+        sv.endComputePass(ctx, False)                                        # no host wait
+        cv.check(lib.chv_event_record(ctx.handle, composed[c]))
+        cv.check(lib.chv_event_wait(dl.handle, composed[c]))
+        slab.download(dl, c, 1, pinned.value + t * fb)
+        cv.check(lib.chv_event_record(dl.handle, copied[c]))
+    sv.endComputePass(dl, True)                                              # the one host wait
+    for t, exp in enumerate(expected):
+        got = host[t * fb:(t + 1) * fb]
+        assert np.array_equal(got[:w * h].reshape(h, w), exp[0]), f"tick {t}: luma"
+        assert np.array_equal(got[w * h:].reshape(h // 2, w // 2, 2), exp[1]), f"tick {t}: chroma"
+    for e in composed + copied:
+        cv.check(lib.chv_event_destroy(e))
+    cv.check(lib.chv_host_free(dl.handle, pinned))
+    sv.destroyComputeContext(dl)
