@@ -127,6 +127,9 @@ def parse_args(argv=None):
     ap.add_argument("--with-upload", action="store_true",
                     help="end-to-end mode only: every step also uploads its source frames from pinned host memory on a side "
                          "stream (PCIe-inclusive rate; reported for DESIGN.md, never the headline value)")
+    ap.add_argument("--threads", action="store_true",
+                    help="with --gpus N: ONE process, one host thread + compute context per device (the shape of the Swift host: a composer "
+                         "with mixers bound to devices, composer.swift:203-224) instead of one process per GPU; the headline workload only")
     ap.add_argument("--stub-device", action="store_true",
                     help="control-plane self-test without a GPU (tests only): every launch is a short sleep, nothing is loaded or "
                          "computed; spawn, rendezvous, calibration, barriers, reductions and the report are the real ones; the line "
@@ -220,10 +223,33 @@ def dist_setup():
     return rank, local, world, dist
 
 
+class ThreadDist:
+    """--threads: the control plane of one process with a host thread per device — a threading.Barrier and a shared list where the
+    process-per-GPU mode has gloo"""
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank = shared, rank
+
+    def barrier(self):
+        self.shared["barrier"].wait()
+
+    def get_rank(self):
+        return self.rank
+
+    def gather(self, value):
+        self.shared["slots"][self.rank] = float(value)
+        self.barrier()
+        out = list(self.shared["slots"])
+        self.barrier()
+        return out
+
+
 def reduce_max(dist, value):
     """MAX over ranks of a host float (gloo all-reduce); identity when not distributed."""
     if dist is None:
         return float(value)
+    if isinstance(dist, ThreadDist):
+        return max(dist.gather(value))
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -234,6 +260,8 @@ def gather_floats(dist, value, world):
     """every rank's value, on every rank"""
     if dist is None:
         return [float(value)]
+    if isinstance(dist, ThreadDist):
+        return dist.gather(value)
     import torch
     t = torch.zeros(world, dtype=torch.float64)
     t[dist.get_rank()] = float(value)
@@ -983,6 +1011,107 @@ def run_per_tick(args, sv, cv, lib, ctx, seconds=0.35, ring=10, distinct=4, mixe
     }
 
 
+def run_thread_scaling(args, sv, cv, lib, ctx, seconds=0.25):
+    """How the one-tick-at-a-time path scales with host threads (one mixer = one thread + context, all on this device), from BOTH hosts: Python
+    threads over ctypes (this process) and native threads over the C ABI (tools/tick_threads.cpp, what a Swift composer's mixer queues would
+    be).  1 / 2 / 4 / 8 mixers, fused tick and the unchanged 1 + 4 launch sequence; ticks per second of all mixers together.  Where the native
+    host scales and the Python host does not, the interpreter lock is the limit; where neither does, the HIP runtime (or the chip) is."""
+    import subprocess
+    import tempfile
+    import threading
+    import util
+    wl = WORKLOADS["pipeline"]
+    sw, sh, dw, dh = wl["sw"], wl["sh"], wl["dw"], wl["dh"]
+    us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in (1.0, 0.75, 0.5, 0.25)]
+    out = {"workload": "per_tick_thread_scaling: the headline tick one at a time with a host wait after each, N mixers = N host threads with a context "
+                       "each on one device; ticks/s of all mixers together at N = 1, 2, 4, 8; Python host (ctypes) and native host (tools/tick_threads.cpp)"}
+    # ---- native host
+    exe = ROOT / "tools" / "tick_threads.bin"
+    if exe.exists():
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            for u in us:
+                f.write(np.asarray(u, dtype=np.float32).tobytes())
+            upath = f.name
+        dev = C.c_int(0)
+        cv.check(lib.chv_context_device(ctx.handle, C.byref(dev)))
+        try:
+            p = subprocess.run([str(exe), upath, str(seconds), str(dev.value)], capture_output=True, text=True, timeout=120)
+            out["native"] = json.loads(p.stdout) if p.returncode == 0 else {"error": p.stderr[-300:]}
+        except Exception as e:    # noqa: BLE001
+            out["native"] = {"error": repr(e)}
+        finally:
+            os.unlink(upath)
+    else:
+        out["native"] = {"error": "tools/tick_threads.bin not built (__graft_entry__.build())"}
+    # ---- Python host
+    host = [util.alloc_image("nv12", sw, sh, seed=0x5EED0000 + 112 + i) for i in range(4)]
+    k_layer, k_clear = sv.ComputeKernel.img_nv12_bgra, sv.ComputeKernel.img_clear_bgra
+
+    class Mixer:
+        def __init__(self, c):
+            self.ctx = c
+            self.src = [sv.uploadComputePicture(c, sv.pictureFromArrays(sv.PixelFormat.nv12, (sw, sh), h), retainCpuBuffer=False) for h in host]
+            self.canvas = [sv.uploadComputePicture(c, sv.createPictureSample((dw, dh), sv.PixelFormat.BGRA), retainCpuBuffer=False) for _ in range(10)]
+            self.tdesc = [sv._image_desc(cn) for cn in self.canvas]
+            self.layer_arr = [sv._layer_array([(k_layer, self.src[(t + l) % 4], us[l], cv.CSC_BT601_LIMITED) for l in range(4)]) for t in range(4)]
+            self.sdesc = [sv._image_desc(x) for x in self.src]
+            self.uni = [(cv.Uniforms).from_buffer_copy(np.asarray(u, dtype=np.float32).tobytes()) for u in us]
+            self.opts = cv.KernelOpts(cv.CSC_BT601_LIMITED)
+            self.n = 0
+
+        def tick_fused(self):
+            t = self.n; self.n += 1
+            h = self.ctx.handle
+            lib.chv_pass_begin(h)
+            lib.chv_composite(h, C.byref(self.tdesc[t % 10]), 1, self.layer_arr[t % 4], 4)
+            lib.chv_pass_end(h, 1)
+
+        def tick_sequence(self):
+            t = self.n; self.n += 1
+            h = self.ctx.handle
+            td = C.byref(self.tdesc[t % 10])
+            lib.chv_pass_begin(h)
+            lib.chv_run_kernel(h, int(k_clear), td, None, 0, None, 0, 0, None)
+            for l in range(4):
+                lib.chv_run_kernel(h, int(k_layer), td, C.byref(self.sdesc[(t + l) % 4]), 1, C.byref(self.uni[l]), 236, 1, C.byref(self.opts))
+            lib.chv_pass_end(h, 1)
+
+    ctxs = [sv.createComputeContext(sharing=ctx) for _ in range(8)]
+    ms = [Mixer(c) for c in ctxs]
+    py = {}
+    for mode in ("fused", "sequence"):
+        py[mode] = {}
+        for n in (1, 2, 4, 8):
+            counts = [0] * n
+            stop = [0.0]
+
+            def worker(i, mode=mode):
+                fn = getattr(ms[i], "tick_" + mode)
+                k = 0
+                while time.perf_counter() < stop[0]:
+                    fn(); k += 1
+                counts[i] = k
+            for m in ms[:n]:
+                for _ in range(10):
+                    getattr(m, "tick_" + mode)()
+            th = [threading.Thread(target=worker, args=(i,)) for i in range(n)]
+            t0 = time.perf_counter(); stop[0] = t0 + seconds
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            py[mode][str(n)] = sum(counts) / (time.perf_counter() - t0)
+    out["python"] = py
+    for c in ctxs:
+        sv.destroyComputeContext(c)
+    for name in ("native", "python"):
+        r = out.get(name, {})
+        for mode in ("fused", "sequence"):
+            if isinstance(r.get(mode), dict) and r[mode].get("1"):
+                out[f"{name}_{mode}_speedup_8_threads"] = r[mode]["8"] / r[mode]["1"]
+    return {"per_tick_thread_scaling": out}
+
+
 def run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p", seconds=0.3, ring=10, distinct=4):
     """The reference-default mixer tick (1080p 4:2:0 canvas <- full-canvas video + two 640x360 BGRA overlays: the `mixer_<fmt>` workload) issued
     ONE AT A TIME with the reference's host wait after it: fused (one chv_composite) and as the unchanged 1 + 3 launch sequence
@@ -1061,12 +1190,43 @@ def run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p", seconds=0.3, ring
     }
 
 
+def run_threads(args):
+    """--gpus N --threads: N host threads in THIS process, thread r with its own compute context on device r (or --device); the threads meet at
+    a barrier around the timed region exactly as the ranks of the process-per-GPU mode do, rank 0 prints the line"""
+    import threading
+    shared = {"barrier": threading.Barrier(args.gpus), "slots": [0.0] * args.gpus}
+    errors = []
+
+    def worker(r):
+        try:
+            run_rank(args, r, r, args.gpus, ThreadDist(shared, r))
+        except BaseException as e:    # noqa: BLE001
+            errors.append((r, e))
+            shared["barrier"].abort()
+
+    th = [threading.Thread(target=worker, args=(r,), name=f"device-{r}") for r in range(args.gpus)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    real = [e for e in errors if not isinstance(e[1], threading.BrokenBarrierError)] or errors
+    if real:
+        raise SystemExit(f"thread of device {real[0][0]} failed: {real[0][1]!r}")
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.threads and args.gpus > 1:
+        args.also = "none"
+        return run_threads(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, argv))
     rank, local, world, dist = dist_setup()
+    run_rank(args, rank, local, world, dist)
+
+
+def run_rank(args, rank, local, world, dist):
     if world != args.gpus:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     n_gpus = max(world, 1)
@@ -1097,7 +1257,7 @@ def main(argv=None):
                                          "frames_per_step_per_gpu": rep["frames_per_launch_per_gpu"] * rep["launches_per_step"],
                                          "kernel": rep["kernel"]}}), flush=True)
         tm.barrier()
-        if dist is not None:
+        if dist is not None and not isinstance(dist, ThreadDist):
             dist.destroy_process_group()
         return
 
@@ -1115,6 +1275,7 @@ def main(argv=None):
     if (others or args.per_tick) and not args.stub_device and not args.no_per_tick and n_gpus == 1:
         reports.update(run_per_tick(args, sv, cv, lib, ctx))
         reports.update(run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p"))
+        reports.update(run_thread_scaling(args, sv, cv, lib, ctx))
 
     if rank == 0:
         wl = WORKLOADS[args.workload]
@@ -1153,7 +1314,8 @@ def main(argv=None):
                        "frames_per_step_per_gpu": head["frames_per_launch_per_gpu"] * head["launches_per_step"],
                        "timed_seconds": head["timed_seconds"], "gpix_counts": "target pixels written",
                        "source_mpix_per_launch_per_gpu": head["source_mpix_per_launch_per_gpu"],
-                       "parallelism": f"{n_gpus} process(es), one per GPU; {head['frames_per_launch_per_gpu']} independent picture "
+                       "parallelism": (f"ONE process, {n_gpus} host threads, a compute context per device" if isinstance(dist, ThreadDist) else
+                                       f"{n_gpus} process(es), one per GPU") + f"; {head['frames_per_launch_per_gpu']} independent picture "
                                       f"buses per device, bus s -> device s mod {n_gpus}; no collective",
                        "per_gpu_gpix": head["per_gpu_gpix"], "per_stream_ticks_per_s": head["per_stream_ticks_per_s"],
                        "kernel": head["kernel"], "verified_vs_oracle": head["verified_vs_oracle"],
@@ -1171,7 +1333,7 @@ def main(argv=None):
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     tm.barrier()
-    if dist is not None:
+    if dist is not None and not isinstance(dist, ThreadDist):
         dist.destroy_process_group()
 
 

@@ -84,6 +84,23 @@ def test_self_launch_spawns_one_rank_per_gpu_and_reports_the_slowest():
     assert "cpu_baseline" not in d                                                    # N = 1 only
 
 
+def test_one_process_with_a_host_thread_per_device():
+    """`--gpus 2 --threads`: ONE process, two host threads, a context per device — the shape of the Swift host (a composer with mixers bound to
+    devices, composer.swift:203-224, SURVEY section 8e "one host feeder thread per device"); the same barrier + slowest-thread reduction as the
+    process-per-GPU mode, through threading primitives (here with --stub-device: thread 1 sleeps 25 % longer per launch)"""
+    d = _run_bench(["--gpus", "2", "--threads", "--stub-device", "--steps", "4", "--warmup", "1", "--min-seconds", "0.3"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["data"].startswith("STUB")
+    cfg = d["config"]
+    assert cfg["parallelism"].startswith("ONE process, 2 host threads")
+    assert len(cfg["per_gpu_gpix"]) == 2 and cfg["per_gpu_gpix"][0] >= cfg["per_gpu_gpix"][1] * 0.95
+    assert 2.0 * min(cfg["per_gpu_gpix"]) * 0.7 <= d["value"] <= 2.0 * min(cfg["per_gpu_gpix"]) * 1.02
+    assert set(d["workloads"]) == {"pipeline"}
+    import bench
+    import threading
+    shared = {"barrier": threading.Barrier(1), "slots": [0.0]}
+    assert bench.reduce_max(bench.ThreadDist(shared, 0), 0.75) == 0.75 and bench.gather_floats(bench.ThreadDist(shared, 0), 0.5, 1) == [0.5]
+
+
 def test_rank_without_a_device_is_an_error_not_a_silent_single_rank_run():
     import bench
     args = bench.parse_args(["--gpus", "2"])
@@ -109,6 +126,18 @@ def test_two_ranks_on_one_device_end_to_end():
 
 
 @pytest.mark.gpu
+def test_two_host_threads_in_one_process_on_one_device():
+    """`--gpus 2 --device 0 --threads`: two contexts of ONE process (each chv_context_create makes its own stream and descriptor rings) driven
+    from two host threads — every thread's canvases verified against the oracle, both reported"""
+    d = _run_bench(["--gpus", "2", "--device", "0", "--threads", "--steps", "3", "--warmup", "1", "--min-seconds", "0.2", "--frames", "32",
+                    "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and len(d["config"]["per_gpu_gpix"]) == 2
+    assert d["config"]["parallelism"].startswith("ONE process, 2 host threads")
+    assert d["config"]["verified_vs_oracle"] is True and d["config"]["kernel"] == "tick_bgra_stream"
+    assert 0 < d["roofline"]["frac"] < 1 and d["value"] <= sum(d["config"]["per_gpu_gpix"]) * 1.01
+
+
+@pytest.mark.gpu
 def test_two_ranks_with_uploads_on_one_device():
     """the end-to-end (H2D-inclusive) mode at N = 2: per-rank pinned frames, side-stream uploads, per-buffer events"""
     d = _run_bench(["--gpus", "2", "--device", "0", "--with-upload", "--steps", "3", "--warmup", "2", "--min-seconds-other", "0.2"])
@@ -126,7 +155,10 @@ def test_default_run_measures_its_hbm_traffic():
     assert set(d["workloads"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12"}
     e2e = d["workloads"]["pipeline_e2e"]
     assert e2e["verified_vs_oracle"] is True and e2e["ticks_per_s"] > 100 and 0 < e2e["d2h_frac_of_link"] < e2e["h2d_frac_of_link"] < 1.1
-    legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence", "mixer_y420p_per_tick", "mixer_y420p_reference_sequence")
+    legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence", "mixer_y420p_per_tick", "mixer_y420p_reference_sequence", "pipeline_e2e", "per_tick_thread_scaling")
+    ts = d["workloads"]["per_tick_thread_scaling"]
+    assert set(ts["python"]["fused"]) == {"1", "2", "4", "8"} and "error" not in ts["native"], ts.get("native")
+    assert ts["native"]["fused"]["8"] > ts["native"]["fused"]["1"] * 0.8
     assert all(v["verified_vs_oracle"] is True for k, v in d["workloads"].items() if k not in legs)
     # the path a Swift VideoMixer takes — one tick at a time with a host wait — fused and as the unchanged 5-launch sequence
     pt, seq = d["workloads"]["pipeline_per_tick"], d["workloads"]["pipeline_reference_sequence"]
