@@ -63,6 +63,14 @@ WORKLOADS = {
                                "inside the wave kernel, the rest stays on the staged path",
                           kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=4, frames=128, logo=True,
                           bytes=4 * NV12_1080 + BGRA_720 + 320 * 180 * 4),
+    "pipeline_y420p": dict(desc="the pipeline tick with PLANAR sources (what FFmpeg's software decoders emit, dec.video.ffmpeg.swift:187-221): 4 x 1920x1080 "
+                                "y420p -> BGRA + bilinear downscale to 1280x720 + 4-layer alpha composite",
+                           kind="yuv_layers", src="y420p", sw=1920, sh=1080, dw=1280, dh=720, layers=4, frames=128,
+                           bytes=4 * NV12_1080 + BGRA_720),
+    "pipeline_grid": dict(desc="a 2 x 2 grid: one full-canvas 1080p NV12 background + four 1080p NV12 streams drawn into the 640x360 quadrants of a "
+                               "720p BGRA canvas (opacity 1 / 1 / .9 / .8 / .7): five layers of two geometries' worth of DISTINCT rectangles",
+                          kind="grid", sw=1920, sh=1080, dw=1280, dh=720, layers=5, frames=128,
+                          bytes=5 * NV12_1080 + BGRA_720),
     "cfg2": dict(desc="1920x1080 NV12 -> BGRA (BT.601 int) + bilinear downscale to 1280x720",
                  kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=1, frames=256,
                  bytes=NV12_1080 + BGRA_720),
@@ -94,7 +102,7 @@ WORKLOADS = {
                   bytes=2 * NV12_1080 + 2 * 921600 + BGRA_720),
 }
 HEADLINE = "pipeline"
-DEFAULT_SET = ["pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12"]
+DEFAULT_SET = ["pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12", "pipeline_y420p", "pipeline_grid"]
 
 
 def parse_args(argv=None):
@@ -108,6 +116,10 @@ def parse_args(argv=None):
     ap.add_argument("--also", default=None,
                     help="comma-separated workloads timed after the headline and reported under \"workloads\" "
                          "(default: the BASELINE set when --workload is the default, none otherwise); 'none' for none")
+    ap.add_argument("--group", type=int, default=0,
+                    help="ticks per launch GROUP of workloads with a second stage (cfg5: composite, then Lanczos): the batch is issued as frames / G "
+                         "pairs of launches (composite G ticks, resize G canvases) so that the second stage reads canvases the first one just wrote "
+                         "(default: the workload's own `group`, 0 = one pair for the whole batch)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="minimum duration of the headline's timed region")
     ap.add_argument("--min-seconds-other", type=float, default=0.6, help="minimum timed region of each other workload")
     ap.add_argument("--launches-per-step", type=int, default=0, help="fixed instead of calibrated (profiling runs)")
@@ -292,7 +304,7 @@ def pick_device(args, local, n_visible):
 # ---------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------
-def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
+def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
     """Device-resident source frames, canvases and the batch descriptor."""
     import util
     from swiftvideo_amd import chipvideo as cv
@@ -380,6 +392,25 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
             finish_tick(f, dst, layers)
         verify = dict(target="bgra", layers=lambda f: [(f"img_{sfmt}_bgra", host_src[(f + l) % distinct], us[l]) for l in range(nl)] +
                                                       ([("img_rgba_bgra_tx", logo, logo_u)] if logo is not None else []))
+    elif wl["kind"] == "grid":
+        skernel = sv.defaultComputeKernelFromString("img_nv12_bgra")
+        for i in range(distinct):
+            host_src.append(util.alloc_image("nv12", sw, sh, seed=seed_base + i))
+        qw, qh = dw // 2, dh // 2
+        us = [util.full_canvas_uniforms((dw, dh), (sw, sh))] + \
+             [util.make_uniforms((dw, dh), rect=(qx * qw, qy * qh, qw, qh), opacity=o, in_size=(sw, sh))
+              for (qx, qy), o in zip(((0, 0), (1, 0), (0, 1), (1, 1)), (1.0, 0.9, 0.8, 0.7))]
+        for f in range(frames):
+            layers = []
+            for l in range(5):
+                src = up(sv.PixelFormat.nv12, (sw, sh), host_src[(f + l) % distinct])
+                keep.append(src)
+                layers.append((skernel, src, us[l], cv.CSC_BT601_LIMITED))
+            dst = blank(sv.PixelFormat.BGRA, (dw, dh))
+            keep.append(dst)
+            canvases.append(dst)
+            finish_tick(f, dst, layers)
+        verify = dict(target="bgra", layers=lambda f: [("img_nv12_bgra", host_src[(f + l) % distinct], us[l]) for l in range(5)])
     elif wl["kind"] == "rgb_layers":
         nl = wl["layers"]
         for i in range(distinct):
@@ -421,17 +452,25 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none"):
                                                        ("img_bgra_bgra_tx", ov[0], us[2]), ("img_rgba_bgra_tx", ov[1], us[3])])
     else:
         raise ValueError(wl["kind"])
-    batch = C.c_void_p()
-    cv.check(lib.chv_batch_create(ctx.handle, ticks, frames, C.byref(batch)))
+    # one batch for all ticks — or, for two-stage workloads with a group size, one batch per group of ticks
+    batches = []
+    g = group if (group and lanczos_pairs and 0 < group < frames) else frames
+    for first in range(0, frames, g):
+        n = min(g, frames - first)
+        sub = (cv.Tick * n).from_address(C.addressof(ticks) + first * C.sizeof(cv.Tick))
+        b = C.c_void_p()
+        cv.check(lib.chv_batch_create(ctx.handle, sub, n, C.byref(b)))
+        batches.append((b, first, n))
     name = C.create_string_buffer(128)
-    cv.check(lib.chv_batch_describe(batch, name, 128, None))
-    return dict(batch=batch, keep=keep, layer_arrays=layer_arrays, ticks=ticks, kernel=name.value.decode(), verify=verify,
+    cv.check(lib.chv_batch_describe(batches[0][0], name, 128, None))
+    return dict(batch=batches[0][0], batches=batches, keep=keep, layer_arrays=layer_arrays, ticks=ticks, kernel=name.value.decode(), verify=verify,
                 lanczos=lanczos_pairs, canvases=canvases)
 
 
 def free_workload(w):
     from swiftvideo_amd import chipvideo as cv
-    cv.check(cv.load().chv_batch_destroy(w["batch"]))
+    for b, _, _ in w["batches"]:
+        cv.check(cv.load().chv_batch_destroy(b))
     w["keep"].clear(); w["canvases"].clear(); w["lanczos"].clear(); w["layer_arrays"].clear()
     import gc
     gc.collect()
@@ -642,14 +681,17 @@ def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
     """Build, warm up, verify, time and free one workload; returns its report (complete on rank 0)."""
     wl = WORKLOADS[name]
     frames = args.frames if (args.frames and headline) else wl["frames"]
-    w = build_workload(sv, ctx, wl, frames, seed_base=0x5EED0000 + 16 * 2 + rank, alias=args.alias if headline else "none")
+    group = args.group or wl.get("group", 0)
+    w = build_workload(sv, ctx, wl, frames, seed_base=0x5EED0000 + 16 * 2 + rank, alias=args.alias if headline else "none", group=group)
 
-    lz = sv.LanczosBatch(w["lanczos"]) if w["lanczos"] else None      # one launch for the batch's resizes (chv_scale_lanczos_batch)
+    # the second stage: one launch per group for the group's resizes (chv_scale_lanczos_batch)
+    lzs = [sv.LanczosBatch(w["lanczos"][first:first + n]) for _, first, n in w["batches"]] if w["lanczos"] else None
 
     def launch():
-        cv.check(lib.chv_batch_run(ctx.handle, w["batch"]))
-        if lz is not None:
-            lz.run(ctx)
+        for i, (b, _, _) in enumerate(w["batches"]):
+            cv.check(lib.chv_batch_run(ctx.handle, b))
+            if lzs is not None:
+                lzs[i].run(ctx)
 
     for _ in range(max(args.warmup, 1)):
         launch()
@@ -660,6 +702,9 @@ def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
     per_step = tm.calibrate(launch, args.steps, args.min_seconds if headline else args.min_seconds_other, args.launches_per_step)
     elapsed, local, launch_ms = tm.run(launch, args.steps, per_step)
     rep = report_of(name, wl, args, tm, n_gpus, frames, per_step, elapsed, local, launch_ms, w["kernel"], verified)
+    if lzs is not None:
+        rep["kernel_launches_per_batch"] = 2 * len(w["batches"])
+        rep["ticks_per_group"] = w["batches"][0][2]
     cpu = None
     if headline and rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and w["verify"] is not None:
         cpu = cpu_baseline(wl, w, args.cpu_seconds)
