@@ -255,6 +255,33 @@ CHV_DEV void ring_ensure(RingState &R, uint32_t lds_base, SrcFn &&src, int lo, i
     }
     R.misc = pos0 | (landk << 8);
 }
+// The same for the usual step of a picture drawn at its own size — the taps have left exactly the oldest batch, one batch follows the window —
+// without the loops and the general bookkeeping (this kernel is bound by the instructions it issues, the scalar ones included); anything else
+// takes ring_ensure
+template <class RC, class SrcFn>
+CHV_DEV void ring_ensure_step(RingState &R, uint32_t lds_base, SrcFn &&src, int lo, int hi, int &issued, int lane) {
+    static_assert(RC::NB == 3, "three batches");
+    const int d = lo - R.a0;
+    if (d >= RC::B && d < 2 * RC::B) {
+        int pos0 = R.misc & 255, landk = R.misc >> 8;
+        ys_taps_done();
+        const int row0 = R.a0 + RC::ROWS;
+        if (row0 <= R.last) { const RingSrc s = src(); issued += ring_request<RC>(lds_base + (uint32_t)(pos0 * RC::PITCH), s, row0, R.last, lane); }
+        R.seq = (R.seq >> 8) | (((uint32_t)issued & 255u) << 16);
+        pos0 = pos0 + RC::B == RC::ROWS ? 0 : pos0 + RC::B;
+        R.a0 += RC::B;
+        landk = landk > 0 ? landk - 1 : 0;
+        const int e = hi - R.a0;
+        const int k = e >= 2 * RC::B ? 2 : e >= RC::B ? 1 : 0;
+        if (k >= landk) {
+            ys_await((int)(((uint32_t)issued - (R.seq >> (8 * k))) & 255u));
+            landk = k + 1;
+        }
+        R.misc = pos0 | (landk << 8);
+    } else {
+        ring_ensure<RC>(R, lds_base, src, lo, hi, issued, lane);
+    }
+}
 // LDS byte offset (inside the ring) of source row r, a0 <= r < a0 + ROWS
 template <class RC>
 CHV_DEV int ring_row(const RingState &R, int r) {
@@ -466,8 +493,8 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
         col[l].off = (uint32_t)o0 | ((uint32_t)o1 << 9) | ((uint32_t)c0 << 18) | ((uint32_t)c1 << 25);
     };
     ys_seq<NL>(setup_layer);
-    // (only layer 0 can touch this strip and chunk, and it is a YUV picture)
-    const bool fast0 = HAS_YUV && (hit & 0xFF) == 1 && (lf[0] & 1) == 0;
+    // (only layer 0 can touch this strip and chunk: an opaque YUV picture whose columns take the short form of the row loops, luma and chroma)
+    const bool fast0 = CHV_YS_CARRY && HAS_YUV && (hit & 0xFF) == 1 && (lf[0] & 17) == 16 && (hit & (1 << 16)) != 0 && (hit & (1 << 24)) != 0;
     // (the rings of a tick's layers, then one row table per layer)
     uint32_t *rowtab = (uint32_t *)(lds + (wave_bytes - NL * YS_TAB_BYTES));
 
@@ -490,12 +517,65 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
         }
     };
 
-    // One trip: four canvas rows through every layer that touches them, then the trip's luma (transposed, pending) and its chroma code.
-    // FAST: a trip of a step in which only layer 0 — an opaque YUV picture drawn at its own size over the whole strip: the full-canvas video of a
-    // mixer tick — touches the strip and all eight rows take the short form of the row loops: no per-layer tests, nothing but the short form
-    // (this kernel is bound by the instructions it issues, scalar ones included: ~100 per canvas row before this path existed, 45 of them scalar)
-    auto trip = [&](int j0, auto fast_c) {
-        constexpr bool FAST = decltype(fast_c)::value;
+    // the end of a trip: its luma codes transposed inside every quad of lanes and left pending (stored after the next trip's waits), its chroma codes
+    // into the group's registers, the group stored every fourth trip
+    auto finish_trip = [&](int j0, uint32_t lw, uint32_t cu, uint32_t cv) {
+        // ---- the trip's luma: a 4 x 4 byte transpose inside every quad of lanes turns "4 rows of one column" into "4 columns of one row" ----
+        {
+            const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+            const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lw, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+            const uint32_t aa = __builtin_amdgcn_perm(p1, lw, sel1);
+            const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)aa, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
+            pend_lw = __builtin_amdgcn_perm(p2, aa, sel2);
+            // (lane 4 c + r holds row r, columns 4 c .. 4 c + 3; lane 16 r + c takes it: a quarter wave then holds 64 contiguous bytes of one row)
+            if (CHV_YS_STORE & 1) pend_lw = (uint32_t)__builtin_amdgcn_ds_bpermute((4 * (lane & 15) + (lane >> 4)) * 4, (int)pend_lw);
+            pend_row = y0 + j0;
+        }
+        // ---- chroma: byte m of the group's registers; stored every fourth trip ----------------------------------------------------
+        {
+            const int m = (j0 >> 2) & 3;
+            const uint32_t sel = 0x03020100u ^ ((uint32_t)(m ^ 4) << (8 * m));       // byte m <- byte 0 of the trip's code, the others stay
+            nu = __builtin_amdgcn_perm(cu, nu, sel);
+            nv = __builtin_amdgcn_perm(cv, nv, sel);
+            if (m == 3 || j0 + 4 >= nrows) {
+                // lane 2k: rows 0, 2, 4, 6 of chroma column k; lane 2k + 1: rows 1, 3, 5, 7  ->  lane 8c + i: row i (+ 4 for lanes 8c + 4 ..) of
+                // columns 4c .. 4c + 3 (kernels_wave_yuv.hip.cpp)
+                const uint32_t selp = (lane & 1) ? 0x03070206u : 0x05010400u;
+                const int srcl = ((lane & ~7) + 2 * (lane & 3) + ((lane >> 2) & 1)) * 4;
+                const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+                auto regroup = [&](uint32_t v) {
+                    const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+                    uint32_t q = __builtin_amdgcn_perm(p, v, selp);
+                    q = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)q);
+                    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0xB1, 0xf, 0xf, false);
+                    const uint32_t bq = __builtin_amdgcn_perm(p1, q, sel1);
+                    const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bq, 0x4E, 0xf, 0xf, false);
+                    return __builtin_amdgcn_perm(p2, bq, sel2);
+                };
+                const uint32_t tu = regroup(nu), tv = regroup(nv);
+                const int g0 = j0 & ~15;                                             // first row of the group inside the chunk
+                const int crow = (lane & 3) + 4 * ((lane >> 2) & 1);
+                const uint32_t ccol = (uint32_t)((x0 >> 1) + 4 * (lane >> 3));
+                const int qy = ((y0 + g0) >> 1) + crow;
+                const bool ok = crow < 2 * (m + 1) && x0 + 8 * (lane >> 3) < TW;
+                if (CHV_YS_ABL & 2) asm volatile("" :: "v"(tu), "v"(tv));
+                else if (ok) {
+                    if (TF == TF_NV12) {
+                        const uint2 w = make_uint2(__builtin_amdgcn_perm(tv, tu, 0x05010400u), __builtin_amdgcn_perm(tv, tu, 0x07030602u));     // u0 v0 u1 v1 | u2 v2 u3 v3
+                        gst_at<chv_u32x2>(PC.ptr + (size_t)qy * PC.pitch, ccol * 2u, chv_u32x2{ w.x, w.y });
+                    } else {
+                        gst_at<uint32_t>(PC.ptr + (size_t)qy * PC.pitch, ccol, tu);
+                        gst_at<uint32_t>(PV.ptr + (size_t)qy * PV.pitch, ccol, tv);
+                    }
+                }
+                nu = 0x80808080u; nv = 0x80808080u;
+            }
+        }
+    };
+
+    // One trip: four canvas rows through every layer that touches them
+    auto trip = [&](int j0) {
+        constexpr bool FAST = false;
         const int jt = j0 & (YS_TAB - 1);
         uint32_t lw = 0;                                 // img_clear_*: Y = 0.0
         uint32_t cu = 128u, cv = 128u;                   // chroma = 0.5 -> 128 (RTE)
@@ -731,62 +811,80 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
                 }
             }
         };
-        if constexpr (FAST) layer(std::integral_constant<int, 0>{}); else ys_seq<NL>(layer);
+        ys_seq<NL>(layer);
+        finish_trip(j0, lw, cu, cv);
+    };
 
-        // ---- the trip's luma: a 4 x 4 byte transpose inside every quad of lanes turns "4 rows of one column" into "4 columns of one row" ----
+    // A step of eight canvas rows in which only layer 0 — an opaque YUV picture drawn at its own size over the whole strip: the full-canvas video
+    // of a mixer tick, the bulk of its pixels — touches the strip, every row taps the source row behind its predecessor's, and the columns take the
+    // short form (tap column 1 right behind tap column 0, both weights one half): no per-layer tests, one ring position per plane walked row by
+    // row, the lower tap row of a pixel carried down the lane as the upper one of the pixel below across both trips.  The same operations per
+    // pixel as the general row loops.  (~100 instructions per canvas row went through the general path, 45 of them scalar; the scalar unit is
+    // shared by the four SIMDs of a CU and the kernel is bound by what it issues.)
+    auto fast_step = [&](int j0, auto planar_c) {
+        constexpr bool PL = decltype(planar_c)::value;
+        using RCc = std::conditional_t<PL, RingCP, RingC2>;
+        constexpr int l = 0;
+        constexpr int BPC = PL ? 1 : 2, VO = PL ? RingCP::SPLIT * 16 : 1;
+        const int jt = j0 & (YS_TAB - 1);
+        const uint32_t *tab = rowtab + jt;
+        const DLayer &Ly = L[0];
+        const uint2 sm = *(const uint2 *)(rowtab + 3 * YS_TAB + (jt >> 2));
+        const uint32_t sy_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)sm.x), sc_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)sm.y);
+        const uint32_t ringY = lds0 + (uint32_t)lbase[0];
+        const int lo = (int)(sy_ & 8191u) - 1, clo = (int)(sc_ & 8191u) - 1;
         {
-            const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
-            const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lw, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
-            const uint32_t aa = __builtin_amdgcn_perm(p1, lw, sel1);
-            const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)aa, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
-            pend_lw = __builtin_amdgcn_perm(p2, aa, sel2);
-            // (lane 4 c + r holds row r, columns 4 c .. 4 c + 3; lane 16 r + c takes it: a quarter wave then holds 64 contiguous bytes of one row)
-            if (CHV_YS_STORE & 1) pend_lw = (uint32_t)__builtin_amdgcn_ds_bpermute((4 * (lane & 15) + (lane >> 4)) * 4, (int)pend_lw);
-            pend_row = y0 + j0;
+            const int hi0 = (int)((sy_ >> 13) & 8191u), hi = hi0 < rY[0].last ? hi0 : rY[0].last;
+            const int chi0 = (int)((sc_ >> 13) & 8191u), chi = chi0 < rC[0].last ? chi0 : rC[0].last;
+            auto srcY = [&]() { if constexpr (KEEP_SRC) return sY[l]; else return ring_src(Ly.src.pl[0], Ly.src.pl[0], cvY[l]); };
+            auto srcC = [&]() { if constexpr (KEEP_SRC) return sC[l]; else return ring_src(Ly.src.pl[1], Ly.src.pl[PL ? 2 : 1], cvC[l]); };
+            ring_ensure_step<RingY>(rY[0], ringY, srcY, lo, hi, issued, lane);
+            ring_ensure_step<RCc>(rC[0], ringY + (uint32_t)RingY::BYTES, srcC, clo, chi, issued, lane);
         }
-        // ---- chroma: byte m of the group's registers; stored every fourth trip ----------------------------------------------------
-        {
-            const int m = (j0 >> 2) & 3;
-            const uint32_t sel = 0x03020100u ^ ((uint32_t)(m ^ 4) << (8 * m));       // byte m <- byte 0 of the trip's code, the others stay
-            nu = __builtin_amdgcn_perm(cu, nu, sel);
-            nv = __builtin_amdgcn_perm(cv, nv, sel);
-            if (m == 3 || j0 + 4 >= nrows) {
-                // lane 2k: rows 0, 2, 4, 6 of chroma column k; lane 2k + 1: rows 1, 3, 5, 7  ->  lane 8c + i: row i (+ 4 for lanes 8c + 4 ..) of
-                // columns 4c .. 4c + 3 (kernels_wave_yuv.hip.cpp)
-                const uint32_t selp = (lane & 1) ? 0x03070206u : 0x05010400u;
-                const int srcl = ((lane & ~7) + 2 * (lane & 3) + ((lane >> 2) & 1)) * 4;
-                const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
-                auto regroup = [&](uint32_t v) {
-                    const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
-                    uint32_t q = __builtin_amdgcn_perm(p, v, selp);
-                    q = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)q);
-                    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0xB1, 0xf, 0xf, false);
-                    const uint32_t bq = __builtin_amdgcn_perm(p1, q, sel1);
-                    const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bq, 0x4E, 0xf, 0xf, false);
-                    return __builtin_amdgcn_perm(p2, bq, sel2);
-                };
-                const uint32_t tu = regroup(nu), tv = regroup(nv);
-                const int g0 = j0 & ~15;                                             // first row of the group inside the chunk
-                const int crow = (lane & 3) + 4 * ((lane >> 2) & 1);
-                const uint32_t ccol = (uint32_t)((x0 >> 1) + 4 * (lane >> 3));
-                const int qy = ((y0 + g0) >> 1) + crow;
-                const bool ok = crow < 2 * (m + 1) && x0 + 8 * (lane >> 3) < TW;
-                if (CHV_YS_ABL & 2) asm volatile("" :: "v"(tu), "v"(tv));
-                else if (ok) {
-                    if (TF == TF_NV12) {
-                        const uint2 w = make_uint2(__builtin_amdgcn_perm(tv, tu, 0x05010400u), __builtin_amdgcn_perm(tv, tu, 0x07030602u));     // u0 v0 u1 v1 | u2 v2 u3 v3
-                        gst_at<chv_u32x2>(PC.ptr + (size_t)qy * PC.pitch, ccol * 2u, chv_u32x2{ w.x, w.y });
-                    } else {
-                        gst_at<uint32_t>(PC.ptr + (size_t)qy * PC.pitch, ccol, tu);
-                        gst_at<uint32_t>(PV.ptr + (size_t)qy * PV.pitch, ccol, tv);
-                    }
-                }
-                nu = 0x80808080u; nv = 0x80808080u;
+        flush();                                         // (the previous trip's luma, after this step's waits)
+        const uint8_t *ldsY = lds + lbase[0], *ldsC = ldsY + RingY::BYTES;
+        const int o0 = ys_o0(col[0].off), c0 = ys_c0(col[0].off);
+        int q = ring_row<RingY>(rY[0], lo), qc = ring_row<RCc>(rC[0], clo);
+        float t0, t1;
+        { const uint8_t *p = ldsY + (q + o0); t0 = ys_t8(p[0]); t1 = ys_t8(p[1]); }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint4 w4 = *(const uint4 *)(tab + YS_TAB + 4 * h);
+            const float rya[4] = { __uint_as_float(w4.x), __uint_as_float(w4.y), __uint_as_float(w4.z), __uint_as_float(w4.w) };
+            uint32_t lw = 0, cu = 128u, cv = 128u;
+            auto row = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const float bw = rya[k], ib = 1.0f - bw;
+                q = ring_next<RingY>(q);
+                const uint8_t *p1 = ldsY + (q + o0);
+                const float b0 = ys_t8(p1[0]), b1 = ys_t8(p1[1]);
+                const float wt = 0.5f * ib, wb = 0.5f * bw;
+                const float v = ys_mix4(wt, wt, wb, wb, t0, t1, b0, b1);
+                t0 = b0; t1 = b1;
+                lw = ys_put<k>(lw, v);
+            };
+            ys_seq<4>(row);
+            {
+                // chroma rows 2 m (even lanes: taps qc, qc + 1) and 2 m + 1 (odd lanes: qc + 1, qc + 2)
+                const uint4 cw4 = *(const uint4 *)(tab + 2 * YS_TAB + 4 * h);
+                const float cbw = __uint_as_float(par ? cw4.z : cw4.x), icb = 1.0f - cbw;
+                const int q1 = ring_next<RCc>(qc), q2 = ring_next<RCc>(q1);
+                const uint8_t *p0 = ldsC + ((par ? q1 : qc) + c0), *p1 = ldsC + ((par ? q2 : q1) + c0);
+                const float wt = 0.5f * icb, wb = 0.5f * cbw;
+                const float fu = ys_mix4(wt, wt, wb, wb, ys_t8(p0[0]), ys_t8(p0[BPC]), ys_t8(p1[0]), ys_t8(p1[BPC]));
+                const float fv = ys_mix4(wt, wt, wb, wb, ys_t8(p0[VO]), ys_t8(p0[VO + BPC]), ys_t8(p1[VO]), ys_t8(p1[VO + BPC]));
+                cu = ys_put<0>(cu, fu); cv = ys_put<0>(cv, fv);
+                qc = q2;
             }
+            if (h == 1) flush();
+            finish_trip(j0 + 4 * h, lw, cu, cv);
         }
     };
 
-    for (int j0 = 0; j0 < nrows; j0 += 4) {
+    for (int jv = 0; jv < nrows; jv += 4) {
+        // (the row counter is wave-uniform, and says so: left to itself hipcc kept it — and with it every mask shift, every ring decision of the
+        // step and all their branches — on the vector unit, with exec-mask branches around each `if`)
+        const int j0 = __builtin_amdgcn_readfirstlane(jv);
         const int jt = j0 & (YS_TAB - 1);
         // ---- row entries of every layer that can touch the strip, YS_TAB rows at a time: lane = row ----------------------------
         if (jt == 0) {
@@ -846,6 +944,14 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
         // ---- residency, once per 8-row step: the YUV layers' rings take the rows the step's two trips tap -------------------------------
         if constexpr (HAS_YUV) {
             if ((j0 & 7) == 0) {
+                // the short way for the bulk of a mixer tick's pixels (fast_step): all eight rows inside the picture, each on the source row behind
+                // its predecessor's, chroma rows likewise
+                if (fast0 && j0 + 8 <= nrows && ((rowm[0] >> jt) & 0xFFu) == 0xFFu && ((unitm[0] >> jt) & 0x7Fu) == 0x7Fu && ((crowm[0] >> jt) & 0x15u) == 0x15u) {
+                    if ((KINDS & YK_PLANAR) != 0 && (((KINDS & YK_NV12) == 0) || (lf[0] & 2) != 0)) fast_step(j0, std::true_type{});
+                    else if constexpr ((KINDS & YK_NV12) != 0) fast_step(j0, std::false_type{});
+                    jv += 4;
+                    continue;
+                }
                 auto step = [&](auto lc) {
                     constexpr int l = decltype(lc)::value;
                     if (!(hit & (1 << l))) return;
@@ -873,17 +979,8 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
                 ys_seq<NL>(step);
             }
         }
-        bool fast = false;
-        if constexpr (HAS_YUV) fast = (j0 & 7) == 0 && fast0 && ((fullm[0] >> jt) & 0x33u) == 0x33u && j0 + 8 <= nrows;
         flush();                                         // (the previous trip's luma, after this trip's waits)
-        if (fast) {
-            trip(j0, std::true_type{});
-            flush();
-            j0 += 4;
-            trip(j0, std::true_type{});
-        } else {
-            trip(j0, std::false_type{});
-        }
+        trip(j0);
     }
     flush();
 }
