@@ -1,4 +1,4 @@
-// kernels_stream.hip.cpp — tick_bgra_stream: ticks of 1..4 full-frame NV12 video layers of ONE geometry onto a cleared BGRA canvas
+// kernels_stream.hip.cpp — tick_bgra_stream: ticks of 1..4 full-frame NV12 (or, all of them, y420p) video layers of ONE geometry onto a cleared BGRA canvas
 // (the bench headline's tick, cfg2's tick; VideoMixer.mix of N camera feeds scaled to the canvas, mix.video.swift:114-124), rows
 // outermost and the layers innermost.
 //
@@ -55,12 +55,16 @@ namespace chv {
 
 constexpr int ST_PITCH = 128;                 // bytes per ring row (8 vectors)
 constexpr int ST_YROWS = 8, ST_CROWS = 4;     // ring rows: luma (batches of 4), chroma (batches of 2)
-constexpr int ST_LAYER = ST_PITCH * (ST_YROWS + ST_CROWS);      // 1536 bytes per layer
 // LDS layout (NL layers): luma [2 batch slots][NL layers][4 rows][128], then chroma [2 batch slots][NL layers][2 rows][128] — the layers of one
 // batch slot lie next to each other so that ONE load instruction fills the rows of two layers (luma: 2 x 4 rows x 8 vectors = 64 lanes) or of
 // all four (chroma: 4 x 2 x 8): a vector memory instruction occupies the CU's address unit for 16 cycles whatever it moves
 // (tools/ubench_vmem.cpp), and with one instruction per layer and plane that unit was a fifth of the kernel's time.
 constexpr int ST_YL = 4 * ST_PITCH, ST_CL = 2 * ST_PITCH;       // bytes of one layer inside a batch slot: 512, 256
+// Planar sources (y420p: what FFmpeg's software decoders emit, dec.video.ffmpeg.swift:187-221): the chroma region holds U rows and, behind
+// them, V rows — each [2 batch slots][NL layers][2 rows][96] (a strip's chroma texels at up to 1.7 : 1 fit six vectors) — filled by one load
+// instruction per plane kind (NL x 2 rows x 6 vectors = 48 lanes at four layers).
+constexpr int ST_CPP = 96, ST_CLP = 2 * ST_CPP;                 // planar chroma: bytes per ring row, bytes of one layer inside a batch slot
+template <int NL, bool PL> constexpr int st_layer_bytes() { return ST_PITCH * ST_YROWS + (PL ? 2 * 2 * ST_CLP : ST_PITCH * ST_CROWS); }       // per layer: 1536 / 1792
 constexpr int ST_TAB = 32;                    // row entries computed at a time (lane = row)
 #ifndef CHV_STREAM_BLOCK
 #define CHV_STREAM_BLOCK 4
@@ -81,15 +85,18 @@ CHV_DEV void st_dma(const uint8_t *p, bool active, uint32_t m0) {
 // ONE: a launch of one tick whose descriptors are kernel ARGUMENTS (tick_bgra_stream_one below) — `ticks` / `layers` point into the kernarg
 // segment, every field is a scalar load at a constant offset from one base, issued together: no tick -> first_layer -> layer chain of
 // dependent loads in front of a lone tick's waves, and no descriptor copy in front of the launch.
-template <int NL, bool ONE>
+template <int NL, bool ONE, bool PL>
 CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restrict__ layers, int n_ticks, int strips_x, int chunks_y, int rows_per_chunk) {
     // ST_WAVES independent waves per block, on neighbouring strips (no barrier anywhere): their source windows overlap by a vector or two,
     // and waves of one block start together on one CU — the shared lines are fetched once (HBM traffic 1.47x -> see profiles/r03_notes.md)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
-    constexpr int WBYTES = NL * ST_LAYER + ST_TAB * (int)(sizeof(uint4) + sizeof(uint32_t));
+    constexpr int LBYTES = st_layer_bytes<NL, PL>();
+    constexpr int CPITCH = PL ? ST_CPP : ST_PITCH, CLB = PL ? ST_CLP : ST_CL;             // chroma ring row, one layer inside a chroma batch slot
+    constexpr int VOFF = PL ? 2 * NL * ST_CLP : 1;                                       // from a U sample to its V sample
+    constexpr int WBYTES = NL * LBYTES + ST_TAB * (int)(sizeof(uint4) + sizeof(uint32_t));
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     uint8_t *lds = lds_all + wave * WBYTES;
-    uint4 *rowtab = (uint4 *)(lds + NL * ST_LAYER);               // [ST_TAB]
+    uint4 *rowtab = (uint4 *)(lds + NL * LBYTES);                 // [ST_TAB]
     uint32_t *rowfl = (uint32_t *)(rowtab + ST_TAB);              // [ST_TAB] row flags
     const uint32_t lds0 = (uint32_t)(size_t)lds;                  // LDS byte address of the rings (the DMA's M0)
     const int lane = threadIdx.x & 63;
@@ -126,11 +133,12 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
     // first source column of the strip (no flips: lane 0 has the smallest positions), as the start of the staged 128 bytes
     const int cy_first = __builtin_amdgcn_readfirstlane(cy), cc_first = __builtin_amdgcn_readfirstlane(cc);
     const int ycol0 = min(max(cy_first, 0), SY.w - 1) & ~15;
-    const int ccol0 = (min(max(cc_first, 0), SC.w - 1) * 2) & ~15;                      // bytes: a chroma texel is a (U, V) pair
+    constexpr int BPC = PL ? 1 : 2;                                                     // bytes per chroma texel of the ring: a U (V) byte / a (U, V) pair
+    const int ccol0 = (min(max(cc_first, 0), SC.w - 1) * BPC) & ~15;
     // byte offsets of the two tap columns inside a ring row, CLAMP_TO_EDGE in x; lanes past the staged bytes (columns outside the canvas
     // or outside the picture, never stored / never taken) read whatever is there
     const int oy0 = min(max(min(max(cy, 0), SY.w - 1) - ycol0, 0), ST_PITCH - 1), oy1 = min(max(min(max(cy + 1, 0), SY.w - 1) - ycol0, 0), ST_PITCH - 1);
-    const int oc0 = min(max(min(max(cc, 0), SC.w - 1) * 2 - ccol0, 0), ST_PITCH - 2), oc1 = min(max(min(max(cc + 1, 0), SC.w - 1) * 2 - ccol0, 0), ST_PITCH - 2);
+    const int oc0 = min(max(min(max(cc, 0), SC.w - 1) * BPC - ccol0, 0), CPITCH - BPC), oc1 = min(max(min(max(cc + 1, 0), SC.w - 1) * BPC - ccol0, 0), CPITCH - BPC);
     // (the chroma offsets are even, and a compiler that knows it fuses a pair's U and V byte reads into one 16-bit read and splits it
     // again with two more vector instructions per tap pair: every tap its own byte read is the cheaper form here, r03_notes.md section 2)
     int oc0v = oc0, oc1v = oc1;
@@ -138,22 +146,25 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
     const float iya = (1.0f - cya) * kTapScale, ya = cya * kTapScale, ica = (1.0f - cca) * kTapScale, ca = cca * kTapScale;
     const bool lane_pic = cfl == AX_ALL && x < T.W;
     // 16-byte vectors of a ring row that some tap of the strip can read (the last lane has the largest offsets): the rest is not requested
-    const int nvecY = (__builtin_amdgcn_readlane(oy1, 63) >> 4) + 1, nvecC = ((__builtin_amdgcn_readlane(oc1, 63) + 1) >> 4) + 1;
+    const int nvecY = (__builtin_amdgcn_readlane(oy1, 63) >> 4) + 1, nvecC = ((__builtin_amdgcn_readlane(oc1, 63) + BPC - 1) >> 4) + 1;
 
     // per-layer constants (wave-uniform), read once: the asm statements below clobber "memory", and every descriptor read after one of
     // them would be a fresh scalar load with its latency in the middle of the ring logic
     CscFolded csc[NL];
     float al[NL], ial[NL];
-    const uint8_t *planeY[NL], *planeC[NL];
+    const uint8_t *planeY[NL], *planeC[NL], *planeV[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) {
         csc[l] = csc_fold_biased(kCsc[L[l].csc & 3]);
         al[l] = 1.0f * L[l].u[U_OPACITY]; ial[l] = 1.f - al[l];
-        planeY[l] = L[l].src.pl[0].ptr; planeC[l] = L[l].src.pl[1].ptr;
+        planeY[l] = L[l].src.pl[0].ptr; planeC[l] = L[l].src.pl[1].ptr; planeV[l] = L[l].src.pl[PL ? 2 : 1].ptr;
     }
     // this lane's place in a batch: (row, vector) and its byte column, luma and chroma
-    const int rrY = (lane >> 3) & 3, rrC = (lane >> 3) & 1;
-    const int colY = min(ycol0 + 16 * (lane & 7), SY.w - 16), colC = min(ccol0 + 16 * (lane & 7), SC.w * 2 - 16);
+    // (planar chroma: a layer's two rows of six vectors are twelve lanes)
+    const int liC = PL ? (lane * 43) >> 9 : lane >> 4, inC = PL ? lane - liC * 12 : lane & 15;      // lane -> layer, place inside the layer's rows
+    static_assert(((63 * 43) >> 9) == 5 && ((47 * 43) >> 9) == 3 && ((48 * 43) >> 9) == 4 && ((11 * 43) >> 9) == 0 && ((12 * 43) >> 9) == 1, "lane / 12");
+    const int rrY = (lane >> 3) & 3, rrC = PL ? (inC >= 6 ? 1 : 0) : (lane >> 3) & 1, vecC = PL ? inC - 6 * rrC : lane & 7;
+    const int colY = min(ycol0 + 16 * (lane & 7), SY.w - 16), colC = min(ccol0 + 16 * vecC, SC.w * BPC - 16);
 
     // the chunk's last tap rows: nothing past them is requested (a chunk's overshoot is another wave's first rows: fetched twice)
     int lastY, lastC;
@@ -237,12 +248,19 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
             }
             while (rc + ST_CROWS / 2 >= nextC && nextC <= lastC) {
                 // two chroma rows of every layer in one instruction
-                const uint32_t slot = (uint32_t)(2 * NL * ST_YL + (((nextC - baseC) >> 1) & 1) * (NL * ST_CL));
+                const uint32_t slot = (uint32_t)(2 * NL * ST_YL + (((nextC - baseC) >> 1) & 1) * (NL * CLB));
                 const int r = min(max(nextC + rrC, 0), SC.h - 1);
                 const size_t roff = (size_t)r * SC.pitch + (size_t)colC;
-                const int li = lane >> 4;
+                const int li = liC;
+                const bool act = li < NL && vecC < nvecC && nextC + rrC <= lastC;
                 const uint8_t *pl = li == 0 ? planeC[0] : li == 1 ? planeC[NL > 1 ? 1 : 0] : li == 2 ? planeC[NL > 2 ? 2 : 0] : planeC[NL > 3 ? 3 : 0];
-                st_dma(pl + roff, li < NL && (lane & 7) < nvecC && nextC + rrC <= lastC, lds0 + slot);
+                st_dma(pl + roff, act, lds0 + slot);
+                if constexpr (PL) {
+                    // the V planes (the shape of the U planes, host-checked) into the region behind the U rows
+                    const uint8_t *pv = li == 0 ? planeV[0] : li == 1 ? planeV[NL > 1 ? 1 : 0] : li == 2 ? planeV[NL > 2 ? 2 : 0] : planeV[NL > 3 ? 3 : 0];
+                    st_dma(pv + roff, act, lds0 + slot + (uint32_t)(2 * NL * ST_CLP));
+                    issued += 1;
+                }
                 nextC += 2; issued += 1; seqC = issued;
             }
             // (first row of a chunk, rows skipped by a strong reduction: what was just requested is needed now)
@@ -255,7 +273,7 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
         if (j > 0 && x < T.W && !(CHV_ST_ABL & 2)) gst_at<uint32_t>(D.ptr + (size_t)(y0 + j - 1) * D.pitch, (uint32_t)x * 4u, pending);
         // ---- tap addresses and weights, once for all layers -----------------------------------------------------------------
         auto yoff = [&](int q) { return ((q >> 2) & 1) * (NL * ST_YL) + (q & 3) * ST_PITCH; };                       // layer 0's copy of luma row baseY + q
-        auto coff = [&](int q) { return 2 * NL * ST_YL + ((q >> 1) & 1) * (NL * ST_CL) + (q & 1) * ST_PITCH; };
+        auto coff = [&](int q) { return 2 * NL * ST_YL + ((q >> 1) & 1) * (NL * CLB) + (q & 1) * CPITCH; };
         const int sY0 = yoff(ry - baseY), sY1 = yoff(ry + 1 - baseY), sC0 = coff(rc - baseC), sC1 = coff(rc + 1 - baseC);
         const uint8_t *pY00 = lds + (oy0 + sY0), *pY10 = lds + (oy1 + sY0), *pY01 = lds + (oy0 + sY1), *pY11 = lds + (oy1 + sY1);
         const uint8_t *pC00 = lds + (oc0v + sC0), *pC10 = lds + (oc1v + sC0), *pC01 = lds + (oc0v + sC1), *pC11 = lds + (oc1v + sC1);
@@ -266,10 +284,10 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             constexpr int dummy = 0; (void)dummy;
-            const int lo = l * ST_YL, lc = l * ST_CL;
+            const int lo = l * ST_YL, lc = l * CLB;
             const float fy = cs_mix_h(w00, w10, w01, w11, tap_h(pY00 + lo), tap_h(pY10 + lo), tap_h(pY01 + lo), tap_h(pY11 + lo));
             const float fu = cs_mix_h(c00, c10, c01, c11, tap_h(pC00 + lc), tap_h(pC10 + lc), tap_h(pC01 + lc), tap_h(pC11 + lc));
-            const float fv = cs_mix_h(c00, c10, c01, c11, tap_h(pC00 + lc + 1), tap_h(pC10 + lc + 1), tap_h(pC01 + lc + 1), tap_h(pC11 + lc + 1));
+            const float fv = cs_mix_h(c00, c10, c01, c11, tap_h(pC00 + lc + VOFF), tap_h(pC10 + lc + VOFF), tap_h(pC01 + lc + VOFF), tap_h(pC11 + lc + VOFF));
             float pb, pg, pr;
             yuv_to_bgr_floats(csc[l], (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv), pb, pg, pr);
             if (l == 0) {                // the cleared canvas: fma(p, a, 0 * (1 - a)) = RN(p * a) for a in [0, 1]
@@ -289,10 +307,10 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
     if (nrows > 0 && x < T.W && !(CHV_ST_ABL & 2)) gst_at<uint32_t>(D.ptr + (size_t)(y0 + nrows - 1) * D.pitch, (uint32_t)x * 4u, pending);
 }
 
-template <int NL>
+template <int NL, bool PL>
 __global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_stream(const DTick *__restrict__ ticks, const DLayer *__restrict__ layers, int n_ticks,
                                                                           int strips_x, int chunks_y, int rows_per_chunk) {
-    stream_body<NL, false>(ticks, layers, n_ticks, strips_x, chunks_y, rows_per_chunk);
+    stream_body<NL, false, PL>(ticks, layers, n_ticks, strips_x, chunks_y, rows_per_chunk);
 }
 
 // one tick, descriptors by value (96 + NL x 344 bytes of kernel arguments)
@@ -301,9 +319,9 @@ struct StreamOne {
     DTick t;
     DLayer l[NL];
 };
-template <int NL>
+template <int NL, bool PL>
 __global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_stream_one(const StreamOne<NL> a, int strips_x, int chunks_y, int rows_per_chunk) {
-    stream_body<NL, true>(&a.t, a.l, 1, strips_x, chunks_y, rows_per_chunk);
+    stream_body<NL, true, PL>(&a.t, a.l, 1, strips_x, chunks_y, rows_per_chunk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -330,19 +348,27 @@ bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks)
         if ((((uintptr_t)T.dst.pl[0].ptr) & 3) != 0 || (T.dst.pl[0].pitch & 3) != 0) return false;
         for (int l = 0; l < nl; l++) {
             const DLayer &Y = layers[T.first_layer + l];
-            if (Y.kind != LK_BGRA_FROM_NV12) return false;
+            // (NV12 or planar sources, one class per launch: LF_SAME_GEOM already says so inside a tick)
+            const int kind0 = layers[ticks[0].first_layer].kind;
+            if ((kind0 != LK_BGRA_FROM_NV12 && kind0 != LK_BGRA_FROM_Y420P) || Y.kind != kind0) return false;
+            const bool planar = kind0 == LK_BGRA_FROM_Y420P;
             const int need = LF_AXIS_ALIGNED | LF_BOUNDED | LF_NO_FILL | (l ? LF_SAME_GEOM : 0);
             if ((Y.flags & need) != need) return false;
             const float op = Y.u[U_OPACITY];
             if (!(op >= 0.f && op <= 1.f)) return false;
             if (!stream_plane_ok(Y.src.pl[0]) || !stream_plane_ok(Y.src.pl[1])) return false;
-            if (Y.src.pl[1].comps != 2 || Y.src.pl[0].comps != 1) return false;
+            if (Y.src.pl[1].comps != (planar ? 1 : 2) || Y.src.pl[0].comps != 1) return false;
+            if (planar) {
+                const DPlane &cu = Y.src.pl[1], &cv = Y.src.pl[2];
+                if (!stream_plane_ok(cv) || cv.comps != 1 || cv.w != cu.w || cv.h != cu.h || cv.pitch != cu.pitch) return false;       // one ring geometry for U and V
+            }
             if (l == 0) {
                 // source texels per canvas pixel: u = (x / W * 2 - 1) * T0 * X0 + ...  =>  du/dx * w = 2 T0 X0 w / W
                 const double kx = 2.0 * (double)Y.u[U_TRANSFORM + 0] * (double)Y.u[U_TEXTURE + 0], ky = 2.0 * (double)Y.u[U_TRANSFORM + 5] * (double)Y.u[U_TEXTURE + 5];
                 if (!(kx > 0.0) || !(ky > 0.0)) return false;                                   // flips: the rings assume rising positions
                 const double sx = kx * Y.src.pl[0].w / (double)T.W;
-                if (!(63.0 * sx + 2.0 + 15.0 + 1.0 <= 128.0)) return false;                     // luma bytes of a strip (chroma: the same count)
+                if (!(63.0 * sx + 2.0 + 15.0 + 1.0 <= 128.0)) return false;                     // luma bytes of a strip (NV12 chroma: the same count)
+                if (planar && !(63.0 * (kx * Y.src.pl[1].w / (double)T.W) + 2.0 + 15.0 + 1.0 <= (double)ST_CPP)) return false;     // a plane's chroma bytes of a strip
                 // source rows per canvas row: the rings are advanced batch by batch (four luma rows per load), so the work per canvas row grows
                 // with the vertical reduction — a picture squeezed into a few canvas rows (a zoom animation's first frames) would issue
                 // hundreds of loads of rows nobody taps per canvas row, and tick_bgra_wave culls by bounding box instead
@@ -374,7 +400,9 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
     const int chunks_y = (maxH + rows - 1) / rows;
     const long total = (long)n_ticks * chunks_y * ((strips_x + ST_WAVES - 1) / ST_WAVES);
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
-    const size_t lds = (size_t)ST_WAVES * ((size_t)nl * ST_LAYER + ST_TAB * (sizeof(uint4) + sizeof(uint32_t)));
+    const bool planar = layers_host[ticks_host[0].first_layer].kind == LK_BGRA_FROM_Y420P;
+    const size_t layer_bytes = planar ? (size_t)st_layer_bytes<1, true>() : (size_t)st_layer_bytes<1, false>();
+    const size_t lds = (size_t)ST_WAVES * ((size_t)nl * layer_bytes + ST_TAB * (sizeof(uint4) + sizeof(uint32_t)));
     if (!ticks) {
         // one tick, descriptors as kernel arguments (launch_transient)
         if (n_ticks != 1 || !layers_host) return hipErrorInvalidValue;
@@ -384,7 +412,8 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
             a.t = ticks_host[0];
             a.t.first_layer = 0;
             for (int l = 0; l < NL; l++) a.l[l] = layers_host[ticks_host[0].first_layer + l];
-            hipLaunchKernelGGL(tick_bgra_stream_one<NL>, grid, dim3(64 * ST_WAVES), lds, stream, a, strips_x, chunks_y, rows);
+            if (planar) hipLaunchKernelGGL((tick_bgra_stream_one<NL, true>), grid, dim3(64 * ST_WAVES), lds, stream, a, strips_x, chunks_y, rows);
+            else hipLaunchKernelGGL((tick_bgra_stream_one<NL, false>), grid, dim3(64 * ST_WAVES), lds, stream, a, strips_x, chunks_y, rows);
         };
         switch (nl) {
         case 1: go(std::integral_constant<int, 1>{}); break;
@@ -394,12 +423,15 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
         }
         return hipGetLastError();
     }
+#define CHV_ST_GO(N) do { if (planar) hipLaunchKernelGGL((tick_bgra_stream<N, true>), grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); \
+                          else hipLaunchKernelGGL((tick_bgra_stream<N, false>), grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); } while (0)
     switch (nl) {
-    case 1: hipLaunchKernelGGL(tick_bgra_stream<1>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;
-    case 2: hipLaunchKernelGGL(tick_bgra_stream<2>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;
-    case 3: hipLaunchKernelGGL(tick_bgra_stream<3>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;
-    default: hipLaunchKernelGGL(tick_bgra_stream<4>, grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); break;
+    case 1: CHV_ST_GO(1); break;
+    case 2: CHV_ST_GO(2); break;
+    case 3: CHV_ST_GO(3); break;
+    default: CHV_ST_GO(4); break;
     }
+#undef CHV_ST_GO
     return hipGetLastError();
 }
 

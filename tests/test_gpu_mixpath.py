@@ -163,6 +163,10 @@ STREAM_CASES = {
     "own_colourspaces": (192, 64, [("img_nv12_bgra", 288, 96, dict(A, csc=c, opacity=o)) for c, o in ((0, 1.0), (1, 0.5), (2, 0.5), (3, 0.25))]),
     "tex_window":       (320, 180, _stack("img_nv12_bgra", 480, 272, dict(tex=(0.05, 0.1, 0.95, 0.9)), (1.0, 0.5))),
 }
+# the same ticks with PLANAR sources (y420p: what FFmpeg's software decoders emit): a third ring per layer; chroma rows are multiples of 16 bytes
+# where the source width is a multiple of 32
+STREAM_CASES.update({name + "_y420p": (cw, ch, [(k.replace("nv12", "y420p"), sw, sh, kw) for k, sw, sh, kw in specs])
+                     for name, (cw, ch, specs) in list(STREAM_CASES.items()) if all(sw % 32 == 0 for _, sw, _, _ in specs)})
 
 
 @pytest.mark.parametrize("case", list(STREAM_CASES))
@@ -190,9 +194,10 @@ def test_lone_stream_tick_matches_oracle(ctx, switch, case, desc):
         kw = dict(kw)
         lcsc = kw.pop("csc", 0)
         u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
-        src = util.alloc_image("nv12", sw, sh, seed=340 + i)
+        fmt = k.split("_")[1]
+        src = util.alloc_image(fmt, sw, sh, seed=340 + i)
         assert O.run_kernel(k, exp, src, u, csc=lcsc, threads=4) == 0
-        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, "nv12", sw, sh, src), u, lcsc))
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, fmt, sw, sh, src), u, lcsc))
     gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
     for _ in range(2):                                   # (twice: the second tick finds the first one's canvas)
         sv.usingContext(ctx, lambda c: sv.compositeTick(c, gd, layers, True))
@@ -203,17 +208,19 @@ def _random_stream_ticks(ctx, seed, nl_low=2):
     """three ticks of different canvas sizes, nl_low..4 NV12 layers of one geometry each -> (ticks, expected canvases, (canvas, w, h))"""
     rng = np.random.default_rng(7100 + seed)
     nl = int(rng.integers(nl_low, 5))
+    fmt = "y420p" if seed % 3 == 2 else "nv12"         # (planar sources: a launch's layers are all of one class)
+    unit = 32 if fmt == "y420p" else 16
     ticks, exps, gds = [], [], []
     for t in range(3):
         cw, ch = int(rng.integers(20, 330)) * 2, int(rng.integers(8, 200)) * 2
-        sw, sh = int(rng.integers(2, 40)) * 16, int(rng.integers(4, 150)) * 2
+        sw, sh = int(rng.integers(2, 640 // unit)) * unit, int(rng.integers(4, 150)) * 2
         kw = {}
         if rng.random() < 0.6:
             rw = float(rng.uniform(0.62, 3.0)) * sw                 # the picture's width on the canvas: source texels per pixel <= 1.6
             kw["rect"] = (float(rng.uniform(-0.3, 0.5) * cw), float(rng.uniform(-0.3, 0.5) * ch), rw, float(rng.uniform(0.2, 2.5)) * sh)
         else:
             if sw / cw > 1.6:
-                sw = max(16, int(cw * 1.5) // 16 * 16)
+                sw = max(unit, int(cw * 1.5) // unit * unit)
         if rng.random() < 0.25:
             kw["tex"] = (0.0, 0.0, float(rng.uniform(1.0, 1.5)), float(rng.uniform(0.6, 1.4)))
         canvas0 = util.alloc_image("bgra", cw, ch, seed=int(rng.integers(1, 1 << 20)))
@@ -224,15 +231,15 @@ def _random_stream_ticks(ctx, seed, nl_low=2):
             op = float(rng.choice([1.0, rng.uniform(0, 1)]))
             csc = int(rng.integers(0, 4))
             u = util.make_uniforms((cw, ch), in_size=(sw, sh), opacity=op, **kw)
-            src = util.alloc_image("nv12", sw, sh, seed=int(rng.integers(1, 1 << 20)))
-            assert O.run_kernel("img_nv12_bgra", exp, src, u, csc=csc, threads=4) == 0
-            layers.append((sv.ComputeKernel.img_nv12_bgra, G.to_gpu(ctx, "nv12", sw, sh, src), u, csc))
+            src = util.alloc_image(fmt, sw, sh, seed=int(rng.integers(1, 1 << 20)))
+            assert O.run_kernel(f"img_{fmt}_bgra", exp, src, u, csc=csc, threads=4) == 0
+            layers.append((sv.defaultComputeKernelFromString(f"img_{fmt}_bgra"), G.to_gpu(ctx, fmt, sw, sh, src), u, csc))
         gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
         ticks.append((gd, True, layers)); exps.append(exp); gds.append((gd, cw, ch))
     return ticks, exps, gds
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(36))
 def test_random_stream_ticks(ctx, switch, seed):
     """Seeded random ticks of the streaming kernel's class: three ticks of different canvas sizes per launch, 2..4 NV12 layers of one
     geometry each — full canvas or a rectangle anywhere (also across the canvas edges), enlargements and reductions up to 1.7 across
@@ -247,7 +254,7 @@ def test_random_stream_ticks(ctx, switch, seed):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed} tick {i} via {name}")
 
 
-@pytest.mark.parametrize("seed", range(100, 112))
+@pytest.mark.parametrize("seed", range(100, 118))
 def test_random_lone_stream_ticks(ctx, seed):
     """the same random ticks (1..4 layers), one at a time through chv_composite: descriptors as kernel arguments (tick_bgra_stream_one)"""
     ticks, exps, gds = _random_stream_ticks(ctx, seed, nl_low=1)
