@@ -69,6 +69,12 @@ namespace chv {
 #define CHV_YS_STORE 0           // luma stores: 0 — a lane writes 4 columns of row (lane & 3) (16-byte pieces of four rows per quarter wave);
                                  // 1 — one more lane shuffle first: a quarter wave writes 64 contiguous bytes of ONE row; bit 1 (2, 3): nontemporal
 #endif
+#ifndef CHV_YS_RGBFAST
+#define CHV_YS_RGBFAST 1         // the encoder-side frame's own trip loop (fast_rgb_trip); 0: the general row loop (A/B)
+#endif
+#ifndef CHV_YS_WAVES_RGBINT
+#define CHV_YS_WAVES_RGBINT 6
+#endif
 #ifndef CHV_YS_CARRY
 #define CHV_YS_CARRY 1           // native-resolution rows: a pixel's lower tap row is the upper one of the pixel below (conversions carried)
 #endif
@@ -348,7 +354,8 @@ CHV_DEV uint32_t ys_put_raw_k(uint32_t w, float v, int k) {
 }
 
 // waves per SIMD an instantiation is compiled for
-constexpr int ys_min_waves(int kinds, int nl) { return (kinds & (YK_RGB | YK_RGBINT)) ? (kinds == YK_RGBINT ? CHV_YS_WAVES_OWN : CHV_YS_WAVES_MIXED) : nl >= 2 ? CHV_YS_WAVES_OWN - 1 : CHV_YS_WAVES_OWN; }
+// (the encoder-side instantiation carries eight texel values down the lane across trips: 96 registers, nothing in scratch)
+constexpr int ys_min_waves(int kinds, int nl) { return (kinds & (YK_RGB | YK_RGBINT)) ? (kinds == YK_RGBINT ? CHV_YS_WAVES_RGBINT : CHV_YS_WAVES_MIXED) : nl >= 2 ? CHV_YS_WAVES_OWN - 1 : CHV_YS_WAVES_OWN; }
 
 // ONE: one tick whose descriptors are kernel ARGUMENTS (tick_yuv_stream_one)
 template <int TF, int NL, int KINDS, bool ONE>
@@ -495,6 +502,8 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
     ys_seq<NL>(setup_layer);
     // (only layer 0 can touch this strip and chunk: an opaque YUV picture whose columns take the short form of the row loops, luma and chroma)
     const bool fast0 = CHV_YS_CARRY && HAS_YUV && (hit & 0xFF) == 1 && (lf[0] & 17) == 16 && (hit & (1 << 16)) != 0 && (hit & (1 << 24)) != 0;
+    // (the same for the encoder side's frame: only layer 0, an integer-matrix RGB picture drawn at its own size over the whole strip)
+    const bool fastR0 = CHV_YS_CARRY && CHV_YS_RGBFAST && KINDS == YK_RGBINT && (hit & 0xFF) == 1 && (lf[0] & 5) == 5 && (hit & (1 << 16)) != 0;
     // (the rings of a tick's layers, then one row table per layer)
     uint32_t *rowtab = (uint32_t *)(lds + (wave_bytes - NL * YS_TAB_BYTES));
 
@@ -815,6 +824,79 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
         finish_trip(j0, lw, cu, cv);
     };
 
+    // A trip of the encoder side's frame — only layer 0, an RGB picture through the integer matrix (img_*_int), drawn at its own size
+    // over the whole strip onto the cleared canvas, its four rows inside the picture and on consecutive source rows: one ring request and one
+    // wait for the trip instead of one per row, the four rows unrolled with their byte positions as immediates, no per-pixel selects on luma,
+    // both column weights one half (two weight products instead of four), the lower texel row of a pixel carried down the lane as the upper one
+    // of the pixel below — across trips too —, the matrix as 24-bit multiply-adds (codes < 2^8, coefficients < 2^16: exact).  Cleared canvas and
+    // first layer: the luma blend fma(p, a, 0 * (1 - a)) is RN(p * a).  The same operations per pixel as the general row loop otherwise.
+    float rt00 = 0.f, rt01 = 0.f, rt02 = 0.f, rt03 = 0.f, rt10 = 0.f, rt11 = 0.f, rt12 = 0.f, rt13 = 0.f;
+    int rt_row = -0x40000000;                        // the source row whose texels rt.. hold
+    auto fast_rgb_trip = [&](int j0, auto swz_c) {
+        constexpr bool SWZ = decltype(swz_c)::value;
+        const int jt = j0 & (YS_TAB - 1);
+        const uint32_t *tab = rowtab + jt;
+        const DLayer &Ly = L[0];
+        const uint32_t ringY = lds0 + (uint32_t)lbase[0];
+        const uint8_t *ldsY = lds + lbase[0];
+        const int ry0 = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)tab[0]) & 8191u) - 1;
+        auto srcY = [&]() { if constexpr (KEEP_SRC) return sY[0]; else return ring_src(Ly.src.pl[0], Ly.src.pl[0], cvY[0]); };
+        const int hi = ry0 + 4 < rY[0].last ? ry0 + 4 : rY[0].last;
+        ring_ensure<RingR>(rY[0], ringY, srcY, ry0, hi, issued, lane);
+        flush();
+        const uint4 w4 = *(const uint4 *)(tab + YS_TAB);
+        const float rya[4] = { __uint_as_float(w4.x), __uint_as_float(w4.y), __uint_as_float(w4.z), __uint_as_float(w4.w) };
+        const int o0 = ys_o0(col[0].off);
+        const R2Y &kk = kR2Y[(lf[0] >> 8) & 3];
+        const int ky0 = kk.y[0], ky1 = kk.y[1], ky2 = kk.y[2], ku0 = kk.u[0], ku1 = kk.u[1], ku2 = kk.u[2], kv0 = kk.v[0], kv1 = kk.v[1], kv2 = kk.v[2];
+        const int cy_ = (kk.yoff << 16) + 32768, cc_ = (128 << 16) + 32768;
+        const float ka = opac[0] * kInv255;
+        auto fix = [&](uint32_t w) { return SWZ ? __builtin_amdgcn_perm(w, w, 0x03000102u) : w; };
+        int q = ring_row<RingR>(rY[0], ry0);
+        if (rt_row != ry0) {
+            const uint8_t *p0 = ldsY + (q + o0);
+            const uint32_t u00 = fix(*(const uint32_t *)p0), u10 = fix(*(const uint32_t *)(p0 + 4));
+            rt00 = ub0(u00); rt01 = ub1(u00); rt02 = ub2(u00); rt03 = ub3(u00);
+            rt10 = ub0(u10); rt11 = ub1(u10); rt12 = ub2(u10); rt13 = ub3(u10);
+        }
+        uint32_t lw = 0, cu = 128u, cv = 128u;
+        auto row = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const float bw = rya[k], ib = 1.0f - bw;
+            q = ring_next<RingR>(q);
+            const uint8_t *p1 = ldsY + (q + o0);
+            const uint32_t u01 = fix(*(const uint32_t *)p1), u11 = fix(*(const uint32_t *)(p1 + 4));
+            const float b00 = ub0(u01), b01 = ub1(u01), b02 = ub2(u01), b03 = ub3(u01);
+            const float b10 = ub0(u11), b11 = ub1(u11), b12 = ub2(u11), b13 = ub3(u11);
+            const float wt = 0.5f * ib, wb = 0.5f * bw;
+            const float q0f = cs_mix(wt, wt, wb, wb, rt00, rt10, b00, b10);
+            const float q1f = cs_mix(wt, wt, wb, wb, rt01, rt11, b01, b11);
+            const float q2f = cs_mix(wt, wt, wb, wb, rt02, rt12, b02, b12);
+            const float q3f = cs_mix(wt, wt, wb, wb, rt03, rt13, b03, b13);
+            rt00 = b00; rt01 = b01; rt02 = b02; rt03 = b03; rt10 = b10; rt11 = b11; rt12 = b12; rt13 = b13;
+            // to_code_raw of a convex combination of codes: no clamp can trigger; rint through the float adder
+            const int cr = (int)(code_biased(q0f) & 255u), cg = (int)(code_biased(q1f) & 255u), cb = (int)(code_biased(q2f) & 255u);
+            const float a2 = q3f * ka, ia2 = 1.f - a2;
+            const int py = (int)clip8(mad24_uniform(cr, ky0, mad24_uniform(cg, ky1, mad24_uniform(cb, ky2, cy_))) >> 16);
+            lw = ys_put_raw<k>(lw, (float)py * a2);
+            if constexpr ((k & 1) == 0) {
+                // chroma of the quad: the even lane's pixel of this (even) row; the trip's second chroma row lives in the odd lane (the values
+                // travel one lane up, quad_perm [0, 0, 2, 2])
+                int pu = (int)clip8(mad24_uniform(cr, ku0, mad24_uniform(cg, ku1, mad24_uniform(cb, ku2, cc_))) >> 16);
+                int pv = (int)clip8(mad24_uniform(cr, kv0, mad24_uniform(cg, kv1, mad24_uniform(cb, kv2, cc_))) >> 16);
+                float sa = a2, sia = ia2;
+                if constexpr (k == 2) { pu = ys_dpp_even(pu); pv = ys_dpp_even(pv); sa = ys_dpp_even(a2); sia = ys_dpp_even(ia2); }
+                const bool mine = par == (k >> 1);            // (every column of the strip is inside the picture and the canvas)
+                const uint32_t nnu = ys_put_raw<0>(cu, __builtin_fmaf((float)pu, sa, ub0(cu) * sia));
+                const uint32_t nnv = ys_put_raw<0>(cv, __builtin_fmaf((float)pv, sa, ub0(cv) * sia));
+                cu = mine ? nnu : cu; cv = mine ? nnv : cv;
+            }
+        };
+        ys_seq<4>(row);
+        rt_row = ry0 + 4;
+        finish_trip(j0, lw, cu, cv);
+    };
+
     // A step of eight canvas rows in which only layer 0 — an opaque YUV picture drawn at its own size over the whole strip: the full-canvas video
     // of a mixer tick, the bulk of its pixels — touches the strip, every row taps the source row behind its predecessor's, and the columns take the
     // short form (tap column 1 right behind tap column 0, both weights one half): no per-layer tests, one ring position per plane walked row by
@@ -977,6 +1059,12 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
                     }
                 };
                 ys_seq<NL>(step);
+            }
+        }
+        if constexpr (KINDS == YK_RGBINT) {
+            if (fastR0 && j0 + 4 <= nrows && ((rowm[0] >> jt) & 15u) == 15u && ((unitm[0] >> jt) & 7u) == 7u) {
+                if ((lf[0] & 8) != 0) fast_rgb_trip(j0, std::true_type{}); else fast_rgb_trip(j0, std::false_type{});
+                continue;
             }
         }
         flush();                                         // (the previous trip's luma, after this trip's waits)

@@ -139,7 +139,8 @@ def _lds_dma_contract(co, min_loads):
 def test_yuv_stream_kernel_owns_m0_and_keeps_its_waves(tmp_path):
     """tick_yuv_stream: the same M0 contract as tick_bgra_stream.  Registers (what the measurements of profiles/r04_notes.md were taken with):
     one video layer slot — 80 VGPRs (6 waves per SIMD) with at most a few registers in scratch (88 registers and 5 waves measured 3 % slower); the
-    encoder-side integer instantiation: nothing in scratch; two video layers 96; the mixer instantiations (video + RGB overlays, three or four
+    encoder-side integer instantiation: 80 registers as well (its trip loop carries eight texel values down the lane; six waves with a handful of registers
+    in scratch measured 0.5575 ms on encode_nv12 against 0.583 at five waves with none and 0.591 at four — same call); two video layers 96; the mixer instantiations (video + RGB overlays, three or four
     layer slots) 128 — their rings leave the LDS to four waves per SIMD anyway."""
     co = _code_object(tmp_path, "kernels_stream_yuv")
     kernels = _find(_kernels(co), "tick_yuv_stream")
@@ -147,9 +148,7 @@ def test_yuv_stream_kernel_owns_m0_and_keeps_its_waves(tmp_path):
     for name, m in kernels.items():
         nl, kinds = [int(x) for x in re.search(r"ILi\d+ELi(\d+)ELi(\d+)E", name).groups()]
         scratch = m.get("private_segment_fixed_size", 0)
-        if kinds == 8:
-            assert m["vgpr_count"] <= 64 and scratch == 0, (name, m)
-        elif kinds in (1, 2) and nl == 1:
+        if kinds in (1, 2, 8) and nl == 1:
             assert m["vgpr_count"] <= 80 and scratch <= 48, (name, m)
         elif kinds in (1, 2):
             assert m["vgpr_count"] <= 96, (name, m)
