@@ -24,10 +24,16 @@ python profiles/summarize.py gpurun_out/prof_${R}_pipeline --kernel tick_bgra_st
 # 4. the same for the reference's own kernels on their default canvas
 bash profiles/run_profile.sh ${R}_mixer --workload mixer_y420p --also none --no-cpu-baseline --no-verify --steps 5 --warmup 2 --launches-per-step 1 > /dev/null 2>&1
 python profiles/summarize.py gpurun_out/prof_${R}_mixer --kernel tick_yuv_wave > $OUT/mixer_y420p_rocprofv3.txt 2>&1
+# 4b. the encoder-side frame through the 4:2:0 streaming kernel
+bash profiles/run_profile.sh ${R}_encode --workload encode_nv12 --also none --no-cpu-baseline --no-verify --steps 5 --warmup 2 --launches-per-step 1 > /dev/null 2>&1
+python profiles/summarize.py gpurun_out/prof_${R}_encode --kernel tick_yuv_stream > $OUT/encode_nv12_rocprofv3.txt 2>&1
 # 5. A/B lines: general kernels, wave kernel on the single-purpose workloads
 for w in pipeline mixer_y420p cfg2; do CHV_FORCE_GENERAL=1 python bench.py --workload $w --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_${w}_general_kernel.json 2>/dev/null; done
 for w in cfg2 cfg3; do CHV_BGRA_PATH=wave python bench.py --workload $w --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_${w}_wave_kernel.json 2>/dev/null; done
 CHV_STREAM=0 python bench.py --workload pipeline --also none --no-cpu-baseline --min-seconds 1.0 > $OUT/bench_pipeline_wave_kernel.json 2>/dev/null
 CHV_BGRA_PATH=stream python bench.py --workload cfg2 --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_cfg2_stream_kernel.json 2>/dev/null
+CHV_STREAM=0 python bench.py --workload pipeline_y420p --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_pipeline_y420p_wave_kernel.json 2>/dev/null
+CHV_YUV_STREAM=0 python bench.py --workload encode_nv12 --also y420p_main --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_yuv_wave_kernel.json 2>/dev/null
+CHV_YUV_STREAM=force python bench.py --workload encode_nv12 --also y420p_main,mixer_y420p,mixer_nv12 --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_yuv_stream_kernel.json 2>/dev/null
 python bench.py --workload mixed --also y420p_main,mixer_nv12,cfg2_y420p,encode_nv12,pipeline_logo --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_more_workloads.json 2>/dev/null
 tail -c 400 $OUT/bench_default.json; echo; tail -5 $OUT/pipeline_rocprofv3.txt

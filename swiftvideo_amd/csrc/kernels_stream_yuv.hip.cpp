@@ -8,16 +8,20 @@
 // strip against 44 ns per pixel row of an opaque layer (profiles/r03_notes.md section 3).  Here the structure that took the BGRA
 // headline from 0.31 to 0.41 of the HBM roofline (kernels_stream.hip.cpp) is applied to them, generalised to layers of DIFFERENT
 // geometry (a full-canvas video under small overlays is the reference mixer's usual tick):
-//   * a wave owns a 64-column strip over a chunk of rows (four neighbouring strips per block, no barrier) and works in TRIPS of four
-//     canvas rows: the lane's four luma codes of a trip are one packed register, the trip's chroma sample of the lane's column pair
-//     one code each for U and V (even lanes: chroma row 2m, odd lanes: 2m + 1 — the reference's `handleChroma` owner is the quad's
-//     even/even pixel, kernels.cl.swift:76, so both lanes sample at the EVEN lane's column);
-//   * every layer has its own column entry (registers), its own row table (LDS, 16 rows at a time) and its own rings: luma 16 rows x
-//     128 B in batches of 4, chroma 8 rows in batches of 2 (NV12: 128-byte rows of (u, v) pairs; planar: U and V rows of 96 bytes side
-//     by side, one load instruction for both), RGB texels 6 (or 12) rows x 320 B in batches of 3.  A batch is one
-//     `global_load_lds_dwordx4` (lane -> row, vector; LDS address M0 + lane x 16), requested as soon as the taps have left the oldest
-//     batch and awaited BY COUNT (`s_waitcnt vmcnt(n)`, n = loads issued since: loads complete in order among themselves) when a tap
-//     row reaches it — two trips later at native size;
+//   * a wave owns a 64-column strip over a chunk of rows (one wave per block, no barrier: the LDS is handed out per wave) and works in
+//     TRIPS of four canvas rows: the lane's four luma codes of a trip are one packed register, the trip's chroma sample of the lane's
+//     column pair one code each for U and V (even lanes: chroma row 2m, odd lanes: 2m + 1 — the reference's `handleChroma` owner is the
+//     quad's even/even pixel, kernels.cl.swift:76, so both lanes sample at the EVEN lane's column);
+//   * every layer has its own column entry (registers), its own row table (LDS, 32 rows at a time, with a two-dword summary per 8-row
+//     STEP) and its own rings: luma 24 rows x 128 B in batches of 8, chroma 12 rows in batches of 4 (NV12: 128-byte rows of (u, v) pairs;
+//     planar: U and V rows of 96 bytes side by side, one load instruction for both), RGB texels 12 (encoder side) or 8 (beside video
+//     layers) rows x 320 B in batches of 3 or 2.  A batch is one `global_load_lds_dwordx4` (lane -> row, vector; LDS address M0 + lane x
+//     16), requested as soon as the taps have left the oldest batch and awaited BY COUNT (`s_waitcnt vmcnt(n)`, n = loads issued since:
+//     loads complete in order among themselves) when a tap row reaches it.  Residency is decided once per step for the YUV layers, per
+//     row for RGB layers (their rows are 2.5x as long);
+//   * the bulk of a mixer tick — steps in which only an opaque same-size video layer touches the strip — and the encoder-side frame take
+//     their own short loops (fast_step, fast_rgb_trip: no per-layer tests, the lower tap row of a pixel carried down the lane as the
+//     upper tap row of the pixel below); the operations per pixel are the general loops';
 //   * layers that miss the strip's columns are dropped at the chunk start, trips outside a layer's rows cost a flag test;
 //   * the luma codes of a trip leave as ONE dword store per lane (a 4 x 4 byte transpose inside every quad of lanes), issued after the
 //     NEXT trip's first wait (gfx950 counts loads and stores in one counter); chroma leaves once per 16 rows as in tick_yuv_wave.
@@ -26,8 +30,8 @@
 // kind), so the bytes are those of oracle/ref_kernels.c::px_yuv_to_yuv / px_rgb_to_yuv / px_rgb_to_yuv_int, layer by layer.
 //
 // Eligibility (yuv_stream_eligible): cleared canvas with W % 8 == 0 and H % 4 == 0, 1..4 layers, every layer axis-aligned, bounded,
-// without fill paint and without flips, horizontal reduction <= 1.7 (YUV) / 1.15 (RGB), vertical <= 2.2, source rows a multiple of
-// 16 bytes.  Everything else keeps tick_yuv_wave.
+// without fill paint and without flips, horizontal reduction <= 1.7 (YUV) / 1.17 (RGB), vertical <= 2.2, source rows a multiple of
+// 16 bytes, at most 16 KB of rings per wave.  Everything else keeps tick_yuv_wave.
 #include "wave_common.hip.h"
 #include "switches.h"
 
