@@ -46,7 +46,7 @@
 namespace chv {
 
 #ifndef CHV_YS_ABL
-#define CHV_YS_ABL 0             // timing-only (wrong pixels): 1 no ring fills, 2 no canvas stores
+#define CHV_YS_ABL 0             // timing-only (wrong pixels): 1 no ring fills, 2 no canvas stores, 4 no luma stores, 8 no chroma stores
 #endif
 #ifndef CHV_YS_BLOCK
 #define CHV_YS_BLOCK 1           // waves (neighbouring strips) per block: 1 / 2 / 4 = 0.370 / 0.374 / 0.404 ms per 128 ticks of y420p_main (the kernel is
@@ -373,15 +373,17 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
     uint8_t *lds = ys_lds_all + wave * wave_bytes;
     const uint32_t lds0 = (uint32_t)(size_t)lds;
     const int lane = threadIdx.x & 63;
-    // XCD-aware numbering: block b runs on XCD b % 8; an XCD owns a contiguous range of (tick, chunk, group of YS_WAVES strips)
-    const int groups_x = (strips_x + YS_WAVES - 1) / YS_WAVES;
-    const int total = n_ticks * chunks_y * groups_x;
+    // XCD-aware numbering: block b runs on XCD b % 8; an XCD owns a contiguous range of blocks, a block YS_WAVES consecutive strips of the
+    // launch's (tick, chunk, strip) list — neighbours along a row except where a row of strips ends inside the block
+    const int per_tick = chunks_y * strips_x;
+    const int total_w = n_ticks * per_tick, total = (total_w + YS_WAVES - 1) / YS_WAVES;
     const int b = blockIdx.x, per_xcd = (total + 7) >> 3;
     const int idx = (b & 7) * per_xcd + (b >> 3);
     if ((b >> 3) >= per_xcd || idx >= total) return;
-    const int tick = idx / (chunks_y * groups_x), rem = idx - tick * (chunks_y * groups_x);
-    const int chunk = rem / groups_x, strip = (rem - chunk * groups_x) * YS_WAVES + wave;
-    if (strip >= strips_x) return;
+    const int widx = idx * YS_WAVES + wave;
+    if (widx >= total_w) return;
+    const int tick = widx / per_tick, rem = widx - tick * per_tick;
+    const int chunk = rem / strips_x, strip = rem - chunk * strips_x;
     const DTick &T = ticks[ONE ? 0 : tick];
     const DLayer *L = layers + (ONE ? 0 : T.first_layer);
     const int x0 = strip * 64, y0 = chunk * rows_per_chunk;
@@ -521,7 +523,7 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
     const bool lcol_ok = (CHV_YS_STORE & 1) ? x0 + 4 * (lane & 15) < TW : x0 + (lane & ~3) < TW;      // (W % 8 == 0: a lane's four columns are inside together)
     auto flush = [&]() {
         if (pend_row >= 0) {
-            if (CHV_YS_ABL & 2) asm volatile("" :: "v"(pend_lw));
+            if (CHV_YS_ABL & 6) asm volatile("" :: "v"(pend_lw));
             else if (lcol_ok) {
                 if (CHV_YS_STORE & 2) gst_stream(PY.ptr + (size_t)pend_row * PY.pitch + loff, pend_lw);
                 else gst_at<uint32_t>(PY.ptr + (size_t)pend_row * PY.pitch, loff, pend_lw);
@@ -571,7 +573,7 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
                 const uint32_t ccol = (uint32_t)((x0 >> 1) + 4 * (lane >> 3));
                 const int qy = ((y0 + g0) >> 1) + crow;
                 const bool ok = crow < 2 * (m + 1) && x0 + 8 * (lane >> 3) < TW;
-                if (CHV_YS_ABL & 2) asm volatile("" :: "v"(tu), "v"(tv));
+                if (CHV_YS_ABL & 10) asm volatile("" :: "v"(tu), "v"(tv));
                 else if (ok) {
                     if (TF == TF_NV12) {
                         const uint2 w = make_uint2(__builtin_amdgcn_perm(tv, tu, 0x05010400u), __builtin_amdgcn_perm(tv, tu, 0x07030602u));     // u0 v0 u1 v1 | u2 v2 u3 v3
@@ -1247,7 +1249,7 @@ hipError_t launch_yuv_stream(int tf, const DTick *ticks_host, const DLayer *laye
     if (CHV_YS_ROWS_FIXED > 0) rows = (CHV_YS_ROWS_FIXED + 3) & ~3;
     rows = std::max(4, rows);
     const int chunks_y = (maxH + rows - 1) / rows;
-    const long total = (long)n_ticks * chunks_y * ((strips_x + YS_WAVES - 1) / YS_WAVES);
+    const long total = ((long)n_ticks * chunks_y * strips_x + YS_WAVES - 1) / YS_WAVES;
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     const size_t lds = (size_t)YS_WAVES * (size_t)wave_bytes;
     if (!ticks && (n_ticks != 1 || !layers_host)) return hipErrorInvalidValue;
