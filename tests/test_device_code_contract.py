@@ -21,7 +21,8 @@ def _code_object(tmp_path, stem):
     if not obj.exists() or not (LLVM / "llvm-objcopy").exists():
         pytest.skip(f"{obj.name} not built here")
     fat, co = tmp_path / f"{stem}.fatbin", tmp_path / f"{stem}.co"
-    subprocess.run([LLVM / "llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj], check=True)
+    # (an output operand: without one llvm-objcopy rewrites the object in place and the next `make` relinks the library)
+    subprocess.run([LLVM / "llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, tmp_path / f"{stem}.copy.o"], check=True)
     subprocess.run([LLVM / "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                     f"--input={fat}", f"--output={co}"], check=True)
     return co

@@ -30,7 +30,8 @@ def classify(op):
 
 def disassemble(obj):
     tmp = Path(tempfile.mkdtemp())
-    subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={tmp}/f.fatbin", obj])
+    # (with no output operand llvm-objcopy rewrites its INPUT in place: the object would look newer than the library it was linked into)
+    subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={tmp}/f.fatbin", obj, f"{tmp}/copy.o"])
     subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                            f"--input={tmp}/f.fatbin", f"--output={tmp}/k.co"])
     return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", "--demangle", f"{tmp}/k.co"], text=True)

@@ -9,7 +9,7 @@ stem = sys.argv[1]
 asm_out = sys.argv[sys.argv.index("--asm") + 1] if "--asm" in sys.argv else None
 with tempfile.TemporaryDirectory() as d:
     d = Path(d)
-    subprocess.run([LLVM / "llvm-objcopy", f"--dump-section=.hip_fatbin={d/'f.fatbin'}", CSRC / f"{stem}.hip.o"], check=True)
+    subprocess.run([LLVM / "llvm-objcopy", f"--dump-section=.hip_fatbin={d/'f.fatbin'}", CSRC / f"{stem}.hip.o", d / "copy.o"], check=True)   # (an output operand: otherwise the input is rewritten in place)
     subprocess.run([LLVM / "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                     f"--input={d/'f.fatbin'}", f"--output={d/'k.co'}"], check=True)
     notes = subprocess.run([LLVM / "llvm-readelf", "--notes", d / "k.co"], check=True, capture_output=True, text=True).stdout
