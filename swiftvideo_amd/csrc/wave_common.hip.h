@@ -151,7 +151,10 @@ CHV_DEV void wstage_store(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, 
 }
 // Slots beyond the registers' share of a plane (stronger downscales, rectangles at a picture edge): further rounds of
 // WTAIL loads in flight, one wait, WTAIL LDS writes (not unrolled beyond that: the edge patching is large code).
-constexpr int WTAIL = 2;
+#ifndef CHV_WTAIL
+#define CHV_WTAIL 2
+#endif
+constexpr int WTAIL = CHV_WTAIL;
 template <int BPT, int N, bool EDGE = true>
 CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int lane, bool swap02) {
 #pragma unroll 1
@@ -173,8 +176,13 @@ CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const Sta
                 }
             }
         }
+        if constexpr (WTAIL == 2) {
 #pragma unroll 1
-        for (int n = 0; n < WTAIL; n++) wstage_put<BPT, EDGE>(n == 0 ? t[0] : t[WTAIL - 1], base + n * 64 + lane, lds, lds_pitch, P, g, swap02);
+            for (int n = 0; n < WTAIL; n++) wstage_put<BPT, EDGE>(n == 0 ? t[0] : t[WTAIL - 1], base + n * 64 + lane, lds, lds_pitch, P, g, swap02);
+        } else {
+#pragma unroll
+            for (int n = 0; n < WTAIL; n++) wstage_put<BPT, EDGE>(t[n], base + n * 64 + lane, lds, lds_pitch, P, g, swap02);
+        }
     }
 }
 
