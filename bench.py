@@ -336,9 +336,11 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
         for i in range(distinct):
             host_src.append(util.alloc_image(sfmt, sw, sh, seed=seed_base + i))
         ov = [util.alloc_image("bgra", 640, 360, seed=seed_base + 100 + i) for i in range(2)]
+        # (diagnostic: BENCH_OVERLAY_POS="x0,y0,x1,y1" moves the two overlays — how much of a mixer tick's time is strips an overlay's edge crosses)
+        ovp = [int(v) for v in os.environ.get("BENCH_OVERLAY_POS", "64,64,1200,640").split(",")]
         us = [util.full_canvas_uniforms((dw, dh), (sw, sh)),
-              util.make_uniforms((dw, dh), rect=(64, 64, 640, 360), opacity=0.8, in_size=(640, 360)),
-              util.make_uniforms((dw, dh), rect=(1200, 640, 640, 360), opacity=0.6, in_size=(640, 360))]
+              util.make_uniforms((dw, dh), rect=(ovp[0], ovp[1], 640, 360), opacity=0.8, in_size=(640, 360)),
+              util.make_uniforms((dw, dh), rect=(ovp[2], ovp[3], 640, 360), opacity=0.6, in_size=(640, 360))]
         k_main = sv.defaultComputeKernelFromString(kmain)
         k_ov = sv.defaultComputeKernelFromString(f"img_bgra_{fmt}")
         govs = [up(sv.PixelFormat.BGRA, (640, 360), o) for o in ov]
