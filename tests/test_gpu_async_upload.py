@@ -129,3 +129,24 @@ def test_async_downloads_overlap_with_kernels_and_stay_ordered(ctx):
         cv.check(lib.chv_event_destroy(e))
     cv.check(lib.chv_host_free(dl.handle, pinned))
     sv.destroyComputeContext(dl)
+
+
+def test_async_download_argument_checks(ctx):
+    """chv_download_async fails like chv_download does (same span checks: the reference's downloadComputeBuffer throws on a size mismatch,
+    compute.cl.swift:381-396) and leaves the context usable"""
+    lib = cv.load()
+    h = C.c_void_p()
+    cv.check(lib.chv_buffer_alloc(ctx.handle, 1024, C.byref(h)))
+    pinned = C.c_void_p()
+    cv.check(lib.chv_host_alloc(ctx.handle, 4096, C.byref(pinned)))
+    ok = lambda *a: lib.chv_download_async(*a)
+    assert ok(None, pinned, 64, h, 0, 64, 64, 16) != 0                  # no context
+    assert ok(ctx.handle, None, 64, h, 0, 64, 64, 16) != 0              # no destination
+    assert ok(ctx.handle, pinned, 64, None, 0, 64, 64, 16) != 0         # no source
+    assert ok(ctx.handle, pinned, 64, h, 0, 64, 64, 17) != 0            # 17 rows of 64 bytes leave the 1024-byte buffer
+    assert ok(ctx.handle, pinned, 64, h, 1000, 64, 64, 1) != 0          # offset + row beyond the end
+    assert ok(ctx.handle, pinned, 32, h, 0, 64, 64, 16) != 0            # destination pitch smaller than a row
+    assert ok(ctx.handle, pinned, 64, h, 0, 64, 64, 16) == 0            # the whole buffer
+    sv.endComputePass(ctx, True)
+    cv.check(lib.chv_host_free(ctx.handle, pinned))
+    cv.check(lib.chv_buffer_free(h))
