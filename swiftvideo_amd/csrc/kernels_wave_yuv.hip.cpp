@@ -598,12 +598,13 @@ static WaveDims wave_dims(const DTick &T, const DLayer &L, int WTH) {
     const int bpt0 = rgb ? 4 : 1;
     int span0 = (int)std::ceil(WTW * sxr * L.src.pl[0].w) + 4;           // texels incl. tap 1 and rounding slack
     d.p0pitch = ((span0 * bpt0 + 15) / 16 + 3) * 16;                      // vectors + alignment + 2 pad vectors
-    d.p0rows = (int)std::ceil(WTH * syr * L.src.pl[0].h) + 3;
+    // (rectangles taller than two rows per strip row are staged as the rows' own tap-row pairs: WGeom::pair, wave_common.hip.h)
+    d.p0rows = std::min((int)std::ceil(WTH * syr * L.src.pl[0].h) + 3, (CHV_WAVE_PAIR && WTH == 8) ? 2 * WTH : (1 << 30));
     if (!rgb) {
         const int bpt1 = planar ? 1 : 2;
         int span1 = (int)std::ceil(WTW * sxr * L.src.pl[1].w) + 4;
         d.p1pitch = ((span1 * bpt1 + 15) / 16 + 3) * 16;
-        d.p1rows = (int)std::ceil(WTH * syr * L.src.pl[1].h) + 3;
+        d.p1rows = std::min((int)std::ceil(WTH * syr * L.src.pl[1].h) + 3, (CHV_WAVE_PAIR && WTH == 8) ? 2 * WTH : (1 << 30));
     }
     return d;
 }

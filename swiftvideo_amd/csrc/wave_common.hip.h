@@ -64,12 +64,36 @@ CHV_DEV AxisSum axis_summary(unsigned long long mask, bool in_canvas, int fl, in
 }
 
 // per-layer state of a strip: column entry (every lane) and staging geometry (uniform); the row entries live in LDS
+// A strip's staging rectangle.  `pair` (uniform): the rectangle holds, for every row j of the strip, that row's OWN two tap rows at LDS rows
+// 2 j and 2 j + 1 (pair_ry: lane j's first tap row) instead of the contiguous source rows r_lo .. r_lo + rows - 1 — for vertical reductions
+// beyond ~1.6:1, where consecutive canvas rows share no tap row and a contiguous rectangle would stage (and fetch) rows nothing reads:
+// 16 instead of 27 luma rows for an 8-row strip at 3:1, which is LDS (waves per SIMD) and HBM traffic.
+struct WGeom : StageGeom {
+    int pair;
+    int r_hi1;                   // pair form: the last first-tap row the rectangle was validated for (clamp of a row's own tap row)
+};
+#ifndef CHV_WAVE_PAIR
+#define CHV_WAVE_PAIR 1
+#endif
+// source row of LDS row r (before CLAMP_TO_EDGE).  Pair form (PAIR instantiations only: stage_impl<EDGE, true>): `pry` holds, in lane j, strip row
+// j's first tap row; executed by ALL lanes (a lane shuffle).  (Kept out of the other instantiations altogether — and free of pointers: a first
+// version that looked the rows up in the LDS row table through a pointer argument made hipcc fetch every plane descriptor field with vector
+// loads, each behind a full wait: cfg3 1.28 -> 2.43 ms.)
+template <bool PAIR>
+CHV_DEV int wstage_row(const WGeom &g, int r, int pry) {
+    if constexpr (!PAIR) return g.r_lo + r;
+    else {
+        const int own = __builtin_amdgcn_ds_bpermute(((r >> 1) & 63) * 4, pry) + (r & 1);
+        return g.pair ? own : g.r_lo + r;
+    }
+}
+
 struct WLayer {
     int cyo, cco;            // staged layers: LDS byte offset of tap 0 inside a staged row (luma / RGB texel, chroma);
                              // unstaged layers: the unclamped tap-0 texel positions themselves
     float cya, cca;          // weight of tap 1
     int cfl;
-    StageGeom g0, g1;
+    WGeom g0, g1;
     bool staged, all_inside;
     bool unit_rows;          // staged, and tap row 0 of every row of the strip is tap row 1 of the row above (source rows advance
                              // one per canvas row: native-resolution layers) — the row loops then convert every texel row once
@@ -105,34 +129,36 @@ CHV_DEV uint32_t row_fast_flags(const uint4 *rowtab, int j) { return ((const uin
 
 // EDGE = false: the caller knows (uniformly) that the rectangle touches no picture edge — no clamping, no patching, no
 // padding vector: the compact instantiation most strips run
-template <int OFF, int N, int NR, bool EDGE = true>
-CHV_DEV void wstage_load(uint4 (&regs)[NR], const DPlane &P, const StageGeom &g, int lane) {
+template <int OFF, int N, int NR, bool EDGE, bool PAIR>
+CHV_DEV void wstage_load(uint4 (&regs)[NR], const DPlane &P, const WGeom &g, int lane, int pry) {
     // exactly one global_load_dwordx4 per slot, straight into its final register (see stage_load, tile_common.hip.h)
 #pragma unroll
     for (int n = 0; n < N; n++) {
         int i = lane + n * 64, r, vv;
         stage_slot(g, i, r, vv);
+        const int srow = wstage_row<PAIR>(g, r, pry);
         if (r < g.rows) {
             if constexpr (EDGE) {
-                int row = min(max(g.r_lo + r, 0), P.h - 1);
+                int row = min(max(srow, 0), P.h - 1);
                 int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
                 if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
                 regs[OFF + n] = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
             } else {
-                regs[OFF + n] = gld<uint4>(P.ptr + (size_t)(g.r_lo + r) * P.pitch + (g.b0 + vv * 16));
+                regs[OFF + n] = gld<uint4>(P.ptr + (size_t)srow * P.pitch + (g.b0 + vv * 16));
             }
         }
     }
 }
 // one slot: CLAMP_TO_EDGE patching (edge rectangles only), optional RGBA -> BGRA, LDS write
-template <int BPT, bool EDGE = true>
-CHV_DEV void wstage_put(uint4 val, int i, uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, bool swap02) {
+template <int BPT, bool EDGE, bool PAIR>
+CHV_DEV void wstage_put(uint4 val, int i, uint8_t *lds, int lds_pitch, const DPlane &P, const WGeom &g, bool swap02, int pry) {
     int r, vv;
     stage_slot(g, i, r, vv);
+    const int srow = wstage_row<PAIR>(g, r, pry);
     if (i < 1024 && r < g.rows) {
         int v = (EDGE && g.edge) ? vv - 1 : vv;
         if (EDGE && g.edge) {
-            int row = min(max(g.r_lo + r, 0), P.h - 1);
+            int row = min(max(srow, 0), P.h - 1);
             int off = g.b0 + v * 16;
             if (off >= 0 && off < P.w * BPT && !vec_loadable(P, row, off)) val = load_tail_vec(P, row, off);
             val = patch_edges<BPT>(val, P, row, off);
@@ -144,10 +170,10 @@ CHV_DEV void wstage_put(uint4 val, int i, uint8_t *lds, int lds_pitch, const DPl
         *(uint4 *)(lds + r * lds_pitch + 16 + v * 16) = val;
     }
 }
-template <int BPT, int OFF, int N, int NR, bool EDGE = true>
-CHV_DEV void wstage_store(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int lane, bool swap02) {
+template <int BPT, int OFF, int N, int NR, bool EDGE, bool PAIR>
+CHV_DEV void wstage_store(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, const DPlane &P, const WGeom &g, int lane, bool swap02, int pry) {
 #pragma unroll
-    for (int n = 0; n < N; n++) wstage_put<BPT, EDGE>(regs[OFF + n], lane + n * 64, lds, lds_pitch, P, g, swap02);
+    for (int n = 0; n < N; n++) wstage_put<BPT, EDGE, PAIR>(regs[OFF + n], lane + n * 64, lds, lds_pitch, P, g, swap02, pry);
 }
 // Slots beyond the registers' share of a plane (stronger downscales, rectangles at a picture edge): further rounds of
 // WTAIL loads in flight, one wait, WTAIL LDS writes (not unrolled beyond that: the edge patching is large code).
@@ -155,8 +181,8 @@ CHV_DEV void wstage_store(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, 
 #define CHV_WTAIL 2
 #endif
 constexpr int WTAIL = CHV_WTAIL;
-template <int BPT, int N, bool EDGE = true>
-CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const StageGeom &g, int lane, bool swap02) {
+template <int BPT, int N, bool EDGE, bool PAIR>
+CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const WGeom &g, int lane, bool swap02, int pry) {
 #pragma unroll 1
     for (int base = N * 64; base < stage_slots(g); base += WTAIL * 64) {
         uint4 t[WTAIL];
@@ -165,23 +191,24 @@ CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const Sta
             int i = base + n * 64 + lane, r, vv;
             stage_slot(g, i, r, vv);
             t[n] = make_uint4(0, 0, 0, 0);
+            const int srow = wstage_row<PAIR>(g, r, pry);
             if (i < 1024 && r < g.rows) {
                 if constexpr (EDGE) {
-                    int row = min(max(g.r_lo + r, 0), P.h - 1);
+                    int row = min(max(srow, 0), P.h - 1);
                     int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
                     if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
                     t[n] = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
                 } else {
-                    t[n] = gld<uint4>(P.ptr + (size_t)(g.r_lo + r) * P.pitch + (g.b0 + vv * 16));
+                    t[n] = gld<uint4>(P.ptr + (size_t)srow * P.pitch + (g.b0 + vv * 16));
                 }
             }
         }
         if constexpr (WTAIL == 2) {
 #pragma unroll 1
-            for (int n = 0; n < WTAIL; n++) wstage_put<BPT, EDGE>(n == 0 ? t[0] : t[WTAIL - 1], base + n * 64 + lane, lds, lds_pitch, P, g, swap02);
+            for (int n = 0; n < WTAIL; n++) wstage_put<BPT, EDGE, PAIR>(n == 0 ? t[0] : t[WTAIL - 1], base + n * 64 + lane, lds, lds_pitch, P, g, swap02, pry);
         } else {
 #pragma unroll
-            for (int n = 0; n < WTAIL; n++) wstage_put<BPT, EDGE>(t[n], base + n * 64 + lane, lds, lds_pitch, P, g, swap02);
+            for (int n = 0; n < WTAIL; n++) wstage_put<BPT, EDGE, PAIR>(t[n], base + n * 64 + lane, lds, lds_pitch, P, g, swap02, pry);
         }
     }
 }
@@ -195,18 +222,18 @@ CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const Sta
 // (profiles/r03_notes.md), so this is run time.
 struct P2Map { int rsub, vcol, rstep, ok; };
 template <int N>
-CHV_DEV P2Map p2_map(const StageGeom &g, int lane) {
+CHV_DEV P2Map p2_map(const WGeom &g, int lane) {
     // sh = ceil(log2(nvec)), uniform
     const int sh = g.nvec <= 1 ? 0 : 32 - __builtin_clz((unsigned)(g.nvec - 1));
     P2Map m;
     m.rstep = 64 >> sh;
-    m.ok = sh <= 6 && N * m.rstep >= g.rows;
+    m.ok = sh <= 6 && N * m.rstep >= g.rows && !g.pair;
     m.rsub = lane >> sh;
     m.vcol = min(lane & ((1 << sh) - 1), g.nvec - 1) * 16;
     return m;
 }
 template <int OFF, int N, int NR, bool SKIP>
-CHV_DEV void wstage_load_p2(uint4 (&regs)[NR], const DPlane &P, const StageGeom &g, const P2Map &m) {
+CHV_DEV void wstage_load_p2(uint4 (&regs)[NR], const DPlane &P, const WGeom &g, const P2Map &m) {
     const uint8_t *base = P.ptr + (size_t)g.r_lo * P.pitch + g.b0;          // (uniform: scalar unit)
 #pragma unroll
     for (int n = 0; n < N; n++) {
@@ -218,7 +245,7 @@ CHV_DEV void wstage_load_p2(uint4 (&regs)[NR], const DPlane &P, const StageGeom 
     }
 }
 template <int OFF, int N, int NR, bool SKIP>
-CHV_DEV void wstage_store_p2(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, const StageGeom &g, const P2Map &m) {
+CHV_DEV void wstage_store_p2(const uint4 (&regs)[NR], uint8_t *lds, int lds_pitch, const WGeom &g, const P2Map &m) {
 #pragma unroll
     for (int n = 0; n < N; n++) {
         if (SKIP && n > 0 && n * m.rstep >= g.rows) break;
@@ -357,6 +384,9 @@ struct WaveStrip {
                 const int col0 = max(cs.lo, 0) & ~(tpv - 1);
                 const int nvec = ((min(cs.hi, S0.w - 1) - col0) >> sh) + 1;
                 w.g0.r_lo = rs.lo; w.g0.rows = rs.hi - rs.lo + 1; w.g0.b0 = col0 << (4 - sh); w.g0.nvec = nvec;
+                w.g0.pair = CHV_WAVE_PAIR && WTH == 8 && w.g0.rows > 2 * WTH;
+                w.g0.r_hi1 = max(rs.hi - 1, rs.lo);
+                if (w.g0.pair) w.g0.rows = 2 * WTH;
                 w.g0.edge = cs.lo < 0 || cs.hi >= S0.w || rs.lo < 0 || rs.hi >= S0.h - 1 + (int)(col0 + nvec * tpv <= S0.w);
                 stage_slots_init(w.g0);
                 ok = (nvec + 2) * 16 <= p0pitch && w.g0.rows <= p0rows && stage_slots(w.g0) <= 1024;
@@ -370,16 +400,19 @@ struct WaveStrip {
                 const int col0 = max(cs.clo, 0) & ~(tpv - 1);
                 const int nvec = ((min(cs.chi, S1.w - 1) - col0) >> sh) + 1;
                 w.g1.r_lo = rs.clo; w.g1.rows = rs.chi - rs.clo + 1; w.g1.b0 = col0 << (4 - sh); w.g1.nvec = nvec;
+                w.g1.pair = CHV_WAVE_PAIR && WTH == 8 && w.g1.rows > 2 * WTH;
+                w.g1.r_hi1 = max(rs.chi - 1, rs.clo);
+                if (w.g1.pair) w.g1.rows = 2 * WTH;
                 w.g1.edge = cs.clo < 0 || cs.chi >= S1.w || rs.clo < 0 || rs.chi >= S1.h - 1 + (int)(col0 + nvec * tpv <= S1.w);
                 stage_slots_init(w.g1);
                 ok = (nvec + 2) * 16 <= p1pitch && w.g1.rows <= p1rows && stage_slots(w.g1) <= 1024;
                 c1off = base1 + 16 + ((min(max(cc, cs.clo), cs.chi - 1) - col0) << (4 - sh));
-                r1off = (min(max(rc, rs.clo), rs.chi - 1) - rs.clo) * p1pitch;
+                r1off = w.g1.pair ? 2 * min(lane, WTH - 1) * p1pitch : (min(max(rc, rs.clo), rs.chi - 1) - rs.clo) * p1pitch;
             }
             if (ok) {
                 w.staged = true;
                 cyo = c0off; cco = c1off;
-                yoff = (min(max(ry, rs.lo), rs.hi - 1) - rs.lo) * p0pitch; coff = r1off;
+                yoff = w.g0.pair ? 2 * min(lane, WTH - 1) * p0pitch : (min(max(ry, rs.lo), rs.hi - 1) - rs.lo) * p0pitch; coff = r1off;
             }
         }
         w.cyo = cyo; w.cco = cco;
@@ -396,36 +429,48 @@ struct WaveStrip {
     }
 
     // issue the global loads of layer l's rectangles, wait once for all of them, write them to this wave's LDS region
-    template <bool EDGE>
+    template <bool EDGE, bool PAIR = false>
     CHV_DEV void stage_impl(int l, const WLayer &w) const {
         const DLayer &Ly = L[l];
+        // pair form: lane j's own first tap rows (the row geometry of setup(), clamped into the rows the rectangles were validated for)
+        int pry0 = 0, pry1 = 0;
+        if constexpr (PAIR) {
+            const float *U = Ly.u;
+            const float t1 = ny * U[U_TRANSFORM + 5] + U[U_TRANSFORM + 7];
+            const float v = t1 * U[U_TEXTURE + 5] + U[U_TRANSFORM + 15] * U[U_TEXTURE + 7];
+            float a_;
+            lin_axis_raw(v, Ly.src.pl[0].h, pry0, a_);
+            lin_axis_raw(v, Ly.src.pl[is_rgb(Ly.kind) ? 0 : 1].h, pry1, a_);
+            pry0 = min(max(pry0, w.g0.r_lo), w.g0.r_hi1);
+            pry1 = min(max(pry1, w.g1.r_lo), w.g1.r_hi1);
+        }
         uint4 regs[WNR];
         if (is_rgb(Ly.kind)) {
-            wstage_load<0, WN_RGB, WNR, EDGE>(regs, Ly.src.pl[0], w.g0, lane);
+            wstage_load<0, WN_RGB, WNR, EDGE, PAIR>(regs, Ly.src.pl[0], w.g0, lane, pry0);
             touch_regs(regs);             // one wait for all of the layer's loads (see touch_regs, pixel_math.hip.h)
             // staged texels are byte-swapped where the layer asks for it (RGBA source on a BGRA canvas: -> BGRA; BGRA source on a
             // 4:2:0 canvas, kernels.cl.swift:518 `.zyxw`: -> RGBA), so the tap loops need no channel select
-            wstage_store<4, 0, WN_RGB, WNR, EDGE>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
-            wstage_tail<4, WN_RGB, EDGE>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0);
+            wstage_store<4, 0, WN_RGB, WNR, EDGE, PAIR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0, pry0);
+            wstage_tail<4, WN_RGB, EDGE, PAIR>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0, pry0);
         } else if (!is_planar(Ly.kind)) {
-            wstage_load<0, WN_Y, WNR, EDGE>(regs, Ly.src.pl[0], w.g0, lane);
-            wstage_load<WN_Y, WN_C, WNR, EDGE>(regs, Ly.src.pl[1], w.g1, lane);
+            wstage_load<0, WN_Y, WNR, EDGE, PAIR>(regs, Ly.src.pl[0], w.g0, lane, pry0);
+            wstage_load<WN_Y, WN_C, WNR, EDGE, PAIR>(regs, Ly.src.pl[1], w.g1, lane, pry1);
             touch_regs(regs);
-            wstage_store<1, 0, WN_Y, WNR, EDGE>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_store<2, WN_Y, WN_C, WNR, EDGE>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
-            wstage_tail<1, WN_Y, EDGE>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_tail<2, WN_C, EDGE>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
+            wstage_store<1, 0, WN_Y, WNR, EDGE, PAIR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false, pry0);
+            wstage_store<2, WN_Y, WN_C, WNR, EDGE, PAIR>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false, pry1);
+            wstage_tail<1, WN_Y, EDGE, PAIR>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false, pry0);
+            wstage_tail<2, WN_C, EDGE, PAIR>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false, pry1);
         } else {
-            wstage_load<0, WN_Y, WNR, EDGE>(regs, Ly.src.pl[0], w.g0, lane);
-            wstage_load<WN_Y, WN_C, WNR, EDGE>(regs, Ly.src.pl[1], w.g1, lane);
-            wstage_load<WN_Y + WN_C, WN_C, WNR, EDGE>(regs, Ly.src.pl[2], w.g1, lane);
+            wstage_load<0, WN_Y, WNR, EDGE, PAIR>(regs, Ly.src.pl[0], w.g0, lane, pry0);
+            wstage_load<WN_Y, WN_C, WNR, EDGE, PAIR>(regs, Ly.src.pl[1], w.g1, lane, pry1);
+            wstage_load<WN_Y + WN_C, WN_C, WNR, EDGE, PAIR>(regs, Ly.src.pl[2], w.g1, lane, pry1);
             touch_regs(regs);
-            wstage_store<1, 0, WN_Y, WNR, EDGE>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_store<1, WN_Y, WN_C, WNR, EDGE>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
-            wstage_store<1, WN_Y + WN_C, WN_C, WNR, EDGE>(regs, smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
-            wstage_tail<1, WN_Y, EDGE>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false);
-            wstage_tail<1, WN_C, EDGE>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false);
-            wstage_tail<1, WN_C, EDGE>(smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false);
+            wstage_store<1, 0, WN_Y, WNR, EDGE, PAIR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false, pry0);
+            wstage_store<1, WN_Y, WN_C, WNR, EDGE, PAIR>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false, pry1);
+            wstage_store<1, WN_Y + WN_C, WN_C, WNR, EDGE, PAIR>(regs, smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false, pry1);
+            wstage_tail<1, WN_Y, EDGE, PAIR>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false, pry0);
+            wstage_tail<1, WN_C, EDGE, PAIR>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false, pry1);
+            wstage_tail<1, WN_C, EDGE, PAIR>(smem + base1 + voff, p1pitch, Ly.src.pl[2], w.g1, lane, false, pry1);
         }
     }
     // YUV pictures, both rectangles interior and narrow: shift-and-mask slot map (wstage_load_p2)
@@ -447,6 +492,11 @@ struct WaveStrip {
     // (rectangles that touch no picture edge — most strips — take the instantiation without clamping and patching code)
     CHV_DEV void stage(int l, const WLayer &w) const {
         const bool rgb = is_rgb(L[l].kind);
+        if constexpr (CHV_WAVE_PAIR && WTH == 8) {
+            // (8-row strips only: the 16-row instantiations are at their register limit, and launches whose rectangles are this tall run 8-row
+            // strips anyway (launch_wave_layers).  Its own instantiation: the row lookup costs the other paths registers)
+            if (w.g0.pair || (!rgb && w.g1.pair)) { stage_impl<true, true>(l, w); return; }
+        }
         if constexpr ((INTERIOR & 4) != 0) {
             if (!rgb && !w.g0.edge && !w.g1.edge && stage_p2(l, w)) return;
         }

@@ -79,6 +79,20 @@ MIXED_CASES = {
     "odd_width":      (131, 19, True, [("img_nv12_bgra", 98, 42, dict()), ("img_bgra_bgra_tx", 97, 41, dict(opacity=0.5))]),
     "down_2x_tail":   (160, 64, True, [("img_nv12_bgra", 320, 128, dict()), ("img_y420p_bgra", 352, 140, dict(opacity=0.5))]),   # luma rectangles > 512 slots: staging tail
     "down_4x":        (96, 40, True, [("img_nv12_bgra", 384, 160, dict(opacity=0.6)), ("img_bgra_bgra_tx", 384, 160, dict(opacity=0.5))]),
+    # rectangles taller than two rows per strip row are staged as every row's OWN pair of tap rows (WGeom::pair, 8-row strips): a 2 x 2 grid of
+    # 3:1 reductions of every source class over a 1.5:1 background, the same across the canvas edges and flipped, 5:1 (chroma pairs as well), a
+    # vertical-only reduction (narrow rectangles: not the shift-and-mask staging), a reduction next to an enlargement
+    "down_3x_grid":   (128, 72, True, [("img_nv12_bgra", 192, 108, dict()), ("img_nv12_bgra", 192, 108, dict(rect=(0, 0, 64, 36), opacity=0.9)),
+                                        ("img_y420p_bgra", 192, 108, dict(rect=(64, 0, 64, 36), opacity=0.8)),
+                                        ("img_bgra_bgra_tx", 192, 108, dict(rect=(0, 36, 64, 36), opacity=0.7)),
+                                        ("img_rgba_bgra_tx", 192, 108, dict(rect=(64, 36, 64, 36)))]),
+    "down_3x_edges":  (160, 64, True, [("img_nv12_bgra", 576, 324, dict(rect=(-20, -10, 192, 108))),
+                                        ("img_y420p_bgra", 480, 200, dict(tex=(1.0, 1.0, -1.0, -1.0), opacity=0.5)),
+                                        ("img_bgra_bgra_tx", 200, 180, dict(rect=(100, -8, 70, 60), opacity=0.6, border=(2, 2, 2, 2), fill=(0.2, 0.3, 0.9, 0.8)))]),
+    "down_5x_yuv":    (128, 72, False, [("img_nv12_bgra", 640, 360, dict(opacity=0.8)), ("img_y420p_bgra", 640, 360, dict(opacity=0.5))]),
+    "down_vertical":  (128, 72, True, [("img_nv12_bgra", 128, 216, dict()), ("img_y420p_bgra", 128, 288, dict(opacity=0.5)),
+                                        ("img_rgba_bgra_tx", 40, 200, dict(rect=(60, 4, 40, 64), opacity=0.7))]),
+    "down_and_up":    (192, 48, True, [("img_y420p_bgra", 64, 160, dict()), ("img_nv12_bgra", 600, 20, dict(opacity=0.5))]),
 }
 
 

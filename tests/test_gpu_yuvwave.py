@@ -108,6 +108,13 @@ CASES = {
                                                  ("img_rgba_nv12_int", 96, 54, dict(rect=(33, 9, 180, 40), border=(5, 3, 7, 2), fill=(0.9, 0.2, 0.1, 0.6), opacity=0.8))]),
     "int_opacity_gt_1": ("y420p", 128, 32, True, [("img_bgra_y420p_int", 128, 32, dict(opacity=1.7)), ("img_rgba_y420p_int", 128, 32, dict(opacity=-0.3, fill=(0.5, 0.5, 0.5, 1.0)))]),
     "down_2.5":         ("nv12", 130, 50, True, [("img_nv12_nv12", 326, 124, dict()), ("img_bgra_nv12", 326, 124, dict(opacity=0.5))]),
+    # rectangles staged as every row's own pair of tap rows (WGeom::pair, 8-row strips): 3:1 video layers, the same flipped and across the canvas
+    # edges, 5:1 (chroma pairs as well), vertical-only reductions, an RGB thumbnail source
+    "down_3x_nv12":     ("nv12", 128, 72, True, [("img_nv12_nv12", 384, 216, dict()), ("img_nv12_nv12", 384, 216, dict(rect=(-12, -6, 100, 60), opacity=0.6))]),
+    "down_3x_y420p":    ("y420p", 128, 72, True, [("img_y420p_y420p", 384, 216, dict()), ("img_y420p_y420p", 300, 230, dict(tex=(1.0, 1.0, -1.0, -1.0), opacity=0.5))]),
+    "down_5x":          ("nv12", 128, 72, False, [("img_y420p_nv12", 640, 360, dict(opacity=0.7)), ("img_nv12_nv12", 640, 400, dict(rect=(20, 10, 90, 50)))]),
+    "down_vertical":    ("y420p", 128, 72, True, [("img_y420p_y420p", 128, 216, dict()), ("img_bgra_y420p", 48, 160, dict(rect=(70, 6, 48, 56), opacity=0.8)),
+                                                    ("img_rgba_y420p", 60, 190, dict(rect=(4, 8, 60, 60), opacity=0.5))]),
 }
 
 
