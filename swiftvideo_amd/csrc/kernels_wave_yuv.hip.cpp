@@ -41,7 +41,8 @@ namespace chv {
 #ifndef CHV_UNORM_TABLE
 #define CHV_UNORM_TABLE 0
 #endif
-constexpr int UNORM_TAB_BYTES = 1024;          // float[256] at the start of the block's LDS
+constexpr int UNORM_TAB_BYTES = CHV_UNORM_TABLE ? 1024 : 0;          // float[256] at the start of the block's LDS (nothing when the table is off: a
+                                                                     // kilobyte per wave is one wave per CU in eighteen on the mixer canvas)
 
 // c / 255.0f, correctly rounded: table lookup (byte index) or the two-term product of pixel_math.hip.h
 CHV_DEV float T8(const float *tab, uint32_t byte) {
