@@ -82,6 +82,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
     using Strip = WaveStrip<WTH, CHV_WAVE_INTERIOR, KINDS>;
     Strip S;
     if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;   // (no block barrier anywhere: waves may leave)
+    p1pitch = S.p1pitch;                 // (the side-by-side layout keeps chroma in the rows of the plane-0 region: WaveStrip::init)
     const DTick &T = *S.T;
     const DLayer *L = S.L;
     const int nl = S.nl, lane = S.lane, x = S.x, y0 = S.y0;

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
     using Strip = WaveStrip<YTH, (KINDS == 1 || KINDS == 2) ? CHV_WAVEY_INTERIOR_OWN : CHV_WAVEY_INTERIOR, KINDS>;
     Strip S;
     if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all + UNORM_TAB_BYTES, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;
+    p1pitch = S.p1pitch;                 // (the side-by-side layout keeps chroma in the rows of the plane-0 region: WaveStrip::init)
     const DTick &T = *S.T;
     const DLayer *L = S.L;
     const int nl = S.nl, x = S.x, x0 = S.x0, y0 = S.y0;
@@ -700,6 +701,27 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     };
     size_t lds = measure(WTH);
     if (WTH == 16 && lds > (size_t)LDS_BUDGET / 2) { WTH = 8; lds = measure(WTH); }      // (keep at least two tall strips' worth per 64 KB)
+    // Side-by-side layout: where RGB rectangles set the row width of the plane-0 region, a YUV layer's luma, chroma / U and V rectangles fit next to
+    // each other in those rows (the mixer canvas: 128 + 96 + 96 bytes in an overlay's 320) — the region is then max(rows) x pitch instead of the sum
+    // of both regions, which on that canvas is 20 instead of 18 waves per CU.
+    int side = 0;
+    if ((kinds & 4) && (kinds & 3) && lds <= (size_t)LDS_BUDGET) {
+        int yneed = 0, cneed = 0;
+        for (int i = 0; i < n_ticks; i++)
+            for (int l = 0; l < ticks_host[i].n_layers; l++) {
+                const DLayer &L = layers_host[ticks_host[i].first_layer + l];
+                if (L.kind == LK_BGRA_METAL || (L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED) || host_src_rgb(L.kind)) continue;
+                const WaveDims d = wave_dims(ticks_host[i], L, WTH);
+                yneed = std::max(yneed, d.p0pitch); cneed = std::max(cneed, d.p1pitch);
+            }
+        const int planes = planar ? 2 : 1;
+        const size_t separate = (size_t)m.p0pitch * m.p0rows + (size_t)m.p1pitch * m.p1rows * planes;
+        const size_t beside = (size_t)m.p0pitch * std::max(m.p0rows, m.p1rows);
+        if (yneed > 0 && yneed + planes * cneed <= m.p0pitch && beside < separate && (yneed >> 4) < 4096 && (cneed >> 4) < 4096) {
+            side = ((yneed >> 4) << 8) | ((cneed >> 4) << 20);
+            lds = lds - (size_t)WAVES * separate + (size_t)WAVES * beside;
+        }
+    }
     if (lds > (size_t)LDS_BUDGET) {
         // per-layer maxima combined exceed the budget: shrink the row counts; rectangles that do not fit fall back to
         // unstaged taps inside the kernel
@@ -724,9 +746,9 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     dim3 grid((unsigned)(blocks_per_xcd * 8));
     const bool clear = ticks_host[0].clear_first != 0;
     if (target_format == TF_BGRA)
-        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0, kinds);
+        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side, kinds);
 #define CHV_LAUNCH_Y(TFV, C, R, K) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
-                                                      strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, planar ? 1 : 0)
+                                                      strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side)
 #define CHV_LAUNCH_YK(TFV, C, R, OWN) do { if (kinds == OWN) CHV_LAUNCH_Y(TFV, C, R, OWN); else if (kinds == (OWN | 4)) CHV_LAUNCH_Y(TFV, C, R, (OWN | 4)); \
                                            else if (kinds & 8) CHV_LAUNCH_Y(TFV, C, R, 15); else CHV_LAUNCH_Y(TFV, C, R, 7); } while (0)
 #define CHV_LAUNCH_YR(TFV, C, OWN) do { if (WTH == 16) CHV_LAUNCH_YK(TFV, C, 16, OWN); else CHV_LAUNCH_YK(TFV, C, 8, OWN); } while (0)
