@@ -40,7 +40,10 @@ hipError_t launch_selftest_pack_codes(const float *in, uint32_t *out, int n, hip
 hipError_t launch_selftest_matrices(int dir, int csc, uint32_t *out, uint32_t *mism, hipStream_t stream);
 // kernels_fast.hip.cpp
 const char *fast_path_name(int path);
-bool fast_path_by_value(int path);      // a lone tick's descriptors can travel as kernel arguments (ticks == layers == nullptr)
+bool fast_path_by_value(int path);
+int split_stream_prefix(const DTick *ticks, const DLayer *layers, int n_ticks);      // kernels_fast.hip.cpp
+int fast_path_stream_bgra();
+int select_tail_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);      // a lone tick's descriptors can travel as kernel arguments (ticks == layers == nullptr)
 int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks, bool transient = false);   // transient: one tick, launched once
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
@@ -349,6 +352,10 @@ struct chv_batch {
     int target_format = 0;
     int maxW = 0, maxH = 0;
     int fast_path = -1;
+    // a second launch that continues on the canvases (split_stream_prefix: the leading video layers through the streaming kernel, then the rest)
+    int fast_path2 = -2;           // -2: none
+    DTick *d_ticks2 = nullptr;
+    std::vector<DTick> h_ticks2;
     DTick *d_ticks = nullptr;
     DLayer *d_layers = nullptr;
     std::vector<BatchDep> deps;    // distinct buffers the descriptors point into + the last upload waited for, per stream
@@ -1141,11 +1148,33 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
         e = hipMemcpy(b->d_layers, dls.data(), sizeof(DLayer) * dls.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(b->d_ticks); (void)hipFree(b->d_layers); return hip_fail(e, "hipMemcpy(descriptors)"); }
     b->fast_path = select_fast_path(tf0, dts.data(), dls.data(), n_ticks);
+    auto path_name = [&](int path) { return path >= 0 ? std::string(fast_path_name(path))
+                                                       : std::string(tf0 == TF_BGRA ? "tick_general_bgra" : (tf0 == TF_NV12 ? "tick_general_yuv<nv12>" : "tick_general_yuv<y420p>")); };
+    b->kernel_name = path_name(b->fast_path);
+    if (tf0 == TF_BGRA && b->fast_path != fast_path_stream_bgra()) {
+        const int k = split_stream_prefix(dts.data(), dls.data(), n_ticks);
+        if (k > 0) {
+            std::vector<DTick> head = dts, tail = dts;
+            for (int i = 0; i < n_ticks; i++) {
+                head[(size_t)i].n_layers = k;
+                tail[(size_t)i].first_layer += k; tail[(size_t)i].n_layers -= k; tail[(size_t)i].clear_first = 0;
+            }
+            const int p1 = select_fast_path(tf0, head.data(), dls.data(), n_ticks), p2 = select_tail_path(tf0, tail.data(), dls.data(), n_ticks);
+            if (p1 == fast_path_stream_bgra()) {
+                e = hipMalloc((void **)&b->d_ticks2, sizeof(DTick) * tail.size());
+                if (e == hipSuccess) e = hipMemcpy(b->d_ticks2, tail.data(), sizeof(DTick) * tail.size(), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(b->d_ticks, head.data(), sizeof(DTick) * head.size(), hipMemcpyHostToDevice);
+                if (e != hipSuccess) { (void)hipFree(b->d_ticks); (void)hipFree(b->d_layers); (void)hipFree(b->d_ticks2); return hip_fail(e, "descriptors of the second launch"); }
+                b->fast_path = p1; b->fast_path2 = p2;
+                b->h_ticks2 = tail;
+                dts = head;
+                b->kernel_name = path_name(p1) + " + " + path_name(p2);
+            }
+        }
+    }
     b->h_ticks = dts;
     b->h_layers = dls;
     b->deps = deps.deps();
-    if (b->fast_path >= 0) b->kernel_name = fast_path_name(b->fast_path);
-    else b->kernel_name = tf0 == TF_BGRA ? "tick_general_bgra" : (tf0 == TF_NV12 ? "tick_general_yuv<nv12>" : "tick_general_yuv<y420p>");
     *out = b.release();
     return CHV_OK;
 }
@@ -1162,6 +1191,12 @@ extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
         ? launch_tick_fast(b->fast_path, b->h_ticks.data(), b->h_layers.data(), b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
         : launch_tick_general(b->target_format, b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    if (b->fast_path2 != -2) {
+        e = b->fast_path2 >= 0
+            ? launch_tick_fast(b->fast_path2, b->h_ticks2.data(), b->h_layers.data(), b->d_ticks2, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
+            : launch_tick_general(b->target_format, b->d_ticks2, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
+        if (e != hipSuccess) return hip_fail(e, "kernel launch (second part of the batch)");
+    }
     return CHV_OK;
 }
 
@@ -1170,6 +1205,7 @@ extern "C" int chv_batch_destroy(chv_batch *b) {
     (void)hipSetDevice(b->device);
     (void)hipFree(b->d_ticks);
     (void)hipFree(b->d_layers);
+    if (b->d_ticks2) (void)hipFree(b->d_ticks2);
     b->d_ticks = nullptr;
     delete b;
     return CHV_OK;
@@ -1178,7 +1214,7 @@ extern "C" int chv_batch_destroy(chv_batch *b) {
 extern "C" int chv_batch_describe(chv_batch *b, char *kernel_name, size_t cap, int *n_launches) {
     if (!b) return fail(CHV_ERR_INVALID_VALUE, "null batch");
     if (kernel_name && cap) snprintf(kernel_name, cap, "%s", b->kernel_name.c_str());
-    if (n_launches) *n_launches = 1;
+    if (n_launches) *n_launches = b->fast_path2 != -2 ? 2 : 1;
     return CHV_OK;
 }
 

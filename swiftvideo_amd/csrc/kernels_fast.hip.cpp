@@ -24,6 +24,7 @@
 // picks a path per batch (select_fast_path) and falls back to the general kernel.
 #include "tile_common.hip.h"
 #include "switches.h"
+#include <vector>
 
 #include <algorithm>
 #include <cmath>
@@ -36,7 +37,7 @@ namespace chv {
 enum FastPath : int { FP_NONE = -1, FP_NV12_BGRA_TILED = 0, FP_Y420P_BGRA_TILED = 1, FP_WAVE_LAYERS = 2, FP_WAVE_NV12 = 3, FP_WAVE_Y420P = 4, FP_STREAM = 5, FP_CLEAR_BGRA = 6, FP_STREAM_NV12 = 7, FP_STREAM_Y420P = 8, FP_COUNT };
 
 // kernels_wave.hip.cpp / kernels_wave_yuv.hip.cpp
-bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks);
+bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks, bool tail = false);
 // kernels_stream.hip.cpp
 bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks);
 hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers, int n_ticks, int maxW, int maxH, hipStream_t stream);
@@ -502,6 +503,32 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     }
     // any mix of NV12 / y420p / BGRA / RGBA layers, any number of them
     return wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks) ? FP_WAVE_LAYERS : FP_NONE;
+}
+
+// A batch whose ticks are "2..4 full-frame videos of one geometry, then something else" (a rotated logo, overlays, a fifth layer): how many
+// leading layers of EVERY tick the streaming kernel takes as a launch of its own (cleared), the rest following in a second launch that continues
+// on the canvas — the layer-by-layer semantics already are that (the canvas is re-quantised between layers either way).  0: no.
+// The point: one layer the strip machinery has to apply per pixel (KINDS bit 3) otherwise puts the WHOLE tick on the strip kernel's most general
+// instantiation (four waves per SIMD): the pipeline tick + a rotated logo 1.268 ms per 128 ticks against 0.62 for its four videos alone.
+int split_stream_prefix(const DTick *ticks, const DLayer *layers, int n_ticks) {
+    if (n_ticks < 1 || !switches().stream.load(std::memory_order_relaxed) || switches().bgra_path.load(std::memory_order_relaxed) != 0) return 0;
+    if (switches().force_general.load(std::memory_order_relaxed)) return 0;
+    int least = 1 << 30;
+    for (int i = 0; i < n_ticks; i++) least = std::min(least, ticks[i].n_layers);
+    std::vector<DTick> head(ticks, ticks + n_ticks);
+    for (int k = std::min(4, least - 1); k >= 2; k--) {            // (every tick keeps at least one layer for the second launch)
+        for (int i = 0; i < n_ticks; i++) head[(size_t)i].n_layers = k;
+        if (bgra_stream_eligible(head.data(), layers, n_ticks)) return k;
+    }
+    return 0;
+}
+int fast_path_stream_bgra() { return FP_STREAM; }
+// the path of a split batch's second launch
+int select_tail_path(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
+    const int p = select_fast_path(target_format, ticks, layers, n_ticks, false);
+    if (p == FP_NONE && target_format == TF_BGRA && !switches().force_general.load(std::memory_order_relaxed) &&
+        wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks, true)) return FP_WAVE_LAYERS;
+    return p;
 }
 
 bool fast_path_by_value(int path) { return path == FP_STREAM || path == FP_STREAM_NV12 || path == FP_STREAM_Y420P || path == FP_NV12_BGRA_TILED || path == FP_Y420P_BGRA_TILED || path == FP_CLEAR_BGRA; }

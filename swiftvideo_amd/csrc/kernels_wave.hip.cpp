@@ -96,6 +96,13 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
     const int voff = S.voff;
     (void)lane;
 
+    // (the layer index is wave-uniform; saying so keeps the descriptor reads on the scalar unit: left to its divergence analysis
+    // the compiler fetched every uniform of a layer with per-lane global loads — 90 vector loads per wave)
+    int l = __builtin_amdgcn_readfirstlane(S.next_hit(0));
+    // a strip no layer touches on a canvas that is not cleared keeps its pixels: nothing to read, nothing to write (the second launch of a
+    // split batch — a logo or overlays over videos the streaming kernel composed — leaves most strips this way)
+    if (!CLEAR && l >= nl) return;
+
     // ---- canvas pixels of this lane: packed BGRA codes, row j in cv[j] -----------------------------------------------
     uint32_t cv[WTH];
 #pragma unroll
@@ -108,10 +115,6 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
 
     WLayer cur;
     bool have_geom = false;            // `cur` and the row table hold the geometry of the layer handled just before (LF_SAME_GEOM)
-    // (the layer index is wave-uniform; saying so keeps the descriptor reads on the scalar unit: left to its divergence analysis
-    // the compiler fetched every uniform of a layer with per-lane global loads — 90 vector loads per wave)
-    int l = __builtin_amdgcn_readfirstlane(S.next_hit(0));
-
     while (l < nl) {
         const DLayer &Ly = L[l];
         if constexpr ((KINDS & 8) != 0) {

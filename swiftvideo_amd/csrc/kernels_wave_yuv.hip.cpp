@@ -615,7 +615,9 @@ static size_t wave_lds(const WaveDims &d, bool planar, int target_format, int ro
            (size_t)WAVES * ((size_t)rows * 48 + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
 }
 
-bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks) {
+// tail: the launch continues on canvases another launch has composed (the second part of a split batch): strips no layer touches leave at once,
+// so the strip kernel is the better choice also where every layer needs the per-pixel path
+bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *layers, int n_ticks, bool tail) {
     bool any_general = false, any_staged = false;
     for (int i = 0; i < n_ticks; i++) {
         const DTick &T = ticks[i];
@@ -647,7 +649,7 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
         }
     }
     // (a launch whose layers ALL need the per-pixel path gains nothing here: the general kernel it is)
-    return any_staged || !any_general;
+    return any_staged || !any_general || tail;
 }
 
 #define CHV_STR2(x) #x

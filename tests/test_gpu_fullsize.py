@@ -101,7 +101,8 @@ def test_default_kernel_family_tick_with_a_bgra_overlay(ctx):
         out = mixer.mix(at=0.0)
         assert out is not None, mixer.result
         G.assert_same(G.from_gpu(ctx, out, "bgra", w, h), exp, f"default family, fused={fused}")
-    # and the launch the fused tick is: the strip kernel, not the general one
+    # and the launches a batch of this tick is: the streaming kernel for the two videos, the strip kernel — not the general one — for the overlay
+    # (chv_batch_create splits "videos of one geometry, then something else")
     gv = [G.to_gpu(ctx, "nv12", w, h, v) for v in vids]
     gl = G.to_gpu(ctx, "bgra", w, h, logo)
     gd = G.to_gpu(ctx, "bgra", w, h, util.alloc_image("bgra", w, h, seed=3))
@@ -110,7 +111,7 @@ def test_default_kernel_family_tick_with_a_bgra_overlay(ctx):
               (sv.ComputeKernel.img_nv12_bgra, gv[1], util.full_canvas_uniforms((w, h), (w, h), opacity=0.5), 0),
               (sv.ComputeKernel.img_bgra_bgra, gl, u, 0)]
     hb, name, keep = G.make_batch(ctx, [(gd, True, layers)])
-    assert name == "tick_bgra_wave"
+    assert name == "tick_bgra_stream + tick_bgra_wave", name
     G.run_batch(ctx, hb)
     G.destroy_batch(hb)
     G.assert_same(G.from_gpu(ctx, gd, "bgra", w, h), exp, "default family as one batch")
@@ -208,7 +209,7 @@ def test_pipeline_with_a_rotated_logo_full_size(ctx):
     layers = [(K.img_nv12_bgra, g, u, 0) for g, u in zip(gs, us)] + [(K.img_rgba_bgra_tx, gl, lu, 0)]
     gds = [G.to_gpu(ctx, "bgra", dw, dh, util.alloc_image("bgra", dw, dh, seed=7 + i)) for i in range(12)]
     h, name, keep = G.make_batch(ctx, [(gd, True, layers) for gd in gds])
-    assert name == "tick_bgra_wave", name
+    assert name == "tick_bgra_stream + tick_bgra_wave", name      # (the four videos, then the logo in the strips it touches)
     G.run_batch(ctx, h)
     G.destroy_batch(h)
     for i in (0, 5, 11):

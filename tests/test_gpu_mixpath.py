@@ -8,6 +8,7 @@ import pytest
 import gpuutil as G
 import util
 from oracle import oracle as O
+from swiftvideo_amd import chipvideo as cv
 from swiftvideo_amd import compute as sv
 from test_gpu_fastpath import NV12_BGRA_CASES, RGB_CASES
 
@@ -366,6 +367,67 @@ def test_default_route_of_a_mixed_tick(ctx, switch):
     switch("CHV_STREAM", "1")
     cw, ch, clear, specs = MIXED_CASES["video_overlays"]
     assert run_tick_case(ctx, cw, ch, clear, specs, expect=None) == WAVE
+
+
+# A batch whose ticks are "2..4 full-frame videos of one geometry, then something else": the streaming kernel composes the videos on the cleared
+# canvas, a second launch continues on it with the rest (chv_batch_create: split_stream_prefix).  Same bytes as one pass — the canvas is
+# re-quantised between layers either way.
+V = dict()
+SPLIT_CASES = {
+    "videos_logo":     (320, 180, [("img_nv12_bgra", 480, 270, dict(opacity=o)) for o in (1.0, 0.75, 0.5, 0.25)] +
+                                   [("img_rgba_bgra_tx", 80, 44, dict(rect=(200, 20, 80, 44), rotation=0.3, opacity=0.9))], 4),
+    "planar_overlays": (320, 180, [("img_y420p_bgra", 480, 270, dict(opacity=o)) for o in (1.0, 0.6, 0.3)] +
+                                   [("img_bgra_bgra_tx", 96, 54, dict(rect=(12, 10, 96, 54), opacity=0.8)),
+                                    ("img_rgba_bgra_tx", 64, 36, dict(rect=(200, 100, 100, 60), opacity=0.6, border=(3, 3, 3, 3), fill=(0.1, 0.9, 0.2, 0.7)))], 3),
+    "two_and_pip":     (256, 96, [("img_nv12_bgra", 384, 144, dict()), ("img_nv12_bgra", 384, 144, dict(opacity=0.5)),
+                                  ("img_nv12_bgra", 192, 72, dict(rect=(150, 8, 96, 36)))], 2),
+    "five_videos":     (192, 64, [("img_nv12_bgra", 288, 96, dict(opacity=1.0 - 0.15 * i)) for i in range(5)], 4),
+    "reference_bgra":  (192, 64, [("img_nv12_bgra", 288, 96, dict(opacity=o)) for o in (1.0, 0.5)] + [("img_bgra_bgra", 64, 24, dict(rect=(10, 10, 64, 24)))], 2),
+    "seven_layers":    (128, 48, [("img_y420p_bgra", 128, 48, dict(opacity=0.9))] * 4 + [("img_nv12_bgra", 128, 48, dict(opacity=0.4)), ("img_bgra_bgra_tx", 128, 48, dict(opacity=0.3)),
+                                  ("img_rgba_bgra_tx", 40, 20, dict(rect=(60, 20, 40, 20)))], 4),
+}
+
+
+@pytest.mark.parametrize("case", list(SPLIT_CASES))
+def test_batches_split_between_the_streaming_kernel_and_the_rest(ctx, case):
+    cw, ch, specs, k = SPLIT_CASES[case]
+    import ctypes as C
+    lib = cv.load()
+    ticks, exps, gds = [], [], []
+    for t in range(3):                                         # three ticks of the same stack, different pictures
+        canvas0 = util.alloc_image("bgra", cw, ch, seed=70 + t)
+        exp = util.copy_image(canvas0)
+        assert O.run_kernel("img_clear_bgra", exp) == 0
+        layers = []
+        for i, (kn, sw, sh, kw) in enumerate(specs):
+            u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+            s = kn.split("_")[1]
+            src = util.alloc_image(s, sw, sh, seed=300 + 17 * t + i)
+            assert O.run_kernel(kn, exp, src, u, threads=4) == 0
+            layers.append((sv.defaultComputeKernelFromString(kn), G.to_gpu(ctx, s, sw, sh, src), u, 0))
+        gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+        ticks.append((gd, True, layers)); exps.append(exp); gds.append(gd)
+    h, name, keep = G.make_batch(ctx, ticks)
+    n = C.c_int(0)
+    cv.check(lib.chv_batch_describe(h, None, 0, C.byref(n)))
+    assert name.startswith(STREAM + " + ") and n.value == 2, (name, n.value)
+    G.run_batch(ctx, h)
+    G.run_batch(ctx, h)                                        # replay: the first launch clears, so the result is the same
+    G.destroy_batch(h)
+    for t in range(3):
+        G.assert_same(G.from_gpu(ctx, gds[t], "bgra", cw, ch), exps[t], f"{case} tick {t} via {name}")
+
+
+def test_batches_that_are_not_split(ctx, switch):
+    """no split: an un-cleared canvas, ticks of different depth of the video stack, a stack of one, every layer taken by the streaming kernel,
+    the strip kernel asked for by switch"""
+    vid = lambda o: ("img_nv12_bgra", 288, 96, dict(opacity=o))
+    logo = ("img_rgba_bgra_tx", 40, 20, dict(rect=(60, 20, 40, 20)))
+    assert run_tick_case(ctx, 192, 64, False, [vid(1.0), vid(0.5), logo], expect=None) == WAVE
+    assert run_tick_case(ctx, 192, 64, True, [vid(1.0), logo], expect=None) == WAVE
+    assert run_tick_case(ctx, 192, 64, True, [vid(1.0), vid(0.5)], expect=None) == STREAM
+    switch("CHV_BGRA_PATH", "wave")
+    assert run_tick_case(ctx, 192, 64, True, [vid(1.0), vid(0.5), logo], expect=None) == WAVE
 
 
 @pytest.mark.parametrize("case", [c for c in NV12_BGRA_CASES if c not in ("huge_downscale", "tiny")])
