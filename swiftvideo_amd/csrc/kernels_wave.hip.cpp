@@ -73,6 +73,9 @@ namespace chv {
 // the rows that go through the per-pixel path where a layer's edge crosses a strip (ticks with small overlays: 0.88 -> 1.05 ms),
 // so they are used when every layer of the launch covers (almost) the whole canvas; 8 rows otherwise (80 VGPRs, 6 waves).      // strip height: rows per lane (16: -14 % on the 4 x NV12 pipeline at 128 VGPRs, but the LDS
                                         // footprint of 4-byte texel rectangles then halves the occupancy of mixed ticks: 3.0 vs 0.85 ms)
+#ifndef CHV_WAVE_PIXEL_UNROLL
+#define CHV_WAVE_PIXEL_UNROLL 4      // rows of a per-pixel layer in flight together (their gathers are dependent chains of L2 round trips)
+#endif
 template <int WTH, bool CLEAR, int KINDS>
 __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAVE_MINW16) : ((KINDS & 8) ? 5 : CHV_WAVE_MINW))) void tick_bgra_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
             // not send the whole tick to the general kernel.
             if (Ly.kind == LK_BGRA_METAL || (Ly.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) {
                 const float gsx = (float)T.W, gsy = (float)TH;
-#pragma unroll 1
+#pragma unroll CHV_WAVE_PIXEL_UNROLL
                 for (int j = 0; j < WTH; j++) {
                     const int y = y0 + j;
                     uint32_t c = cv[0];
