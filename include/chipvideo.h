@@ -289,7 +289,9 @@ typedef struct chv_tick {
 int chv_batch_create(chv_context *ctx, const chv_tick *ticks, int n_ticks, chv_batch **out);
 int chv_batch_run(chv_context *ctx, chv_batch *batch);
 int chv_batch_destroy(chv_batch *batch);
-/* Name of the device kernel a batch dispatches to and its launch count (for profiling). */
+/* Name of the device kernel a batch dispatches to and its launch count (for profiling).  A batch whose ticks start with 2..4
+ * full-frame videos of one geometry and go on with other layers runs as TWO launches on the context's stream ("tick_bgra_stream +
+ * tick_bgra_wave": the videos, then the rest continuing on the canvas); the bytes are those of one pass. */
 int chv_batch_describe(chv_batch *batch, char *kernel_name, size_t cap, int *n_launches);
 
 /* ---- custom kernels ------------------------------------------------------ */
