@@ -59,8 +59,8 @@ WORKLOADS = {
                           "alpha composite (opacity 1/.75/.5/.25) onto one 720p BGRA canvas, one launch per batch of ticks",
                      kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=4, frames=256,
                      bytes=4 * NV12_1080 + BGRA_720),
-    "pipeline_logo": dict(desc="the pipeline tick + one ROTATED 320x180 RGBA logo (opacity .9) on top: the rotated layer is applied per pixel "
-                               "inside the wave kernel, the rest stays on the staged path",
+    "pipeline_logo": dict(desc="the pipeline tick + one ROTATED 320x180 RGBA logo (opacity .9) on top: two launches per batch — the streaming kernel "
+                               "for the four videos, the strip kernel for the logo (applied per pixel, in the strips it touches)",
                           kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=4, frames=128, logo=True,
                           bytes=4 * NV12_1080 + BGRA_720 + 320 * 180 * 4),
     "pipeline_y420p": dict(desc="the pipeline tick with PLANAR sources (what FFmpeg's software decoders emit, dec.video.ffmpeg.swift:187-221): 4 x 1920x1080 "
@@ -102,7 +102,7 @@ WORKLOADS = {
                   bytes=2 * NV12_1080 + 2 * 921600 + BGRA_720),
 }
 HEADLINE = "pipeline"
-DEFAULT_SET = ["pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12", "pipeline_y420p", "pipeline_grid"]
+DEFAULT_SET = ["pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12", "pipeline_y420p", "pipeline_grid", "pipeline_logo"]
 
 
 def parse_args(argv=None):
@@ -464,9 +464,10 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
         cv.check(lib.chv_batch_create(ctx.handle, sub, n, C.byref(b)))
         batches.append((b, first, n))
     name = C.create_string_buffer(128)
-    cv.check(lib.chv_batch_describe(batches[0][0], name, 128, None))
+    nl = C.c_int(1)
+    cv.check(lib.chv_batch_describe(batches[0][0], name, 128, C.byref(nl)))
     return dict(batch=batches[0][0], batches=batches, keep=keep, layer_arrays=layer_arrays, ticks=ticks, kernel=name.value.decode(), verify=verify,
-                lanczos=lanczos_pairs, canvases=canvases)
+                lanczos=lanczos_pairs, canvases=canvases, launches_per_batch=nl.value)
 
 
 def free_workload(w):
@@ -707,6 +708,8 @@ def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
     if lzs is not None:
         rep["kernel_launches_per_batch"] = 2 * len(w["batches"])
         rep["ticks_per_group"] = w["batches"][0][2]
+    elif w.get("launches_per_batch", 1) > 1:
+        rep["kernel_launches_per_batch"] = w["launches_per_batch"]       # (a split batch: the videos, then the rest; `launch_ms` covers both)
     cpu = None
     if headline and rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and w["verify"] is not None:
         cpu = cpu_baseline(wl, w, args.cpu_seconds)

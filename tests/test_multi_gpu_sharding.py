@@ -152,7 +152,7 @@ def test_default_run_measures_its_hbm_traffic():
     which)."""
     import shutil
     d = _run_bench(["--steps", "2", "--warmup", "1", "--min-seconds", "0.1", "--min-seconds-other", "0.05", "--no-cpu-baseline"])
-    assert set(d["workloads"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12", "pipeline_y420p", "pipeline_grid"}
+    assert set(d["workloads"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12", "pipeline_y420p", "pipeline_grid", "pipeline_logo"}
     e2e = d["workloads"]["pipeline_e2e"]
     assert e2e["verified_vs_oracle"] is True and e2e["ticks_per_s"] > 100 and 0 < e2e["d2h_frac_of_link"] < e2e["h2d_frac_of_link"] < 1.1
     legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence", "mixer_y420p_per_tick", "mixer_y420p_reference_sequence", "pipeline_e2e", "per_tick_thread_scaling")
