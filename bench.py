@@ -464,10 +464,10 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
         cv.check(lib.chv_batch_create(ctx.handle, sub, n, C.byref(b)))
         batches.append((b, first, n))
     name = C.create_string_buffer(128)
-    nl = C.c_int(1)
-    cv.check(lib.chv_batch_describe(batches[0][0], name, 128, C.byref(nl)))
+    n_launch = C.c_int(1)
+    cv.check(lib.chv_batch_describe(batches[0][0], name, 128, C.byref(n_launch)))
     return dict(batch=batches[0][0], batches=batches, keep=keep, layer_arrays=layer_arrays, ticks=ticks, kernel=name.value.decode(), verify=verify,
-                lanczos=lanczos_pairs, canvases=canvases, launches_per_batch=nl.value)
+                lanczos=lanczos_pairs, canvases=canvases, launches_per_batch=n_launch.value)
 
 
 def free_workload(w):
