@@ -835,8 +835,30 @@ static int32_t layer_flags(const float *u) {
 // computed in double with a 2-pixel margin, far more than the float evaluation can differ by.
 static void layer_bbox(DLayer *L, int W, int H) {
     L->bbox[0] = 0; L->bbox[1] = 0; L->bbox[2] = W; L->bbox[3] = H;
-    if (!(L->flags & LF_AXIS_ALIGNED)) return;
     const float *B = L->u + U_BORDER;
+    if (!(L->flags & LF_AXIS_ALIGNED)) {
+        // Rotated / sheared layers: the border coordinates are affine in the pixel — b = A n + t with n = (2 x / W - 1, 2 y / H - 1), z = 0, w = 1
+        // (geometry(), pixel_math.hip.h) — so the pixels a layer can touch lie in the parallelogram A^-1 ([0,1]^2 - t).  Its box, in double with the
+        // same 2-pixel margin; entries large enough for the float evaluation to differ by more than that (or a singular A) keep the whole canvas.
+        // (Until round 4 these layers had the whole canvas for a box: a rotated logo made EVERY strip of the tick run its per-pixel loop.)
+        const double a = B[0], b = B[1], c = B[4], d = B[5], tx = B[3], ty = B[7];
+        double big = 0.0;
+        for (double v : { a, b, c, d, tx, ty }) { if (!(v - v == 0.0)) return; big = std::max(big, std::fabs(v)); }
+        const double det = a * d - b * c;
+        if (!(big < 1048576.0) || !(std::fabs(det) > 1e-9 * std::max(1.0, big * big))) return;
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (int k = 0; k < 4; k++) {
+            const double u = (k & 1) - tx, v = (k >> 1) - ty;
+            const double nx = (d * u - b * v) / det, ny = (-c * u + a * v) / det;
+            const double px = (nx + 1.0) * W / 2.0, py = (ny + 1.0) * H / 2.0;
+            x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+        }
+        if (!(x0 - x0 == 0.0 && x1 - x1 == 0.0 && y0 - y0 == 0.0 && y1 - y1 == 0.0)) return;
+        auto clampi = [](double v, int n) { return (int32_t)std::min(std::max(v, 0.0), (double)n); };
+        L->bbox[0] = clampi(std::floor(x0) - 2.0, W); L->bbox[2] = clampi(std::ceil(x1) + 3.0, W);
+        L->bbox[1] = clampi(std::floor(y0) - 2.0, H); L->bbox[3] = clampi(std::ceil(y1) + 3.0, H);
+        return;
+    }
     auto range = [](double k, double c, int n, int32_t *lo, int32_t *hi) {
         // 0 <= k * (2*x/n - 1) + c <= 1
         if (!(k - k == 0.0) || !(c - c == 0.0)) return;
