@@ -430,6 +430,47 @@ def test_batches_that_are_not_split(ctx, switch):
     assert run_tick_case(ctx, 192, 64, True, [vid(1.0), vid(0.5), logo], expect=None) == WAVE
 
 
+@pytest.mark.parametrize("target", ["bgra", "nv12"])
+@pytest.mark.parametrize("seed", range(12))
+def test_bounding_boxes_of_rotated_and_sheared_layers(ctx, switch, seed, target):
+    """A layer that is not axis-aligned is culled by the box of the parallelogram its border coordinates map to [0,1]^2 (chipvideo.cpp::layer_bbox):
+    random rotations (any angle), anisotropic sizes, a shear multiplied into the matrices by hand, borders with fill paint, layers hanging off
+    every canvas edge and layers entirely outside — through the strip kernel (per-pixel layers in the strips the box touches) and through the
+    general kernel (pixels outside the box skipped), three layers per tick so that a box too small for one layer shows"""
+    rng = np.random.default_rng(31000 + seed)
+    cw, ch = int(rng.integers(40, 200)) * 2, int(rng.integers(20, 90)) * 2
+    fam = ["img_bgra_bgra_tx", "img_rgba_bgra_tx", "img_nv12_bgra", "img_y420p_bgra"] if target == "bgra" else ["img_bgra_nv12", "img_rgba_nv12", "img_nv12_nv12", "img_y420p_nv12"]
+    canvas0 = util.alloc_image(target, cw, ch, seed=seed + 1)
+    exp = util.copy_image(canvas0)
+    assert O.run_kernel(f"img_clear_{target}", exp) == 0
+    layers = []
+    for l in range(3):
+        k = fam[int(rng.integers(0, 4))]
+        s = k.split("_")[1]
+        sw, sh = int(rng.integers(8, 60)) * 2, int(rng.integers(4, 40)) * 2
+        w, h = float(rng.uniform(0.1, 0.9) * cw), float(rng.uniform(0.1, 0.9) * ch)
+        x, y = float(rng.uniform(-0.4, 1.1) * cw), float(rng.uniform(-0.4, 1.1) * ch)
+        kw = dict(rect=(x, y, w, h), rotation=float(rng.uniform(-3.2, 3.2)), opacity=float(rng.choice([1.0, rng.uniform(0.2, 1.0)])))
+        if rng.random() < 0.5:
+            kw["border"] = tuple(float(v) for v in rng.uniform(0, 12, 4)); kw["fill"] = tuple(float(v) for v in rng.uniform(0, 1, 4))
+        u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+        if rng.random() < 0.5:
+            # a shear on top: kernel rows are rows of M^-1, so M' = M S  <=>  rows' = S^-1 rows (transform and border alike)
+            S = np.eye(4, dtype=np.float64); S[0, 1] = float(rng.uniform(-0.7, 0.7)); Si = np.linalg.inv(S)
+            for o in (0, 32):
+                u[o:o + 16] = (Si @ u[o:o + 16].astype(np.float64).reshape(4, 4)).astype(np.float32).reshape(-1)
+        src = util.alloc_image(s, sw, sh, seed=int(rng.integers(1, 1 << 20)))
+        assert O.run_kernel(k, exp, src, u, threads=4) == 0
+        layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, s, sw, sh, src), u, 0))
+    for general in ("0", "1"):
+        switch("CHV_FORCE_GENERAL", general)
+        gd = G.to_gpu(ctx, target, cw, ch, canvas0)
+        h, name, keep = G.make_batch(ctx, [(gd, True, layers)])
+        G.run_batch(ctx, h)
+        G.destroy_batch(h)
+        G.assert_same(G.from_gpu(ctx, gd, target, cw, ch), exp, f"seed {seed} {cw}x{ch} via {name}")
+
+
 @pytest.mark.parametrize("case", [c for c in NV12_BGRA_CASES if c not in ("huge_downscale", "tiny")])
 @pytest.mark.parametrize("fmt", ["nv12", "y420p"])
 def test_single_yuv_layer_through_the_multi_layer_kernels(ctx, path, case, fmt):
