@@ -703,24 +703,29 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     };
     size_t lds = measure(WTH);
     if (WTH == 16 && lds > (size_t)LDS_BUDGET / 2) { WTH = 8; lds = measure(WTH); }      // (keep at least two tall strips' worth per 64 KB)
-    // Side-by-side layout: where RGB rectangles set the row width of the plane-0 region, a YUV layer's luma, chroma / U and V rectangles fit next to
-    // each other in those rows (the mixer canvas: 128 + 96 + 96 bytes in an overlay's 320) — the region is then max(rows) x pitch instead of the sum
-    // of both regions, which on that canvas is 20 instead of 18 waves per CU.
+    // Side-by-side layout: a YUV layer's luma, chroma / U and V rectangles next to each other in the rows of ONE region whose rows are as wide as the
+    // widest need of the launch — an RGB rectangle (the mixer canvas: a video layer's 128 + 96 + 96 bytes in an overlay's 320) or luma + chroma of
+    // the widest video layer — instead of a plane-0 region followed by chroma regions.  The region is then max(rows) x pitch instead of the sum of
+    // the regions; taken where that is smaller (18 -> 23 waves' worth of LDS per CU on the mixer canvas, 20 -> 26 for video + overlays on BGRA).
     int side = 0;
-    if ((kinds & 4) && (kinds & 3) && lds <= (size_t)LDS_BUDGET) {
-        int yneed = 0, cneed = 0;
+    if ((kinds & 3) && lds <= (size_t)LDS_BUDGET) {
+        int yneed = 0, c_nv12 = 0, c_planar = 0;
         for (int i = 0; i < n_ticks; i++)
             for (int l = 0; l < ticks_host[i].n_layers; l++) {
                 const DLayer &L = layers_host[ticks_host[i].first_layer + l];
                 if (L.kind == LK_BGRA_METAL || (L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED) || host_src_rgb(L.kind)) continue;
                 const WaveDims d = wave_dims(ticks_host[i], L, WTH);
-                yneed = std::max(yneed, d.p0pitch); cneed = std::max(cneed, d.p1pitch);
+                yneed = std::max(yneed, d.p0pitch);
+                if (host_src_planar(L.kind)) c_planar = std::max(c_planar, d.p1pitch); else c_nv12 = std::max(c_nv12, d.p1pitch);
             }
         const int planes = planar ? 2 : 1;
+        const int pitch = std::max(m.p0pitch, yneed + std::max(c_nv12, 2 * c_planar));
         const size_t separate = (size_t)m.p0pitch * m.p0rows + (size_t)m.p1pitch * m.p1rows * planes;
-        const size_t beside = (size_t)m.p0pitch * std::max(m.p0rows, m.p1rows);
-        if (yneed > 0 && yneed + planes * cneed <= m.p0pitch && beside < separate && (yneed >> 4) < 4096 && (cneed >> 4) < 4096) {
-            side = ((yneed >> 4) << 8) | ((cneed >> 4) << 20);
+        const size_t beside = (size_t)pitch * std::max(m.p0rows, m.p1rows);
+        if (yneed > 0 && beside < separate && (yneed >> 4) < 4096 && (c_planar >> 4) < 4096) {
+            // bits 8-19: luma columns / 16; bits 20-31: columns of ONE planar chroma plane / 16 (0: no planar picture in the launch)
+            side = ((yneed >> 4) << 8) | ((c_planar >> 4) << 20) | (1 << 7);
+            m.p0pitch = pitch;
             lds = lds - (size_t)WAVES * separate + (size_t)WAVES * beside;
         }
     }

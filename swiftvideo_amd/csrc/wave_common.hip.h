@@ -287,7 +287,7 @@ struct WaveStrip {
     uint8_t *smem;                     // this wave's LDS region: row table, plane-0 rectangle, chroma / U, (planar) V
     uint4 *rowtab;
     int base0, base1, voff, p0pitch, p0rows, p1pitch, p1rows;
-    int ylim, clim;                    // bytes a YUV layer's luma / chroma rectangle row may take (the pitches, or the columns of the side-by-side layout)
+    int ylim, clim, plim;              // bytes a YUV layer's luma / NV12 chroma / planar chroma-plane rectangle row may take (the pitches, or the columns of the side-by-side layout)
 
     // XCD-aware numbering: block b runs on XCD b % 8; every XCD gets one contiguous range of the launch's strips (whole
     // frames when there are >= 8 ticks), so halo rows are shared through that XCD's L2.  false: nothing to do for this wave.
@@ -306,17 +306,17 @@ struct WaveStrip {
         lane = tid & 63;
         const int wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);      // (one wave per block: no per-wave LDS offset arithmetic)
         p0pitch = p0pitch_; p0rows = p0rows_; p1pitch = p1pitch_; p1rows = p1rows_;
-        // planar_any: bit 0 — the launch has planar pictures; bits 8-19 / 20-31 (units of 16 bytes), when not zero: the SIDE-BY-SIDE layout — the rows
-        // of the plane-0 region are as wide as the launch's widest RGB rectangle, and a YUV layer keeps luma, chroma / U and V next to each other
-        // in them (launch_wave_layers: a video layer's 128 + 96 + 96 bytes in an overlay's 320-byte rows instead of behind its 19 rows)
-        const int ycols = ((planar_any >> 8) & 0xFFF) * 16, ccols = ((planar_any >> 20) & 0xFFF) * 16;
+        // planar_any: bit 0 — the launch has planar pictures; bit 7: the SIDE-BY-SIDE layout (launch_wave_layers) — one region whose rows hold a YUV
+        // layer's luma columns (bits 8-19, units of 16 bytes), then its chroma: the (u, v) rows of an NV12 picture, or the U and V rows of a planar
+        // one, each bits 20-31 wide — instead of a plane-0 region followed by chroma regions; RGB rectangles use the whole rows
+        const int ycols = ((planar_any >> 8) & 0xFFF) * 16, pcols = ((planar_any >> 20) & 0xFFF) * 16;
         int wbytes;
         base0 = ROWTAB_BYTES;
-        if (ycols) {
-            p1pitch = p0pitch; voff = ccols; base1 = base0 + ycols; ylim = ycols; clim = ccols;
+        if (planar_any & 128) {
+            p1pitch = p0pitch; voff = pcols; base1 = base0 + ycols; ylim = ycols; clim = p0pitch - ycols; plim = pcols;
             wbytes = ROWTAB_BYTES + p0pitch * max(p0rows, p1rows);
         } else {
-            voff = p1rows * p1pitch; base1 = base0 + p0rows * p0pitch; ylim = p0pitch; clim = p1pitch;
+            voff = p1rows * p1pitch; base1 = base0 + p0rows * p0pitch; ylim = p0pitch; clim = p1pitch; plim = p1pitch;
             wbytes = ROWTAB_BYTES + p0rows * p0pitch + voff * ((planar_any & 1) ? 2 : 1);
         }
         smem = smem_all + wave * wbytes;
@@ -416,7 +416,7 @@ struct WaveStrip {
                 if (w.g1.pair) w.g1.rows = 2 * WTH;
                 w.g1.edge = cs.clo < 0 || cs.chi >= S1.w || rs.clo < 0 || rs.chi >= S1.h - 1 + (int)(col0 + nvec * tpv <= S1.w);
                 stage_slots_init(w.g1);
-                ok = (nvec + 2) * 16 <= clim && w.g1.rows <= p1rows && stage_slots(w.g1) <= 1024;
+                ok = (nvec + 2) * 16 <= (is_planar(Ly.kind) ? plim : clim) && w.g1.rows <= p1rows && stage_slots(w.g1) <= 1024;
                 c1off = base1 + 16 + ((min(max(cc, cs.clo), cs.chi - 1) - col0) << (4 - sh));
                 r1off = w.g1.pair ? 2 * min(lane, WTH - 1) * p1pitch : (min(max(rc, rs.clo), rs.chi - 1) - rs.clo) * p1pitch;
             }
