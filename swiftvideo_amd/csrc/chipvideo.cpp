@@ -874,6 +874,31 @@ static void layer_bbox(DLayer *L, int W, int H) {
     range((double)B[5], (double)B[7], H, &L->bbox[1], &L->bbox[3]);
 }
 
+// LF_COVERS + ibox (device_types.h): the canvas pixels an opaque YUV-source layer replaces for sure — where border, transform and texture
+// coordinates all lie in [0, 1] — shrunk by two pixels per side (the same margin layer_bbox adds).  Axis-aligned, bounded layers on BGRA canvases.
+static void layer_inner_box(DLayer *L, int W, int H, int target_format) {
+    L->ibox[0] = L->ibox[1] = L->ibox[2] = L->ibox[3] = 0;
+    L->flags &= ~LF_COVERS;
+    const int need = LF_AXIS_ALIGNED | LF_BOUNDED | LF_OPAQUE;
+    if (target_format != TF_BGRA || (L->flags & need) != need) return;
+    if (L->kind != LK_BGRA_FROM_NV12 && L->kind != LK_BGRA_FROM_Y420P) return;          // (RGB sources carry per-pixel alpha)
+    const float *T = L->u + U_TRANSFORM, *X = L->u + U_TEXTURE, *B = L->u + U_BORDER;
+    // per axis: v(n) = k n + c in [0, 1] for the three coordinates; n = 2 p / size - 1
+    auto inner = [](double k, double c, int n, double *lo, double *hi) {
+        if (!(k - k == 0.0) || !(c - c == 0.0) || k == 0.0) { *lo = 1.0; *hi = 0.0; return; }
+        double a = ((0.0 - c) / k + 1.0) * n / 2.0, b = ((1.0 - c) / k + 1.0) * n / 2.0;
+        if (a > b) std::swap(a, b);
+        *lo = std::max(*lo, std::ceil(a) + 2.0); *hi = std::min(*hi, std::floor(b) - 2.0);
+    };
+    const double t3 = T[15];
+    double xl = 0.0, xh = W, yl = 0.0, yh = H;
+    inner(B[0], B[3], W, &xl, &xh); inner(T[0], T[3], W, &xl, &xh); inner((double)T[0] * X[0], (double)T[3] * X[0] + t3 * X[3], W, &xl, &xh);
+    inner(B[5], B[7], H, &yl, &yh); inner(T[5], T[7], H, &yl, &yh); inner((double)T[5] * X[5], (double)T[7] * X[5] + t3 * X[7], H, &yl, &yh);
+    if (!(xl < xh && yl < yh)) return;
+    L->ibox[0] = (int32_t)xl; L->ibox[2] = (int32_t)xh; L->ibox[1] = (int32_t)yl; L->ibox[3] = (int32_t)yh;
+    L->flags |= LF_COVERS;
+}
+
 static int layer_to_device(const chv_layer &l, int device, int *target_format, DLayer *out) {
     KernelShape s;
     int rc = kernel_shape(l.kernel, &s);
@@ -932,6 +957,8 @@ static int tick_to_device(const chv_tick &t, int device, int forced_target_forma
         DLayer &L = (*layers)[i];
         if (L.kind == LK_BGRA_METAL) { L.bbox[0] = 0; L.bbox[1] = 0; L.bbox[2] = dt->W; L.bbox[3] = dt->H; }
         else layer_bbox(&L, dt->W, dt->H);
+        layer_inner_box(&L, dt->W, dt->H, tf);
+        if ((L.flags & LF_COVERS) && i - first < 31) dt->cover_mask |= 1 << (i - first);
     }
     // LF_SAME_GEOM (device_types.h): a layer whose geometry inputs equal its predecessor's
     if (switches().same_geom.load(std::memory_order_relaxed)) {
@@ -1179,7 +1206,9 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
             std::vector<DTick> head = dts, tail = dts;
             for (int i = 0; i < n_ticks; i++) {
                 head[(size_t)i].n_layers = k;
+                head[(size_t)i].cover_mask &= (1 << k) - 1;
                 tail[(size_t)i].first_layer += k; tail[(size_t)i].n_layers -= k; tail[(size_t)i].clear_first = 0;
+                tail[(size_t)i].cover_mask = (int32_t)((uint32_t)tail[(size_t)i].cover_mask >> k);
             }
             const int p1 = select_fast_path(tf0, head.data(), dls.data(), n_ticks), p2 = select_tail_path(tf0, tail.data(), dls.data(), n_ticks);
             if (p1 == fast_path_stream_bgra()) {

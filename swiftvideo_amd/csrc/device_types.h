@@ -44,7 +44,12 @@ struct DLayer {
     // so kernels may skip the layer there without evaluating the geometry.
     int32_t bbox[4];
     int32_t pad;
+    // LF_COVERS layers: canvas pixels [x0, x1) x [y0, y1) that lie inside border, transform AND texture range for sure (host-side, a few pixels
+    // of margin): there the layer's opaque sample replaces whatever is beneath, so a strip inside this box starts at this layer.
+    int32_t ibox[4];
+    int32_t pad2[2];
 };
+static_assert(sizeof(DLayer) % 8 == 0, "DLayer arrays follow a DTick in descriptor slots and kernel arguments");
 
 enum LayerFlags : int32_t {
     LF_AXIS_ALIGNED = 1,  // no rotation/shear: tx.x/uv.x depend on x only, tx.y/uv.y on y only
@@ -56,7 +61,10 @@ enum LayerFlags : int32_t {
     // POINTERS may differ).  Every geometry value the strip kernels derive (column entries, row table, rectangles, slot maps) is
     // a function of exactly these inputs, so they keep the predecessor's — same inputs, same bits.  True for every layer but
     // the first of the BASELINE composite configurations (N full-canvas pictures of one size: mix.video.swift:114-124).
-    LF_SAME_GEOM = 16
+    LF_SAME_GEOM = 16,
+    // An opaque picture without per-pixel alpha (a YUV source, opacity 1) whose inner box `ibox` is not empty: inside it the layers beneath do not
+    // show — a picture-in-picture inset, the quadrants of a grid over a background
+    LF_COVERS = 32
 };
 
 enum TargetFormat : int32_t { TF_NV12 = 0, TF_Y420P = 1, TF_BGRA = 2 };
@@ -67,7 +75,7 @@ struct DTick {
     int32_t clear_first;
     int32_t n_layers;
     int32_t first_layer;   // index into the batch's DLayer array
-    int32_t pad;
+    int32_t cover_mask;    // bit l: layer l of the tick is flagged LF_COVERS (most ticks: 0 — the strip kernels look no further)
 };
 
 // uniforms blob offsets (floats)

@@ -73,6 +73,9 @@ namespace chv {
 // the rows that go through the per-pixel path where a layer's edge crosses a strip (ticks with small overlays: 0.88 -> 1.05 ms),
 // so they are used when every layer of the launch covers (almost) the whole canvas; 8 rows otherwise (80 VGPRs, 6 waves).      // strip height: rows per lane (16: -14 % on the 4 x NV12 pipeline at 128 VGPRs, but the LDS
                                         // footprint of 4-byte texel rectangles then halves the occupancy of mixed ticks: 3.0 vs 0.85 ms)
+#ifndef CHV_WAVE_COVER
+#define CHV_WAVE_COVER 1
+#endif
 #ifndef CHV_WAVE_PIXEL_UNROLL
 #define CHV_WAVE_PIXEL_UNROLL 4      // rows of a per-pixel layer in flight together (their gathers are dependent chains of L2 round trips)
 #endif
@@ -101,7 +104,22 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
 
     // (the layer index is wave-uniform; saying so keeps the descriptor reads on the scalar unit: left to its divergence analysis
     // the compiler fetched every uniform of a layer with per-lane global loads — 90 vector loads per wave)
-    int l = __builtin_amdgcn_readfirstlane(S.next_hit(0));
+    // A strip that lies inside the inner box of an opaque picture (LF_COVERS: a picture-in-picture inset, a quadrant of a grid) starts at that
+    // layer: whatever is beneath does not show.  (CHV_WAVE_COVER=0: the A/B.)
+    int first = 0;
+    if (CHV_WAVE_COVER) {
+        // (the tick says which of its layers can cover: no bit, no descriptor reads)
+        uint32_t cm = (uint32_t)T.cover_mask & ~1u;
+        const int x1 = min(S.x0 + WTW, T.W), y1 = min(y0 + WTH, TH);
+        while (cm) {
+            const int k = 31 - __builtin_clz(cm);
+            cm &= ~(1u << k);
+            if (k >= nl) continue;
+            const DLayer &K = L[k];
+            if (S.x0 >= K.ibox[0] && x1 <= K.ibox[2] && y0 >= K.ibox[1] && y1 <= K.ibox[3]) { first = k; break; }
+        }
+    }
+    int l = __builtin_amdgcn_readfirstlane(S.next_hit(first));
     // a strip no layer touches on a canvas that is not cleared keeps its pixels: nothing to read, nothing to write (the second launch of a
     // split batch — a logo or overlays over videos the streaming kernel composed — leaves most strips this way)
     if (!CLEAR && l >= nl) return;

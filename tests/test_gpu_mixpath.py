@@ -94,6 +94,19 @@ MIXED_CASES = {
     "down_vertical":  (128, 72, True, [("img_nv12_bgra", 128, 216, dict()), ("img_y420p_bgra", 128, 288, dict(opacity=0.5)),
                                         ("img_rgba_bgra_tx", 40, 200, dict(rect=(60, 4, 40, 64), opacity=0.7))]),
     "down_and_up":    (192, 48, True, [("img_y420p_bgra", 64, 160, dict()), ("img_nv12_bgra", 600, 20, dict(opacity=0.5))]),
+    # strips inside the inner box of an opaque YUV-source picture start at that picture (LF_COVERS): an inset over a background, opaque quadrants
+    # over a background and under a translucent one, an opaque picture with a painted border ring (the ring still blends), an opaque RGB picture
+    # (per-pixel alpha: nothing is culled), an uncleared canvas, an opaque picture hanging off the canvas, flipped
+    "pip_opaque":     (320, 96, True, [("img_nv12_bgra", 480, 144, dict()), ("img_bgra_bgra_tx", 64, 36, dict(rect=(10, 10, 64, 36), opacity=0.7)),
+                                        ("img_y420p_bgra", 240, 72, dict(rect=(70, 8, 230, 80)))]),
+    "grid_opaque":    (256, 128, True, [("img_nv12_bgra", 384, 192, dict())] +
+                                        [(("img_nv12_bgra", "img_y420p_bgra")[i % 2], 192, 108, dict(rect=(128 * (i % 2), 64 * (i // 2), 128, 64))) for i in range(4)] +
+                                        [("img_rgba_bgra_tx", 64, 32, dict(rect=(96, 48, 64, 32), opacity=0.5))]),
+    "cover_ring":     (256, 96, False, [("img_rgba_bgra_tx", 256, 96, dict(opacity=0.9)),
+                                         ("img_nv12_bgra", 192, 72, dict(rect=(24, 12, 200, 72), border=(10, 6, 14, 8), fill=(0.2, 0.8, 0.3, 0.6)))]),
+    "cover_rgb_not":  (192, 64, True, [("img_nv12_bgra", 192, 64, dict()), ("img_bgra_bgra_tx", 192, 64, dict())]),
+    "cover_offcanvas": (200, 80, False, [("img_y420p_bgra", 100, 40, dict(opacity=0.6)), ("img_nv12_bgra", 300, 120, dict(rect=(-40, -20, 300, 120))),
+                                          ("img_y420p_bgra", 96, 54, dict(rect=(60, 10, 130, 60), tex=(1.0, 1.0, -1.0, -1.0)))]),
 }
 
 
