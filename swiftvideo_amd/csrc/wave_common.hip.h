@@ -506,7 +506,11 @@ struct WaveStrip {
         if constexpr (CHV_WAVE_PAIR && WTH == 8) {
             // (8-row strips only: the 16-row instantiations are at their register limit, and launches whose rectangles are this tall run 8-row
             // strips anyway (launch_wave_layers).  Its own instantiation: the row lookup costs the other paths registers)
-            if (w.g0.pair || (!rgb && w.g1.pair)) { stage_impl<true, true>(l, w); return; }
+            if (w.g0.pair || (!rgb && w.g1.pair)) {
+                if (INTERIOR != 0 && !w.g0.edge && (rgb || !w.g1.edge)) stage_impl<false, true>(l, w);        // (no clamping, no patching)
+                else stage_impl<true, true>(l, w);
+                return;
+            }
         }
         if constexpr ((INTERIOR & 4) != 0) {
             if (!rgb && !w.g0.edge && !w.g1.edge && stage_p2(l, w)) return;
