@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_str
     stream_body<NL, false, PL>(ticks, layers, n_ticks, strips_x, chunks_y, rows_per_chunk);
 }
 
-// one tick, descriptors by value (96 + NL x 344 bytes of kernel arguments)
+// one tick, descriptors by value (96 + NL x 368 bytes of kernel arguments)
 template <int NL>
 struct StreamOne {
     DTick t;

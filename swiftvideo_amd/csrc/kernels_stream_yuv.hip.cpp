@@ -1085,7 +1085,7 @@ void tick_yuv_stream(const DTick *__restrict__ ticks, const DLayer *__restrict__
     ys_body<TF, NL, KINDS, false>(ticks, layers, n_ticks, strips_x, chunks_y, rows_per_chunk, wave_bytes);
 }
 
-// one tick, descriptors by value (96 + NL x 344 bytes of kernel arguments): no descriptor copy in front of a lone tick's launch, no
+// one tick, descriptors by value (96 + NL x 368 bytes of kernel arguments): no descriptor copy in front of a lone tick's launch, no
 // tick -> first_layer -> layer chain of dependent loads in front of its waves
 template <int NL>
 struct YsOne {
