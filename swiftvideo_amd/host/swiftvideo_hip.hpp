@@ -334,6 +334,23 @@ inline PictureSample downloadComputePicture(const ComputeContext &ctx, const Pic
     return r;
 }
 
+// The D2H half of a download barrier that overlaps the next tick (chv_download_async; swift/compute.hip.swift::downloadComputePictureAsync): the
+// picture's planes, tightly packed one after the other, into PINNED host memory (chv_host_alloc); the bytes are there once the context's stream
+// has passed the copies — endComputePass(ctx, true), or an event recorded behind them.  Returns the bytes the picture takes.
+inline size_t downloadComputePictureAsync(const ComputeContext &ctx, const PictureSample &pict, void *pinned) {
+    if (pict.bufferType() != BufferType::gpu || !pict.img) throw ComputeError(CHV_ERR_BAD_INPUT, "Missing device image");
+    const ImageBuffer &image = *pict.img;
+    size_t offset = 0;
+    for (size_t i = 0; i < image.computeTextures.size(); i++) {
+        const Plane &p = image.planes[i];
+        const size_t rowBytes = (size_t)p.size.x * (size_t)planeComponents(p), rows = (size_t)p.size.y;
+        check(chv_download_async(ctx.get(), (uint8_t *)pinned + offset, rowBytes, image.computeTextures[i]->handle, image.gpuOffsets[i],
+                                 image.gpuPitches[i], rowBytes, rows));
+        offset += rowBytes * rows;
+    }
+    return offset;
+}
+
 // ---- kernels (compute.swift:76-86,145-170; compute.cl.swift:250-344) ------------------------------
 using ImageUniforms = chv_uniforms;        // 236 bytes, same layout as the Swift struct
 

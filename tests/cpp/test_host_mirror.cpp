@@ -194,6 +194,27 @@ static void gpuTests() {
             auto da = down(a.value), db = down(b.value);
             EXPECT(da.kind == da.just && samePlanes(da.value, exp));
             EXPECT(db.kind == db.just && samePlanes(db.value, exp));
+            // the same canvas through the asynchronous download: packed planes in pinned memory, complete after the pass's wait
+            void *pinned = nullptr;
+            EXPECT(chv_host_alloc(ctx.get(), (size_t)CW * CH * 2, &pinned) == 0);
+            if (pinned) {
+                std::memset(pinned, 0xA5, (size_t)CW * CH * 2);
+                sv::beginComputePass(ctx);
+                const size_t n = sv::downloadComputePictureAsync(ctx, a.value, pinned);
+                sv::endComputePass(ctx, true);
+                EXPECT(n == (size_t)CW * CH * 3 / 2);
+                bool same = true;
+                size_t off = 0;
+                for (size_t i = 0; i < exp.img->planes.size(); i++) {
+                    const sv::Plane &p = exp.img->planes[i];
+                    const size_t rb = (size_t)p.size.x * (size_t)sv::planeComponents(p);
+                    for (int y = 0; y < (int)p.size.y; y++)
+                        same = same && std::memcmp((const uint8_t *)pinned + off + (size_t)y * rb, exp.img->buffers[i]->data() + (size_t)y * p.stride, rb) == 0;
+                    off += rb * (size_t)p.size.y;
+                }
+                EXPECT(same);
+                EXPECT(chv_host_free(ctx.get(), pinned) == 0);
+            }
         }
         // a layer format the target has no kernel for surfaces as an event error (mix.video.swift:133-137)
         if (fmt == sv::PixelFormat::y420p) {
