@@ -682,9 +682,25 @@ extern "C" int chv_download(chv_context *c, void *dst, size_t dst_pitch, chv_buf
 // OTHER contexts that writes `src` (the mixer's tick) is ordered in front of it with chv_event_record there and chv_event_wait here, as
 // between any two contexts: a download barrier running on a context of its own (GPUBarrierDownload, compute.swift:217-255) then overlaps the
 // D2H copy of tick t with the kernels of tick t + 1.
+// `dst` must be pinned (chv_host_alloc, or memory the caller registered with the runtime): into pageable memory the runtime stages the copy and
+// blocks the host, and "valid once the stream has passed the copy" holds only loosely — such a destination gets the synchronous path instead
+// (the bytes are there when the call returns; nothing the caller does afterwards can be wrong).
+static bool host_range_is_pinned(const void *p, size_t bytes) {
+    if (!p || bytes == 0) return false;
+    for (const uint8_t *q : { (const uint8_t *)p, (const uint8_t *)p + bytes - 1 }) {
+        hipPointerAttribute_t a;
+        memset(&a, 0, sizeof a);
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
 extern "C" int chv_download_async(chv_context *c, void *dst, size_t dst_pitch, chv_buffer *src,
                                   size_t src_offset, size_t src_pitch, size_t width_bytes, size_t rows) {
-    return download_enqueue(c, dst, dst_pitch, src, src_offset, src_pitch, width_bytes, rows);
+    int rc = download_enqueue(c, dst, dst_pitch, src, src_offset, src_pitch, width_bytes, rows);
+    if (rc) return rc;
+    if (rows && width_bytes && !host_range_is_pinned(dst, (rows - 1) * dst_pitch + width_bytes)) HIP_TRY(hipStreamSynchronize(c->stream));
+    return CHV_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -846,6 +862,11 @@ static void layer_bbox(DLayer *L, int W, int H) {
         for (double v : { a, b, c, d, tx, ty }) { if (!(v - v == 0.0)) return; big = std::max(big, std::fabs(v)); }
         const double det = a * d - b * c;
         if (!(big < 1048576.0) || !(std::fabs(det) > 1e-9 * std::max(1.0, big * big))) return;
+        // The device evaluates b = A n + t in float (error ~ 4e-7 big) and the box is the image of [0,1]^2 under A^-1, which amplifies that by
+        // ~ big / |det|: the float-accepted pixels can stick out of the double parallelogram by ~ 8e-7 big^2 / |det| * W / 2 pixels — more than
+        // the 2-pixel margin once big^2 / |det| passes a few thousand (thin or strongly sheared layers with a large translation term).  Those keep
+        // the whole canvas, as every such layer did before round 4.
+        if (!(big * big / std::fabs(det) < 1e3)) return;
         double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
         for (int k = 0; k < 4; k++) {
             const double u = (k & 1) - tx, v = (k >> 1) - ty;
@@ -891,6 +912,12 @@ static void layer_inner_box(DLayer *L, int W, int H, int target_format) {
         *lo = std::max(*lo, std::ceil(a) + 2.0); *hi = std::min(*hi, std::floor(b) - 2.0);
     };
     const double t3 = T[15];
+    // The device evaluates u = fl(fl(t0 X0) + fl(t3 X3)) in float; with large, mutually cancelling terms its error can exceed the 2-pixel
+    // shrink, and a strip judged covered would drop the layers beneath pixels that are in fact outside the texture range.  Modest magnitudes only
+    // (the animator's matrices are O(canvas / picture): single digits to a few hundred).
+    for (double m : { (double)T[3] * X[0], t3 * X[3], (double)T[7] * X[5], t3 * X[7], (double)T[3], (double)T[7], (double)B[3], (double)B[7],
+                      (double)T[0] * X[0], (double)T[5] * X[5], (double)B[0], (double)B[5] })
+        if (!(std::fabs(m) < 1e3)) return;
     double xl = 0.0, xh = W, yl = 0.0, yh = H;
     inner(B[0], B[3], W, &xl, &xh); inner(T[0], T[3], W, &xl, &xh); inner((double)T[0] * X[0], (double)T[3] * X[0] + t3 * X[3], W, &xl, &xh);
     inner(B[5], B[7], H, &yl, &yh); inner(T[5], T[7], H, &yl, &yh); inner((double)T[5] * X[5], (double)T[7] * X[5] + t3 * X[7], H, &yl, &yh);

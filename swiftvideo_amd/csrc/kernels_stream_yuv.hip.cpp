@@ -1198,7 +1198,10 @@ bool yuv_stream_eligible(int tf, const DTick *ticks, const DLayer *layers, int n
             const double kx = 2.0 * (double)Y.u[U_TRANSFORM + 0] * (double)Y.u[U_TEXTURE + 0], ky = 2.0 * (double)Y.u[U_TRANSFORM + 5] * (double)Y.u[U_TEXTURE + 5];
             if (!(kx > 0.0) || !(ky > 0.0)) return false;                                   // flips: the rings assume rising positions
             const double sxr = kx * Y.src.pl[0].w / (double)T.W, syr = ky * Y.src.pl[0].h / (double)T.H;
-            if (!std::isfinite(sxr) || !std::isfinite(syr) || syr > 2.2) return false;        // (an 8-row step's tap rows inside the 24-row luma ring)
+            // An 8-row step asks the 24-row luma ring for the rows ry(row 0) .. ry(row 7) + 1, and ring_ensure holds hi - lo <= ROWS - B = 16:
+            // ry(7) - ry(0) <= ceil(7 * syr) must stay <= 15, i.e. syr < 15 / 7 = 2.143 (at 2.2 a step could span 17 rows and row 7 would tap a
+            // slot already holding the row 24 below: stale luma).  2.1 is the bound the fixed cases and the fuzzers exercise.
+            if (!std::isfinite(sxr) || !std::isfinite(syr) || syr > 2.1) return false;
             // bytes of a ring row a strip's taps span: 63 steps + tap 1 + rounding slack, the start's alignment
             if (rgb) { if (!((63.0 * sxr + 3.0) * 4.0 + 12.0 <= 320.0)) return false; }
             else {

@@ -149,6 +149,12 @@ def test_yuv_stream_eligibility(ctx):
     assert run_tick(ctx, "y420p", 256, 66, [("img_y420p_y420p", 256, 64, dict())], expect=None) == wave
     assert run_tick(ctx, "y420p", 128, 64, [("img_y420p_y420p", 256, 64, dict())], expect=None) == wave                # 2 : 1 across
     assert run_tick(ctx, "y420p", 256, 40, [("img_y420p_y420p", 256, 96, dict())], expect=None) == wave                # 2.4 : 1 down
+    # between the tested 2.1 and the ring's arithmetic limit 15 / 7: an 8-row step may span 17 source rows at 2.2 — declined
+    assert run_tick(ctx, "y420p", 256, 40, [("img_y420p_y420p", 256, 86, dict())], expect=None) == wave                # 2.15 : 1 down
+    assert run_tick(ctx, "y420p", 256, 40, [("img_y420p_y420p", 256, 88, dict())], expect=None) == wave                # 2.2 : 1 down
+    for sh in (86, 88):                                                                                                # ... also as lone ticks (the default transient route)
+        run_tick(ctx, "y420p", 256, 40, [("img_y420p_y420p", 256, sh, dict())], expect=None, lone=True)
+    run_tick(ctx, "nv12", 1920, 496, [("img_nv12_nv12", 1920, 1080, dict())], expect=None, lone=True)                    # the advisor's example: 1080 rows into 496
     assert run_tick(ctx, "y420p", 192, 64, [("img_bgra_y420p", 256, 64, dict())], expect=None) == wave                  # RGB texels: 1.33 across
     assert run_tick(ctx, "y420p", 256, 64, [own] * 5, expect=None) == wave
     assert run_tick(ctx, "y420p", 256, 64, [own] * 4, expect=None) == wave
