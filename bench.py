@@ -131,6 +131,8 @@ def parse_args(argv=None):
     ap.add_argument("--upload-streams", type=int, default=2, help="upload streams (contexts) in the upload-inclusive leg")
     ap.add_argument("--no-per-tick", action="store_true", help="skip the one-tick-at-a-time legs (pipeline_per_tick, pipeline_reference_sequence)")
     ap.add_argument("--per-tick", action="store_true", help="run the one-tick-at-a-time legs even with --also none")
+    ap.add_argument("--route-regret", action="store_true", help="run the route-regret leg even with --also none (for the headline workload)")
+    ap.add_argument("--no-route-regret", action="store_true", help="skip the route-regret leg of the default run")
     ap.add_argument("--alias", default="none", choices=("none", "src", "dst", "both"),
                     help="DIAGNOSTIC (single-layer YUV workloads): every tick reads frame 0's source and/or writes frame 0's "
                          "canvas, so that side of the traffic stays in cache; the line is marked and is not a benchmark result")
@@ -1240,6 +1242,75 @@ def run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p", seconds=0.3, ring
     }
 
 
+# Routes a batch can take, as switch settings (chv_debug_set_switch); every one gives the oracle's bytes (tests/test_gpu_fuzz.py forces each),
+# so the only question is which is fastest — and whether the library's own choice (no switch set) is that one.
+ROUTES_BGRA = [("stream_off", {"CHV_STREAM": "0"}), ("stream_forced", {"CHV_BGRA_PATH": "stream"}), ("tiled", {"CHV_BGRA_PATH": "tiled"}),
+               ("strip_8_rows", {"CHV_BGRA_PATH": "wave", "CHV_WAVE_ROWS": "8"}), ("strip_16_rows", {"CHV_BGRA_PATH": "wave", "CHV_WAVE_ROWS": "16"})]
+ROUTES_420 = [("yuv_stream_off_8_rows", {"CHV_YUV_STREAM": "0", "CHV_WAVE_ROWS": "8"}), ("yuv_stream_off_16_rows", {"CHV_YUV_STREAM": "0", "CHV_WAVE_ROWS": "16"}),
+              ("yuv_stream_forced", {"CHV_YUV_STREAM": "force"})]
+
+
+def run_route_regret(args, sv, cv, lib, ctx, names, seconds=0.12, rounds=2):
+    """For each workload: the batch as the library routes it, and the same ticks (same device buffers, a new chv_batch_create under
+    switches) through every other route that accepts them; ms per launch between stream events, routes interleaved, best of `rounds`.
+    regret = t(chosen) / t(best) - 1.  The general kernels (the fallback of everything) are not a choice and are left out."""
+    dev = HipDevice(cv, lib, ctx)
+    out = {}
+    for name in names:
+        wl = WORKLOADS[name]
+        w = build_workload(sv, ctx, wl, wl["frames"], seed_base=0x5EED0000 + 16 * 3)
+        n = len(w["ticks"])
+        routes = [("chosen", {}, w["batch"], w["kernel"], w.get("launches_per_batch", 1))]
+        seen = {(w["kernel"], w.get("launches_per_batch", 1), None)}
+        for label, sw in (ROUTES_420 if wl["kind"] == "mixer420" else ROUTES_BGRA):
+            for k, v in sw.items():
+                cv.set_switch(k, v)
+            b = C.c_void_p()
+            rc = lib.chv_batch_create(ctx.handle, w["ticks"], n, C.byref(b))
+            for k in sw:
+                cv.set_switch(k, None)
+            if rc != 0:
+                continue
+            kname = C.create_string_buffer(128)
+            nl = C.c_int(1)
+            cv.check(lib.chv_batch_describe(b, kname, 128, C.byref(nl)))
+            kn = kname.value.decode()
+            rows = sw.get("CHV_WAVE_ROWS") if "wave" in kn else None           # (strip height only matters where a strip kernel runs)
+            if "general" in kn or (kn, nl.value, rows) in seen or (rows is None and any(s[0] == kn and s[1] == nl.value for s in seen)):
+                cv.check(lib.chv_batch_destroy(b))
+                continue
+            seen.add((kn, nl.value, rows))
+            routes.append((label, sw, b, kn, nl.value))
+        times = {r[0]: float("inf") for r in routes}
+        e0, e1 = dev.event(), dev.event()
+        for r in routes:                                                        # warm up every route once
+            cv.check(lib.chv_batch_run(ctx.handle, r[2]))
+        dev.sync()
+        for _ in range(rounds):
+            for label, sw, b, kn, nl in routes:
+                reps, el = 2, 0.0
+                while True:
+                    dev.record(e0)
+                    for _ in range(reps):
+                        cv.check(lib.chv_batch_run(ctx.handle, b))
+                    dev.record(e1)
+                    dev.sync()
+                    el = dev.elapsed_ms(e0, e1)
+                    if el >= seconds * 1e3 or reps >= 4096:
+                        break
+                    reps = max(reps * 2, int(reps * seconds * 1e3 / max(el, 1e-3)) + 1)
+                times[label] = min(times[label], el / reps)
+        dev.destroy(e0); dev.destroy(e1)
+        for r in routes[1:]:
+            cv.check(lib.chv_batch_destroy(r[2]))
+        best = min(times, key=times.get)
+        out[name] = {"chosen": routes[0][3], "chosen_ms": round(times["chosen"], 4), "best": best if best != "chosen" else "chosen",
+                     "best_kernel": next(r[3] for r in routes if r[0] == best), "regret": round(times["chosen"] / times[best] - 1.0, 4),
+                     "routes_ms": {r[0]: [round(times[r[0]], 4), r[3]] for r in routes}}
+        free_workload(w)
+    return out
+
+
 def run_threads(args):
     """--gpus N --threads: N host threads in THIS process, thread r with its own compute context on device r (or --device); the threads meet at
     a barrier around the timed region exactly as the ranks of the process-per-GPU mode do, rank 0 prints the line"""
@@ -1326,6 +1397,9 @@ def run_rank(args, rank, local, world, dist):
         reports.update(run_per_tick(args, sv, cv, lib, ctx))
         reports.update(run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p"))
         reports.update(run_thread_scaling(args, sv, cv, lib, ctx))
+    regret = None
+    if (others or args.route_regret) and not args.stub_device and not args.no_route_regret and n_gpus == 1:
+        regret = run_route_regret(args, sv, cv, lib, ctx, [n for n in ([args.workload] + others) if n in WORKLOADS])
 
     if rank == 0:
         wl = WORKLOADS[args.workload]
@@ -1369,10 +1443,24 @@ def run_rank(args, rank, local, world, dist):
                                       f"buses per device, bus s -> device s mod {n_gpus}; no collective",
                        "per_gpu_gpix": head["per_gpu_gpix"], "per_stream_ticks_per_s": head["per_stream_ticks_per_s"],
                        "kernel": head["kernel"], "verified_vs_oracle": head["verified_vs_oracle"],
-                       "build_flags": None if args.stub_device else cv.build_flags()},
+                       "build_flags": None if args.stub_device else cv.build_flags(),
+                       # every workload of the run where the driver's parser keeps it: name -> [fraction of the 8 TB/s HBM peak, ms per launch, kernel]
+                       "workload_fracs": {k: [round(v["roofline"]["frac"], 4), round(v["launch_ms"], 4), v["kernel"]] for k, v in reports.items() if "roofline" in v},
+                       "legs": {**{k + "_us_per_tick": round(v["us_per_tick"], 2) for k, v in reports.items() if "us_per_tick" in v},
+                                **({"pipeline_e2e_ticks_per_s": round(reports["pipeline_e2e"]["ticks_per_s"], 1),
+                                    "pipeline_e2e_h2d_GBps": round(reports["pipeline_e2e"]["h2d_GBps_per_gpu"], 2)} if "pipeline_e2e" in reports else {}),
+                                **({"cfg2_upload_h2d_GBps": round(reports["cfg2_upload"]["h2d_GBps_per_gpu"], 2),
+                                    "pinned_numa_node": reports["cfg2_upload"]["pinned_numa_node"]} if "cfg2_upload" in reports else {}),
+                                **({"native_fused_speedup_8_threads": round(reports["per_tick_thread_scaling"]["native_fused_speedup_8_threads"], 2)}
+                                   if "per_tick_thread_scaling" in reports and "native_fused_speedup_8_threads" in reports["per_tick_thread_scaling"] else {})},
+                       # is the kernel the library picks for each workload the fastest of the routes that accept it?  regret = t(chosen) / t(best) - 1
+                       "route_regret": None if regret is None else {k: {"chosen": v["chosen"], "best": v["best"], "regret": v["regret"]} for k, v in regret.items()},
+                       "route_regret_max": None if not regret else max(v["regret"] for v in regret.values())},
             "roofline": roof,
             "workloads": {k: {kk: vv for kk, vv in v.items() if kk not in ("source_mpix_per_launch_per_gpu",)} for k, v in reports.items()},
         }
+        if regret is not None:
+            out["workloads"]["route_regret"] = regret
         if args.stub_device:
             out["data"] = "STUB --stub-device: launches are sleeps; control-plane self-test, not a benchmark result"
             out["roofline"]["frac"] = None

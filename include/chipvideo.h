@@ -82,8 +82,8 @@ typedef enum chv_kernel {
     CHV_K_IMG_CLEAR_RGBA = 10,  /* name resolves to CLEAR_BGRA, compute.swift:101 */
     CHV_K_IMG_RGBA_Y420P = 11,
     CHV_K_IMG_BGRA_Y420P = 12,
-    CHV_K_SND_S16I_S16I = 13,   /* not part of the picture path */
-    CHV_K_ME_FULLSEARCH = 14,   /* not part of the picture path */
+    CHV_K_SND_S16I_S16I = 13,   /* audio mix; chv_snd_uniforms below */
+    CHV_K_ME_FULLSEARCH = 14,   /* block motion search; chv_me_uniforms below */
     /* Kernels VideoMixer.findKernel can name (mix.video.swift:142-146) but no
      * reference backend implements; specification in DESIGN.md section 4. */
     CHV_K_IMG_NV12_BGRA = 32,
@@ -238,6 +238,27 @@ typedef struct chv_kernel_opts {
     int32_t colorspace;   /* chv_colorspace; YUV->BGRA kernels only */
     int32_t reserved[3];
 } chv_kernel_opts;
+
+/* Uniforms of the two kernels of `enum ComputeKernel` no caller of the reference dispatches (compute.swift:67,70); both run through
+ * chv_run_kernel in the reference's bind order [outputs][inputs][uniforms] (compute.cl.swift:288-327):
+ *   CHV_K_SND_S16I_S16I (kernels.cl.swift:534-562)  target: ONE plane of 2-byte texels = interleaved-stereo int16 samples (width x height
+ *       samples; rows contiguous when height > 1), updated in place (out[gid] += ...); inputs: inputCount..8 images of the same shape;
+ *       uniforms: the 100-byte chv_snd_uniforms.  A float product below -32768 wraps as on the CPU the kernel string was compiled for
+ *       (OpenCL leaves it undefined; oracle/ref_kernels.c::snd_cvt).
+ *   CHV_K_ME_FULLSEARCH (kernels.metal:129-267)  target: one RGBA8 texel per block, (mv.x, 0.5, mv.y, 1) normalised to [0, 1]; inputs[0] =
+ *       reference picture, inputs[1] = current picture (plane 0 of each, 1-component: the luma plane of an NV12 / y420p picture);
+ *       uniforms: the 24-byte chv_me_uniforms, blockSize 1..64.  Bit-for-bit the Metal source, its sliding-window SAD included. */
+typedef struct chv_snd_uniforms {     /* BufferUniforms, kernels.cl.swift:536-541 */
+    int32_t input_count;
+    int32_t input_offsets[8];         /* (not read by the kernel) */
+    float input_gains[8];
+    float input_fade[8];
+} chv_snd_uniforms;
+typedef struct chv_me_uniforms {      /* MotionEstimationUniforms, kernels.metal:33-37 */
+    int32_t block_size[2];
+    int32_t search_window_size[2];
+    int32_t image_size[2];
+} chv_me_uniforms;
 
 /* ---- compute passes ----------------------------------------------------- */
 /* beginComputePass, compute.cl.swift:234-237 */

@@ -183,3 +183,15 @@ int clref_run(const char *name, const shim_image *t, int nt, const shim_image *i
     }
     return 0;
 }
+
+/* snd_s16i_s16i (kernels.cl.swift:534-562): buffers, a 1-D range of n work-items; the kernel needs get_global_id and min from above only.
+ * Unused input pointers may be NULL (the kernel indexes inputs[i] for i < inputCount only). */
+void snd_s16i_s16i(short *, const void *, short *, short *, short *, short *, short *, short *, short *, short *);
+int clref_run_snd(short *out, int n, short *const *in, const void *uniforms) {
+    g_gsize[0] = (unsigned)n; g_gsize[1] = 1;
+    for (int gid = 0; gid < n; gid++) {
+        g_gid[0] = (unsigned)gid; g_gid[1] = 0;
+        snd_s16i_s16i(out, uniforms, in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7]);
+    }
+    return 0;
+}

@@ -75,6 +75,12 @@ def lib():
         _lib.orc_yuv2rgb_int.argtypes = [C.c_int, C.c_uint8, C.c_uint8, C.c_uint8, C.c_void_p]
         _lib.orc_rgb2yuv_int.restype = None
         _lib.orc_rgb2yuv_int.argtypes = [C.c_int, C.c_uint8, C.c_uint8, C.c_uint8, C.c_void_p]
+        _lib.orc_snd_s16i_s16i.restype = C.c_int
+        _lib.orc_snd_s16i_s16i.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
+        _lib.orc_me_fullsearch.restype = C.c_int
+        _lib.orc_me_fullsearch.argtypes = [C.POINTER(Plane), C.POINTER(Plane), C.POINTER(Plane), C.c_void_p]
+        _lib.orc_me_cost_table.restype = None
+        _lib.orc_me_cost_table.argtypes = [C.c_void_p, C.c_int]
     return _lib
 
 
@@ -93,6 +99,9 @@ def clref():
         _clref = C.CDLL(str(p))
         _clref.clref_run.restype = C.c_int
         _clref.clref_run.argtypes = [C.c_char_p, C.POINTER(Plane), C.c_int, C.POINTER(Plane), C.c_int, C.c_void_p]
+        if hasattr(_clref, "clref_run_snd"):
+            _clref.clref_run_snd.restype = C.c_int
+            _clref.clref_run_snd.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
     return _clref
 
 
@@ -160,3 +169,51 @@ def rgb2yuv_int(csc, r, g, b):
     out = (C.c_uint8 * 3)()
     lib().orc_rgb2yuv_int(csc, r, g, b, out)
     return tuple(out)
+
+
+def snd_uniforms(gains, fades, offsets=None):
+    """BufferUniforms, kernels.cl.swift:536-541: int inputCount; int inputOffsets[8]; float inputGains[8]; float inputFade[8] (100 bytes)"""
+    n = len(gains)
+    u = np.zeros(25, dtype=np.int32)
+    u[0] = n
+    if offsets is not None:
+        u[1:1 + n] = offsets
+    u[9:9 + n] = np.asarray(gains, dtype=np.float32).view(np.int32)
+    u[17:17 + n] = np.asarray(fades, dtype=np.float32).view(np.int32)
+    return u
+
+
+def _snd(fn, out, inputs, uniforms):
+    assert out.dtype == np.int16 and out.ndim == 1 and out.flags.c_contiguous
+    ptrs = (C.c_void_p * 8)()
+    for i, a in enumerate(inputs):
+        assert a.dtype == np.int16 and a.shape == out.shape and a.flags.c_contiguous
+        ptrs[i] = a.ctypes.data
+    u = np.ascontiguousarray(uniforms, dtype=np.int32)
+    assert u.size == 25
+    return fn(out.ctypes.data, out.size, ptrs, u.ctypes.data)
+
+
+def snd_s16i_s16i(out, inputs, uniforms):
+    """out (int16, interleaved stereo) += the mix of `inputs`, in place"""
+    return _snd(lib().orc_snd_s16i_s16i, out, inputs, uniforms)
+
+
+def clref_snd_s16i_s16i(out, inputs, uniforms):
+    l = clref()
+    if l is None or not hasattr(l, "clref_run_snd"):
+        raise RuntimeError("libclref.so (with snd_s16i_s16i) not built")
+    return _snd(l.clref_run_snd, out, inputs, uniforms)
+
+
+def me_fullsearch(out, ref, cur, block, window, image_size=None):
+    """out: (blocks down, blocks across, 4) uint8, written in place; ref / cur: (h, w) uint8 luma planes"""
+    u = np.array([block[0], block[1], window[0], window[1]] + list(image_size or (cur.shape[1], cur.shape[0])), dtype=np.int32)
+    o, r, c = _planes([out]), _planes([ref]), _planes([cur])
+    return lib().orc_me_fullsearch(o, r, c, u.ctypes.data)
+
+
+def me_cost_table(n=256):
+    t = np.zeros(n, dtype=np.float32)
+    lib().orc_me_cost_table(t.ctypes.data, n)
+    return t

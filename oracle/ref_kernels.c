@@ -702,3 +702,115 @@ int orc_lanczos_bgra(const orc_plane *dst, const orc_plane *src, int threads) {
     free(fx); free(fy); free(wx); free(wy); free(tmp);
     return rc;
 }
+
+/* ------------------------------------------------------------------------ */
+/* The two idle kernels of `enum ComputeKernel` (compute.swift:67,70; no caller in the reference dispatches them)   */
+/* ------------------------------------------------------------------------ */
+
+/* snd_s16i_s16i, kernels.cl.swift:534-562.  One work-item per interleaved-stereo sample:
+ *   channel = gid % 2
+ *   for i < inputCount:  value = min((float)in_i[gid] * gain_i * (channel == 0 ? 1 - fade_i : fade_i), 32767.f);  out[gid] += (short)value
+ * Products left to right, no contraction.  `min` only caps the top (:557), so a value below -32768 reaches the conversion: OpenCL C leaves
+ * float -> short out of range undefined; fixed here as what the compiled kernel string does on x86-64 (and the HIP kernel on gfx950): convert
+ * to int32 toward zero (out of int32 range and NaN: INT32_MIN) and keep the low 16 bits.  The += wraps modulo 2^16.  inputOffsets is not read
+ * by the kernel (:548-560). */
+INL int16_t snd_cvt(float v) {
+    int32_t i = (v >= -2147483648.0f && v < 2147483648.0f) ? (int32_t)v : INT32_MIN;   /* cvttss2si; NaN fails both tests */
+    return (int16_t)(uint16_t)(uint32_t)i;
+}
+int orc_snd_s16i_s16i(int16_t *out, int n, const int16_t *const *in, const orc_snd_uniforms *u) {
+    if (!out || !u || n < 0 || u->inputCount < 0 || u->inputCount > 8) return ORC_ERR_INVALID_VALUE;
+    for (int i = 0; i < u->inputCount; i++) if (!in || !in[i]) return ORC_ERR_BAD_INPUT;
+    for (int gid = 0; gid < n; gid++) {
+        int channel = gid % 2;
+        for (int i = 0; i < u->inputCount; i++) {
+            float k = channel == 0 ? 1.f - u->inputFade[i] : u->inputFade[i];
+            float x = (float)in[i][gid] * u->inputGains[i] * k;
+            float value = 32767.f < x ? 32767.f : x;                     /* min(x, y) = y < x ? y : x, OpenCL 1.2 6.12.4 */
+            out[gid] = (int16_t)(uint16_t)((uint16_t)out[gid] + (uint16_t)snd_cvt(value));
+        }
+    }
+    return ORC_OK;
+}
+
+/* me_fullsearch, kernels.metal:129-267 (Metal only; restated by hand).  One thread per block of the CURRENT picture: every candidate
+ * position of the block inside the search area of the REFERENCE picture is scored as deltaCost2(mv) + SAD * 256 (:236-237), candidates
+ * visited column by column, top to bottom (:229-256), the first strict minimum kept (:241); the clamped vector is normalised to
+ * [0, 1] and written as (mv.x, 0.5, mv.y, 1) (:262-264).
+ *
+ * Faithful to the source INCLUDING its sliding-window SAD (:152-166): when the previous candidate's top-row SAD is > 0 the function
+ * sums the new top row, then runs a second loop for the bottom row whose counters were left at the end by the first — it adds nothing —
+ * and returns previousSad - previousSide.  A clean full search is NOT what the reference computes.
+ * Texel reads are R8Unorm -> c / 255.0f (ld8); reads outside a picture (an origin block hanging over the right / bottom edge) return 0
+ * (Metal leaves them undefined).  Sums accumulate in float in source order: row-major over the block (:168-183).
+ * deltaCost2 (:135-142) goes through log2: the table of per-component costs is built by the HOST's log2f for both the oracle and the
+ * product (the HIP kernel receives the same table), so that no device libm enters the comparison. */
+static float me_component_cost(int d) {           /* lambda * (log2(|v| + 1) * 2 + 0.718 + (v != 0)) + 0.5, :136-141 */
+    const float lambda = 4.0f;
+    float l2 = log2f((float)d + 1.0f);
+    float rounding = d != 0 ? 1.0f : 0.0f;
+    return lambda * (l2 * 2.0f + 0.718f + rounding) + 0.5f;
+}
+void orc_me_cost_table(float *table, int n) { for (int d = 0; d < n; d++) table[d] = me_component_cost(d); }
+INL float me_rd(const orc_plane *p, int x, int y) { return (x >= 0 && y >= 0 && x < p->w && y < p->h) ? ld8(texel(p, x, y)[0]) : 0.0f; }
+typedef struct { float side, sad; } me_sad_t;
+static me_sad_t me_sad(const int b1[4], const int b2[4], const orc_plane *t1, const orc_plane *t2, float prevSide, float prevSad) {
+    int p1x = b1[0], p1y = b1[1], p2x = b2[0], p2y = b2[1];
+    float sum = 0.f, top = 0.f;
+    if (prevSide > 0.f) {
+        float bottom = 0.f;
+        for (; p1x < b1[2] && p2x < b2[2]; p1x++, p2x++) top += fabsf(me_rd(t1, p1x, b1[1]) - me_rd(t2, p2x, b2[1]));
+        for (; p1x < b1[2] && p2x < b2[2]; p1x++, p2x++) bottom += fabsf(me_rd(t1, p1x, b1[3] - 1) - me_rd(t2, p2x, b2[3] - 1));   /* (never entered) */
+        sum = prevSad - prevSide + bottom;
+    } else {
+        while (p1y < b1[3] && p2y < b2[3]) {
+            p1x = b1[0]; p2x = b2[0];
+            while (p1x < b1[2] && p2x < b2[2]) {
+                float d = fabsf(me_rd(t1, p1x, p1y) - me_rd(t2, p2x, p2y));
+                sum += d;
+                if (p1y == b1[1] && p2y == b2[1]) top += d;
+                p1x++; p2x++;
+            }
+            p1y++; p2y++;
+        }
+    }
+    me_sad_t r = { top, sum };
+    return r;
+}
+INL int me_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }     /* Metal clamp(x, lo, hi) = min(max(x, lo), hi) */
+INL float me_clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+int orc_me_fullsearch(const orc_plane *out, const orc_plane *ref, const orc_plane *cur, const orc_me_uniforms *u) {
+    if (!plane_ok(out, 4)) return ORC_ERR_BAD_TARGET;
+    if (!plane_ok(ref, 1) || !plane_ok(cur, 1) || !u) return ORC_ERR_BAD_INPUT;
+    const int bsx = u->blockSize[0], bsy = u->blockSize[1];
+    if (bsx < 1 || bsy < 1 || bsx > 64 || bsy > 64 || u->searchWindowSize[0] < 0 || u->searchWindowSize[1] < 0) return ORC_ERR_INVALID_VALUE;
+    float cost[256];
+    orc_me_cost_table(cost, 256);
+    const int swx = u->searchWindowSize[0] < 64 ? u->searchWindowSize[0] : 64, swy = u->searchWindowSize[1] < 64 ? u->searchWindowSize[1] : 64;   /* MAX_SEARCH_SIZE */
+    const float maxx = (float)(u->searchWindowSize[0] / 2), maxy = (float)(u->searchWindowSize[1] / 2);
+    for (int by = 0; by < out->h; by++) for (int bx = 0; bx < out->w; bx++) {
+        const int ob[4] = { bx * bsx, by * bsy, bx * bsx + bsx, by * bsy + bsy };
+        const int left = me_clampi(ob[0] + bsx / 2 - swx / 2, 0, u->imageSize[0]), top = me_clampi(ob[1] + bsy / 2 - swy / 2, 0, u->imageSize[1]);
+        const int right = me_clampi(left + swx, 0, u->imageSize[0]), bottom = me_clampi(top + swy, 0, u->imageSize[1]);
+        int rb[4] = { left, top, left + bsx, top + bsy };
+        float bestScore = 3.402823466e+38f, bmx = 0.f, bmy = 0.f, side = 0.f, prev = 0.f;
+        while (rb[2] < right) {
+            rb[1] = top; rb[3] = rb[1] + bsy;
+            while (rb[3] < bottom) {
+                me_sad_t s = me_sad(ob, rb, cur, ref, side, prev);
+                const int mx = ob[0] - rb[0], my = ob[1] - rb[1];
+                const int ax = mx < 0 ? -mx : mx, ay = my < 0 ? -my : my;
+                const float score = 4.0f * (cost[ax > 255 ? 255 : ax] + cost[ay > 255 ? 255 : ay]) + s.sad * 256.0f;
+                prev = s.sad; side = s.side;
+                if (score < bestScore) { bestScore = score; bmx = me_clampf((float)mx, -maxx, maxx); bmy = me_clampf((float)my, -maxy, maxy); }
+                rb[1]++; rb[3]++;              /* (threshold = 0, :221: a score is never negative, no early exit) */
+            }
+            side = 0.f; prev = 0.f; rb[0]++; rb[2]++;
+        }
+        bmx = bmx / maxx; bmy = bmy / maxy;
+        bmx = bmx * 0.5f + 0.5f; bmy = bmy * 0.5f + 0.5f;
+        uint8_t *d = (uint8_t *)texel(out, bx, by);
+        d[0] = st8(bmx); d[1] = st8(0.5f); d[2] = st8(bmy); d[3] = st8(1.0f);
+    }
+    return ORC_OK;
+}

@@ -56,8 +56,8 @@ enum {
     ORC_IMG_CLEAR_RGBA = 10, /* compute.swift:101 maps the name to img_clear_bgra */
     ORC_IMG_RGBA_Y420P = 11, /* kernels.cl.swift:336-403 */
     ORC_IMG_BGRA_Y420P = 12, /* kernels.cl.swift:267-335 */
-    ORC_SND_S16I_S16I = 13,  /* out of scope */
-    ORC_ME_FULLSEARCH = 14,  /* out of scope */
+    ORC_SND_S16I_S16I = 13,  /* kernels.cl.swift:534-562: orc_snd_s16i_s16i (buffers, not images) */
+    ORC_ME_FULLSEARCH = 14,  /* kernels.metal:129-267: orc_me_fullsearch */
     /* spec owned by this repo */
     ORC_IMG_NV12_BGRA = 32,
     ORC_IMG_Y420P_BGRA = 33,
@@ -127,6 +127,15 @@ uint8_t orc_store_unorm8(float f);
 float orc_load_unorm8(uint8_t c);
 void orc_yuv2rgb_int(int csc, uint8_t y, uint8_t u, uint8_t v, uint8_t rgb[3]);
 void orc_rgb2yuv_int(int csc, uint8_t r, uint8_t g, uint8_t b, uint8_t yuv[3]);
+
+/* The two idle kernels (compute.swift:67,70).  BufferUniforms, kernels.cl.swift:536-541; MotionEstimationUniforms, kernels.metal:33-37. */
+typedef struct { int32_t inputCount; int32_t inputOffsets[8]; float inputGains[8]; float inputFade[8]; } orc_snd_uniforms;
+typedef struct { int32_t blockSize[2], searchWindowSize[2], imageSize[2]; } orc_me_uniforms;
+int orc_snd_s16i_s16i(int16_t *out, int n, const int16_t *const *in, const orc_snd_uniforms *u);
+/* out: one RGBA8 texel per block (w = blocks across, h = blocks down); ref, cur: 1-component planes */
+int orc_me_fullsearch(const orc_plane *out, const orc_plane *ref, const orc_plane *cur, const orc_me_uniforms *u);
+/* per-component motion-vector cost for |v| = 0 .. n-1 (deltaCost2, kernels.metal:135-142) through the host's log2f */
+void orc_me_cost_table(float *table, int n);
 
 #ifdef __cplusplus
 }

@@ -79,7 +79,15 @@ class Tick(C.Structure):
                 ("layers", C.POINTER(Layer))]
 
 
-assert C.sizeof(Uniforms) == 236
+class SndUniforms(C.Structure):      # BufferUniforms, kernels.cl.swift:536-541
+    _fields_ = [("input_count", C.c_int32), ("input_offsets", C.c_int32 * 8), ("input_gains", C.c_float * 8), ("input_fade", C.c_float * 8)]
+
+
+class MeUniforms(C.Structure):       # MotionEstimationUniforms, kernels.metal:33-37
+    _fields_ = [("block_size", C.c_int32 * 2), ("search_window_size", C.c_int32 * 2), ("image_size", C.c_int32 * 2)]
+
+
+assert C.sizeof(Uniforms) == 236 and C.sizeof(SndUniforms) == 100 and C.sizeof(MeUniforms) == 24
 
 _SIGNATURES = {
     # name: (restype, argtypes) — one entry per function declared in include/chipvideo.h

@@ -29,7 +29,7 @@ __all__ = [
     "destroyComputeContext", "beginComputePass", "endComputePass", "usingContext", "runComputeKernel",
     "applyComputeImage", "uploadComputePicture", "downloadComputePicture", "uploadComputeBuffer",
     "downloadComputeBuffer", "createPictureSample", "GPUBarrierUpload", "GPUBarrierDownload", "VideoMixer",
-    "compositeTick", "scaleLanczos", "LanczosBatch", "PictureFilter", "CustomKernel", "buildComputeKernel", "TickBatch", "VideoMixerGroup",
+    "compositeTick", "scaleLanczos", "LanczosBatch", "PictureFilter", "CustomKernel", "buildComputeKernel", "TickBatch", "VideoMixerGroup", "BufferImage",
 ]
 
 
@@ -477,7 +477,24 @@ class ImageUniforms:
         return u
 
 
+class BufferImage:
+    """A ComputeBuffer bound where a kernel expects an image: one plane of `width` x `height` texels of `components` bytes.  The two kernels of
+    `enum ComputeKernel` that work on buffers rather than pictures take these — snd_s16i_s16i (kernels.cl.swift:534-562: interleaved-stereo
+    int16 samples = 2-byte texels) — and me_fullsearch's output (one RGBA8 texel per block) may be one as well."""
+
+    def __init__(self, buffer, width, height=1, components=2, pitch=None, offset=0):
+        self.buffer, self.width, self.height, self.components = buffer, int(width), int(height), int(components)
+        self.pitch = int(pitch) if pitch else self.width * self.components
+        self.offset = int(offset)
+
+
 def _image_desc(sample, maxPlanes=3):
+    if isinstance(sample, BufferImage):
+        d = cv.Image()
+        d.format = cv.FMT_INVALID
+        d.width, d.height, d.n_planes = sample.width, sample.height, 1
+        d.planes[0] = cv.Plane(sample.buffer._h, sample.offset, sample.width, sample.height, sample.pitch, sample.components)
+        return d
     image = sample.imageBuffer()
     if image is None or image.bufferType != "gpu" or not image.computeTextures:
         return None
@@ -499,6 +516,10 @@ def _uniform_blob(uniforms):
         return None
     if isinstance(uniforms, ImageUniforms):
         return uniforms.blob()
+    if isinstance(uniforms, (bytes, bytearray)):          # any value type's bytes (MemoryLayout<T>.size are bound, compute.cl.swift:508-512)
+        return np.frombuffer(bytes(uniforms), dtype=np.uint8)
+    if isinstance(uniforms, np.ndarray) and uniforms.dtype != np.float32 and uniforms.dtype != np.float64:
+        return np.ascontiguousarray(uniforms).reshape(-1)   # e.g. the int32 / float32 words of BufferUniforms, MotionEstimationUniforms
     return np.ascontiguousarray(uniforms, dtype=np.float32).reshape(-1)
 
 

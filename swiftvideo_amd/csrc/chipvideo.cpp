@@ -48,6 +48,10 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,
                             const DTick *ticks, const DLayer *layers, int n_ticks,
                             int maxW, int maxH, hipStream_t stream);
+// kernels_idle.hip.cpp
+hipError_t launch_snd_s16i(int16_t *out, const int16_t *const *in, int count, int n, const float *gain, const float *fade, hipStream_t stream);
+hipError_t launch_me_fullsearch(const DPlane &out, const DPlane &ref, const DPlane &cur, const int32_t *block, const int32_t *window, const int32_t *image,
+                                const float *cost256, hipStream_t stream);
 // kernels_lanczos.hip.cpp
 hipError_t launch_lanczos(const DPlane &dst, const DPlane &src, const int32_t *fx, const float *wx,
                           int tx, const int32_t *fy, const float *wy, int ty, hipStream_t stream,
@@ -187,6 +191,9 @@ static const KernelName kNames[] = {
     { "img_rgba_bgra", CHV_K_IMG_RGBA_BGRA_TX },
     { "img_bgra_nv12_int", CHV_K_IMG_BGRA_NV12_INT }, { "img_rgba_nv12_int", CHV_K_IMG_RGBA_NV12_INT },
     { "img_bgra_y420p_int", CHV_K_IMG_BGRA_Y420P_INT }, { "img_rgba_y420p_int", CHV_K_IMG_RGBA_Y420P_INT },
+    // the two cases of the enum the reference's table leaves out (compute.swift:91-105; nothing dispatches them there): resolvable here, so that
+    // every case that has a kernel can be asked for by its name
+    { "snd_s16i_s16i", CHV_K_SND_S16I_S16I }, { "me_fullsearch", CHV_K_ME_FULLSEARCH },
 };
 
 extern "C" int chv_kernel_from_string(const char *name, int *kernel) {
@@ -740,9 +747,12 @@ static int kernel_shape(int kernel, KernelShape *s) {
     case CHV_K_IMG_CLEAR_NV12: s->is_clear = true; s->target_format = TF_NV12; break;
     case CHV_K_IMG_CLEAR_Y420P: s->is_clear = true; s->target_format = TF_Y420P; break;
     case CHV_K_IMG_CLEAR_BGRA: case CHV_K_IMG_CLEAR_RGBA: s->is_clear = true; s->target_format = TF_BGRA; break;
-    case CHV_K_IMG_CLEAR_YUVS: case CHV_K_SND_S16I_S16I: case CHV_K_ME_FULLSEARCH:
-        // enum cases for which no backend of the reference has a kernel either
+    case CHV_K_IMG_CLEAR_YUVS:
+        // an enum case for which no backend of the reference has a kernel either
         return fail(CHV_ERR_KERNEL_NOT_FOUND, "kernel %s has no implementation", chv_kernel_name(kernel));
+    case CHV_K_SND_S16I_S16I: case CHV_K_ME_FULLSEARCH:
+        // (not layer kernels: chv_run_kernel runs them directly, run_idle_kernel)
+        return fail(CHV_ERR_INVALID_OPERATION, "%s is not a picture-layer kernel: issue it through chv_run_kernel", chv_kernel_name(kernel));
     default:
         return fail(CHV_ERR_KERNEL_NOT_FOUND, "unknown kernel id %d", kernel);
     }
@@ -1109,12 +1119,74 @@ extern "C" int chv_pass_end(chv_context *c, int wait) {
     return CHV_OK;
 }
 
+// snd_s16i_s16i / me_fullsearch (kernels_idle.hip.cpp): buffers and luma planes bound as the reference binds them, no tick descriptors
+static int run_idle_kernel(chv_context *c, int kernel, const chv_image *target, const chv_image *inputs, int n_inputs,
+                           const void *uniforms, size_t uniforms_size) {
+    DepScope deps;
+    if (target->n_planes < 1) return fail(CHV_ERR_BAD_TARGET, "%s: target without planes", chv_kernel_name(kernel));
+    if (n_inputs < 0 || (n_inputs > 0 && !inputs)) return fail(CHV_ERR_BAD_INPUT, "null inputs");
+    for (int i = 0; i < n_inputs; i++) if (inputs[i].n_planes < 1) return fail(CHV_ERR_BAD_INPUT, "%s: input %d has no planes", chv_kernel_name(kernel), i);
+    int rc;
+    if (kernel == CHV_K_SND_S16I_S16I) {
+        if (!uniforms || uniforms_size != sizeof(chv_snd_uniforms))
+            return fail(CHV_ERR_INVALID_VALUE, "snd_s16i_s16i needs the 100-byte BufferUniforms, got %zu bytes", uniforms_size);
+        chv_snd_uniforms u;
+        memcpy(&u, uniforms, sizeof u);
+        if (u.input_count < 0 || u.input_count > 8) return fail(CHV_ERR_INVALID_VALUE, "snd_s16i_s16i: inputCount %d", u.input_count);
+        if (n_inputs < u.input_count) return fail(CHV_ERR_BAD_INPUT, "snd_s16i_s16i: inputCount %d, %d buffers given", u.input_count, n_inputs);
+        DPlane out;
+        if ((rc = plane_to_device(target->planes[0], 2, c->device, &out, CHV_ERR_BAD_TARGET, "target", 0))) return rc;
+        if (out.h > 1 && out.pitch != out.w * 2) return fail(CHV_ERR_BAD_TARGET, "snd_s16i_s16i: rows of samples must be contiguous");
+        if (((uintptr_t)out.ptr) & 1) return fail(CHV_ERR_BAD_TARGET, "snd_s16i_s16i: samples must be 2-byte aligned");
+        const int16_t *in[8] = { nullptr };
+        for (int i = 0; i < u.input_count; i++) {
+            DPlane p;
+            if ((rc = plane_to_device(inputs[i].planes[0], 2, c->device, &p, CHV_ERR_BAD_INPUT, "input", i))) return rc;
+            if (p.w != out.w || p.h != out.h || (p.h > 1 && p.pitch != p.w * 2) || (((uintptr_t)p.ptr) & 1))
+                return fail(CHV_ERR_BAD_INPUT, "snd_s16i_s16i: input %d does not have the output's shape", i);
+            in[i] = (const int16_t *)p.ptr;
+        }
+        auto dp = deps.deps();
+        HIP_TRY(hipSetDevice(c->device));
+        if ((rc = wait_for_uploads(c->stream, dp))) return rc;
+        HIP_TRY(launch_snd_s16i((int16_t *)out.ptr, in, u.input_count, out.w * out.h, u.input_gains, u.input_fade, c->stream));
+        return CHV_OK;
+    }
+    if (!uniforms || uniforms_size != sizeof(chv_me_uniforms))
+        return fail(CHV_ERR_INVALID_VALUE, "me_fullsearch needs the 24-byte MotionEstimationUniforms, got %zu bytes", uniforms_size);
+    chv_me_uniforms u;
+    memcpy(&u, uniforms, sizeof u);
+    if (n_inputs != 2) return fail(CHV_ERR_BAD_INPUT, "me_fullsearch takes the reference and the current picture, got %d images", n_inputs);
+    if (u.block_size[0] < 1 || u.block_size[1] < 1 || u.block_size[0] > 64 || u.block_size[1] > 64 || u.search_window_size[0] < 0 || u.search_window_size[1] < 0)
+        return fail(CHV_ERR_INVALID_VALUE, "me_fullsearch: block %dx%d, window %dx%d", u.block_size[0], u.block_size[1], u.search_window_size[0], u.search_window_size[1]);
+    DPlane out, ref, cur;
+    if ((rc = plane_to_device(target->planes[0], 4, c->device, &out, CHV_ERR_BAD_TARGET, "target", 0))) return rc;
+    if ((rc = plane_to_device(inputs[0].planes[0], 1, c->device, &ref, CHV_ERR_BAD_INPUT, "reference picture", 0))) return rc;
+    if ((rc = plane_to_device(inputs[1].planes[0], 1, c->device, &cur, CHV_ERR_BAD_INPUT, "current picture", 0))) return rc;
+    // deltaCost2 (kernels.metal:135-142) per vector component, by |v|: lambda * (log2(|v| + 1) * 2 + 0.718 + (v != 0)) + 0.5 through the HOST's
+    // log2f, the table oracle/ref_kernels.c builds the same way — no device libm in the comparison
+    static float cost[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int d = 0; d < 256; d++) {
+            const float l2 = log2f((float)d + 1.0f), rounding = d != 0 ? 1.0f : 0.0f;
+            cost[d] = 4.0f * (l2 * 2.0f + 0.718f + rounding) + 0.5f;
+        }
+    });
+    auto dp = deps.deps();
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = wait_for_uploads(c->stream, dp))) return rc;
+    HIP_TRY(launch_me_fullsearch(out, ref, cur, u.block_size, u.search_window_size, u.image_size, cost, c->stream));
+    return CHV_OK;
+}
+
 extern "C" int chv_run_kernel(chv_context *c, int kernel, const chv_image *target,
                               const chv_image *inputs, int n_inputs,
                               const void *uniforms, size_t uniforms_size, int blends,
                               const chv_kernel_opts *opts) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
     if (!target) return fail(CHV_ERR_BAD_TARGET, "null target");
+    if (kernel == CHV_K_SND_S16I_S16I || kernel == CHV_K_ME_FULLSEARCH) return run_idle_kernel(c, kernel, target, inputs, n_inputs, uniforms, uniforms_size);
     KernelShape s;
     int rc = kernel_shape(kernel, &s);
     if (rc) return rc;

@@ -38,6 +38,8 @@ def test_struct_layouts():
     assert cv.Uniforms.image_time.offset == 228 and cv.Uniforms.target_time.offset == 232
     assert C.sizeof(cv.Plane) == 32 and C.sizeof(cv.Image) == 16 + 3 * 32
     assert C.sizeof(cv.KernelOpts) == 16
+    assert C.sizeof(cv.SndUniforms) == 100 and cv.SndUniforms.input_gains.offset == 36 and cv.SndUniforms.input_fade.offset == 68     # kernels.cl.swift:536-541
+    assert C.sizeof(cv.MeUniforms) == 24 and cv.MeUniforms.image_size.offset == 16                                                       # kernels.metal:33-37
     assert C.sizeof(cv.Layer) == 8 + C.sizeof(cv.Image) + 236 + 16 - 4 or C.sizeof(cv.Layer) % 8 == 0
 
 

@@ -115,3 +115,53 @@ def test_concurrent_contexts_from_threads(ctx):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+# ---- forced-route equivalence over further seeds (the fuzzers that used to live under tools/ and were run by hand) --------------------
+# Every kernel family that can take a tick is FORCED to take it and held to the oracle's bytes: a regression in one route cannot hide behind
+# the default route choosing another.  The seeded generators are the ones of the per-family test files; the seed ranges continue theirs.
+import test_gpu_mixpath as MIX  # noqa: E402
+import test_gpu_parity as PAR  # noqa: E402
+import test_gpu_yuvstream as YST  # noqa: E402
+import test_gpu_yuvwave as YWV  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(36, 90))
+def test_fuzz_bgra_stream_route(ctx, switch, seed):
+    """tick_bgra_stream forced (CHV_BGRA_PATH=stream), batched; then the same ticks one at a time (descriptors as kernel arguments)"""
+    MIX.test_random_stream_ticks(ctx, switch, seed)
+    switch("CHV_BGRA_PATH", None)
+    MIX.test_random_lone_stream_ticks(ctx, seed)
+
+
+@pytest.mark.parametrize("rows", ["8", "16"])
+@pytest.mark.parametrize("seed", range(100, 126))
+def test_fuzz_strip_routes(ctx, switch, rows, seed):
+    """tick_bgra_wave and tick_yuv_wave forced, both strip heights: strong reductions (the pair form), flips, borders, fill, layers across edges"""
+    switch("CHV_BGRA_PATH", "wave")
+    switch("CHV_YUV_STREAM", "0")
+    switch("CHV_WAVE_ROWS", rows)
+    MIX.test_random_mixed_ticks(ctx, MIX.WAVE, seed)
+    YWV.test_random_yuv_ticks(ctx, rows, seed)
+
+
+@pytest.mark.parametrize("seed", range(200, 252))
+def test_fuzz_yuv_stream_route(ctx, switch, seed):
+    """tick_yuv_stream forced for every eligible launch: float and integer-matrix RGB layers, batched and lone"""
+    switch("CHV_YUV_STREAM", "force")
+    YST.test_random_yuv_stream_ticks(ctx, seed)
+    YST.test_random_yuv_stream_ticks(ctx, f"int{seed}")
+    YST.test_random_lone_yuv_stream_ticks(ctx, seed)
+
+
+@pytest.mark.parametrize("seed", range(48, 100))
+def test_fuzz_lanczos(ctx, seed):
+    PAR.test_lanczos_random_geometries(ctx, seed)
+
+
+@pytest.mark.parametrize("seed", range(40, 60))
+def test_fuzz_general_route(ctx, switch, seed):
+    """the general kernels forced (CHV_FORCE_GENERAL=1) on the strip kernels' random ticks: the route everything else falls back to"""
+    switch("CHV_FORCE_GENERAL", "1")
+    MIX.test_random_mixed_ticks(ctx, None, seed)
+    YWV.test_random_yuv_ticks(ctx, "8", seed)
