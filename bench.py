@@ -429,6 +429,8 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
                 layers.append((sv.ComputeKernel.img_bgra_bgra_tx, src, us[l], 0))
             dst = blank(sv.PixelFormat.BGRA, (dw, dh))
             keep.append(dst)
+            if canvases and alias in ("dst", "both"):       # (diagnostic: every tick onto frame 0's canvas — cache-resident stores)
+                dst = canvases[0]
             canvases.append(dst)
             if "lanczos" in wl:
                 small = blank(sv.PixelFormat.BGRA, wl["lanczos"])
@@ -1284,10 +1286,16 @@ def run_route_regret(args, sv, cv, lib, ctx, names, seconds=0.12, rounds=2):
         times = {r[0]: float("inf") for r in routes}
         e0, e1 = dev.event(), dev.event()
         for r in routes:                                                        # warm up every route once
+            for k, v in r[1].items():
+                cv.set_switch(k, v)
             cv.check(lib.chv_batch_run(ctx.handle, r[2]))
+            for k in r[1]:
+                cv.set_switch(k, None)
         dev.sync()
         for _ in range(rounds):
             for label, sw, b, kn, nl in routes:
+                for k, v in sw.items():                                         # (strip and tile heights are picked per LAUNCH: the route's switches stay set while it runs)
+                    cv.set_switch(k, v)
                 reps, el = 2, 0.0
                 while True:
                     dev.record(e0)
@@ -1300,6 +1308,8 @@ def run_route_regret(args, sv, cv, lib, ctx, names, seconds=0.12, rounds=2):
                         break
                     reps = max(reps * 2, int(reps * seconds * 1e3 / max(el, 1e-3)) + 1)
                 times[label] = min(times[label], el / reps)
+                for k in sw:
+                    cv.set_switch(k, None)
         dev.destroy(e0); dev.destroy(e1)
         for r in routes[1:]:
             cv.check(lib.chv_batch_destroy(r[2]))

@@ -155,7 +155,8 @@ def test_default_run_measures_its_hbm_traffic():
     assert set(d["workloads"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12", "pipeline_y420p", "pipeline_grid", "pipeline_logo"}
     e2e = d["workloads"]["pipeline_e2e"]
     assert e2e["verified_vs_oracle"] is True and e2e["ticks_per_s"] > 100 and 0 < e2e["d2h_frac_of_link"] < e2e["h2d_frac_of_link"] < 1.1
-    legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence", "mixer_y420p_per_tick", "mixer_y420p_reference_sequence", "pipeline_e2e", "per_tick_thread_scaling")
+    legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence", "mixer_y420p_per_tick", "mixer_y420p_reference_sequence", "pipeline_e2e", "per_tick_thread_scaling",
+            "route_regret")
     ts = d["workloads"]["per_tick_thread_scaling"]
     assert set(ts["python"]["fused"]) == {"1", "2", "4", "8"} and "error" not in ts["native"], ts.get("native")
     assert ts["native"]["fused"]["8"] > ts["native"]["fused"]["1"] * 0.8
@@ -169,6 +170,12 @@ def test_default_run_measures_its_hbm_traffic():
     assert mt["fused_equals_sequence"] is True and mt["launches_per_tick"] == 1 and mseq["launches_per_tick"] == 4
     assert 5 < mt["us_per_tick"] < mseq["us_per_tick"] < 2000
     assert d["config"]["build_flags"].startswith("arch=gfx950;") and "abl=0" in d["config"]["build_flags"]
+    # every workload's fraction and the route-regret leg where the driver's parser keeps them (keys under `config`)
+    cfg = d["config"]
+    assert set(cfg["workload_fracs"]) >= {"pipeline", "cfg2", "cfg3", "cfg5", "mixer_y420p", "encode_nv12", "pipeline_y420p", "pipeline_grid", "pipeline_logo"}
+    assert all(0 < f[0] < 1 and f[1] > 0 and isinstance(f[2], str) for f in cfg["workload_fracs"].values())
+    assert cfg["legs"]["pipeline_e2e_ticks_per_s"] > 100 and cfg["legs"]["pipeline_per_tick_us_per_tick"] > 5
+    assert set(cfg["route_regret"]) == set(cfg["workload_fracs"]) and cfg["route_regret_max"] < 0.25, cfg["route_regret"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
     if shutil.which("rocprofv3"):
