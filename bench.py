@@ -650,6 +650,7 @@ class Timer:
 
 def report_of(name, wl, args, tm, n_gpus, frames, per_step, elapsed, local, launch_ms, kernel, verified):
     locals_ = gather_floats(tm.dist, local, n_gpus)
+    launch_all = gather_floats(tm.dist, launch_ms, n_gpus)
     px_per_launch = frames * wl["dw"] * wl["dh"] if "lanczos" not in wl else frames * wl["lanczos"][0] * wl["lanczos"][1]
     bytes_per_launch = frames * wl["bytes"]
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
@@ -661,7 +662,7 @@ def report_of(name, wl, args, tm, n_gpus, frames, per_step, elapsed, local, laun
         "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "frac_of_copy_ceiling": achieved / HBM_COPY_GBS},
-        "per_gpu_gpix": [px_per_launch * per_step * args.steps / t / 1e9 for t in locals_],
+        "per_gpu_gpix": [px_per_launch * per_step * args.steps / t / 1e9 for t in locals_], "per_gpu_launch_ms": launch_all,
         # a tick belongs to one PictureSample bus: `frames` streams per GPU advance by one tick per launch
         "per_stream_ticks_per_s": 1e3 / launch_ms,
         "source_mpix_per_launch_per_gpu": frames * wl["sw"] * wl["sh"] * (wl["layers"] if wl["kind"] != "mixer420" else 1) / 1e6,
@@ -721,23 +722,57 @@ def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
     return rep, cpu
 
 
+def bind_to_node(node):
+    """Bind this thread (a rank's main thread, or a --threads worker) to the CPUs of NUMA node `node`; returns the previous affinity, or None
+    when the platform does not say / the node has none of our CPUs."""
+    if node < 0:
+        return None
+    try:
+        cpus = set()
+        for part in Path(f"/sys/devices/system/node/node{node}/cpulist").read_text().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        prev = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, cpus & prev or prev)
+        return prev
+    except (OSError, ValueError):
+        return None
+
+
 def bind_to_device_node(cv, lib, ctx):
     """Bind this thread to the CPUs of the NUMA node the device hangs off (chv_context_numa_node) so that the pinned upload ring
     is first-touched there; returns (node, previous affinity) — node -1 / None when the platform does not say."""
     node = C.c_int(-1)
     cv.check(lib.chv_context_numa_node(ctx.handle, C.byref(node)))
-    prev = None
-    if node.value >= 0:
-        try:
-            cpus = set()
-            for part in Path(f"/sys/devices/system/node/node{node.value}/cpulist").read_text().strip().split(","):
-                lo, _, hi = part.partition("-")
-                cpus.update(range(int(lo), int(hi or lo) + 1))
-            prev = os.sched_getaffinity(0)
-            os.sched_setaffinity(0, cpus & prev or prev)
-        except OSError:
-            prev = None
-    return node.value, prev
+    return node.value, bind_to_node(node.value)
+
+
+def run_with_upload_stub(args, tm, rank, n_gpus):
+    """--stub-device --with-upload: the per-rank plumbing of the upload-inclusive mode (node binding, per-rank gathers, the report's keys)
+    with sleeps for the copies and launches; rank r is (1 + r / 4) x slower.  Every rank binds to node 0 (the one every Linux box has)."""
+    prev = bind_to_node(0)
+    try:
+        bound_cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        bound_cpus = -1
+    pause = 0.0006 * (1.0 + rank / 4.0)
+
+    def launch():
+        time.sleep(pause)
+
+    per_step = tm.calibrate(launch, args.steps, args.min_seconds_other, args.launches_per_step)
+    elapsed, local, launch_ms = tm.run(launch, args.steps, per_step)
+    frames, fbytes = 64, NV12_1080
+    h2d = frames * fbytes * per_step * args.steps / local / 1e9
+    per_rank = {"h2d_GBps": gather_floats(tm.dist, h2d, n_gpus), "launch_ms": gather_floats(tm.dist, launch_ms, n_gpus),
+                "pinned_numa_node": [int(v) for v in gather_floats(tm.dist, 0.0, n_gpus)],
+                "cpus_bound": [int(v) for v in gather_floats(tm.dist, float(bound_cpus), n_gpus)]}
+    if prev is not None:
+        os.sched_setaffinity(0, prev)
+    return {"workload": "cfg2_upload (STUB: sleeps)", "value": whole_job_gpix(n_gpus, frames * 1280 * 720 * per_step, args.steps, elapsed), "unit": "Gpix/s",
+            "ms_per_step": elapsed / args.steps * 1e3, "launches_per_step": per_step, "timed_seconds": elapsed, "frames_per_launch_per_gpu": frames,
+            "kernel": "stub", "h2d_GBps_per_gpu": h2d, "h2d_frac_of_link": h2d / H2D_LINK_GBS, "h2d_link_GBps": H2D_LINK_GBS, "upload_copy_MB": 8 * fbytes / 1e6,
+            "upload_streams": args.upload_streams, "pinned_numa_node": 0, "per_stream_ticks_per_s": 1e3 / launch_ms, "verified_vs_oracle": None, "per_rank": per_rank}
 
 
 def run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=64, group=8, streams=2):
@@ -812,6 +847,14 @@ def run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=64, group=8
     elapsed, local, launch_ms = tm.run(launch, args.steps, per_step)
     px = frames * dw * dh
     h2d = frames * fbytes * per_step * args.steps / local / 1e9
+    # per rank (whoever runs the 8-GPU line sees WHICH rank bent the curve, and whether its pinned ring sat on the device's own NUMA node)
+    try:
+        bound_cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        bound_cpus = -1
+    per_rank = {"h2d_GBps": gather_floats(tm.dist, h2d, n_gpus), "launch_ms": gather_floats(tm.dist, launch_ms, n_gpus),
+                "pinned_numa_node": [int(v) for v in gather_floats(tm.dist, float(node), n_gpus)],
+                "cpus_bound": [int(v) for v in gather_floats(tm.dist, float(bound_cpus), n_gpus)]}
     rep = {
         "workload": f"cfg2_upload: cfg2 END-TO-END incl. H2D upload of every 1080p NV12 source frame from a pinned host ring, {group} frames "
                     f"({group * fbytes / 1e6:.1f} MB) per copy on {streams} side streams (PCIe-bound; never the headline value)",
@@ -820,7 +863,7 @@ def run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, frames=64, group=8
         "frames_per_launch_per_gpu": frames, "kernel": sets[0]["batch"].kernelName,
         "h2d_GBps_per_gpu": h2d, "h2d_frac_of_link": h2d / H2D_LINK_GBS, "h2d_link_GBps": H2D_LINK_GBS,
         "upload_copy_MB": group * fbytes / 1e6, "upload_streams": streams, "pinned_numa_node": node,
-        "per_stream_ticks_per_s": 1e3 / launch_ms, "verified_vs_oracle": verified,
+        "per_stream_ticks_per_s": 1e3 / launch_ms, "verified_vs_oracle": verified, "per_rank": per_rank,
     }
     for e in done:
         cv.check(lib.chv_event_destroy(e))
@@ -1375,8 +1418,9 @@ def run_rank(args, rank, local, world, dist):
     do = (lambda name, headline: measure_stub(name, args, tm, rank, n_gpus, headline)) if args.stub_device else \
          (lambda name, headline: measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline))
 
-    if args.with_upload and not args.stub_device:
-        rep = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
+    if args.with_upload:
+        rep = run_with_upload_stub(args, tm, rank, n_gpus) if args.stub_device else \
+            run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": rep["value"], "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak",
@@ -1385,6 +1429,7 @@ def run_rank(args, rank, local, world, dist):
                                          "launches_per_step": rep["launches_per_step"], "h2d_GBps_per_gpu": rep["h2d_GBps_per_gpu"],
                                          "h2d_frac_of_link": rep["h2d_frac_of_link"], "upload_copy_MB": rep["upload_copy_MB"], "upload_streams": rep["upload_streams"],
                                          "pinned_numa_node": rep["pinned_numa_node"], "verified_vs_oracle": rep["verified_vs_oracle"],
+                                         "per_rank": rep["per_rank"],
                                          "frames_per_step_per_gpu": rep["frames_per_launch_per_gpu"] * rep["launches_per_step"],
                                          "kernel": rep["kernel"]}}), flush=True)
         tm.barrier()
@@ -1451,7 +1496,7 @@ def run_rank(args, rank, local, world, dist):
                        "parallelism": (f"ONE process, {n_gpus} host threads, a compute context per device" if isinstance(dist, ThreadDist) else
                                        f"{n_gpus} process(es), one per GPU") + f"; {head['frames_per_launch_per_gpu']} independent picture "
                                       f"buses per device, bus s -> device s mod {n_gpus}; no collective",
-                       "per_gpu_gpix": head["per_gpu_gpix"], "per_stream_ticks_per_s": head["per_stream_ticks_per_s"],
+                       "per_gpu_gpix": head["per_gpu_gpix"], "per_gpu_launch_ms": head["per_gpu_launch_ms"], "per_stream_ticks_per_s": head["per_stream_ticks_per_s"],
                        "kernel": head["kernel"], "verified_vs_oracle": head["verified_vs_oracle"],
                        "build_flags": None if args.stub_device else cv.build_flags(),
                        # every workload of the run where the driver's parser keeps it: name -> [fraction of the 8 TB/s HBM peak, ms per launch, kernel]

@@ -143,6 +143,9 @@ def test_two_ranks_with_uploads_on_one_device():
     d = _run_bench(["--gpus", "2", "--device", "0", "--with-upload", "--steps", "3", "--warmup", "2", "--min-seconds-other", "0.2"])
     assert d["n_gpus"] == 2 and d["config"]["h2d_GBps_per_gpu"] > 1.0
     assert "END-TO-END" in d["config"]["mode"]
+    pr = d["config"]["per_rank"]            # which rank bent the curve, and where its pinned ring sat
+    assert len(pr["h2d_GBps"]) == len(pr["launch_ms"]) == len(pr["pinned_numa_node"]) == len(pr["cpus_bound"]) == 2
+    assert all(v > 1.0 for v in pr["h2d_GBps"]) and all(v > 0 for v in pr["launch_ms"]) and all(c >= 1 for c in pr["cpus_bound"])
 
 
 @pytest.mark.gpu
@@ -183,3 +186,14 @@ def test_default_run_measures_its_hbm_traffic():
         assert 0.97 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.10 * r["algorithmic_bytes_per_launch"], r
     else:
         assert r["traffic"] is None or "NOT measured in this run" in r["traffic_source"]
+
+
+@pytest.mark.parametrize("mode", [[], ["--threads"]])
+def test_upload_mode_per_rank_plumbing_on_stub_devices(mode):
+    """--with-upload at N = 2 without a GPU: every rank (process or thread) binds to a NUMA node's CPUs and reports its own H2D rate, launch
+    time, node and CPU count under config.per_rank — what whoever runs the 8-GPU line reads to see which rank bent the curve."""
+    d = _run_bench(["--gpus", "2", "--stub-device", "--with-upload", "--steps", "3", "--warmup", "1", "--min-seconds-other", "0.2"] + mode)
+    pr = d["config"]["per_rank"]
+    assert d["n_gpus"] == 2 and len(pr["h2d_GBps"]) == 2 and len(pr["launch_ms"]) == 2
+    assert pr["launch_ms"][1] > pr["launch_ms"][0] * 1.1             # the stub's rank 1 is 25 % slower: the per-rank numbers are per rank
+    assert pr["pinned_numa_node"] == [0, 0] and all(c >= 1 for c in pr["cpus_bound"])
