@@ -188,7 +188,7 @@ def test_hand_awaited_loads_are_not_touched_while_in_flight(tmp_path):
 
 @pytest.mark.parametrize("stem", ["kernels_wave", "kernels_wave_yuv"])
 def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem):
-    """One wave per strip: <= 80 VGPRs = 6 waves per SIMD (5 measured 8 % slower on the 4 x NV12
+    """One wave per strip (profiles/HISTORY.md 5.1): <= 80 VGPRs = 6 waves per SIMD (5 measured 8 % slower on the 4 x NV12
     pipeline), at most the two spills of the per-pixel fallback; and the tick / layer descriptors — uniform, read-only — come
     through the scalar unit.  They stopped doing so twice while these kernels were written: once through a fence over all
     memory, once through an `asm volatile` (touch_regs), either of which makes the compiler treat later descriptor reads as

@@ -93,4 +93,11 @@ if __name__ == "__main__":
             if n >= int(sys.argv[sys.argv.index("--min") + 1]) if "--min" in sys.argv else n >= 40:
                 ns = sum(c[k] * NS[k] for k in c)
                 print(f"{i:>8} {n:>5} {c['F']:>4} {c['S']:>4} {c['Q']:>3} {salu:>5} {lds:>4} {vmem:>4} {smem:>4} {ns:>7.1f}")
+                if "--hist" in sys.argv and i == int(sys.argv[sys.argv.index("--hist") + 1]):      # opcode histogram of one block
+                    h = {}
+                    for op in b["ins"]:
+                        key = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
+                        h[key] = h.get(key, 0) + 1
+                    for op, k in sorted(h.items(), key=lambda kv: -kv[1]):
+                        print(f"           {k:>5}  {op}" + (f"  [{classify(op)}]" if op.startswith("v_") else ""))
         print(f"   total static VALU: {sum(tot.values())} (F {tot['F']}, S {tot['S']}, Q {tot['Q']})")
