@@ -780,14 +780,14 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
                                 // to_code_raw of a convex combination of codes: no clamp can trigger; rint through the float adder
                                 const int cr = (int)(code_biased(q0f) & 255u), cg = (int)(code_biased(q1f) & 255u), cb = (int)(code_biased(q2f) & 255u);
                                 const float a2 = q3f * ka, ia2 = 1.f - a2;
-                                const int py = clip8((kk.y[0] * cr + kk.y[1] * cg + kk.y[2] * cb + (kk.yoff << 16) + 32768) >> 16);
+                                const int py = clip8(r2y_row(kk.y[0], kk.y[1], kk.y[2], (kk.yoff << 16) + 32768, cr, cg, cb) >> 16);
                                 const uint32_t nlw = ys_put_raw_k(lw, __builtin_fmaf((float)py, a2, curf * ia2), k);
                                 lw = tk ? nlw : lw;
                                 if (even_row) {
                                     // chroma of the quad: the even lane's pixel of this (even) row; the trip's second chroma row lives in the odd
                                     // lane (the values travel one lane up, quad_perm [0, 0, 2, 2])
-                                    int pu = clip8((kk.u[0] * cr + kk.u[1] * cg + kk.u[2] * cb + (128 << 16) + 32768) >> 16);
-                                    int pv = clip8((kk.v[0] * cr + kk.v[1] * cg + kk.v[2] * cb + (128 << 16) + 32768) >> 16);
+                                    int pu = clip8(r2y_row(kk.u[0], kk.u[1], kk.u[2], (128 << 16) + 32768, cr, cg, cb) >> 16);
+                                    int pv = clip8(r2y_row(kk.v[0], kk.v[1], kk.v[2], (128 << 16) + 32768, cr, cg, cb) >> 16);
                                     float sa = a2, sia = ia2;
                                     int stk = (tk && owner_lane) ? 1 : 0;
                                     if (k == 2) { pu = ys_dpp_even(pu); pv = ys_dpp_even(pv); sa = ys_dpp_even(a2); sia = ys_dpp_even(ia2); stk = ys_dpp_even(stk); }

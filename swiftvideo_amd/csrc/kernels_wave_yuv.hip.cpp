@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                     // to_code_raw of a convex combination of codes: no clamp can trigger; rint through the float adder
                     const int cr = (int)(code_biased(q0) & 255u), cg = (int)(code_biased(q1) & 255u), cb = (int)(code_biased(q2) & 255u);
                     const float a2 = q3 * ka, ia2 = 1.f - a2;
-                    const int py = clip8((k.y[0] * cr + k.y[1] * cg + k.y[2] * cb + (k.yoff << 16) + 32768) >> 16);
+                    const int py = clip8(r2y_row(k.y[0], k.y[1], k.y[2], (k.yoff << 16) + 32768, cr, cg, cb) >> 16);
                     uint32_t &lw = ly[j >> 2];
                     const float cyf = ubk<j & 3>(lw);
                     const float r0 = FILL ? clampf(__builtin_fmaf(fyf, af, cyf * iaf), 0.f, 255.f) : cyf;
@@ -376,8 +376,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                         // chroma of the quad: the even lane's pixel of this (even) row; chroma row jj = j / 2 lives in the even lane
                         // (jj even) or in its odd neighbour (jj odd: the values travel one lane up, quad_perm [0, 0, 2, 2])
                         constexpr int jj = j >> 1, m = jj >> 1;
-                        int pu = clip8((k.u[0] * cr + k.u[1] * cg + k.u[2] * cb + (128 << 16) + 32768) >> 16);
-                        int pv = clip8((k.v[0] * cr + k.v[1] * cg + k.v[2] * cb + (128 << 16) + 32768) >> 16);
+                        int pu = clip8(r2y_row(k.u[0], k.u[1], k.u[2], (128 << 16) + 32768, cr, cg, cb) >> 16);
+                        int pv = clip8(r2y_row(k.v[0], k.v[1], k.v[2], (128 << 16) + 32768, cr, cg, cb) >> 16);
                         float sa = a2, sia = ia2;
                         int stk = (tk && owner_lane) ? 1 : 0;
                         if constexpr ((jj & 1) != 0) {
