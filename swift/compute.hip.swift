@@ -283,6 +283,45 @@ func runComputeKernel<T>(_ context: ComputeContext,
     return context
 }
 
+// MARK: - The two buffer kernels of `ComputeKernel` (compute.swift:67,70; kernels.cl.swift:534-562, kernels.metal:129-267)
+//
+// Nothing in the reference dispatches `.snd_s16i_s16i` / `.me_fullsearch`; CHIPVideo runs them through chv_run_kernel in the reference's bind
+// order [outputs][inputs][uniforms].  A ComputeBuffer is bound where the kernel expects an image: one plane of `width` x `height` texels of
+// `components` bytes (interleaved-stereo Int16 samples = 2-byte texels; a luma plane = 1; me_fullsearch's output = one RGBA8 texel per block).
+struct BufferImage {
+    let buffer: ComputeBuffer
+    let width: Int
+    var height: Int = 1
+    var components: Int = 2
+    var offset: Int = 0
+    func describe() -> chv_image {
+        var d = chv_image()
+        d.format = Int32(CHV_FMT_INVALID.rawValue)
+        d.width = Int32(width); d.height = Int32(height); d.n_planes = 1
+        d.planes.0 = chv_plane(buffer: buffer.handle, offset: offset, width: Int32(width), height: Int32(height),
+                               pitch: Int32(width * components), components: Int32(components))
+        return d
+    }
+}
+typealias BufferUniforms = chv_snd_uniforms                // kernels.cl.swift:536-541 (100 bytes)
+typealias MotionEstimationUniforms = chv_me_uniforms       // kernels.metal:33-37 (24 bytes)
+
+func runComputeKernel<T>(_ context: ComputeContext,
+                         buffers: [BufferImage],
+                         target: BufferImage,
+                         kernel: ComputeKernel,
+                         uniforms: T) throws -> ComputeContext {
+    var targetDesc = target.describe()
+    var inputs = buffers.map { $0.describe() }
+    var u = uniforms
+    let id = try kernelId(kernel)
+    let status = withUnsafeBytes(of: &u) { raw in
+        chv_run_kernel(context.handle, id, &targetDesc, &inputs, Int32(inputs.count), raw.baseAddress, MemoryLayout<T>.size, 0, nil)
+    }
+    try check(status, kernel: kernel)
+    return context
+}
+
 // MARK: - Transfers (compute.cl.swift:361-498)
 
 func uploadComputeBuffer(_ ctx: ComputeContext, src: Data, dst: ComputeBuffer?) throws -> ComputeBuffer {

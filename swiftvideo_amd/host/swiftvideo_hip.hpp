@@ -382,6 +382,39 @@ inline ComputeContext runComputeKernel(ComputeContext ctx, const std::vector<Pic
     return ctx;
 }
 
+// ---- the two kernels of the enum that work on buffers (compute.swift:67,70; kernels.cl.swift:534-562, kernels.metal:129-267) ----
+// A ComputeBuffer bound where a kernel expects an image: one plane of `width` x `height` texels of `components` bytes — interleaved-stereo
+// int16 samples are 2-byte texels (snd_s16i_s16i), a luma plane 1-byte ones, me_fullsearch's output one RGBA8 texel per block.
+struct BufferImage { ComputeBufferRef buffer; int width = 0, height = 1, components = 2; size_t offset = 0; };
+using BufferUniforms = chv_snd_uniforms;               // kernels.cl.swift:536-541
+using MotionEstimationUniforms = chv_me_uniforms;      // kernels.metal:33-37
+inline chv_image describe(const BufferImage &b) {
+    chv_image d;
+    std::memset(&d, 0, sizeof d);
+    d.format = CHV_FMT_INVALID; d.width = b.width; d.height = b.height; d.n_planes = 1;
+    d.planes[0] = chv_plane{ b.buffer ? b.buffer->handle : nullptr, b.offset, b.width, b.height, b.width * b.components, b.components };
+    return d;
+}
+inline ComputeBufferRef uploadComputeBuffer(const ComputeContext &ctx, const void *src, size_t bytes) {      // compute.cl.swift:361-379
+    chv_buffer *h = nullptr;
+    check(chv_buffer_alloc(ctx.get(), bytes, &h));
+    auto b = std::make_shared<ComputeBuffer>(h, bytes, 0);
+    check(chv_upload(ctx.get(), h, 0, bytes, src, bytes, bytes, 1, 0));
+    return b;
+}
+inline void downloadComputeBuffer(const ComputeContext &ctx, const ComputeBufferRef &src, void *dst) {       // compute.cl.swift:381-396
+    check(chv_download(ctx.get(), dst, src->size, src->handle, 0, src->size, src->size, 1));
+}
+template <typename T>
+inline ComputeContext runComputeKernel(ComputeContext ctx, const std::vector<BufferImage> &images, const BufferImage &target, ComputeKernel kernel,
+                                       const T &uniforms) {
+    chv_image t = describe(target);
+    std::vector<chv_image> in;
+    for (const BufferImage &b : images) in.push_back(describe(b));
+    check(chv_run_kernel(ctx.get(), (int)kernel, &t, in.data(), (int)in.size(), &uniforms, sizeof(T), 0, nullptr));
+    return ctx;
+}
+
 // ---- ComputeKernel.custom(name:) (compute.swift:72-73) + buildComputeKernel (compute.cl.swift:153-195) ----
 struct CustomKernel { std::string name; };
 

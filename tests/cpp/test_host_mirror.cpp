@@ -368,6 +368,43 @@ static void gpuTests() {
         }
         EXPECT(ok);
     }
+    // the two buffer kernels of the enum (compute.swift:67,70) through runComputeKernel's bind order, against the oracle
+    {
+        const int n = 1003;
+        std::vector<int16_t> out(n), in0(n), in1(n), exp;
+        for (int i = 0; i < n; i++) { out[i] = (int16_t)(i * 37 - 9000); in0[i] = (int16_t)(i * 131 + 77); in1[i] = (int16_t)(30000 - i * 59); }
+        exp = out;
+        sv::BufferUniforms u{};
+        u.input_count = 2; u.input_gains[0] = 0.8f; u.input_gains[1] = -3.5f; u.input_fade[0] = 0.25f; u.input_fade[1] = 0.9f;
+        const int16_t *ins[2] = { in0.data(), in1.data() };
+        orc_snd_uniforms ou;
+        std::memcpy(&ou, &u, sizeof ou);
+        EXPECT(orc_snd_s16i_s16i(exp.data(), n, ins, &ou) == 0);
+        auto gout = sv::uploadComputeBuffer(ctx, out.data(), n * 2), g0 = sv::uploadComputeBuffer(ctx, in0.data(), n * 2), g1 = sv::uploadComputeBuffer(ctx, in1.data(), n * 2);
+        EXPECT(sv::defaultComputeKernelFromString("snd_s16i_s16i") == sv::ComputeKernel::snd_s16i_s16i);
+        ctx = sv::usingContext(ctx, [&](sv::ComputeContext c) {
+            return sv::runComputeKernel(c, { sv::BufferImage{ g0, n }, sv::BufferImage{ g1, n } }, sv::BufferImage{ gout, n }, sv::ComputeKernel::snd_s16i_s16i, u);
+        });
+        sv::downloadComputeBuffer(ctx, gout, out.data());
+        EXPECT(out == exp);
+
+        const int W = 96, H = 64;
+        std::vector<uint8_t> ref((size_t)W * H), cur((size_t)W * H);
+        for (int i = 0; i < W * H; i++) { ref[i] = (uint8_t)((i * 2654435761u) >> 24); cur[i] = (uint8_t)(((i + 3 * W + 2) * 2654435761u) >> 24); }
+        sv::MotionEstimationUniforms mu{ { 16, 16 }, { 32, 32 }, { W, H } };
+        std::vector<uint8_t> mv((size_t)(W / 16) * (H / 16) * 4), mexp(mv.size());
+        orc_plane po{ mexp.data(), W / 16, H / 16, (W / 16) * 4, 4 }, pr{ ref.data(), W, H, W, 1 }, pc{ cur.data(), W, H, W, 1 };
+        orc_me_uniforms omu;
+        std::memcpy(&omu, &mu, sizeof omu);
+        EXPECT(orc_me_fullsearch(&po, &pr, &pc, &omu) == 0);
+        auto gr = sv::uploadComputeBuffer(ctx, ref.data(), ref.size()), gc = sv::uploadComputeBuffer(ctx, cur.data(), cur.size()), gm = sv::uploadComputeBuffer(ctx, mv.data(), mv.size());
+        ctx = sv::usingContext(ctx, [&](sv::ComputeContext c) {
+            return sv::runComputeKernel(c, { sv::BufferImage{ gr, W, H, 1 }, sv::BufferImage{ gc, W, H, 1 } }, sv::BufferImage{ gm, W / 16, H / 16, 4 },
+                                        sv::ComputeKernel::me_fullsearch, mu);
+        });
+        sv::downloadComputeBuffer(ctx, gm, mv.data());
+        EXPECT(mv == mexp);
+    }
     sv::destroyComputeContext(ctx);
 }
 

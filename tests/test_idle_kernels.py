@@ -212,3 +212,48 @@ def test_gpu_me_matches_oracle(ctx, case):
                                                        sv.BufferImage(gout, nbx, nby, 4), sv.ComputeKernel.me_fullsearch, uniforms=u))
     got = sv.downloadComputeBuffer(ctx, gout).reshape(nby, nbx, 4)
     assert np.array_equal(got, exp), f"{np.argwhere((got != exp).any(axis=2))[:5]}"
+
+
+# ---- committed golden vectors (tests/golden/idle_vectors.npz, tests/golden/gen_idle_golden.py) ---------------------------------------------
+from pathlib import Path  # noqa: E402
+
+GOLD = np.load(Path(__file__).resolve().parent / "golden" / "idle_vectors.npz")
+GOLD_KEYS = GOLD["index"].tolist()
+
+
+@pytest.mark.parametrize("key", GOLD_KEYS)
+def test_oracle_reproduces_idle_golden_vectors(key):
+    exp = GOLD[key + "/expected"]
+    if key.startswith("snd"):
+        out = GOLD[key + "/out0"].copy()
+        ins = [GOLD[f"{key}/in{i}"] for i in range(int(GOLD[key + "/n_inputs"][0]))]
+        assert O.snd_s16i_s16i(out, ins, GOLD[key + "/uniforms"]) == 0
+    else:
+        u = GOLD[key + "/uniforms"].tolist()
+        out = np.zeros_like(exp)
+        assert O.me_fullsearch(out, GOLD[key + "/ref"], GOLD[key + "/cur"], u[0:2], u[2:4], u[4:6]) == 0
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", GOLD_KEYS)
+def test_gpu_reproduces_idle_golden_vectors(ctx, key):
+    from swiftvideo_amd import compute as sv
+    exp = GOLD[key + "/expected"]
+    if key.startswith("snd"):
+        n = exp.size
+        gout = sv.uploadComputeBuffer(ctx, GOLD[key + "/out0"].tobytes())
+        gins = [sv.uploadComputeBuffer(ctx, GOLD[f"{key}/in{i}"].tobytes()) for i in range(int(GOLD[key + "/n_inputs"][0]))]
+        sv.usingContext(ctx, lambda c: sv.runComputeKernel(c, [sv.BufferImage(g, n) for g in gins], sv.BufferImage(gout, n),
+                                                           sv.ComputeKernel.snd_s16i_s16i, uniforms=GOLD[key + "/uniforms"]))
+        got = np.frombuffer(sv.downloadComputeBuffer(ctx, gout).tobytes(), dtype=np.int16)
+    else:
+        ref, cur = GOLD[key + "/ref"], GOLD[key + "/cur"]
+        h, w = cur.shape
+        gref, gcur = sv.uploadComputeBuffer(ctx, ref.tobytes()), sv.uploadComputeBuffer(ctx, cur.tobytes())
+        gout = sv.uploadComputeBuffer(ctx, np.zeros(exp.size, dtype=np.uint8).tobytes())
+        sv.usingContext(ctx, lambda c: sv.runComputeKernel(c, [sv.BufferImage(gref, w, h, 1), sv.BufferImage(gcur, w, h, 1)],
+                                                           sv.BufferImage(gout, exp.shape[1], exp.shape[0], 4), sv.ComputeKernel.me_fullsearch,
+                                                           uniforms=GOLD[key + "/uniforms"]))
+        got = sv.downloadComputeBuffer(ctx, gout).reshape(exp.shape)
+    assert np.array_equal(got, exp), key
