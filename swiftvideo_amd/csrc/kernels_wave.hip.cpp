@@ -46,9 +46,38 @@
 #ifndef CHV_WAVE_PRIO
 #define CHV_WAVE_PRIO 1
 #endif
+// RGB rectangles that touch no picture edge and need no byte swap are filled by LDS-DMA (global_load_lds_dwordx4): no staging registers, no slot
+// arithmetic, no LDS write instructions — cfg3 1.3035 -> 1.2485 ms, cfg5 2.140 -> 2.050 (same call, profiles/r05_notes.md section 9, where the
+// version that also PREFETCHED the next layer's rectangle into a second region is recorded: the LDS it takes costs more waves than the overlap
+// returns).  0: off (the A/B; CHV_WAVE_DMA=0 in the environment does the same at run time).
+#ifndef CHV_DMA_MUTATE
+#define CHV_DMA_MUTATE 0      // (tests of the tests: a non-zero value shifts what the DMA fetches)
+#endif
+#ifndef CHV_WAVE_DMA
+#define CHV_WAVE_DMA 1
+#endif
 #pragma clang fp contract(off)
 
 namespace chv {
+
+// one LDS-DMA instruction: the lane's 16 bytes from ITS global address to LDS at m0 + lane * 16 (tools/probe_lds_dma.cpp; kernels_stream.hip.cpp).
+// M0 is set here every time; tests/test_device_code_contract.py checks that nothing else in the object touches it.
+// NOT `asm volatile`, no memory clobber: either makes every later read of the tick / layer descriptors "possibly clobbered" and the compiler
+// fetches them per lane (75 instead of 16 global_load_dword in the RGB-only instantiation, cfg3 1.35 -> 2.41 ms measured).  What orders these
+// instructions against the LDS reads is a token instead: a VGPR the asm statements pretend to update — it goes in after depending on the
+// previous layer's pixels (wave_dma_after), and the row loops' LDS addresses depend on it after the wait (wave_dma_wait).
+CHV_DEV void wave_dma16(const uint8_t *p, bool active, uint32_t m0, int &tok) {
+    if (active) asm("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" : "+v"(tok) : "s"(m0), "v"(p));
+}
+CHV_DEV void wave_dma_wait(int &tok) { asm("s_waitcnt vmcnt(0)" : "+v"(tok)); }
+template <int N>
+CHV_DEV void wave_dma_after(int &tok, const uint32_t (&cv)[N]) {
+    if constexpr (N == 16)
+        asm("" : "+v"(tok) : "v"(cv[0]), "v"(cv[1]), "v"(cv[2]), "v"(cv[3]), "v"(cv[4]), "v"(cv[5]), "v"(cv[6]), "v"(cv[7]), "v"(cv[8]), "v"(cv[9]), "v"(cv[10]),
+            "v"(cv[11]), "v"(cv[12]), "v"(cv[13]), "v"(cv[14]), "v"(cv[15]));
+    else
+        asm("" : "+v"(tok) : "v"(cv[0]), "v"(cv[1]), "v"(cv[2]), "v"(cv[3]), "v"(cv[4]), "v"(cv[5]), "v"(cv[6]), "v"(cv[7]));
+}
 
 // Integer colour matrix on biased codes, channels returned as float codes (cf. yuv_to_bgra_word).
 // clip8(x >> 16) = byte 2 of clamp(x, 0, 0xFFFFFF): v_med3_i32 + v_cvt_f32_ubyte2 per channel (two slow-class instructions,
@@ -136,6 +165,16 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
 
     WLayer cur;
     bool have_geom = false;            // `cur` and the row table hold the geometry of the layer handled just before (LF_SAME_GEOM)
+    // DMA staging (planar_any bit 5: on): lane -> (row, vector) of one instruction — a region's rows are p0pitch bytes = P16 vectors apart, an
+    // instruction fills 64 / P16 of them; `tok`: see wave_dma16
+    constexpr bool DMA = CHV_WAVE_DMA && ((KINDS & 15) == 4 || (CHV_WAVE_DMA > 1 && (KINDS & 4) != 0));
+    const bool dma_on = DMA && (planar_any & 32) != 0;
+    const int P16 = p0pitch >> 4, RPI = P16 > 0 ? 64 / P16 : 0;
+    int lr = 0, lv = lane, tok = 0;
+    if (DMA) {
+        while (lv >= P16 && lr < 64) { lv -= P16; lr++; }
+        asm("v_mov_b32 %0, 0" : "=v"(tok));              // (0, but the compiler does not know)
+    }
     while (l < nl) {
         const DLayer &Ly = L[l];
         if constexpr ((KINDS & 8) != 0) {
@@ -169,9 +208,24 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
         // the predecessor was a hit for this strip as well) keep its column entry, row table and rectangles; only the planes change.
         if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) S.setup(ptok, cur);      // (overwrites the row table: the previous layer's pixels are done)
         have_geom = true;
-        if (cur.staged && !(CHV_ABL & 1)) S.stage(l, cur);
+        // a rectangle LDS-DMA can fill: texels in canvas order, away from every picture edge, contiguous rows (not the pair form), at most eight
+        // instructions' worth of them
+        if (DMA && dma_on && cur.staged && Strip::is_rgb(Ly.kind) && Ly.swizzle == 0 && !cur.g0.edge && !cur.g0.pair && RPI > 0 && cur.g0.rows <= 8 * RPI && cur.g0.nvec + 1 <= P16 && !(CHV_ABL & 1)) {
+            const DPlane &P = Ly.src.pl[0];
+            const uint8_t *base = P.ptr + (size_t)cur.g0.r_lo * P.pitch + cur.g0.b0;                  // (uniform)
+            const uint32_t lds0 = (uint32_t)(size_t)(smem + S.base0);
+            const bool lane_ok = lr < RPI && lv >= 1 && lv <= cur.g0.nvec;
+            wave_dma_after(tok, cv);          // (the region's last readers — the rows of the layer before — are done)
+            for (int r0 = 0; r0 < cur.g0.rows; r0 += RPI) {
+                const int row = r0 + lr;
+                wave_dma16(base + (size_t)row * P.pitch + (size_t)((lv - 1) * 16) + CHV_DMA_MUTATE, lane_ok && row < cur.g0.rows,
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)(r0 * p0pitch))), tok);
+            }
+            wave_dma_wait(tok);
+        } else if (cur.staged && !(CHV_ABL & 1)) S.stage(l, cur);
         wave_lds_fence();
         const int ln = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
+        const int cyo_r = DMA ? cur.cyo + tok : cur.cyo;         // (tap 0 of this lane's column; through the token: not before the wait)
         if (CHV_WAVE_PRIO) { asm("s_setprio 0" : "+s"(ptok)); cur.cyo += ptok - l; }       // (ptok - l = 0, opaque: pins the asm here)
 
         if (CHV_ABL & 2) cv[0] += (uint32_t)(cur.cyo ^ cur.cco ^ __float_as_int(cur.cya) ^ __float_as_int(cur.cca) ^ cur.cfl);
@@ -220,7 +274,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
                         WAVE_ROW_FENCE(j);
                         const RowFast rw = row_fast<WTH, false>(rowtab, j);
                         const float b = rw.yb, ib = rw.iyb;
-                        const uint8_t *p0 = smem + (rw.yoff + cur.cyo);
+                        const uint8_t *p0 = smem + (rw.yoff + cyo_r);
                         const uint8_t *p1 = p0 + p0pitch;
                         const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
                         const uint32_t u01 = ((const uint32_t *)p1)[0], u11 = ((const uint32_t *)p1)[1];
@@ -239,7 +293,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
                 // of a pixel is the upper tap row of the pixel below it, so its eight code-to-float conversions — a third of the
                 // row's slow-class instructions — and its LDS reads are carried down the lane instead of repeated.
                 auto rgb_rows_carried = [&]() {
-                    const uint8_t *p = smem + (row_fast<WTH, false>(rowtab, 0).yoff + cur.cyo);
+                    const uint8_t *p = smem + (row_fast<WTH, false>(rowtab, 0).yoff + cyo_r);
                     uint32_t ut0 = ((const uint32_t *)p)[0], ut1 = ((const uint32_t *)p)[1];
                     float t00 = ub0(ut0), t01 = ub1(ut0), t02 = ub2(ut0), t03 = ub3(ut0);
                     float t10 = ub0(ut1), t11 = ub1(ut1), t12 = ub2(ut1), t13 = ub3(ut1);
@@ -334,7 +388,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
                         if (rgb) {
                             uint32_t u00, u10, u01, u11;
                             if (cur.staged) {
-                                const uint8_t *q0 = smem + (ry + cur.cyo);
+                                const uint8_t *q0 = smem + (ry + cyo_r);
                                 const uint8_t *q1 = q0 + p0pitch;
                                 u00 = ((const uint32_t *)q0)[0]; u10 = ((const uint32_t *)q0)[1]; u01 = ((const uint32_t *)q1)[0]; u11 = ((const uint32_t *)q1)[1];
                             } else {
@@ -402,6 +456,11 @@ const char *bgra_wave_build_flags() { return "tick_bgra_wave:abl=" CHV_STR(CHV_A
 
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
                             int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds) {
+    // bit 5 of `planar`: rectangles are staged by DMA where their shape allows (the RGB-only instantiation)
+    {
+        static const int dma_env = [] { const char *e = getenv("CHV_WAVE_DMA"); return e ? atoi(e) : 1; }();
+        if (CHV_WAVE_DMA && dma_env && (kinds == 4 || (CHV_WAVE_DMA > 1 && (kinds & 4)))) planar |= 32;
+    }
 #define CHV_LAUNCH_B(R, C, K) hipLaunchKernelGGL((tick_bgra_wave<R, C, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                  strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar)
 #define CHV_LAUNCH_BK(R, C) do { if (kinds == 1) CHV_LAUNCH_B(R, C, 1); else if (kinds == 2) CHV_LAUNCH_B(R, C, 2); \

@@ -752,8 +752,9 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     long blocks_per_xcd = (per_xcd + WAVES - 1) / WAVES;
     dim3 grid((unsigned)(blocks_per_xcd * 8));
     const bool clear = ticks_host[0].clear_first != 0;
-    if (target_format == TF_BGRA)
+    if (target_format == TF_BGRA) {
         return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side, kinds);
+    }
 #define CHV_LAUNCH_Y(TFV, C, R, K) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                       strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side)
 #define CHV_LAUNCH_YK(TFV, C, R, OWN) do { if (kinds == OWN) CHV_LAUNCH_Y(TFV, C, R, OWN); else if (kinds == (OWN | 4)) CHV_LAUNCH_Y(TFV, C, R, (OWN | 4)); \

@@ -213,3 +213,25 @@ def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem)
     scalar = len(re.findall(r"\bs_load_dword", asm))
     vector1 = len(re.findall(r"\bglobal_load_dword\s", asm))        # single-dword vector loads: what a uniform read degrades to
     assert scalar >= 300 and vector1 * 4 <= scalar, f"{stem}: {scalar} scalar loads, {vector1} single-dword vector loads"
+
+
+def test_wave_kernel_dma_staging_owns_m0_and_leaves_descriptor_reads_scalar(tmp_path):
+    """tick_bgra_wave<.., KINDS = 4> (launches of RGB layers only: cfg3, cfg5) fills interior rectangles by global_load_lds_dwordx4 — the M0
+    contract of the streaming kernels — from asm statements that are NOT volatile and clobber no memory: a first version that was volatile made
+    every descriptor read after it a per-lane load (75 instead of 16 global_load_dword in this instantiation, cfg3 1.35 -> 2.41 ms on the GPU,
+    profiles/r05_notes.md section 9).  Per instantiation, not over the object: the aggregate test above did not notice."""
+    co = _code_object(tmp_path, "kernels_wave")
+    _lds_dma_contract(co, 4)
+    asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    bodies = re.split(r"\n[0-9a-f]+ <(_ZN3chv14tick_bgra_wave[^>]*)>:\n", asm)
+    seen = 0
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        body = re.split(r"\n[0-9a-f]+ <_Z", body)[0]
+        rgb_only = re.search(r"ELi4EEEv", name) is not None
+        assert ("global_load_lds_dwordx4" in body) == rgb_only, name
+        if rgb_only:
+            seen += 1
+            scalar, vector1 = len(re.findall(r"\bs_load_dword", body)), len(re.findall(r"\bglobal_load_dword\s", body))
+            assert scalar >= 80 and vector1 <= 40, (name, scalar, vector1)       # (CLEAR = false: one canvas load per row on top of the 16 of the per-pixel path)
+            assert "s_waitcnt vmcnt(0)" in body
+    assert seen == 4

@@ -606,6 +606,54 @@ def test_random_mixed_ticks(ctx, path, seed):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed} tick {i} ({len(ticks[i][2])} layers) via {name}")
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_rgb_only_ticks(ctx, path, seed):
+    """Launches of RGB layers only — the instantiation of tick_bgra_wave that fills interior rectangles by LDS-DMA (kernels_wave.hip.cpp,
+    CHV_WAVE_DMA): canvases several strips wide and tall, so that strips lie inside a layer (DMA), on its edge and across the picture's edge
+    (the register path), layers of BGRA (DMA) and RGBA (byte swap: register path) pictures in one tick, stacks that share their predecessor's
+    geometry, up- and downscales between 3:1 and 1:3 (rows per DMA instruction from 1 to 16, the pair form beyond 1.6:1)."""
+    rng = np.random.default_rng(9500 + seed)
+    clear = bool(rng.integers(0, 2))
+    ticks, exps, gds = [], [], []
+    for t in range(2):
+        cw, ch = int(rng.integers(130, 420)), int(rng.integers(40, 150))
+        canvas0 = util.alloc_image("bgra", cw, ch, seed=int(rng.integers(1, 1 << 20)))
+        exp = util.copy_image(canvas0)
+        if clear:
+            assert O.run_kernel("img_clear_bgra", exp) == 0
+        layers = []
+        u = sw = sh = None
+        for l in range(int(rng.integers(1, 7))):
+            k = "img_bgra_bgra_tx" if rng.random() < 0.75 else "img_rgba_bgra_tx"
+            if u is None or rng.random() < 0.5:
+                scale = float(np.exp(rng.uniform(np.log(1 / 3), np.log(3))))
+                sw = max(8, int(cw * scale * rng.uniform(0.7, 1.2)) // 4 * 4)
+                sh = max(4, int(ch * scale * rng.uniform(0.7, 1.2)) // 2 * 2)
+                kw = {"opacity": float(rng.choice([1.0, rng.uniform(0, 1)]))}
+                if rng.random() < 0.6:
+                    kw["rect"] = (float(rng.uniform(-0.2, 0.3) * cw), float(rng.uniform(-0.2, 0.3) * ch),
+                                  float(rng.uniform(0.6, 1.4) * cw), float(rng.uniform(0.6, 1.4) * ch))
+                if rng.random() < 0.3:
+                    kw["tex"] = (float(rng.uniform(0.0, 0.3)), float(rng.uniform(0.0, 0.3)),
+                                 float(rng.uniform(0.5, 1.0)) * (1 if rng.random() < 0.8 else -1), float(rng.uniform(0.5, 1.0)))
+                if rng.random() < 0.15:
+                    kw["fill"] = tuple(float(v) for v in rng.uniform(0, 1, 4))
+                u = util.make_uniforms((cw, ch), in_size=(sw, sh), **kw)
+            src = util.alloc_image("bgra", sw, sh, seed=int(rng.integers(1, 1 << 20)))
+            assert O.run_kernel(k, exp, src, u, threads=4) == 0
+            layers.append((sv.defaultComputeKernelFromString(k), G.to_gpu(ctx, "bgra", sw, sh, src), u, 0))
+        gd = G.to_gpu(ctx, "bgra", cw, ch, canvas0)
+        ticks.append((gd, clear, layers))
+        exps.append(exp)
+        gds.append((gd, cw, ch))
+    h, name, keep = G.make_batch(ctx, ticks)
+    assert name == WAVE, name
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    for i, ((gd, cw, ch), exp) in enumerate(zip(gds, exps)):
+        G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"seed {seed} tick {i} ({len(ticks[i][2])} layers)")
+
+
 @pytest.mark.parametrize("kernel", ["tick_bgra_stream", WAVE])
 def test_pipeline_full_size(ctx, switch, kernel):
     """The headline tick at full size: 4 x 1080p NV12 -> 720p BGRA canvas, opacities 1/.75/.5/.25 == oracle's clear + 4 kernel calls;
