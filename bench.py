@@ -133,6 +133,8 @@ def parse_args(argv=None):
     ap.add_argument("--per-tick", action="store_true", help="run the one-tick-at-a-time legs even with --also none")
     ap.add_argument("--route-regret", action="store_true", help="run the route-regret leg even with --also none (for the headline workload)")
     ap.add_argument("--no-route-regret", action="store_true", help="skip the route-regret leg of the default run")
+    ap.add_argument("--power-probe", action="store_true", help="run the clock / power leg even with --also none (for the headline workload)")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the clock / power leg of the default run")
     ap.add_argument("--alias", default="none", choices=("none", "src", "dst", "both"),
                     help="DIAGNOSTIC (single-layer YUV workloads): every tick reads frame 0's source and/or writes frame 0's "
                          "canvas, so that side of the traffic stays in cache; the line is marked and is not a benchmark result")
@@ -1364,6 +1366,69 @@ def run_route_regret(args, sv, cv, lib, ctx, names, seconds=0.12, rounds=2):
     return out
 
 
+def smi_parse(text):
+    """(shader clock MHz, socket power W) of every JSON object rocm-smi printed into `text`"""
+    got = []
+    for line in text.splitlines():
+        line = line.strip()
+        if not line.startswith("{"):
+            continue
+        try:
+            c = next(iter(json.loads(line).values()))
+            sclk = next((v for k, v in c.items() if k.startswith("sclk clock speed")), None)
+            power = next((v for k, v in c.items() if "Package Power" in k), None)
+            if sclk and power:
+                got.append((float(sclk.strip("()").lower().replace("mhz", "")), float(power)))
+        except Exception:       # noqa: BLE001
+            pass
+    return got
+
+
+def smi_power_cap(device):
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device), "--showmaxpower", "--json"], capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout[r.stdout.index("{"):])
+        return float(next(v for k, v in next(iter(j.values())).items() if "Max Graphics Package Power" in k))
+    except Exception:       # noqa: BLE001
+        return None
+
+
+def run_power_probe(args, sv, cv, lib, ctx, names, device, samples=3, limit=8.0):
+    """Shader clock and socket power WHILE each workload's batch runs back to back (outside every timed region; the sampler is one child
+    process per workload: a short wait for the governor to settle, then `samples` rocm-smi readings).  On this part the path runs at the
+    socket's power cap: a plain copy moves 5.5 TB/s at ~860 W and 2400 MHz, the composite kernels sit at 1400 W with the clock pulled
+    down to 1.96-2.35 GHz (profiles/r05_notes.md section 10) — the roofline fraction of a kernel that is at neither its instruction floor
+    nor its memory floor is set by the energy its instructions cost."""
+    import shutil
+    if shutil.which("rocm-smi") is None:
+        return None
+    dev = HipDevice(cv, lib, ctx)
+    cap = smi_power_cap(device)
+    cmd = "sleep 0.8; " + "; sleep 0.1; ".join([f"rocm-smi -d {int(device)} --showclocks --showpower --json"] * samples)
+    out = {}
+    for name in names:
+        wl = WORKLOADS[name]
+        w = build_workload(sv, ctx, wl, wl["frames"], seed_base=0x5EED0000 + 16 * 5)
+        cv.check(lib.chv_batch_run(ctx.handle, w["batch"]))
+        dev.sync()
+        t0 = time.time()
+        child = subprocess.Popen(["bash", "-c", cmd], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        while child.poll() is None and time.time() - t0 < limit:
+            for _ in range(4):
+                cv.check(lib.chv_batch_run(ctx.handle, w["batch"]))
+            dev.sync()
+        if child.poll() is None:
+            child.kill()
+        text = child.communicate()[0]
+        free_workload(w)
+        got = smi_parse(text)
+        if got:
+            sclk, power = sum(g[0] for g in got) / len(got), sum(g[1] for g in got) / len(got)
+            out[name] = {"sclk_mhz": round(sclk), "power_w": round(power), "power_cap_w": cap, "at_power_cap": bool(cap and power >= 0.97 * cap),
+                         "kernel": w["kernel"], "probe_seconds": round(time.time() - t0, 2)}
+    return out or None
+
+
 def run_threads(args):
     """--gpus N --threads: N host threads in THIS process, thread r with its own compute context on device r (or --device); the threads meet at
     a barrier around the timed region exactly as the ranks of the process-per-GPU mode do, rank 0 prints the line"""
@@ -1456,9 +1521,17 @@ def run_rank(args, rank, local, world, dist):
     if (others or args.route_regret) and not args.stub_device and not args.no_route_regret and n_gpus == 1:
         regret = run_route_regret(args, sv, cv, lib, ctx, [n for n in ([args.workload] + others) if n in WORKLOADS])
 
+    power = None
+    if (others or args.power_probe) and not args.stub_device and not args.no_power_probe and n_gpus == 1:
+        power = run_power_probe(args, sv, cv, lib, ctx, [n for n in ([args.workload] + others) if n in WORKLOADS],
+                                args.device if args.device is not None else 0)
+
     if rank == 0:
         wl = WORKLOADS[args.workload]
         roof = dict(head["roofline"])
+        if power and args.workload in power:
+            # (the clock the kernel actually ran at and the power the socket drew meanwhile — sampled in a leg of its own after the timed regions)
+            roof.update({k: power[args.workload][k] for k in ("sclk_mhz", "power_w", "power_cap_w", "at_power_cap")})
         roof.update({"traffic": None, "traffic_source": None, "kernel": head["kernel"], "launch_ms": head["launch_ms"],
                      "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"]})
         # HBM traffic cannot be counted inside this process (PMC needs rocprofv3 around it, in passes of their own); what is
@@ -1510,12 +1583,16 @@ def run_rank(args, rank, local, world, dist):
                                    if "per_tick_thread_scaling" in reports and "native_fused_speedup_8_threads" in reports["per_tick_thread_scaling"] else {})},
                        # is the kernel the library picks for each workload the fastest of the routes that accept it?  regret = t(chosen) / t(best) - 1
                        "route_regret": None if regret is None else {k: {"chosen": v["chosen"], "best": v["best"], "regret": v["regret"]} for k, v in regret.items()},
-                       "route_regret_max": None if not regret else max(v["regret"] for v in regret.values())},
+                       "route_regret_max": None if not regret else max(v["regret"] for v in regret.values()),
+                       # name -> [shader clock MHz, socket power W] while the workload's batch runs back to back (cap: roofline.power_cap_w)
+                       "workload_power": None if not power else {k: [v["sclk_mhz"], v["power_w"]] for k, v in power.items()}},
             "roofline": roof,
             "workloads": {k: {kk: vv for kk, vv in v.items() if kk not in ("source_mpix_per_launch_per_gpu",)} for k, v in reports.items()},
         }
         if regret is not None:
             out["workloads"]["route_regret"] = regret
+        if power:
+            out["workloads"]["power_probe"] = power
         if args.stub_device:
             out["data"] = "STUB --stub-device: launches are sleeps; control-plane self-test, not a benchmark result"
             out["roofline"]["frac"] = None

@@ -591,6 +591,10 @@ struct WaveDims { int p0pitch, p0rows, p1pitch, p1rows; };
 static int strip_rows(int) { return 8; }      // (the height every eligible tick must fit; launches may pick 16, see launch_wave_layers)
 
 // LDS rectangles one strip of this layer can touch, from the layer's scale factors
+// rows of slack in a staged rectangle beyond ceil(strip rows x vertical ratio): tap row 1, and the ratio's rounding on both sides
+#ifndef CHV_P0ROWS_SLACK
+#define CHV_P0ROWS_SLACK 3
+#endif
 static WaveDims wave_dims(const DTick &T, const DLayer &L, int WTH) {
     const float *U = L.u;
     double sxr = std::fabs((double)U[U_TEXTURE + 0] * (double)U[U_TRANSFORM + 0] * 2.0 / (double)T.W);
@@ -601,7 +605,7 @@ static WaveDims wave_dims(const DTick &T, const DLayer &L, int WTH) {
     int span0 = (int)std::ceil(WTW * sxr * L.src.pl[0].w) + 4;           // texels incl. tap 1 and rounding slack
     d.p0pitch = ((span0 * bpt0 + 15) / 16 + 3) * 16;                      // vectors + alignment + 2 pad vectors
     // (rectangles taller than two rows per strip row are staged as the rows' own tap-row pairs: WGeom::pair, wave_common.hip.h)
-    d.p0rows = std::min((int)std::ceil(WTH * syr * L.src.pl[0].h) + 3, (CHV_WAVE_PAIR && WTH == 8) ? 2 * WTH : (1 << 30));
+    d.p0rows = std::min((int)std::ceil(WTH * syr * L.src.pl[0].h) + CHV_P0ROWS_SLACK, (CHV_WAVE_PAIR && WTH == 8) ? 2 * WTH : (1 << 30));
     if (!rgb) {
         const int bpt1 = planar ? 1 : 2;
         int span1 = (int)std::ceil(WTW * sxr * L.src.pl[1].w) + 4;

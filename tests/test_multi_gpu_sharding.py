@@ -159,7 +159,7 @@ def test_default_run_measures_its_hbm_traffic():
     e2e = d["workloads"]["pipeline_e2e"]
     assert e2e["verified_vs_oracle"] is True and e2e["ticks_per_s"] > 100 and 0 < e2e["d2h_frac_of_link"] < e2e["h2d_frac_of_link"] < 1.1
     legs = ("cfg2_upload", "pipeline_per_tick", "pipeline_reference_sequence", "mixer_y420p_per_tick", "mixer_y420p_reference_sequence", "pipeline_e2e", "per_tick_thread_scaling",
-            "route_regret")
+            "route_regret", "power_probe")
     ts = d["workloads"]["per_tick_thread_scaling"]
     assert set(ts["python"]["fused"]) == {"1", "2", "4", "8"} and "error" not in ts["native"], ts.get("native")
     assert ts["native"]["fused"]["8"] > ts["native"]["fused"]["1"] * 0.8
@@ -181,6 +181,11 @@ def test_default_run_measures_its_hbm_traffic():
     assert set(cfg["route_regret"]) == set(cfg["workload_fracs"]) and cfg["route_regret_max"] < 0.25, cfg["route_regret"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    # the clock the kernels ran at and the socket power meanwhile (the path runs at the power cap: profiles/r05_notes.md section 10)
+    if shutil.which("rocm-smi") and cfg["workload_power"]:
+        assert set(cfg["workload_power"]) == set(cfg["workload_fracs"]), cfg["workload_power"]
+        assert all(500 <= v[0] <= 3000 and 100 <= v[1] <= 2000 for v in cfg["workload_power"].values()), cfg["workload_power"]
+        assert r["power_cap_w"] is None or r["power_w"] <= 1.05 * r["power_cap_w"]
     if shutil.which("rocprofv3"):
         assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
         assert 0.97 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.10 * r["algorithmic_bytes_per_launch"], r
