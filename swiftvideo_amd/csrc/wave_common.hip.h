@@ -213,6 +213,48 @@ CHV_DEV void wstage_tail(uint8_t *lds, int lds_pitch, const DPlane &P, const WGe
     }
 }
 
+// the same for the rest of TWO rectangles at once (an NV12 picture's luma and chroma): WTAIL loads of each in flight, one wait per round
+#ifndef CHV_WAVE_NV12_WIDE
+#define CHV_WAVE_NV12_WIDE 1
+#endif
+template <bool EDGE, bool PAIR>
+CHV_DEV uint4 wstage_tail_load(const DPlane &P, const WGeom &g, int i, int pry) {
+    int r, vv;
+    stage_slot(g, i, r, vv);
+    uint4 t = make_uint4(0, 0, 0, 0);
+    const int srow = wstage_row<PAIR>(g, r, pry);
+    if (i < 1024 && r < g.rows) {
+        if constexpr (EDGE) {
+            int row = min(max(srow, 0), P.h - 1);
+            int off = g.b0 + (g.edge ? vv - 1 : vv) * 16;
+            if (g.edge) off = vec_loadable(P, row, off) ? off : 0;
+            t = gld<uint4>(P.ptr + (size_t)row * P.pitch + off);
+        } else {
+            t = gld<uint4>(P.ptr + (size_t)srow * P.pitch + (g.b0 + vv * 16));
+        }
+    }
+    return t;
+}
+template <int BPT0, int BPT1, int N0, int N1, bool EDGE, bool PAIR>
+CHV_DEV void wstage_tail2(uint8_t *lds0, int pitch0, const DPlane &P0, const WGeom &g0, int pry0,
+                          uint8_t *lds1, int pitch1, const DPlane &P1, const WGeom &g1, int pry1, int lane) {
+    const int n0 = stage_slots(g0), n1 = stage_slots(g1);
+#pragma unroll 1
+    for (int b0 = N0 * 64, b1 = N1 * 64; b0 < n0 || b1 < n1; b0 += WTAIL * 64, b1 += WTAIL * 64) {
+        uint4 t0[WTAIL], t1[WTAIL];
+#pragma unroll
+        for (int n = 0; n < WTAIL; n++) {
+            t0[n] = wstage_tail_load<EDGE, PAIR>(P0, g0, min(b0 + n * 64 + lane, 1024), pry0);
+            t1[n] = wstage_tail_load<EDGE, PAIR>(P1, g1, min(b1 + n * 64 + lane, 1024), pry1);
+        }
+#pragma unroll
+        for (int n = 0; n < WTAIL; n++) {
+            wstage_put<BPT0, EDGE, PAIR>(t0[n], min(b0 + n * 64 + lane, 1024), lds0, pitch0, P0, g0, false, pry0);
+            wstage_put<BPT1, EDGE, PAIR>(t1[n], min(b1 + n * 64 + lane, 1024), lds1, pitch1, P1, g1, false, pry1);
+        }
+    }
+}
+
 // ---- shift-and-mask staging of narrow interior rectangles ------------------------------------------------------------
 // Rectangles that touch no picture edge and are at most 8 vectors wide (luma and chroma of YUV pictures up to ~1.9x downscale: the
 // pipeline, cfg2, every native-resolution video layer): lane -> (row of the round, vector) is lane >> sh, lane & mask with
@@ -464,13 +506,21 @@ struct WaveStrip {
             wstage_store<4, 0, WN_RGB, WNR, EDGE, PAIR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0, pry0);
             wstage_tail<4, WN_RGB, EDGE, PAIR>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, Ly.swizzle != 0, pry0);
         } else if (!is_planar(Ly.kind)) {
+            // (two planes: the interleaved chroma rectangle takes the registers a planar picture's V plane would — in pair form it has as many
+            // slots as the luma rectangle — and what is left of BOTH rectangles finishes in one loop, one wait per round of it: a grid
+            // quadrant's 2 x 208 slots are two waits instead of four)
+            constexpr int WN_C2 = CHV_WAVE_NV12_WIDE ? 2 * WN_C : WN_C;
             wstage_load<0, WN_Y, WNR, EDGE, PAIR>(regs, Ly.src.pl[0], w.g0, lane, pry0);
-            wstage_load<WN_Y, WN_C, WNR, EDGE, PAIR>(regs, Ly.src.pl[1], w.g1, lane, pry1);
+            wstage_load<WN_Y, WN_C2, WNR, EDGE, PAIR>(regs, Ly.src.pl[1], w.g1, lane, pry1);
             touch_regs(regs);
             wstage_store<1, 0, WN_Y, WNR, EDGE, PAIR>(regs, smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false, pry0);
-            wstage_store<2, WN_Y, WN_C, WNR, EDGE, PAIR>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false, pry1);
-            wstage_tail<1, WN_Y, EDGE, PAIR>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false, pry0);
-            wstage_tail<2, WN_C, EDGE, PAIR>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false, pry1);
+            wstage_store<2, WN_Y, WN_C2, WNR, EDGE, PAIR>(regs, smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false, pry1);
+            if constexpr (CHV_WAVE_NV12_WIDE) {
+                wstage_tail2<1, 2, WN_Y, WN_C2, EDGE, PAIR>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, pry0, smem + base1, p1pitch, Ly.src.pl[1], w.g1, pry1, lane);
+            } else {
+                wstage_tail<1, WN_Y, EDGE, PAIR>(smem + base0, p0pitch, Ly.src.pl[0], w.g0, lane, false, pry0);
+                wstage_tail<2, WN_C, EDGE, PAIR>(smem + base1, p1pitch, Ly.src.pl[1], w.g1, lane, false, pry1);
+            }
         } else {
             wstage_load<0, WN_Y, WNR, EDGE, PAIR>(regs, Ly.src.pl[0], w.g0, lane, pry0);
             wstage_load<WN_Y, WN_C, WNR, EDGE, PAIR>(regs, Ly.src.pl[1], w.g1, lane, pry1);
