@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 # 1. the default line, exactly as the driver runs it
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 # 2. kernel-trace stats of every workload's kernel (shorter timed regions: the profiler keeps every dispatch)
-(cd /tmp && timeout -k 5 240 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_all/stats -o stats -- python $ROOT/bench.py --no-cpu-baseline --no-verify --no-live-pmc --no-per-tick --no-upload-leg --min-seconds 0.3 --min-seconds-other 0.15 --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> /dev/null)
+(cd /tmp && timeout -k 5 240 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_all/stats -o stats -- python $ROOT/bench.py --no-cpu-baseline --no-verify --no-live-pmc --no-per-tick --no-upload-leg --no-route-regret --no-power-probe --min-seconds 0.3 --min-seconds-other 0.15 --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> /dev/null)
 python profiles/summarize.py gpurun_out/prof_${R}_all > $OUT/all_workloads_rocprofv3.txt 2>&1
 # 3a. the headline workload alone under kernel-trace, long enough (hundreds of launches) for the average to be comparable with the
 #     HIP-event figure of the default line
