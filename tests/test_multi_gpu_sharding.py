@@ -202,3 +202,21 @@ def test_upload_mode_per_rank_plumbing_on_stub_devices(mode):
     assert d["n_gpus"] == 2 and len(pr["h2d_GBps"]) == 2 and len(pr["launch_ms"]) == 2
     assert pr["launch_ms"][1] > pr["launch_ms"][0] * 1.1             # the stub's rank 1 is 25 % slower: the per-rank numbers are per rank
     assert pr["pinned_numa_node"] == [0, 0] and all(c >= 1 for c in pr["cpus_bound"])
+
+
+def test_clock_and_power_readings_are_parsed_from_what_rocm_smi_prints():
+    """bench.py's clock / power leg reads `rocm-smi --showclocks --showpower --json` (one JSON object per call, warnings in between): the shader
+    clock in "(1965Mhz)" form and the socket power as a string; a call that printed something else contributes nothing."""
+    import bench
+    text = "\n".join([
+        "WARNING: AMD GPU device(s) is/are in a low-power state. Check power control/runtime_status",
+        '{"card0": {"fclk clock speed:": "(1250Mhz)", "fclk clock level:": "0", "mclk clock speed:": "(2000Mhz)", "mclk clock level:": "0", '
+        '"sclk clock speed:": "(1965Mhz)", "sclk clock level:": "1", "socclk clock speed:": "(50Mhz)", "socclk clock level:": "S", '
+        '"Current Socket Graphics Package Power (W)": "1400.0"}}',
+        "/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory",
+        '{"card0": {"sclk clock speed:": "(1971Mhz)", "Current Socket Graphics Package Power (W)": "1398.0"}}',
+        '{"card0": {"mclk clock speed:": "(2000Mhz)"}}',
+        "{not json",
+    ])
+    assert bench.smi_parse(text) == [(1965.0, 1400.0), (1971.0, 1398.0)]
+    assert bench.smi_parse("") == []
