@@ -1,3 +1,5 @@
+"""tools/h2d_probe.py — pinned host -> device copy rate by copy size (1 MiB ... 128 MiB) on one side stream: what the link gives hipMemcpyAsync, the
+yardstick of bench.py's upload-inclusive legs.  Run on the GPU box."""
 import ctypes as C, time
 hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
 def chk(e): assert e == 0, e
