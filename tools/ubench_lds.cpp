@@ -4,6 +4,7 @@
 // Build: hipcc --offload-arch=gfx950 -O2 tools/ubench_lds.cpp -o tools/ubench_lds.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 
 #define REP4(x) x x x x
@@ -87,9 +88,46 @@ void run(const char *name, uint32_t *d_out, int waves_per_simd, int per_group = 
     printf("%-34s waves/SIMD=%d  %.3f ns per wave-instruction per CU (%.2f clk @2.4GHz)\n", name, waves_per_simd, ns, ns * 2.4);
     fflush(stdout);
 }
+// sustained mode (ubench_lds.bin <case> <seconds>): one form for seconds, so that the power governor settles — sample rocm-smi beside it
+// (tools/power_classes.sh; profiles/r05_notes.md section 10)
+#include <chrono>
+template <int OP, int MODE>
+void sustained(const char *name, uint32_t *d_out, double seconds) {
+    const int iters = 1000, waves_per_simd = 4;
+    dim3 block(256), grid(256 * waves_per_simd);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((bench<OP, MODE>), grid, block, 16384, 0, d_out, iters, 5u);
+    (void)hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
+    double last_ms = 0;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+        (void)hipEventRecord(e0);
+        for (int k = 0; k < 8; k++) hipLaunchKernelGGL((bench<OP, MODE>), grid, block, 16384, 0, d_out, iters, 5u);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        last_ms = ms / 8;
+    }
+    const double n_inst = (double)iters * 16.0 * 8 * waves_per_simd * 4;
+    printf("%-34s sustained %.3f ns per wave-instruction per CU\n", name, last_ms * 1e6 / n_inst);
+}
 #define RUN(OP, MODE, NAME) for (int w : {2, 4}) run<OP, MODE>(NAME, d_out, w);
-int main() {
+int main(int argc, char **argv) {
     uint32_t *d_out; (void)hipMalloc(&d_out, 1024);
+    if (argc > 2) {
+        const double sec = atof(argv[2]);
+        switch (atoi(argv[1])) {
+            case 0: sustained<0, 0>("ds_read_u8 lane*1.5", d_out, sec); break;
+            case 1: sustained<1, 0>("ds_read_u16 lane*1.5&~1", d_out, sec); break;
+            case 2: sustained<2, 1>("ds_read_b32 lane*4", d_out, sec); break;
+            case 3: sustained<5, 4>("ds_read_b64 lane*8", d_out, sec); break;
+            case 4: sustained<6, 1>("ds_read2_b32 lane*4", d_out, sec); break;
+            case 5: sustained<7, 2>("ds_read_b128 lane*16", d_out, sec); break;
+            case 6: sustained<8, 2>("ds_write_b128 lane*16", d_out, sec); break;
+            case 7: sustained<0, 3>("ds_read_u8 broadcast", d_out, sec); break;
+            default: printf("unknown case\n");
+        }
+        return 0;
+    }
     RUN(0, 0, "ds_read_u8 lane*1.5") RUN(0, 1, "ds_read_u8 lane*4") RUN(0, 3, "ds_read_u8 broadcast")
     RUN(1, 0, "ds_read_u16 lane*1.5&~1") RUN(2, 0, "ds_read_b32 lane*1.5&~3") RUN(2, 1, "ds_read_b32 lane*4")
     RUN(3, 0, "ds_read_u8_d16 lane*1.5") RUN(4, 0, "ds_read_u8_d16_hi lane*1.5")
