@@ -29,7 +29,7 @@
 namespace chv {
 
 #ifndef CHV_ST_ABL
-#define CHV_ST_ABL 0        // timing-only (wrong pixels): 1 no ring fills, 2 no canvas stores
+#define CHV_ST_ABL 0        // timing-only (wrong pixels): 1 no ring fills, 2 no canvas stores, 4 no layer arithmetic (rings and stores only)
 #endif
 #ifndef CHV_STREAM_ROWS_FIXED
 #define CHV_STREAM_ROWS_FIXED 0
@@ -282,7 +282,7 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
         const float c00 = ica * icb, c10 = ca * icb, c01 = ica * cbw, c11 = ca * cbw;
         float r0 = 0.f, r1 = 0.f, r2 = 0.f;                          // img_clear_bgra: (0, 0, 0, 1) — the canvas pixel as float codes
 #pragma unroll
-        for (int l = 0; l < NL; l++) {
+        for (int l = 0; l < ((CHV_ST_ABL & 4) ? 0 : NL); l++) {
             constexpr int dummy = 0; (void)dummy;
             const int lo = l * ST_YL, lc = l * CLB;
             const float fy = cs_mix_h(w00, w10, w01, w11, tap_h(pY00 + lo), tap_h(pY10 + lo), tap_h(pY01 + lo), tap_h(pY11 + lo));
