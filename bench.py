@@ -57,6 +57,7 @@ WORKLOADS = {
     # algorithmic bytes per tick = every distinct input byte once + every output byte once
     "pipeline": dict(desc="4 x 1920x1080 NV12 streams -> BGRA (BT.601 int) + bilinear downscale to 1280x720 + 4-layer "
                           "alpha composite (opacity 1/.75/.5/.25) onto one 720p BGRA canvas, one launch per batch of ticks",
+                     short="4 x 1080p NV12 -> BGRA (BT.601 int) + bilinear scale to 720p + 4-layer alpha composite, one launch per batch",
                      kind="yuv_layers", src="nv12", sw=1920, sh=1080, dw=1280, dh=720, layers=4, frames=256,
                      bytes=4 * NV12_1080 + BGRA_720),
     "pipeline_logo": dict(desc="the pipeline tick + one ROTATED 320x180 RGBA logo (opacity .9) on top: two launches per batch — the streaming kernel "
@@ -126,6 +127,13 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--full", action="store_true",
+                    help="every leg on top of the default command (headline + the default workloads + live PMC + CPU sample): the upload-inclusive "
+                         "and end-to-end legs, the one-tick-at-a-time legs, thread scaling, route regret, clock / power of every workload.  "
+                         "They go to bench_detail.json; the last stdout line stays the compact one either way")
+    ap.add_argument("--detail-json", default=None,
+                    help="where rank 0 writes the full report (every workload's record, the legs, build flags, prose): default bench_detail.json "
+                         "next to this script; 'none' to write nothing")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the end-to-end (H2D-inclusive) cfg2 measurement")
     ap.add_argument("--upload-group", type=int, default=8, help="frames per H2D copy in the upload-inclusive leg")
     ap.add_argument("--upload-streams", type=int, default=2, help="upload streams (contexts) in the upload-inclusive leg")
@@ -657,7 +665,7 @@ def report_of(name, wl, args, tm, n_gpus, frames, per_step, elapsed, local, laun
     bytes_per_launch = frames * wl["bytes"]
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
     return {
-        "workload": f"{name}: {wl['desc']}",
+        "workload": f"{name}: {wl['desc']}", "workload_short": f"{name}: {wl.get('short', wl['desc'])}",
         "value": whole_job_gpix(n_gpus, px_per_launch * per_step, args.steps, elapsed), "unit": "Gpix/s",
         "ms_per_step": elapsed / args.steps * 1e3, "launches_per_step": per_step, "timed_seconds": elapsed,
         "frames_per_launch_per_gpu": frames, "kernel": kernel, "verified_vs_oracle": verified,
@@ -1487,16 +1495,16 @@ def run_rank(args, rank, local, world, dist):
         rep = run_with_upload_stub(args, tm, rank, n_gpus) if args.stub_device else \
             run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
         if rank == 0:
-            print(json.dumps({"metric": METRIC, "value": rep["value"], "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps,
-                              "warmup": args.warmup, "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": rep["workload"], "mode": "END-TO-END (not the headline mode)",
-                                         "launches_per_step": rep["launches_per_step"], "h2d_GBps_per_gpu": rep["h2d_GBps_per_gpu"],
-                                         "h2d_frac_of_link": rep["h2d_frac_of_link"], "upload_copy_MB": rep["upload_copy_MB"], "upload_streams": rep["upload_streams"],
-                                         "pinned_numa_node": rep["pinned_numa_node"], "verified_vs_oracle": rep["verified_vs_oracle"],
-                                         "per_rank": rep["per_rank"],
-                                         "frames_per_step_per_gpu": rep["frames_per_launch_per_gpu"] * rep["launches_per_step"],
-                                         "kernel": rep["kernel"]}}), flush=True)
+            print(compact_line({"metric": METRIC, "value": rep["value"], "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps,
+                                "warmup": args.warmup, "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                                "config": {"workload": rep["workload"], "mode": "END-TO-END (not the headline mode)",
+                                           "launches_per_step": rep["launches_per_step"], "h2d_GBps_per_gpu": rep["h2d_GBps_per_gpu"],
+                                           "h2d_frac_of_link": rep["h2d_frac_of_link"], "upload_copy_MB": rep["upload_copy_MB"], "upload_streams": rep["upload_streams"],
+                                           "pinned_numa_node": rep["pinned_numa_node"], "verified_vs_oracle": rep["verified_vs_oracle"],
+                                           "per_rank": rep["per_rank"], "frames_per_launch_per_gpu": rep["frames_per_launch_per_gpu"],
+                                           "frames_per_step_per_gpu": rep["frames_per_launch_per_gpu"] * rep["launches_per_step"],
+                                           "kernel": rep["kernel"]}}), flush=True)
         tm.barrier()
         if dist is not None and not isinstance(dist, ThreadDist):
             dist.destroy_process_group()
@@ -1510,101 +1518,224 @@ def run_rank(args, rank, local, world, dist):
     reports = {args.workload: head}
     for name in others:
         reports[name], _ = do(name, False)
-    if others and not args.no_upload_leg and not args.stub_device:
+    # ---- the legs: behind --full (or their own switch); none of them feeds `value`
+    real = not args.stub_device
+    if args.full and others and real and not args.no_upload_leg:
         reports["cfg2_upload"] = run_with_upload(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
         reports["pipeline_e2e"] = run_e2e(args, sv, cv, lib, ctx, tm, rank, n_gpus, group=args.upload_group, streams=args.upload_streams)
-    if (others or args.per_tick) and not args.stub_device and not args.no_per_tick and n_gpus == 1:
+    if ((args.full and others) or args.per_tick) and real and not args.no_per_tick and n_gpus == 1:
         reports.update(run_per_tick(args, sv, cv, lib, ctx))
         reports.update(run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p"))
         reports.update(run_thread_scaling(args, sv, cv, lib, ctx))
     regret = None
-    if (others or args.route_regret) and not args.stub_device and not args.no_route_regret and n_gpus == 1:
+    if ((args.full and others) or args.route_regret) and real and not args.no_route_regret and n_gpus == 1:
         regret = run_route_regret(args, sv, cv, lib, ctx, [n for n in ([args.workload] + others) if n in WORKLOADS])
-
     power = None
-    if (others or args.power_probe) and not args.stub_device and not args.no_power_probe and n_gpus == 1:
-        power = run_power_probe(args, sv, cv, lib, ctx, [n for n in ([args.workload] + others) if n in WORKLOADS],
-                                args.device if args.device is not None else 0)
+    if real and not args.no_power_probe and n_gpus == 1 and (others or args.power_probe):
+        # the default command samples the headline's clock / power only (1.5 s); --full every workload's
+        probed = [n for n in ([args.workload] + (others if (args.full or args.power_probe) else [])) if n in WORKLOADS]
+        power = run_power_probe(args, sv, cv, lib, ctx, probed, args.device if args.device is not None else 0)
 
     if rank == 0:
-        wl = WORKLOADS[args.workload]
-        roof = dict(head["roofline"])
-        if power and args.workload in power:
-            # (the clock the kernel actually ran at and the power the socket drew meanwhile — sampled in a leg of its own after the timed regions)
-            roof.update({k: power[args.workload][k] for k in ("sclk_mhz", "power_w", "power_cap_w", "at_power_cap")})
-        roof.update({"traffic": None, "traffic_source": None, "kernel": head["kernel"], "launch_ms": head["launch_ms"],
-                     "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"]})
-        # HBM traffic cannot be counted inside this process (PMC needs rocprofv3 around it, in passes of their own); what is
-        # reported is the committed measurement of the same workload and batch size — and the field says so
-        pmc_path = Path(args.pmc_json) if args.pmc_json else ROOT / "profiles" / "pmc_latest.json"
-        live_err = None
-        # (the default run only — what the driver times; `--also …` runs are the builder's A/Bs and profiling passes)
-        if n_gpus == 1 and args.also is None and not args.no_live_pmc and not args.stub_device and args.alias == "none" and not args.pmc_json:
-            kname = head["kernel"].split("<")[0]
-            t, live_err = live_traffic(args.workload, head["frames_per_launch_per_gpu"], kname, args.device if args.device is not None else 0)
-            if t is not None:
-                roof["traffic"] = t
-                roof["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in two separate child passes of "
-                                          f"`bench.py --workload {args.workload}` (3 launches each), FETCH_SIZE x 2 (gfx950), KB = 1024 B, kernel {kname}")
-        if roof["traffic"] is None and pmc_path.exists():
+        detail = build_detail(args, dist, n_gpus, head, cpu, reports, regret, power, None if args.stub_device else cv.build_flags())
+        line = compact_line(detail)
+        path = None if args.detail_json == "none" else Path(args.detail_json or ROOT / "bench_detail.json")
+        if path is not None:
             try:
-                j = json.loads(pmc_path.read_text())
-                if j.get("workload") == args.workload and j.get("frames") == head["frames_per_launch_per_gpu"]:
-                    roof["traffic"] = j.get("hbm_bytes_per_launch")
-                    roof["traffic_source"] = (f"NOT measured in this run: {pmc_path.name}, rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE "
-                                              f"in separate passes of `bench.py --workload {args.workload}` (profiles/collect_round.sh), kernel {j.get('kernel')}")
-                    if live_err:
-                        roof["traffic_source"] += f" (live measurement unavailable: {live_err})"
-            except Exception as e:    # noqa: BLE001
-                roof["traffic_source"] = f"unreadable {pmc_path}: {e}"
-        out = {
-            "metric": METRIC, "value": head["value"], "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": head["workload"], "launches_per_step": head["launches_per_step"],
-                       "frames_per_launch_per_gpu": head["frames_per_launch_per_gpu"],
-                       "frames_per_step_per_gpu": head["frames_per_launch_per_gpu"] * head["launches_per_step"],
-                       "timed_seconds": head["timed_seconds"], "gpix_counts": "target pixels written",
-                       "source_mpix_per_launch_per_gpu": head["source_mpix_per_launch_per_gpu"],
-                       "parallelism": (f"ONE process, {n_gpus} host threads, a compute context per device" if isinstance(dist, ThreadDist) else
-                                       f"{n_gpus} process(es), one per GPU") + f"; {head['frames_per_launch_per_gpu']} independent picture "
-                                      f"buses per device, bus s -> device s mod {n_gpus}; no collective",
-                       "per_gpu_gpix": head["per_gpu_gpix"], "per_gpu_launch_ms": head["per_gpu_launch_ms"], "per_stream_ticks_per_s": head["per_stream_ticks_per_s"],
-                       "kernel": head["kernel"], "verified_vs_oracle": head["verified_vs_oracle"],
-                       "build_flags": None if args.stub_device else cv.build_flags(),
-                       # every workload of the run where the driver's parser keeps it: name -> [fraction of the 8 TB/s HBM peak, ms per launch, kernel]
-                       "workload_fracs": {k: [round(v["roofline"]["frac"], 4), round(v["launch_ms"], 4), v["kernel"]] for k, v in reports.items() if "roofline" in v},
-                       "legs": {**{k + "_us_per_tick": round(v["us_per_tick"], 2) for k, v in reports.items() if "us_per_tick" in v},
-                                **({"pipeline_e2e_ticks_per_s": round(reports["pipeline_e2e"]["ticks_per_s"], 1),
-                                    "pipeline_e2e_h2d_GBps": round(reports["pipeline_e2e"]["h2d_GBps_per_gpu"], 2)} if "pipeline_e2e" in reports else {}),
-                                **({"cfg2_upload_h2d_GBps": round(reports["cfg2_upload"]["h2d_GBps_per_gpu"], 2),
-                                    "pinned_numa_node": reports["cfg2_upload"]["pinned_numa_node"]} if "cfg2_upload" in reports else {}),
-                                **({"native_fused_speedup_8_threads": round(reports["per_tick_thread_scaling"]["native_fused_speedup_8_threads"], 2)}
-                                   if "per_tick_thread_scaling" in reports and "native_fused_speedup_8_threads" in reports["per_tick_thread_scaling"] else {})},
-                       # is the kernel the library picks for each workload the fastest of the routes that accept it?  regret = t(chosen) / t(best) - 1
-                       "route_regret": None if regret is None else {k: {"chosen": v["chosen"], "best": v["best"], "regret": v["regret"]} for k, v in regret.items()},
-                       "route_regret_max": None if not regret else max(v["regret"] for v in regret.values()),
-                       # name -> [shader clock MHz, socket power W] while the workload's batch runs back to back (cap: roofline.power_cap_w)
-                       "workload_power": None if not power else {k: [v["sclk_mhz"], v["power_w"]] for k, v in power.items()}},
-            "roofline": roof,
-            "workloads": {k: {kk: vv for kk, vv in v.items() if kk not in ("source_mpix_per_launch_per_gpu",)} for k, v in reports.items()},
-        }
-        if regret is not None:
-            out["workloads"]["route_regret"] = regret
-        if power:
-            out["workloads"]["power_probe"] = power
-        if args.stub_device:
-            out["data"] = "STUB --stub-device: launches are sleeps; control-plane self-test, not a benchmark result"
-            out["roofline"]["frac"] = None
-        if args.alias != "none":
-            out["data"] = f"DIAGNOSTIC --alias {args.alias}: ticks share frame 0's buffers, cache-resident traffic; not a benchmark result"
-            out["roofline"]["frac"] = None
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+                path.write_text(json.dumps(detail, indent=1) + "\n")
+                print(f"bench: full report (every workload's record, legs, prose) -> {path}", file=sys.stderr, flush=True)
+            except OSError as e:
+                print(f"bench: could not write {path}: {e}", file=sys.stderr, flush=True)
+        print(line, flush=True)
     tm.barrier()
     if dist is not None and not isinstance(dist, ThreadDist):
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the report: bench_detail.json (everything) and the ONE compact stdout line (what the driver parses)
+# ---------------------------------------------------------------------------------------------------------------
+# What bounds each workload's kernel — named by the probes, not by the roofline's name (SURVEY 8d fixes the roofline at HBM):
+#   valu_issue  the kernel's arithmetic alone takes >= 90 % of the shipped launch at full clock (CHV_ST_ABL / CHV_ABL halves:
+#               profiles/r05_notes.md 10.4; mixer_y420p: section 4 + r06_notes.md — 128 VALU per overlay row, LDS pipe idle, below the cap)
+#   power_cap   at the socket's 1400 W with the shader clock pulled >= 5 % below its 2.4 GHz maximum (r05_notes.md section 10)
+#   latency     below the cap at full clock, staging alone 1.2-1.7x its bytes' copy time (r05_notes.md 10.5)
+# A live clock / power sample (the headline in the default run, every workload under --full) overrides the table where it shows the cap.
+LIMITER_TABLE = {"pipeline": "valu_issue", "pipeline_y420p": "valu_issue", "pipeline_logo": "valu_issue", "cfg2": "valu_issue", "cfg2_y420p": "valu_issue",
+                 "cfg3": "power_cap", "cfg5": "power_cap", "mixer_y420p": "valu_issue", "mixer_nv12": "valu_issue", "y420p_main": "valu_issue",
+                 "encode_nv12": "valu_issue", "pipeline_grid": "latency", "mixed": "latency"}
+SCLK_MAX_MHZ = 2400.0
+# the headline kernel's additive issue model (profiles/r03_notes.md section 1, r05_notes.md 10.4): per 64-pixel row of a 4-layer tick one wave issues
+# 83 full-rate + 95 half-rate vector instructions + 48 LDS instructions at 1.1 / 1.8 / 1.05 ns; 256 CUs x 4 SIMDs issue in parallel
+ISSUE_MODEL = {"tick_bgra_stream": {"layers": 4, "fast": 83, "slow": 95, "lds": 48, "ns": (1.1, 1.8, 1.05), "simds": 1024}}
+
+
+def limiter_of(name, probe):
+    lim = LIMITER_TABLE.get(name)
+    if probe and probe.get("at_power_cap") and probe.get("sclk_mhz", SCLK_MAX_MHZ) <= 0.95 * SCLK_MAX_MHZ and lim != "valu_issue":
+        lim = "power_cap"
+    return lim
+
+
+def issue_model_ms(kernel, wl, frames):
+    m = ISSUE_MODEL.get(kernel)
+    if m is None or wl.get("layers") != m["layers"] or wl["kind"] != "yuv_layers" or wl.get("logo"):
+        return None
+    row_ns = m["fast"] * m["ns"][0] + m["slow"] * m["ns"][1] + m["lds"] * m["ns"][2]
+    wave_rows = frames * wl["dh"] * math.ceil(wl["dw"] / 64)
+    return wave_rows / m["simds"] * row_ns * 1e-6
+
+
+def build_detail(args, dist, n_gpus, head, cpu, reports, regret, power, build_flags):
+    """Everything the run measured, as one dict (bench_detail.json)."""
+    wl = WORKLOADS[args.workload]
+    roof = dict(head["roofline"])
+    probe = (power or {}).get(args.workload)
+    if probe:
+        # (the clock the kernel actually ran at and the power the socket drew meanwhile — sampled in a leg of its own after the timed regions)
+        roof.update({k: probe[k] for k in ("sclk_mhz", "power_w", "power_cap_w", "at_power_cap")})
+    roof.update({"limiter": limiter_of(args.workload, probe), "traffic": None, "traffic_ratio": None, "traffic_source": None, "kernel": head["kernel"],
+                 "launch_ms": head["launch_ms"], "issue_model_ms": issue_model_ms(head["kernel"], wl, head["frames_per_launch_per_gpu"]),
+                 "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"]})
+    # HBM traffic cannot be counted inside this process (PMC needs rocprofv3 around it, in passes of their own): two short child passes of
+    # this script after the timed regions; where rocprofv3 is missing, the committed measurement of the same workload — and the field says which
+    pmc_path = Path(args.pmc_json) if args.pmc_json else ROOT / "profiles" / "pmc_latest.json"
+    live_err = None
+    # (the default run only — what the driver times; `--also …` runs are the builder's A/Bs and profiling passes)
+    if n_gpus == 1 and args.also is None and not args.no_live_pmc and not args.stub_device and args.alias == "none" and not args.pmc_json:
+        kname = head["kernel"].split("<")[0]
+        t, live_err = live_traffic(args.workload, head["frames_per_launch_per_gpu"], kname, args.device if args.device is not None else 0)
+        if t is not None:
+            roof["traffic"] = t
+            roof["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in two separate child passes of "
+                                      f"`bench.py --workload {args.workload}` (3 launches each), FETCH_SIZE x 2 (gfx950), KB = 1024 B, kernel {kname}")
+    if roof["traffic"] is None and pmc_path.exists():
+        try:
+            j = json.loads(pmc_path.read_text())
+            if j.get("workload") == args.workload and j.get("frames") == head["frames_per_launch_per_gpu"]:
+                roof["traffic"] = j.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = (f"NOT measured in this run: {pmc_path.name}, rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE "
+                                          f"in separate passes of `bench.py --workload {args.workload}` (profiles/collect_round.sh), kernel {j.get('kernel')}")
+                if live_err:
+                    roof["traffic_source"] += f" (live measurement unavailable: {live_err})"
+        except Exception as e:    # noqa: BLE001
+            roof["traffic_source"] = f"unreadable {pmc_path}: {e}"
+    if roof["traffic"]:
+        roof["traffic_ratio"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+    for k, v in reports.items():          # every workload's own limiter beside its fraction
+        if "roofline" in v:
+            v["roofline"]["limiter"] = limiter_of(k, (power or {}).get(k))
+    out = {
+        "metric": METRIC, "value": head["value"], "unit": "Gpix/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": head["workload"], "workload_short": head["workload_short"], "launches_per_step": head["launches_per_step"],
+                   "frames_per_launch_per_gpu": head["frames_per_launch_per_gpu"],
+                   "frames_per_step_per_gpu": head["frames_per_launch_per_gpu"] * head["launches_per_step"],
+                   "timed_seconds": head["timed_seconds"], "gpix_counts": "target pixels written",
+                   "source_mpix_per_launch_per_gpu": head["source_mpix_per_launch_per_gpu"],
+                   "parallelism": (f"ONE process, {n_gpus} host threads, a compute context per device" if isinstance(dist, ThreadDist) else
+                                   f"{n_gpus} process(es), one per GPU") + f"; {head['frames_per_launch_per_gpu']} independent picture "
+                                  f"buses per device, bus s -> device s mod {n_gpus}; no collective",
+                   "per_gpu_gpix": head["per_gpu_gpix"], "per_gpu_launch_ms": head["per_gpu_launch_ms"], "per_stream_ticks_per_s": head["per_stream_ticks_per_s"],
+                   "kernel": head["kernel"], "verified_vs_oracle": head["verified_vs_oracle"], "build_flags": build_flags, "full": bool(args.full),
+                   # every workload of the run: name -> [fraction of the 8 TB/s HBM peak, ms per launch, kernel]
+                   "workload_fracs": {k: [round(v["roofline"]["frac"], 4), round(v["launch_ms"], 4), v["kernel"]] for k, v in reports.items() if "roofline" in v},
+                   "workload_limiters": {k: v["roofline"]["limiter"] for k, v in reports.items() if "roofline" in v},
+                   "legs": {**{k + "_us_per_tick": round(v["us_per_tick"], 2) for k, v in reports.items() if "us_per_tick" in v},
+                            **({"pipeline_e2e_ticks_per_s": round(reports["pipeline_e2e"]["ticks_per_s"], 1),
+                                "pipeline_e2e_h2d_GBps": round(reports["pipeline_e2e"]["h2d_GBps_per_gpu"], 2)} if "pipeline_e2e" in reports else {}),
+                            **({"cfg2_upload_h2d_GBps": round(reports["cfg2_upload"]["h2d_GBps_per_gpu"], 2),
+                                "pinned_numa_node": reports["cfg2_upload"]["pinned_numa_node"]} if "cfg2_upload" in reports else {}),
+                            **({"native_fused_speedup_8_threads": round(reports["per_tick_thread_scaling"]["native_fused_speedup_8_threads"], 2)}
+                               if "per_tick_thread_scaling" in reports and "native_fused_speedup_8_threads" in reports["per_tick_thread_scaling"] else {})},
+                   # is the kernel the library picks for each workload the fastest of the routes that accept it?  regret = t(chosen) / t(best) - 1
+                   "route_regret": None if regret is None else {k: {"chosen": v["chosen"], "best": v["best"], "regret": v["regret"]} for k, v in regret.items()},
+                   "route_regret_max": None if not regret else max(v["regret"] for v in regret.values()),
+                   # name -> [shader clock MHz, socket power W] while the workload's batch runs back to back (cap: roofline.power_cap_w)
+                   "workload_power": None if not power else {k: [v["sclk_mhz"], v["power_w"]] for k, v in power.items()}},
+        "roofline": roof,
+        "workloads": {k: {kk: vv for kk, vv in v.items() if kk not in ("source_mpix_per_launch_per_gpu",)} for k, v in reports.items()},
+    }
+    if regret is not None:
+        out["workloads"]["route_regret"] = regret
+    if power:
+        out["workloads"]["power_probe"] = power
+    if args.stub_device:
+        out["data"] = "STUB --stub-device: launches are sleeps; control-plane self-test, not a benchmark result"
+        out["roofline"]["frac"] = None
+    if args.alias != "none":
+        out["data"] = f"DIAGNOSTIC --alias {args.alias}: ticks share frame 0's buffers, cache-resident traffic; not a benchmark result"
+        out["roofline"]["frac"] = None
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
+
+
+COMPACT_LIMIT = 4096      # bytes: the driver keeps a bounded tail of stdout and parses its last line (BENCH_r05.json: a 20 KB line did not parse)
+STRING_LIMIT = 120
+
+
+def _short(text, limit=STRING_LIMIT):
+    text = str(text)
+    return text if len(text) <= limit else text[: limit - 1].rstrip() + "…"
+
+
+def _num(v, digits=5):
+    """a float with `digits` significant digits (the full precision stays in bench_detail.json)"""
+    if isinstance(v, bool) or v is None or isinstance(v, int):
+        return v
+    if isinstance(v, float):
+        if not math.isfinite(v):
+            return None                     # never NaN / Infinity in the line: they are not JSON
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, (list, tuple)):
+        return [_num(x, digits) for x in v]
+    return v
+
+
+def compact_line(d):
+    """The ONE line the driver parses: the contract's keys + roofline + cpu_baseline + numeric per-workload fractions, < COMPACT_LIMIT bytes,
+    no string longer than STRING_LIMIT, no NaN / Infinity.  Everything else lives in bench_detail.json."""
+    cfg, roof = d["config"], d.get("roofline")
+    c = {"workload": _short(cfg.get("workload_short") or cfg["workload"]), "launches_per_step": cfg.get("launches_per_step"),
+         "frames_per_launch_per_gpu": cfg.get("frames_per_launch_per_gpu"), "kernel": _short(cfg.get("kernel")),
+         "verified_vs_oracle": cfg.get("verified_vs_oracle"), "parallelism": _short(cfg.get("parallelism", "")),
+         "per_gpu_gpix": _num(cfg.get("per_gpu_gpix")), "per_gpu_launch_ms": _num(cfg.get("per_gpu_launch_ms"))}
+    for k in ("mode", "h2d_GBps_per_gpu", "h2d_frac_of_link", "upload_copy_MB", "upload_streams", "pinned_numa_node", "frames_per_step_per_gpu"):
+        if k in cfg and cfg.get("mode"):            # (--with-upload lines)
+            c[k] = _num(cfg[k]) if not isinstance(cfg[k], str) else _short(cfg[k])
+    if cfg.get("per_rank"):
+        c["per_rank"] = {k: _num(v) for k, v in cfg["per_rank"].items()}
+    if cfg.get("workload_fracs"):
+        c["workload_fracs"] = {k: [_num(v[0], 4), _num(v[1], 4)] for k, v in cfg["workload_fracs"].items()}       # name -> [frac of 8 TB/s, ms per launch]
+        c["workload_limiters"] = cfg.get("workload_limiters")
+    c["full"] = cfg.get("full", False)
+    r = None
+    if roof is not None:
+        keys = ("bound", "limiter", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio", "kernel", "launch_ms", "issue_model_ms",
+                "algorithmic_bytes_per_launch", "sclk_mhz", "power_w", "power_cap_w")
+        r = {k: (_short(roof[k]) if isinstance(roof.get(k), str) else _num(roof.get(k))) for k in keys if k in roof}
+        if roof.get("traffic_source"):
+            r["traffic_measured_in_this_run"] = roof["traffic_source"].startswith("measured in this run")
+    out = {k: (_num(d[k]) if not isinstance(d[k], str) else d[k]) for k in
+           ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype")}
+    out["data"] = _short(d["data"])
+    out["config"] = c
+    if r is not None:
+        out["roofline"] = r
+    if "cpu_baseline" in d:
+        cb = d["cpu_baseline"]
+        out["cpu_baseline"] = {"value": _num(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": _short(cb["sample"])}
+    line = json.dumps(out, separators=(",", ":"), allow_nan=False)
+    # should a future key push the line over the limit, optional keys go first — the contract's keys, roofline and cpu_baseline never
+    for victim in ("workload_limiters", "per_rank", "workload_fracs", "parallelism"):
+        if len(line.encode()) < COMPACT_LIMIT:
+            break
+        out["config"].pop(victim, None)
+        line = json.dumps(out, separators=(",", ":"), allow_nan=False)
+    assert len(line.encode()) < COMPACT_LIMIT, len(line.encode())
+    return line
 
 
 if __name__ == "__main__":

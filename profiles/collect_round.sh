@@ -9,7 +9,10 @@ OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 # 1. the default line, exactly as the driver runs it
-python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+/usr/bin/time -f "default command: %e s wall" -o $OUT/bench_default.time python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+cp bench_detail.json $OUT/bench_default_detail.json
+# 1b. every leg (upload / end-to-end / one tick at a time / thread scaling / route regret / clock and power of every workload): --full
+python bench.py --gpus 1 --steps 20 --warmup 5 --full --detail-json $OUT/bench_full_detail.json > $OUT/bench_full.json 2> $OUT/bench_full.err
 # 2. kernel-trace stats of every workload's kernel (shorter timed regions: the profiler keeps every dispatch)
 (cd /tmp && timeout -k 5 240 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_all/stats -o stats -- python $ROOT/bench.py --no-cpu-baseline --no-verify --no-live-pmc --no-per-tick --no-upload-leg --no-route-regret --no-power-probe --min-seconds 0.3 --min-seconds-other 0.15 --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> /dev/null)
 python profiles/summarize.py gpurun_out/prof_${R}_all > $OUT/all_workloads_rocprofv3.txt 2>&1
