@@ -124,7 +124,7 @@ def parse_args(argv=None):
     ap.add_argument("--min-seconds", type=float, default=2.0, help="minimum duration of the headline's timed region")
     ap.add_argument("--min-seconds-other", type=float, default=0.6, help="minimum timed region of each other workload")
     ap.add_argument("--launches-per-step", type=int, default=0, help="fixed instead of calibrated (profiling runs)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--full", action="store_true",
@@ -551,8 +551,7 @@ def cpu_baseline(wl, w, budget_s):
     n = sum(counts)
     gpix = n * dw * dh / el / 1e9
     return {"value": gpix, "unit": "Gpix/s", "cores": cores, "kind": "port",
-            "sample": f"{n} ticks of the same workload in {el:.1f} s: oracle/ref_kernels.c, {cores} threads each "
-                      f"compositing whole ticks (clear + {n_kernels} layer kernel(s) per tick, as the reference issues them)"}
+            "sample": f"{n} ticks of the same workload in {el:.1f} s, oracle/ref_kernels.c, {cores} threads x whole ticks (clear + {n_kernels} layer kernels)"}
 
 
 class HipDevice:

@@ -740,7 +740,8 @@ int orc_snd_s16i_s16i(int16_t *out, int n, const int16_t *const *in, const orc_s
  *
  * Faithful to the source INCLUDING its sliding-window SAD (:152-166): when the previous candidate's top-row SAD is > 0 the function
  * sums the new top row, then runs a second loop for the bottom row whose counters were left at the end by the first — it adds nothing —
- * and returns previousSad - previousSide.  A clean full search is NOT what the reference computes.
+ * and returns previousSad - previousSide.  A clean full search is NOT what the reference computes: that running value falls below zero in
+ * tall search windows, and the first negative score ends the search through earlyExit (:221,228-232,247-249).
  * Texel reads are R8Unorm -> c / 255.0f (ld8); reads outside a picture (an origin block hanging over the right / bottom edge) return 0
  * (Metal leaves them undefined).  Sums accumulate in float in source order: row-major over the block (:168-183).
  * deltaCost2 (:135-142) goes through log2: the table of per-component costs is built by the HOST's log2f for both the oracle and the
@@ -794,16 +795,23 @@ int orc_me_fullsearch(const orc_plane *out, const orc_plane *ref, const orc_plan
         const int right = me_clampi(left + swx, 0, u->imageSize[0]), bottom = me_clampi(top + swy, 0, u->imageSize[1]);
         int rb[4] = { left, top, left + bsx, top + bsy };
         float bestScore = 3.402823466e+38f, bmx = 0.f, bmy = 0.f, side = 0.f, prev = 0.f;
-        while (rb[2] < right) {
+        const float threshold = 0.f;           /* :221 */
+        int earlyExit = 0;                     /* :228 */
+        while (rb[2] < right && !earlyExit) {
             rb[1] = top; rb[3] = rb[1] + bsy;
-            while (rb[3] < bottom) {
+            while (rb[3] < bottom && !earlyExit) {
                 me_sad_t s = me_sad(ob, rb, cur, ref, side, prev);
                 const int mx = ob[0] - rb[0], my = ob[1] - rb[1];
                 const int ax = mx < 0 ? -mx : mx, ay = my < 0 ? -my : my;
                 const float score = 4.0f * (cost[ax > 255 ? 255 : ax] + cost[ay > 255 ? 255 : ay]) + s.sad * 256.0f;
                 prev = s.sad; side = s.side;
                 if (score < bestScore) { bestScore = score; bmx = me_clampf((float)mx, -maxx, maxx); bmy = me_clampf((float)my, -maxy, maxy); }
-                rb[1]++; rb[3]++;              /* (threshold = 0, :221: a score is never negative, no early exit) */
+                /* :247-249.  A score DOES go negative: the sliding form above returns previousSad - previousSide row after row, so down one
+                 * column the "SAD" loses one top-row SAD per candidate and falls below zero once the column is a little taller than the
+                 * block (every window >= about three block heights).  The first such candidate in visiting order (columns left to right,
+                 * rows top to bottom) has just become the best one — every earlier score was >= 0 — and ends the whole search. */
+                if (score < threshold) earlyExit = 1;
+                rb[1]++; rb[3]++;
             }
             side = 0.f; prev = 0.f; rb[0]++; rb[2]++;
         }

@@ -1138,12 +1138,21 @@ static int run_idle_kernel(chv_context *c, int kernel, const chv_image *target, 
         if ((rc = plane_to_device(target->planes[0], 2, c->device, &out, CHV_ERR_BAD_TARGET, "target", 0))) return rc;
         if (out.h > 1 && out.pitch != out.w * 2) return fail(CHV_ERR_BAD_TARGET, "snd_s16i_s16i: rows of samples must be contiguous");
         if (((uintptr_t)out.ptr) & 1) return fail(CHV_ERR_BAD_TARGET, "snd_s16i_s16i: samples must be 2-byte aligned");
+        // the kernel's sample count is an int (the reference's get_global_size(0)): a buffer of 2^31 samples or more is refused, not truncated
+        if ((int64_t)out.w * (int64_t)out.h > (int64_t)INT32_MAX)
+            return fail(CHV_ERR_BAD_TARGET, "snd_s16i_s16i: %lld samples exceed the kernel's 32-bit count", (long long)((int64_t)out.w * out.h));
+        const size_t span = (size_t)out.w * (size_t)out.h * 2;
         const int16_t *in[8] = { nullptr };
         for (int i = 0; i < u.input_count; i++) {
             DPlane p;
             if ((rc = plane_to_device(inputs[i].planes[0], 2, c->device, &p, CHV_ERR_BAD_INPUT, "input", i))) return rc;
             if (p.w != out.w || p.h != out.h || (p.h > 1 && p.pitch != p.w * 2) || (((uintptr_t)p.ptr) & 1))
                 return fail(CHV_ERR_BAD_INPUT, "snd_s16i_s16i: input %d does not have the output's shape", i);
+            // The source accumulates INTO out[gid] input after input (kernels.cl.swift:548-560), so an input that is the output would read the
+            // partially mixed sample; the kernel keeps the accumulator in a register and reads every input once.  Not a case any caller has
+            // (the inputs are other tracks' buffers): overlapping buffers are refused rather than mixed differently.
+            if ((uintptr_t)p.ptr < (uintptr_t)out.ptr + span && (uintptr_t)out.ptr < (uintptr_t)p.ptr + span)
+                return fail(CHV_ERR_BAD_INPUT, "snd_s16i_s16i: input %d overlaps the output buffer", i);
             in[i] = (const int16_t *)p.ptr;
         }
         auto dp = deps.deps();

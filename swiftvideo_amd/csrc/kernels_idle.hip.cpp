@@ -68,6 +68,7 @@ hipError_t launch_snd_s16i(int16_t *out, const int16_t *const *in, int count, in
         a.vec = a.vec && (((uintptr_t)in[i]) & 15) == 0;
     }
     const int threads = (n + 7) / 8;
+    (void)hipGetLastError();                   // (a stale error of an earlier call is not this launch's)
     hipLaunchKernelGGL(snd_s16i_s16i_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
@@ -75,7 +76,8 @@ hipError_t launch_snd_s16i(int16_t *out, const int16_t *const *in, int count, in
 // ---------------------------------------------------------------------------------------------------------------------
 // me_fullsearch: one WAVE per block of the current picture; lane = one column of candidate positions in the reference picture's search area
 // (at most 63: MAX_SEARCH_SIZE 64, kernels.metal:204), walked top to bottom exactly as the source walks it — including its sliding-window
-// SAD, which after a candidate with a non-zero top-row SAD returns previousSad - previousSide (:152-166, the second loop never runs).  Sums
+// SAD, which after a candidate with a non-zero top-row SAD returns previousSad - previousSide (:152-166, the second loop never runs), and the
+// early exit that value triggers when it falls below zero (threshold 0, :221,247-249: a wave ballot picks the first column that got there).  Sums
 // accumulate in float in source order, so there is nothing to reduce across lanes but the final (score, visiting order) minimum.
 // The current block and the search area are staged in LDS as bytes (<= 4 KB each); texel values are c / 255.0f like every R8Unorm read here.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(64) void me_fullsearch_kernel(const MeArgs a) {
     }
     __syncthreads();
     float best = 3.402823466e+38f, bmx = 0.f, bmy = 0.f;
+    bool negative = false;                                       // this column reached a score < threshold = 0 (:221,247-249)
     const int ncols = aw - a.bsx, nrows = ah - a.bsy;            // candidates: refBlock.z < searchArea.z, refBlock.w < searchArea.w (strict, :229,232)
     if (lane < ncols) {
         float side = 0.f, prev = 0.f;
@@ -130,9 +133,20 @@ __global__ __launch_bounds__(64) void me_fullsearch_kernel(const MeArgs a) {
                 bmx = __builtin_fminf(__builtin_fmaxf((float)mx, -a.maxx), a.maxx);
                 bmy = __builtin_fminf(__builtin_fmaxf((float)my, -a.maxy), a.maxy);
             }
+            // earlyExit: the running "SAD" of the sliding form loses a top-row SAD per row and does go negative in tall windows.  Every score
+            // before this one in the column was >= 0, so this candidate has just become the column's best; the column stops here
+            if (score < 0.f) { negative = true; break; }
         }
     }
-    // the first strict minimum in visiting order: columns left to right, so among equal scores the lowest lane
+    // The source visits columns left to right and ends the WHOLE search at the first negative score: the lowest column that has one wins with
+    // that candidate (all scores of the columns before it are >= 0 and lose to it; the columns after it are never visited).
+    const unsigned long long negs = __ballot(negative);
+    if (negs != 0ull) {
+        const int first = __ffsll((long long)negs) - 1;
+        bmx = __shfl(bmx, first); bmy = __shfl(bmy, first);
+        best = -3.402823466e+38f;                                // (every lane now holds the winner: the reduction below keeps it)
+    }
+    // otherwise the first strict minimum in visiting order: columns left to right, so among equal scores the lowest lane
     int who = lane;
     for (int off = 32; off >= 1; off >>= 1) {
         const float ob = __shfl_xor(best, off);
@@ -158,6 +172,7 @@ hipError_t launch_me_fullsearch(const DPlane &out, const DPlane &ref, const DPla
     a.imw = image[0]; a.imh = image[1];
     a.maxx = (float)(window[0] / 2); a.maxy = (float)(window[1] / 2);
     memcpy(a.cost, cost256, sizeof a.cost);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(me_fullsearch_kernel, dim3((unsigned)out.w, (unsigned)out.h), dim3(64), 0, stream, a);
     return hipGetLastError();
 }

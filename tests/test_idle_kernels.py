@@ -62,7 +62,7 @@ def test_snd_first_principles():
 F = np.float32
 
 
-def me_python(ref, cur, block, window, image):
+def me_python(ref, cur, block, window, image, trace=None, honour_early_exit=True):
     bsx, bsy = block
     cost = O.me_cost_table(256)
     swx, swy = min(window[0], 64), min(window[1], 64)
@@ -78,10 +78,11 @@ def me_python(ref, cur, block, window, image):
             right = clamp(left + swx, 0, image[0]); bottom = clamp(top + swy, 0, image[1])
             best, bmx, bmy = F(3.402823466e+38), F(0), F(0)
             rx = left
-            while rx + bsx < right:
+            early_exit = False                                  # kernels.metal:228
+            while rx + bsx < right and not early_exit:
                 side, prev = F(0), F(0)
                 ry = top
-                while ry + bsy < bottom:
+                while ry + bsy < bottom and not early_exit:
                     tp, sm = F(0), F(0)
                     if side > 0:
                         for x in range(bsx):
@@ -99,6 +100,10 @@ def me_python(ref, cur, block, window, image):
                     prev, side = sm, tp
                     if score < best:
                         best, bmx, bmy = score, clamp(F(mx), -maxx, maxx), clamp(F(my), -maxy, maxy)
+                    if score < F(0) and honour_early_exit:      # threshold = 0, :221,247-249
+                        early_exit = True
+                        if trace is not None:
+                            trace.append((bx, by, rx - left, ry - top, float(score)))
                     ry += 1
                 rx += 1
             with np.errstate(divide="ignore", invalid="ignore"):
@@ -151,6 +156,33 @@ def test_me_sliding_window_is_the_reference_s_not_a_clean_search():
     assert O.me_fullsearch(out, ref, cur, (16, 16), (32, 32)) == 0
     clean = O.lib().orc_store_unorm8(float(F(F(3.0) / F(16.0)) * F(0.5) + F(0.5)))
     assert not (out[1:-1, 1:-1, 0] == clean).all()
+
+
+def test_me_early_exit_is_taken_in_tall_windows_and_decides_the_vector():
+    """kernels.metal:221,228-232,247-249: `threshold = 0` looks like a dead early exit, but the sliding form's running value (previousSad -
+    previousSide, row after row) falls below zero once a column of candidates is a little taller than the block — the first negative score in
+    visiting order ends the search and IS the answer.  ME_CASES[2] (8 x 4 blocks, 64 x 64 window) takes it in every interior block."""
+    seed, w, h, block, window, smooth = ME_CASES[2]
+    ref, cur = me_frames(seed, w, h, smooth)
+    trace = []
+    exp = me_python(ref, cur, block, window, (w, h), trace=trace)
+    assert len(trace) >= exp.shape[0] * exp.shape[1] // 2 and all(t[4] < 0 for t in trace)
+    out = np.zeros_like(exp)
+    assert O.me_fullsearch(out, ref, cur, block, window) == 0
+    assert np.array_equal(out, exp)
+    # the block's answer is the candidate the search stopped at: mv = origin - (left + col, top + row), clamped to +- window / 2, normalised
+    for bx, by, col, row, _ in trace:
+        ox, oy = bx * block[0], by * block[1]
+        left = min(max(ox + block[0] // 2 - 32, 0), w); top = min(max(oy + block[1] // 2 - 32, 0), h)
+        mx, my = F(min(max(ox - (left + col), -32), 32)), F(min(max(oy - (top + row), -32), 32))
+        want = [O.lib().orc_store_unorm8(float(F(F(mx / F(32)) * F(0.5) + F(0.5)))), 128, O.lib().orc_store_unorm8(float(F(F(my / F(32)) * F(0.5) + F(0.5)))), 255]
+        assert out[by, bx].tolist() == want
+    # ... and it is not what a search that ignored the exit would return
+    assert not np.array_equal(me_python(ref, cur, block, window, (w, h), honour_early_exit=False), exp)
+    # a window no taller than the block plus a few rows never gets there
+    trace = []
+    me_python(*me_frames(1, 64, 48), (16, 16), (24, 24), (64, 48), trace=trace)
+    assert trace == []
 
 
 # ---- GPU ------------------------------------------------------------------------------------------------------------------------
