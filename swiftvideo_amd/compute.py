@@ -511,15 +511,19 @@ def _image_desc(sample, maxPlanes=3):
     return d
 
 
-def _uniform_blob(uniforms):
+def _uniform_blob(uniforms, raw=False):
+    """The bytes bound as the kernel's uniforms (MemoryLayout<T>.size of them, compute.cl.swift:508-512).  Picture kernels take ImageUniforms:
+    anything array-like is its 59 floats and is converted to float32 (a list or an int64 array of matrix rows stays what it always was).
+    `raw` (the two buffer kernels and .custom kernels, whose uniforms are other value types — BufferUniforms, MotionEstimationUniforms, a
+    user's struct): uint8 / int32 / uint32 arrays pass as the bytes they are.  bytes / bytearray always pass unchanged."""
     if uniforms is None:
         return None
     if isinstance(uniforms, ImageUniforms):
         return uniforms.blob()
-    if isinstance(uniforms, (bytes, bytearray)):          # any value type's bytes (MemoryLayout<T>.size are bound, compute.cl.swift:508-512)
+    if isinstance(uniforms, (bytes, bytearray)):
         return np.frombuffer(bytes(uniforms), dtype=np.uint8)
-    if isinstance(uniforms, np.ndarray) and uniforms.dtype != np.float32 and uniforms.dtype != np.float64:
-        return np.ascontiguousarray(uniforms).reshape(-1)   # e.g. the int32 / float32 words of BufferUniforms, MotionEstimationUniforms
+    if raw and isinstance(uniforms, np.ndarray) and uniforms.dtype in (np.uint8, np.int32, np.uint32):
+        return np.ascontiguousarray(uniforms).reshape(-1)
     return np.ascontiguousarray(uniforms, dtype=np.float32).reshape(-1)
 
 
@@ -557,12 +561,12 @@ def runComputeKernel(ctx, images, target, kernel, maxPlanes=3, requiredMemory=No
         if isinstance(uniforms, (bytes, bytearray)):
             u = np.frombuffer(bytes(uniforms), dtype=np.uint8)
         else:
-            u = _uniform_blob(uniforms)
+            u = _uniform_blob(uniforms, raw=True)
         cv.check(cv.load().chv_run_custom(ctx.handle, kernel.name.encode(), C.byref(tdesc), descs, len(images),
                                           u.ctypes.data if u is not None else None,
                                           u.nbytes if u is not None else 0, 1 if blends else 0))
         return ctx
-    u = _uniform_blob(uniforms)
+    u = _uniform_blob(uniforms, raw=int(kernel) in (int(ComputeKernel.snd_s16i_s16i), int(ComputeKernel.me_fullsearch)))
     opts = cv.KernelOpts(colorspace=int(colorspace))
     cv.check(cv.load().chv_run_kernel(ctx.handle, int(kernel), C.byref(tdesc), descs, len(images),
                                       u.ctypes.data if u is not None else None,

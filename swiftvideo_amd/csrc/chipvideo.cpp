@@ -75,17 +75,21 @@ static int parse_switch(const char *name, const char *value, int *out) {
     if (n == "CHV_DESC") { *out = v == "host" ? 1 : v == "device" ? 2 : 0; return 5; }
     if (n == "CHV_STREAM") { *out = v == "0" ? 0 : 1; return 6; }
     if (n == "CHV_YUV_STREAM") { *out = v == "0" ? 0 : (v == "force" || v == "2") ? 2 : 1; return 7; }
+    if (n == "CHV_WAVE_DMA") { *out = v == "0" ? 0 : 1; return 8; }
+    if (n == "CHV_PASS_FUSE") { *out = v == "0" ? 0 : 1; return 9; }
     return -1;
 }
 static void store_switch(Switches &s, int which, int val) {
-    std::atomic<int> *slots[8] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom, &s.desc_host, &s.stream, &s.yuv_stream };
+    std::atomic<int> *slots[10] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom, &s.desc_host, &s.stream, &s.yuv_stream, &s.wave_dma,
+                                    &s.pass_fuse };
     slots[which]->store(val, std::memory_order_relaxed);
 }
 Switches &chv::switches() {
     static Switches s;
     static std::once_flag once;
     std::call_once(once, [] {
-        static const char *const names[8] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC", "CHV_STREAM", "CHV_YUV_STREAM" };
+        static const char *const names[10] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC", "CHV_STREAM", "CHV_YUV_STREAM",
+                                               "CHV_WAVE_DMA", "CHV_PASS_FUSE" };
         for (const char *n : names) {
             const char *v = getenv(n);
             int val = 0, which = v ? parse_switch(n, v, &val) : -1;
@@ -99,7 +103,7 @@ extern "C" int chv_debug_set_switch(const char *name, const char *value) {
     Switches &s = switches();                     // (environment first, so that a later first use cannot overwrite this)
     const int which = parse_switch(name, value, &val);
     if (which < 0) { g_detail_set("unknown switch"); return CHV_ERR_INVALID_VALUE; }
-    if (!value || !*value) val = (which == 4 || which == 6 || which == 7) ? 1 : 0;      // empty / NULL: back to "the library decides"
+    if (!value || !*value) val = (which == 4 || which == 6 || which == 7 || which == 8 || which == 9) ? 1 : 0;      // empty / NULL: back to "the library decides"
     store_switch(s, which, val);
     return CHV_OK;
 }
@@ -318,6 +322,17 @@ struct chv_context {
     int next_desc = 0;
     // `library` of the reference's ComputeContext (compute.cl.swift:66-73): name -> built kernel
     std::map<std::string, std::shared_ptr<CustomKernel>> library;
+    // The picture kernels of the pass in progress that have been accepted but not launched yet (PendingPass below): inside
+    // chv_pass_begin ... chv_pass_end nothing has to be visible before the pass ends, so `clear + N layer kernels on one target` — what an
+    // unchanged VideoMixer issues per tick, mix.video.swift:116-124 — leaves as the ONE launch chv_composite would have made of it.
+    struct PendingPass {
+        bool active = false;
+        chv_image target;
+        int clear_first = 0;
+        int clear_tf = -1;                     // the target format a clear kernel fixed (kernel_shape), -1: the layers decide
+        std::vector<chv_layer> layers;         // POD copies: the caller's structs need not outlive chv_run_kernel
+        std::vector<chv_buffer *> pins;        // every buffer the pending kernels name, held against chv_buffer_free until they are launched
+    } pending;
 };
 
 struct chv_buffer {
@@ -335,7 +350,17 @@ struct chv_buffer {
     hipEvent_t ready = nullptr;
     hipStream_t ready_stream = nullptr;
     uint64_t ready_seq = 0;
+    // Deferred passes (chv_context::PendingPass): kernels that were accepted but not launched yet hold their buffers.  chv_buffer_free on a held
+    // buffer marks it `doomed` and returns; the release that drops the last hold frees it (OpenCL keeps a cl_mem alive the same way from
+    // clSetKernelArg / enqueue to completion — a ComputeBuffer's deinit may run the moment runComputeKernel returns, compute.cl.swift:55-57).
+    // Both fields are guarded by g_pin_mu.
+    int pins = 0;
+    bool doomed = false;
 };
+static std::mutex g_pin_mu;
+// (passes and kernels, below) launch what the pass in progress has accepted so far; every entry point that touches the context's stream starts with it
+static int flush_pending(chv_context *c);
+#define FLUSH_PENDING(c) do { if ((c)->pending.active) { int frc_ = flush_pending(c); if (frc_) return frc_; } } while (0)
 
 // after an asynchronous copy into `b` was enqueued on `stream`: record the buffer's event
 static int mark_uploaded(chv_buffer *b, hipStream_t stream);
@@ -450,6 +475,7 @@ extern "C" int chv_context_share(chv_context *parent, chv_context **out) {
 extern "C" int chv_context_destroy(chv_context *c) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
     (void)hipSetDevice(c->device);
+    (void)flush_pending(c);             // (a pass left open: its kernels were accepted, they run)
     (void)hipStreamSynchronize(c->stream);
     for (auto &s : c->staging) {
         if (s.done) (void)hipEventDestroy(s.done);
@@ -488,6 +514,7 @@ extern "C" int chv_context_numa_node(chv_context *c, int *node) {
 }
 extern "C" int chv_context_stream(chv_context *c, void **s) {
     if (!ctx_ok(c) || !s) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);       // (whoever asks for the stream is about to put work behind what the pass holds)
     *s = (void *)c->stream;
     return CHV_OK;
 }
@@ -520,8 +547,17 @@ extern "C" int chv_buffer_wrap(chv_context *c, void *device_ptr, size_t bytes, c
     return CHV_OK;
 }
 
+static int buffer_free_now(chv_buffer *b);
 extern "C" int chv_buffer_free(chv_buffer *b) {
     if (!b || b->magic != 0x43485642) return fail(CHV_ERR_INVALID_VALUE, "bad buffer");
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mu);
+        if (b->doomed) return fail(CHV_ERR_INVALID_VALUE, "buffer freed twice");
+        if (b->pins > 0) { b->doomed = true; return CHV_OK; }      // a pending pass still names it: freed when that pass has been launched
+    }
+    return buffer_free_now(b);
+}
+static int buffer_free_now(chv_buffer *b) {
     if (b->owned && b->ptr) {
         // any thread, any time: make the owning device current first
         // (compute.cuda.swift:82-88 pushes the context in deinit for the same reason)
@@ -572,6 +608,7 @@ static int check_span(const chv_buffer *b, size_t offset, size_t pitch, size_t w
 extern "C" int chv_upload(chv_context *c, chv_buffer *dst, size_t dst_offset, size_t dst_pitch,
                           const void *src, size_t src_pitch, size_t width_bytes, size_t rows, int async) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);
     if (!src) return fail(CHV_ERR_BAD_INPUT, "null source");
     int rc = check_span(dst, dst_offset, dst_pitch, width_bytes, rows, "upload");
     if (rc) return rc;
@@ -660,6 +697,7 @@ extern "C" int chv_host_free(chv_context *c, void *ptr) {
 static int download_enqueue(chv_context *c, void *dst, size_t dst_pitch, chv_buffer *src,
                             size_t src_offset, size_t src_pitch, size_t width_bytes, size_t rows) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);
     if (!dst) return fail(CHV_ERR_BAD_INPUT, "null destination");
     int rc = check_span(src, src_offset, src_pitch, width_bytes, rows, "download");
     if (rc) return rc;
@@ -1102,8 +1140,47 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
 // ---------------------------------------------------------------------------
 // passes and kernels
 // ---------------------------------------------------------------------------
+static int composite_now(chv_context *c, const chv_image *target, int clear_first, int forced_tf, const chv_layer *layers, int n_layers);
+
+static void pending_release(chv_context *c) {
+    std::vector<chv_buffer *> dead;
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mu);
+        for (chv_buffer *b : c->pending.pins)
+            if (--b->pins == 0 && b->doomed) dead.push_back(b);
+    }
+    for (chv_buffer *b : dead) (void)buffer_free_now(b);          // (hipFree waits for the launch that just went out)
+    c->pending.pins.clear();
+    c->pending.layers.clear();
+    c->pending.active = false;
+    c->pending.clear_first = 0;
+    c->pending.clear_tf = -1;
+}
+
+// Launch what the pass has accepted so far.  Called by every entry point that puts work on the context's stream, hands the stream out, or
+// waits for it — the pending kernels keep their place in the stream's order.  Their arguments were validated when they were accepted, so what
+// can still fail here is the launch itself.
+static int flush_pending(chv_context *c) {
+    if (!c->pending.active) return CHV_OK;
+    const int rc = composite_now(c, &c->pending.target, c->pending.clear_first, c->pending.clear_tf,
+                                 c->pending.layers.empty() ? nullptr : c->pending.layers.data(), (int)c->pending.layers.size());
+    pending_release(c);
+    return rc;
+}
+
+static bool same_target(const chv_image &a, const chv_image &b) {
+    if (a.n_planes != b.n_planes) return false;
+    for (int i = 0; i < a.n_planes && i < 3; i++) {
+        const chv_plane &p = a.planes[i], &q = b.planes[i];
+        if (p.buffer != q.buffer || p.offset != q.offset || p.pitch != q.pitch || p.width != q.width || p.height != q.height || p.components != q.components)
+            return false;
+    }
+    return true;
+}
+
 extern "C" int chv_pass_begin(chv_context *c) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);   // (a pass begun twice without its end: what the first one accepted goes out first)
     c->in_pass = true;  // no device work: like OpenCL, a pass is just a bracket (compute.cl.swift:234-237)
     return CHV_OK;
 }
@@ -1112,6 +1189,8 @@ extern "C" int chv_pass_end(chv_context *c, int wait) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
     c->in_pass = false;
     HIP_TRY(hipSetDevice(c->device));
+    // the pass's picture kernels, held back since chv_run_kernel accepted them: one fused launch where they are `clear + layers on one target`
+    FLUSH_PENDING(c);
     // (hipStreamSynchronize already polls before it blocks: a hand-written hipStreamQuery loop in front of it measured the
     // same 16-17 us for an empty tick, tools/tick_latency.py — that floor is the launch + completion path of the runtime)
     if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1122,6 +1201,7 @@ extern "C" int chv_pass_end(chv_context *c, int wait) {
 // snd_s16i_s16i / me_fullsearch (kernels_idle.hip.cpp): buffers and luma planes bound as the reference binds them, no tick descriptors
 static int run_idle_kernel(chv_context *c, int kernel, const chv_image *target, const chv_image *inputs, int n_inputs,
                            const void *uniforms, size_t uniforms_size) {
+    FLUSH_PENDING(c);
     DepScope deps;
     if (target->n_planes < 1) return fail(CHV_ERR_BAD_TARGET, "%s: target without planes", chv_kernel_name(kernel));
     if (n_inputs < 0 || (n_inputs > 0 && !inputs)) return fail(CHV_ERR_BAD_INPUT, "null inputs");
@@ -1226,8 +1306,28 @@ extern "C" int chv_run_kernel(chv_context *c, int kernel, const chv_image *targe
     std::vector<DLayer> dl;
     int tf = -1;
     DepScope deps;
-    rc = tick_to_device(t, c->device, s.is_clear ? s.target_format : -1, &dt, &dl, &tf);
+    rc = tick_to_device(t, c->device, s.is_clear ? s.target_format : -1, &dt, &dl, &tf);      // (every argument error surfaces here, in this call)
     if (rc) return rc;
+    if (c->in_pass && switches().pass_fuse.load(std::memory_order_relaxed)) {
+        // Inside a pass: accept the kernel, launch it with the rest of the pass (flush_pending).  A kernel on another target, or a clear
+        // after something else, first sends out what is held — the stream sees the kernels in the order they were issued.
+        chv_context::PendingPass &pp = c->pending;
+        if (pp.active && (s.is_clear || !same_target(pp.target, *target) || (pp.clear_tf >= 0 && pp.clear_tf != tf))) FLUSH_PENDING(c);
+        if (!pp.active) {
+            pp.active = true;
+            pp.target = *target;
+            pp.clear_first = 0;
+            pp.clear_tf = -1;
+        }
+        if (s.is_clear) { pp.clear_first = 1; pp.clear_tf = s.target_format; }
+        else pp.layers.push_back(layer);
+        {
+            std::lock_guard<std::mutex> lock(g_pin_mu);
+            for (chv_buffer *b : deps.bufs) { b->pins++; pp.pins.push_back(b); }
+        }
+        return CHV_OK;
+    }
+    FLUSH_PENDING(c);
     auto dp = deps.deps();
     rc = wait_for_uploads(c->stream, dp);
     if (rc) return rc;
@@ -1240,6 +1340,12 @@ extern "C" int chv_composite(chv_context *c, const chv_image *target, int clear_
     if (!target) return fail(CHV_ERR_BAD_TARGET, "null target");
     if (n_layers < 0) return fail(CHV_ERR_INVALID_VALUE, "%d layers", n_layers);
     if (n_layers > 0 && !layers) return fail(CHV_ERR_BAD_INPUT, "null layers");
+    FLUSH_PENDING(c);
+    return composite_now(c, target, clear_first, -1, layers, n_layers);
+}
+
+// (`forced_tf`: the target format a clear kernel of a deferred pass fixed; -1: the layers' kernels decide, the plane count if there are none)
+static int composite_now(chv_context *c, const chv_image *target, int clear_first, int forced_tf, const chv_layer *layers, int n_layers) {
     // A mixer composes any number of layers (mix.video.swift:116-124).  One launch takes up to CHV_MAX_LAYERS of them;
     // a deeper tick becomes several launches on the context's stream — the first clears, the others continue on the
     // canvas.  Byte-identical to one pass: the canvas is re-quantised between layers either way.
@@ -1247,7 +1353,7 @@ extern "C" int chv_composite(chv_context *c, const chv_image *target, int clear_
     const int n_chunks = n_layers <= CHV_MAX_LAYERS ? 1 : (n_layers + CHV_MAX_LAYERS - 1) / CHV_MAX_LAYERS;
     std::vector<DTick> dts((size_t)n_chunks);
     std::vector<std::vector<DLayer>> dls((size_t)n_chunks);
-    int tf = -1;
+    int tf = forced_tf;
     DepScope deps;
     for (int k = 0; k < n_chunks; k++) {
         chv_tick t;
@@ -1340,6 +1446,7 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
 
 extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);
     if (!b || !b->d_ticks) return fail(CHV_ERR_INVALID_VALUE, "bad batch");
     if (b->device != c->device) return fail(CHV_ERR_INVALID_CONTEXT, "batch belongs to device %d", b->device);
     HIP_TRY(hipSetDevice(c->device));
@@ -1508,6 +1615,7 @@ extern "C" int chv_run_custom(chv_context *c, const char *name, const chv_image 
                               const chv_image *inputs, int n_inputs,
                               const void *uniforms, size_t uniforms_size, int blends) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);
     if (!name) return fail(CHV_ERR_INVALID_VALUE, "null kernel name");
     auto it = c->library.find(name);
     if (it == c->library.end()) return fail(CHV_ERR_KERNEL_NOT_FOUND, "no custom kernel named %s in this context's library", name);
@@ -1633,6 +1741,7 @@ static int lanczos_table(chv_context *c, int in_size, int out_size, LanczosRef *
 
 extern "C" int chv_scale_lanczos(chv_context *c, const chv_image *dst, const chv_image *src) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);
     if (!dst || dst->n_planes != 1) return fail(CHV_ERR_BAD_TARGET, "Lanczos target must be one 4-component plane");
     if (!src || src->n_planes != 1) return fail(CHV_ERR_BAD_INPUT, "Lanczos source must be one 4-component plane");
     DPlane d, s;
@@ -1660,6 +1769,7 @@ extern "C" int chv_scale_lanczos(chv_context *c, const chv_image *dst, const chv
 // several streams per device issues per tick (a 2160p -> 1080p pass is 28 us of device time, of the order of a launch).
 extern "C" int chv_scale_lanczos_batch(chv_context *c, const chv_image *dsts, const chv_image *srcs, int n) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);
     if (n <= 0 || !dsts || !srcs) return fail(CHV_ERR_INVALID_VALUE, "empty batch");
     std::vector<DPlane> pairs((size_t)2 * n);
     DepScope deps;
@@ -1718,6 +1828,7 @@ extern "C" int chv_event_create(chv_context *c, chv_event **out) {
 }
 extern "C" int chv_event_record(chv_context *c, chv_event *ev) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);
     if (!ev || !ev->ev) return fail(CHV_ERR_INVALID_VALUE, "bad event");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(ev->ev, c->stream));
@@ -1725,6 +1836,7 @@ extern "C" int chv_event_record(chv_context *c, chv_event *ev) {
 }
 extern "C" int chv_event_wait(chv_context *c, chv_event *ev) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);
     if (!ev || !ev->ev) return fail(CHV_ERR_INVALID_VALUE, "bad event");
     if (ev->device != c->device) return fail(CHV_ERR_INVALID_VALUE, "event belongs to device %d", ev->device);
     HIP_TRY(hipSetDevice(c->device));
@@ -1752,6 +1864,7 @@ extern "C" int chv_event_destroy(chv_event *ev) {
 }
 extern "C" int chv_device_synchronize(chv_context *c) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
+    FLUSH_PENDING(c);
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
     return CHV_OK;

@@ -26,6 +26,7 @@
 // bytes are those of kernels_general.hip.cpp (= oracle/ref_kernels.c::px_to_bgra layer by layer).
 #include "wave_common.hip.h"
 #include "bgra_pixel.hip.h"
+#include "switches.h"
 
 #include <algorithm>
 #include <cmath>
@@ -49,7 +50,7 @@
 // RGB rectangles that touch no picture edge and need no byte swap are filled by LDS-DMA (global_load_lds_dwordx4): no staging registers, no slot
 // arithmetic, no LDS write instructions — cfg3 1.3035 -> 1.2485 ms, cfg5 2.140 -> 2.050 (same call, profiles/r05_notes.md section 9, where the
 // version that also PREFETCHED the next layer's rectangle into a second region is recorded: the LDS it takes costs more waves than the overlap
-// returns).  0: off (the A/B; CHV_WAVE_DMA=0 in the environment does the same at run time).
+// returns).  0: off (the A/B; CHV_WAVE_DMA=0 in the environment, or chv_debug_set_switch("CHV_WAVE_DMA", "0"), does the same at run time).
 #ifndef CHV_DMA_MUTATE
 #define CHV_DMA_MUTATE 0      // (tests of the tests: a non-zero value shifts what the DMA fetches)
 #endif
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
         } else if (cur.staged && !(CHV_ABL & 1)) S.stage(l, cur);
         wave_lds_fence();
         const int ln = __builtin_amdgcn_readfirstlane(S.next_hit(l + 1));
-        const int cyo_r = DMA ? cur.cyo + tok : cur.cyo;         // (tap 0 of this lane's column; through the token: not before the wait)
         if (CHV_WAVE_PRIO) { asm("s_setprio 0" : "+s"(ptok)); cur.cyo += ptok - l; }       // (ptok - l = 0, opaque: pins the asm here)
+        const int cyo_r = DMA ? cur.cyo + tok : cur.cyo;         // (tap 0 of this lane's column; after the pin above, and through the token: not before the wait)
 
         if (CHV_ABL & 2) cv[0] += (uint32_t)(cur.cyo ^ cur.cco ^ __float_as_int(cur.cya) ^ __float_as_int(cur.cca) ^ cur.cfl);
         else {
@@ -458,8 +459,8 @@ hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStre
                             int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds) {
     // bit 5 of `planar`: rectangles are staged by DMA where their shape allows (the RGB-only instantiation)
     {
-        static const int dma_env = [] { const char *e = getenv("CHV_WAVE_DMA"); return e ? atoi(e) : 1; }();
-        if (CHV_WAVE_DMA && dma_env && (kinds == 4 || (CHV_WAVE_DMA > 1 && (kinds & 4)))) planar |= 32;
+        const int dma_on = switches().wave_dma.load(std::memory_order_relaxed);        // (CHV_WAVE_DMA=0 / chv_debug_set_switch: register staging)
+        if (CHV_WAVE_DMA && dma_on && (kinds == 4 || (CHV_WAVE_DMA > 1 && (kinds & 4)))) planar |= 32;
     }
 #define CHV_LAUNCH_B(R, C, K) hipLaunchKernelGGL((tick_bgra_wave<R, C, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                  strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar)

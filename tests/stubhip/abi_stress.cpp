@@ -13,6 +13,7 @@
 #include "chipvideo.h"
 
 void stubhip_fail_launch_after(int n);      // stub_runtime.cpp
+long stubhip_launches();                    // kernel launches issued so far (all threads)
 
 #define CK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s:%d %s -> %s (%s)\n", __FILE__, __LINE__, #x, chv_error_string(rc_), chv_last_error_detail()); exit(2); } } while (0)
 #define EXPECT(cond) do { if (!(cond)) { fprintf(stderr, "%s:%d expectation failed: %s\n", __FILE__, __LINE__, #cond); exit(3); } } while (0)
@@ -141,6 +142,81 @@ static void single_thread(chv_context *c) {
         for (int i = 0; i < 200; i++) CK(chv_composite(c, &canvas.img, 0, mixed, 3));       // three times round the ring
         CK(chv_pass_end(c, 1));
     }
+    // ---- deferred passes: picture kernels issued inside a pass are held and leave as ONE launch at its end (an unchanged VideoMixer tick,
+    // mix.video.swift:116-124: clear + N x runComputeKernel + endComputePass)
+    {
+        chv_uniforms us[4] = { full_canvas(1.f), full_canvas(.75f), full_canvas(.5f), full_canvas(.25f) };
+        long l0 = stubhip_launches();
+        CK(chv_pass_begin(c));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        for (int l = 0; l < 4; l++) CK(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &canvas.img, &nv.img, 1, &us[l], sizeof us[l], 1, nullptr));
+        EXPECT(stubhip_launches() == l0);                                  // nothing has been launched yet
+        CK(chv_pass_end(c, 1));
+        EXPECT(stubhip_launches() == l0 + 1);                              // ... and the five kernels were one launch
+        // outside a pass every kernel launches at once, as before
+        l0 = stubhip_launches();
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &canvas.img, &nv.img, 1, &us[0], sizeof us[0], 1, nullptr));
+        EXPECT(stubhip_launches() == l0 + 2);
+        // two canvases in one pass: two launches, in issue order; a clear after layers starts a new launch
+        l0 = stubhip_launches();
+        CK(chv_pass_begin(c));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &canvas.img, &nv.img, 1, &us[0], sizeof us[0], 1, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_NV12, &canvas420.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        EXPECT(stubhip_launches() == l0 + 1);                              // (the first canvas went out when the second one appeared)
+        CK(chv_run_kernel(c, CHV_K_IMG_NV12_NV12, &canvas420.img, &nv.img, 1, &us[0], sizeof us[0], 1, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_NV12, &canvas420.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_BGRA_NV12, &canvas420.img, &rgb.img, 1, &us[1], sizeof us[1], 1, nullptr));
+        CK(chv_pass_end(c, 0));
+        EXPECT(stubhip_launches() == l0 + 3);
+        // a ComputeBuffer released between runComputeKernel and endComputePass (deinit may run the moment the call returns,
+        // compute.cl.swift:55-57): held until the pass has been launched, then freed; a second free of it is an error, not a crash
+        Pic tmp = make_pic(c, CHV_FMT_NV12, W, H), tmp_canvas = make_pic(c, CHV_FMT_BGRA, W, H);
+        CK(chv_pass_begin(c));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &tmp_canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &tmp_canvas.img, &tmp.img, 1, &us[0], sizeof us[0], 1, nullptr));
+        CK(chv_buffer_free(tmp.buf));
+        EXPECT(chv_buffer_free(tmp.buf) != CHV_OK);
+        CK(chv_buffer_free(tmp_canvas.buf));                               // (the target too)
+        CK(chv_pass_end(c, 1));
+        // an argument error comes back from the call that made it; the pass goes on without that kernel
+        l0 = stubhip_launches();
+        CK(chv_pass_begin(c));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        EXPECT(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &canvas.img, &nv.img, 1, &us[0], 17, 1, nullptr) == CHV_ERR_INVALID_VALUE);
+        EXPECT(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &canvas.img, &rgb.img, 1, &us[0], sizeof us[0], 1, nullptr) != CHV_OK);      // BGRA planes for an NV12 kernel
+        CK(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &canvas.img, &nv.img, 1, &us[0], sizeof us[0], 1, nullptr));
+        // a download in the middle of the pass sees what was issued before it
+        CK(chv_download(c, host.data(), (size_t)W * 4, canvas.buf, 0, canvas.img.planes[0].pitch, (size_t)W * 4, H));
+        EXPECT(stubhip_launches() == l0 + 1);
+        CK(chv_run_kernel(c, CHV_K_IMG_Y420P_BGRA, &canvas.img, &yp.img, 1, &us[2], sizeof us[2], 1, nullptr));
+        CK(chv_pass_end(c, 1));
+        EXPECT(stubhip_launches() == l0 + 2);
+        // a pass deeper than one launch (CHV_MAX_LAYERS): chunks, like chv_composite
+        l0 = stubhip_launches();
+        CK(chv_pass_begin(c));
+        for (int l = 0; l < 40; l++) CK(chv_run_kernel(c, CHV_K_IMG_BGRA_BGRA_TX, &canvas.img, &rgb.img, 1, &us[l & 3], sizeof us[0], 1, nullptr));
+        CK(chv_pass_end(c, 1));
+        EXPECT(stubhip_launches() == l0 + 3);
+        // the launch fails when the pass ends: the error comes back from chv_pass_end, nothing stays held, the context stays usable
+        stubhip_fail_launch_after(1);
+        CK(chv_pass_begin(c));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &canvas.img, &nv.img, 1, &us[0], sizeof us[0], 1, nullptr));
+        EXPECT(chv_pass_end(c, 1) != CHV_OK);
+        stubhip_fail_launch_after(0);
+        CK(chv_pass_end(c, 1));
+        // the escape switch: every kernel of a pass launches at once again
+        CK(chv_debug_set_switch("CHV_PASS_FUSE", "0"));
+        l0 = stubhip_launches();
+        CK(chv_pass_begin(c));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        for (int l = 0; l < 4; l++) CK(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &canvas.img, &nv.img, 1, &us[l], sizeof us[l], 1, nullptr));
+        EXPECT(stubhip_launches() == l0 + 5);
+        CK(chv_pass_end(c, 1));
+        CK(chv_debug_set_switch("CHV_PASS_FUSE", nullptr));
+    }
     // bad arguments: codes, not crashes
     EXPECT(chv_composite(c, nullptr, 1, vids, 4) != CHV_OK);
     EXPECT(chv_composite(c, &canvas420.img, 1, vids, 4) != CHV_OK);                       // BGRA-target kernels on a 4:2:0 canvas
@@ -177,14 +253,22 @@ static void many_threads(chv_context *parent, int n_threads) {
             CK(chv_upload(up, src.buf, 0, W, frame.data(), W, W, (size_t)H * 3 / 2, 1));          // the upload barrier's context
             chv_layer ls[2] = { layer_of(CHV_K_IMG_NV12_BGRA, src, 1.f), layer_of(CHV_K_IMG_BGRA_BGRA_TX, ov, .5f) };
             CK(chv_pass_begin(c));
-            CK(chv_composite(c, &canvas.img, 1, ls, (it & 1) ? 2 : 1));                            // waits for the upload on its own stream
+            bool src_freed = false;
+            if (it % 3 == 2 && it >= 8) {
+                // the unchanged mixer sequence (held, launched by whatever touches the stream next: here the event record), its source picture
+                // dropped before the pass ends
+                CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+                for (int l = 0; l < ((it & 1) ? 2 : 1); l++) CK(chv_run_kernel(c, ls[l].kernel, &canvas.img, &ls[l].image, 1, &ls[l].uniforms, sizeof ls[l].uniforms, 1, nullptr));
+                CK(chv_buffer_free(src.buf)); src_freed = true;
+            } else
+                CK(chv_composite(c, &canvas.img, 1, ls, (it & 1) ? 2 : 1));                        // waits for the upload on its own stream
             CK(chv_event_record(c, ev));
             CK(chv_pass_end(c, 0));
             CK(chv_event_wait(up, ev));                                                            // the download barrier's side
             CK(chv_download_async(up, pinned, (size_t)W * 4, canvas.buf, 0, canvas.img.planes[0].pitch, (size_t)W * 4, H));
             if (it % 7 == 0) CK(chv_pass_end(up, 1));
             // hand some buffers to another thread to free, free the rest here — with work still queued behind them
-            if (it < 8) { orphans[(size_t)t * 8 + it].store(src.buf, std::memory_order_release); ready++; } else CK(chv_buffer_free(src.buf));
+            if (it < 8) { orphans[(size_t)t * 8 + it].store(src.buf, std::memory_order_release); ready++; } else if (!src_freed) CK(chv_buffer_free(src.buf));
             CK(chv_buffer_free(canvas.buf)); CK(chv_buffer_free(ov.buf));
         }
         CK(chv_pass_end(c, 1)); CK(chv_pass_end(up, 1));

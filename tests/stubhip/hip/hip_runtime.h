@@ -82,6 +82,7 @@ void stubhip_enqueue(hipStream_t st, std::function<void()> fn);
 // the n-th launcher call from now on (1 = the next) reports hipErrorLaunchFailure instead of enqueuing; 0 = never
 void stubhip_fail_launch_after(int n);
 bool stubhip_launch_should_fail();
+long stubhip_launches();
 long stubhip_ops_executed();
 #define HIP_LAUNCH_PARAM_BUFFER_POINTER ((void *)0x01)
 #define HIP_LAUNCH_PARAM_BUFFER_SIZE ((void *)0x02)

@@ -62,7 +62,10 @@ void stubhip_enqueue(hipStream_t st, std::function<void()> fn) {
     if (s->q.size() > 2048) drain(s, s->issued - 1024);       // a device does make progress on its own — but far later than a 64-slot ring wraps
 }
 void stubhip_fail_launch_after(int n) { g_fail_in = n; }
+static std::atomic<long> g_launches{0};
+long stubhip_launches() { return g_launches.load(); }         // every launcher asks stubhip_launch_should_fail() exactly once
 bool stubhip_launch_should_fail() {
+    g_launches++;
     int v = g_fail_in.load();
     while (v > 0) { if (g_fail_in.compare_exchange_weak(v, v - 1)) return v == 1; }
     return false;
