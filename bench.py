@@ -146,6 +146,9 @@ def parse_args(argv=None):
     ap.add_argument("--alias", default="none", choices=("none", "src", "dst", "both"),
                     help="DIAGNOSTIC (single-layer YUV workloads): every tick reads frame 0's source and/or writes frame 0's "
                          "canvas, so that side of the traffic stays in cache; the line is marked and is not a benchmark result")
+    ap.add_argument("--content", default=os.environ.get("BENCH_CONTENT", "random"), choices=("random", "gradient", "natural"),
+                    help="bytes of the source pictures (content_image): `random` is the benchmark's; the others are diagnostics for data-dependent "
+                         "hardware paths and mark the line (config.content, data)")
     ap.add_argument("--device", type=int, default=None,
                     help="device index for every rank (default: LOCAL_RANK); lets the N>1 path be exercised on a 1-GPU box")
     ap.add_argument("--with-upload", action="store_true",
@@ -195,10 +198,14 @@ def live_traffic(workload, frames, kernel_substr, device):
                 rows = con.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? "
                                    "group by kernel_name", (counter,)).fetchall()
                 con.close()
-                hit = [r for r in rows if kernel_substr in r[0]]
-                if not hit:
-                    return None, f"kernel {kernel_substr} not in the {counter} pass"
-                vals[counter] = float(max(hit, key=lambda r: r[2])[1])
+                # one kernel, or — a workload of two stages (cfg5: the composite, then the resize) — the sum over its kernels' averages
+                total = 0.0
+                for sub in ([kernel_substr] if isinstance(kernel_substr, str) else kernel_substr):
+                    hit = [r for r in rows if sub in r[0]]
+                    if not hit:
+                        return None, f"kernel {sub} not in the {counter} pass"
+                    total += float(max(hit, key=lambda r: r[2])[1])
+                vals[counter] = total
         return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, None
     except Exception as e:    # noqa: BLE001
         return None, f"{type(e).__name__}: {e}"
@@ -316,11 +323,54 @@ def pick_device(args, local, n_visible):
 # ---------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------
-def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
+def content_image(util, fmt, w, h, seed, content="random"):
+    """A source picture's bytes.  `random` (the default and the only content `value` is ever quoted on): uniform bytes from splitmix64, SURVEY 8d.
+    `gradient`: SURVEY 8d's second set (Y = (x + 2y) & 255, U = 3x & 255, V = 5y & 255; RGB pictures B / G / R the same three, alpha x ^ y).
+    `natural`: low-pass-filtered noise — neighbouring samples correlated the way decoded video's are (three box blurs of radius 6 over the
+    random plane, stretched back to the full code range, +-2 codes of grain).  Content changes no instruction count; it changes what
+    data-dependent hardware paths see: LDS bank conflicts of a byte-indexed table, DRAM / cache compression, the power of toggling bits."""
+    planes = util.alloc_image(fmt, w, h, seed=seed)
+    if content == "random":
+        return planes
+    for k, p in enumerate(planes):
+        hh, ww = p.shape[0], p.shape[1]
+        comps = 1 if p.ndim == 2 else p.shape[2]
+        v = p.reshape(hh, ww, comps)
+        # sample coordinates in luma units (chroma planes are half size)
+        sub = 2 if (fmt in ("nv12", "y420p") and k > 0) else 1
+        yy, xx = np.mgrid[0:hh, 0:ww]
+        xx, yy = xx * sub, yy * sub
+        if content == "gradient":
+            chans = {"nv12": [[(xx + 2 * yy)], [3 * xx, 5 * yy]], "y420p": [[(xx + 2 * yy)], [3 * xx], [5 * yy]]}.get(fmt)
+            if chans is None:
+                chans = [[xx + 2 * yy, 3 * xx, 5 * yy, xx ^ yy]]
+            for c in range(comps):
+                v[:, :, c] = (chans[k][c] & 255).astype(np.uint8)
+        elif content == "natural":
+            for c in range(comps):
+                f = v[:, :, c].astype(np.float32)
+                for _ in range(3):
+                    for axis in (0, 1):
+                        r = 6
+                        pad = np.concatenate([np.repeat(f.take([0], axis=axis), r + 1, axis=axis), f, np.repeat(f.take([-1], axis=axis), r, axis=axis)], axis=axis)
+                        cs = np.cumsum(pad, axis=axis, dtype=np.float64)
+                        n = f.shape[axis]
+                        f = ((cs.take(range(2 * r + 1, 2 * r + 1 + n), axis=axis) - cs.take(range(0, n), axis=axis)) / (2 * r + 1)).astype(np.float32)
+                lo, hi = float(f.min()), float(f.max())
+                f = (f - lo) / max(hi - lo, 1e-6) * 255.0
+                grain = (v[:, :, c] % 5).astype(np.float32) - 2.0
+                v[:, :, c] = np.clip(np.rint(f + grain), 0, 255).astype(np.uint8)
+        else:
+            raise ValueError(content)
+    return planes
+
+
+def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0, content="random"):
     """Device-resident source frames, canvases and the batch descriptor."""
     import util
     from swiftvideo_amd import chipvideo as cv
     lib = cv.load()
+    src_image = lambda fmt, w, h, seed: content_image(util, fmt, w, h, seed, content)      # noqa: E731
     sw, sh, dw, dh = wl["sw"], wl["sh"], wl["dw"], wl["dh"]
     distinct = 4
     host_src = []
@@ -346,8 +396,8 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
         fmt = wl["mixer"]
         sfmt, kmain = wl.get("main_src", fmt), wl.get("main_kernel", f"img_{fmt}_{fmt}")
         for i in range(distinct):
-            host_src.append(util.alloc_image(sfmt, sw, sh, seed=seed_base + i))
-        ov = [util.alloc_image("bgra", 640, 360, seed=seed_base + 100 + i) for i in range(2)]
+            host_src.append(src_image(sfmt, sw, sh, seed=seed_base + i))
+        ov = [src_image("bgra", 640, 360, seed=seed_base + 100 + i) for i in range(2)]
         # (diagnostic: BENCH_OVERLAY_POS="x0,y0,x1,y1" moves the two overlays — how much of a mixer tick's time is strips an overlay's edge crosses)
         ovp = [int(v) for v in os.environ.get("BENCH_OVERLAY_POS", "64,64,1200,640").split(",")]
         us = [util.full_canvas_uniforms((dw, dh), (sw, sh)),
@@ -374,13 +424,13 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
         sfmt, nl = wl["src"], wl["layers"]
         skernel = sv.defaultComputeKernelFromString(f"img_{sfmt}_bgra")
         for i in range(distinct):
-            host_src.append(util.alloc_image(sfmt, sw, sh, seed=seed_base + i))
+            host_src.append(src_image(sfmt, sw, sh, seed=seed_base + i))
         ops = (1.0, 0.75, 0.5, 0.25)
         us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=ops[l]) for l in range(nl)]
         first_src = first_dst = None
         logo = logo_u = glogo = None
         if wl.get("logo"):
-            logo = util.alloc_image("rgba", 320, 180, seed=seed_base + 200)
+            logo = src_image("rgba", 320, 180, seed=seed_base + 200)
             logo_u = util.make_uniforms((dw, dh), rect=(820, 60, 320, 180), rotation=0.3, opacity=0.9, in_size=(320, 180))
             glogo = up(sv.PixelFormat.RGBA, (320, 180), logo)
             keep.append(glogo)
@@ -409,7 +459,7 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
     elif wl["kind"] == "grid":
         skernel = sv.defaultComputeKernelFromString("img_nv12_bgra")
         for i in range(distinct):
-            host_src.append(util.alloc_image("nv12", sw, sh, seed=seed_base + i))
+            host_src.append(src_image("nv12", sw, sh, seed=seed_base + i))
         qw, qh = dw // 2, dh // 2
         us = [util.full_canvas_uniforms((dw, dh), (sw, sh))] + \
              [util.make_uniforms((dw, dh), rect=(qx * qw, qy * qh, qw, qh), opacity=o, in_size=(sw, sh))
@@ -428,7 +478,7 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
     elif wl["kind"] == "rgb_layers":
         nl = wl["layers"]
         for i in range(distinct):
-            host_src.append(util.alloc_image("bgra", sw, sh, seed=seed_base + i))
+            host_src.append(src_image("bgra", sw, sh, seed=seed_base + i))
         ops = (1.0, 0.75, 0.5, 0.25) if nl <= 4 else (1.0, 0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3)
         us = [util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=o) for o in ops[:nl]]
         for f in range(frames):
@@ -448,9 +498,9 @@ def build_workload(sv, ctx, wl, frames, seed_base, alias="none", group=0):
             finish_tick(f, dst, layers)
         verify = dict(target="bgra", layers=lambda f: [("img_bgra_bgra_tx", host_src[(f + l) % distinct], us[l]) for l in range(nl)])
     elif wl["kind"] == "mixed":
-        nv = [util.alloc_image("nv12", sw, sh, seed=seed_base + i) for i in range(distinct)]
-        yp = [util.alloc_image("y420p", sw, sh, seed=seed_base + 50 + i) for i in range(distinct)]
-        ov = [util.alloc_image("bgra", 640, 360, seed=seed_base + 100), util.alloc_image("rgba", 640, 360, seed=seed_base + 101)]
+        nv = [src_image("nv12", sw, sh, seed=seed_base + i) for i in range(distinct)]
+        yp = [src_image("y420p", sw, sh, seed=seed_base + 50 + i) for i in range(distinct)]
+        ov = [src_image("bgra", 640, 360, seed=seed_base + 100), src_image("rgba", 640, 360, seed=seed_base + 101)]
         us = [util.full_canvas_uniforms((dw, dh), (sw, sh)), util.full_canvas_uniforms((dw, dh), (sw, sh), opacity=0.5),
               util.make_uniforms((dw, dh), rect=(48, 40, 426, 240), opacity=0.8, in_size=(640, 360)),
               util.make_uniforms((dw, dh), rect=(800, 430, 426, 240), opacity=0.6, in_size=(640, 360))]
@@ -699,7 +749,7 @@ def measure(name, args, sv, cv, lib, ctx, tm, rank, n_gpus, headline):
     wl = WORKLOADS[name]
     frames = args.frames if (args.frames and headline) else wl["frames"]
     group = args.group or wl.get("group", 0)
-    w = build_workload(sv, ctx, wl, frames, seed_base=0x5EED0000 + 16 * 2 + rank, alias=args.alias if headline else "none", group=group)
+    w = build_workload(sv, ctx, wl, frames, seed_base=0x5EED0000 + 16 * 2 + rank, alias=args.alias if headline else "none", group=group, content=args.content)
 
     # the second stage: one launch per group for the group's resizes (chv_scale_lanczos_batch)
     lzs = [sv.LanczosBatch(w["lanczos"][first:first + n]) for _, first, n in w["batches"]] if w["lanczos"] else None
@@ -1621,6 +1671,13 @@ def build_detail(args, dist, n_gpus, head, cpu, reports, regret, power, build_fl
             roof["traffic_source"] = f"unreadable {pmc_path}: {e}"
     if roof["traffic"]:
         roof["traffic_ratio"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+    # --full: the counted traffic of cfg5 as well — the one workload that moves more than its algorithmic bytes (the 2160p canvases travel out
+    # and back between the composite and the resize): both kernels of the pair, per batch
+    if args.full and "cfg5" in reports and n_gpus == 1 and not args.no_live_pmc and not args.stub_device and args.workload != "cfg5":
+        t5, err5 = live_traffic("cfg5", reports["cfg5"]["frames_per_launch_per_gpu"], ["tick_bgra_wave", "lanczos3"], args.device if args.device is not None else 0)
+        r5 = reports["cfg5"]["roofline"]
+        r5["traffic"], r5["traffic_error"] = t5, err5
+        r5["traffic_ratio"] = None if t5 is None else t5 / reports["cfg5"]["algorithmic_bytes_per_launch"]
     for k, v in reports.items():          # every workload's own limiter beside its fraction
         if "roofline" in v:
             v["roofline"]["limiter"] = limiter_of(k, (power or {}).get(k))
@@ -1663,6 +1720,9 @@ def build_detail(args, dist, n_gpus, head, cpu, reports, regret, power, build_fl
     if args.stub_device:
         out["data"] = "STUB --stub-device: launches are sleeps; control-plane self-test, not a benchmark result"
         out["roofline"]["frac"] = None
+    out["config"]["content"] = args.content
+    if args.content != "random":
+        out["data"] = f"synthetic, DIAGNOSTIC --content {args.content} (the benchmark's content is uniform random bytes)"
     if args.alias != "none":
         out["data"] = f"DIAGNOSTIC --alias {args.alias}: ticks share frame 0's buffers, cache-resident traffic; not a benchmark result"
         out["roofline"]["frac"] = None
@@ -1710,6 +1770,8 @@ def compact_line(d):
         c["workload_fracs"] = {k: [_num(v[0], 4), _num(v[1], 4)] for k, v in cfg["workload_fracs"].items()}       # name -> [frac of 8 TB/s, ms per launch]
         c["workload_limiters"] = cfg.get("workload_limiters")
     c["full"] = cfg.get("full", False)
+    if cfg.get("content", "random") != "random":
+        c["content"] = cfg["content"]
     r = None
     if roof is not None:
         keys = ("bound", "limiter", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio", "kernel", "launch_ms", "issue_model_ms",

@@ -63,7 +63,7 @@ int chv_version(void);
 const char *chv_build_flags(void);
 /* Measurement / test hook: path-selection switches.  Names and values are those of the environment variables read once at
  * first use (CHV_FORCE_GENERAL=1, CHV_BGRA_PATH=wave|tiled|stream, CHV_WAVE_ROWS=8|16, CHV_TILE_ROWS=16|32, CHV_SAME_GEOM=0,
- * CHV_DESC=host|device, CHV_STREAM=0, CHV_YUV_STREAM=0|force);
+ * CHV_DESC=host|device, CHV_STREAM=0, CHV_YUV_STREAM=0|force, CHV_WAVE_DMA=0, CHV_PASS_FUSE=0);
  * NULL or "" restores the default.  Process-wide, atomic; not part of the Swift-facing contract. */
 int chv_debug_set_switch(const char *name, const char *value);
 
@@ -162,7 +162,9 @@ typedef struct chv_buffer chv_buffer;
 int chv_buffer_alloc(chv_context *ctx, size_t bytes, chv_buffer **out);
 /* Adopt device memory owned by someone else (e.g. a decoder surface); never freed here. */
 int chv_buffer_wrap(chv_context *ctx, void *device_ptr, size_t bytes, chv_buffer **out);
-/* ComputeBuffer.deinit, compute.cl.swift:55-57; callable from any thread. */
+/* ComputeBuffer.deinit, compute.cl.swift:55-57; callable from any thread.  A buffer that kernels of a pass in progress name (chv_pass_begin)
+ * is released when they have been launched; the call returns at once either way.  A second free of the same buffer is CHV_ERR_INVALID_VALUE
+ * while the first is pending, undefined afterwards (as for any freed handle). */
 int chv_buffer_free(chv_buffer *buf);
 int chv_buffer_info(chv_buffer *buf, void **device_ptr, size_t *bytes);
 /* One plane of createTexture (compute.cl.swift:532-581): `components` bytes
@@ -261,7 +263,17 @@ typedef struct chv_me_uniforms {      /* MotionEstimationUniforms, kernels.metal
 } chv_me_uniforms;
 
 /* ---- compute passes ----------------------------------------------------- */
-/* beginComputePass, compute.cl.swift:234-237 */
+/* beginComputePass, compute.cl.swift:234-237.
+ * Between chv_pass_begin and chv_pass_end the picture kernels issued through chv_run_kernel are ACCEPTED — every argument check runs in the
+ * call and its error comes back from it — and HELD: nothing has to be visible before the pass ends (usingContext, compute.swift:131-134), so
+ * `img_clear_* + N layer kernels on one target`, what an unchanged VideoMixer issues per tick (mix.video.swift:116-124), leaves as the ONE
+ * launch chv_composite would have made of it: same bytes (that equality is chv_composite's definition), one launch instead of N + 1.  What is
+ * held goes out, in issue order, at chv_pass_end — or before anything else that touches ctx's stream: an upload or download through ctx, a
+ * batch, a custom or buffer kernel, an event, chv_context_stream, a kernel on another target, a clear after layers.  Buffers named by held
+ * kernels may be passed to chv_buffer_free before the pass ends (a ComputeBuffer's deinit can run as soon as runComputeKernel returns,
+ * compute.cl.swift:55-57): the free takes effect once they have been launched.  Work of OTHER contexts is ordered against a pass's kernels at the
+ * pass's end, as against any kernel: events, or the per-buffer upload events.  CHV_PASS_FUSE=0 (environment / chv_debug_set_switch) launches
+ * every kernel in its call, as rounds 1-5 did. */
 int chv_pass_begin(chv_context *ctx);
 /* runComputeKernel (both overloads), compute.cl.swift:250-344.  Launch domain
  * is the target's plane-0 size (:329).  `inputs`/`n_inputs`: the images array;
@@ -272,8 +284,8 @@ int chv_run_kernel(chv_context *ctx, int kernel, const chv_image *target,
                    const chv_image *inputs, int n_inputs,
                    const void *uniforms, size_t uniforms_size, int blends,
                    const chv_kernel_opts *opts);
-/* endComputePass, compute.cl.swift:346-359: wait != 0 -> block until the
- * stream is idle (clFinish), else just make sure work is submitted (clFlush). */
+/* endComputePass, compute.cl.swift:346-359: launches what the pass holds (above; a launch error of those kernels is returned here), then
+ * wait != 0 -> block until the stream is idle (clFinish), else just make sure work is submitted (clFlush). */
 int chv_pass_end(chv_context *ctx, int wait);
 
 /* ---- one mixer tick in one launch --------------------------------------- */

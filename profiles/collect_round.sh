@@ -30,6 +30,9 @@ python profiles/summarize.py gpurun_out/prof_${R}_mixer --kernel tick_yuv_wave >
 # 4b. the encoder-side frame through the 4:2:0 streaming kernel
 bash profiles/run_profile.sh ${R}_encode --workload encode_nv12 --also none --no-cpu-baseline --no-verify --steps 5 --warmup 2 --launches-per-step 1 > /dev/null 2>&1
 python profiles/summarize.py gpurun_out/prof_${R}_encode --kernel tick_yuv_stream > $OUT/encode_nv12_rocprofv3.txt 2>&1
+# 4c. cfg5 (the strip kernel on eight 2160p RGB layers with LDS-DMA staging, then lanczos3_strip2): stats + counters of both kernels
+bash profiles/run_profile.sh ${R}_cfg5 --workload cfg5 --also none --no-cpu-baseline --no-verify --steps 5 --warmup 2 --launches-per-step 1 > /dev/null 2>&1
+python profiles/summarize.py gpurun_out/prof_${R}_cfg5 --kernel tick_bgra_wave > $OUT/cfg5_rocprofv3.txt 2>&1
 # 5. A/B lines: general kernels, wave kernel on the single-purpose workloads
 for w in pipeline mixer_y420p cfg2; do CHV_FORCE_GENERAL=1 python bench.py --workload $w --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_${w}_general_kernel.json 2>/dev/null; done
 for w in cfg2 cfg3; do CHV_BGRA_PATH=wave python bench.py --workload $w --also none --no-cpu-baseline --min-seconds 0.5 > $OUT/bench_${w}_wave_kernel.json 2>/dev/null; done

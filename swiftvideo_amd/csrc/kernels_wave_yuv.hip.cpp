@@ -35,34 +35,16 @@
 
 namespace chv {
 
-// CHV_UNORM_TABLE = 1: UNORM8 loads through a 256-entry LDS table (one shift + one LDS read per tap instead of three VALU
-// instructions).  Measured and left off: on uncorrelated bytes the lookups collide in the LDS banks (SQ_LDS_BANK_CONFLICT
-// 3.8 M -> 93 M cycles per launch) and the launch is 3 % slower than with the arithmetic form (profiles/r02_notes.md).
-#ifndef CHV_UNORM_TABLE
-#define CHV_UNORM_TABLE 0
-#endif
-constexpr int UNORM_TAB_BYTES = CHV_UNORM_TABLE ? 1024 : 0;          // float[256] at the start of the block's LDS (nothing when the table is off: a
-                                                                     // kilobyte per wave is one wave per CU in eighteen on the mixer canvas)
-
-// c / 255.0f, correctly rounded: table lookup (byte index) or the two-term product of pixel_math.hip.h
-CHV_DEV float T8(const float *tab, uint32_t byte) {
-#if CHV_UNORM_TABLE
-    return tab[byte];
-#else
-    (void)tab;
-    return unorm8(byte);
-#endif
-}
-// the same for byte k of a packed word
+// UNORM8 loads: c / 255.0f, correctly rounded — the two-term product of pixel_math.hip.h (cvt + mul + fma per byte; a single multiply is wrong
+// for 126 of 256 codes).  A 256-entry LDS table in their place was measured in rounds 2 and 6 and is gone from the source
+// (profiles/r06_unorm_table_experiment.patch, r06_notes.md section 3): it removes 8 % of the launch's vector instructions and is 6 % SLOWER on
+// conflict-free content (gradients: 4.9 M bank-conflict cycles), 6-7 % on low-pass noise (34 M), 6-10 % on random bytes (121 M) — an LDS read
+// occupies the CU's one LDS pipe for as long as one of its four SIMDs would have spent on the arithmetic.
+CHV_DEV float T8(uint32_t byte) { return unorm8(byte); }
+// the same for byte K of a packed word
 template <int K>
-CHV_DEV float T8k(const float *tab, uint32_t w) {
-#if CHV_UNORM_TABLE
-    const uint32_t idx4 = K == 0 ? (w << 2) & 0x3FCu : (w >> (8 * K - 2)) & 0x3FCu;     // byte * 4
-    return *(const float *)((const uint8_t *)tab + idx4);
-#else
-    (void)tab;
+CHV_DEV float T8k(uint32_t w) {
     return unorm8f(K == 0 ? (float)(w & 255u) : K == 1 ? (float)((w >> 8) & 255u) : K == 2 ? (float)((w >> 16) & 255u) : (float)(w >> 24));
-#endif
 }
 // convert_uchar_sat_rte(f * 255) into byte K of w (v_cvt_pk_u8_f32: RTE, clamp to [0, 255], NaN -> 0 = to_code)
 template <int K>
@@ -98,6 +80,10 @@ CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float 
 
 #ifndef CHV_WAVEY_CARRY
 #define CHV_WAVEY_CARRY 1
+#endif
+// 1: uncleared launches cover the strips their layers' bounding boxes touch, not the canvas (launch_wave_layers); 0: the A/B
+#ifndef CHV_WAVE_BBOX_GRID
+#define CHV_WAVE_BBOX_GRID 1
 #endif
 // (bit 2: narrow interior YUV rectangles through the shift-and-mask slot map, wstage_load_p2; bit 3 — skip its unneeded rounds —
 // measured and left off: mixer_y420p 0.649 -> 0.663 ms, mixer_nv12 0.637 -> 0.664 with it)
@@ -136,15 +122,10 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                                                                          int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
     constexpr int YLW = YTH / 4;                     // registers holding the lane's luma codes (4 rows per register)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
-    float *tab = (float *)smem_all;
-#if CHV_UNORM_TABLE
-    for (int i = threadIdx.x; i < 256; i += WAVE_BLOCK) tab[i] = unorm8((uint32_t)i);
-    __syncthreads();                      // the only block barrier, before any wave leaves
-#endif
     // (compact staging of interior rectangles: measured better for the mixed-class instantiations, worse for the own-format one)
     using Strip = WaveStrip<YTH, (KINDS == 1 || KINDS == 2) ? CHV_WAVEY_INTERIOR_OWN : CHV_WAVEY_INTERIOR, KINDS>;
     Strip S;
-    if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all + UNORM_TAB_BYTES, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;
+    if (!S.init(ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, smem_all, p0pitch, p0rows, p1pitch, p1rows, planar_any)) return;
     p1pitch = S.p1pitch;                 // (the side-by-side layout keeps chroma in the rows of the plane-0 region: WaveStrip::init)
     const DTick &T = *S.T;
     const DLayer *L = S.L;
@@ -260,7 +241,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                 // two UNORM8 conversions, three instructions each, are carried down the lane)
                 const bool carry = CHV_WAVEY_CARRY && cur.unit_rows;
                 float t0 = 0.f, t1 = 0.f;
-                if (carry) { const uint8_t *py = smem + (row_fast<YTH, false>(rowtab, 0).yoff + cur.cyo); t0 = T8(tab, py[0]); t1 = T8(tab, py[1]); }
+                if (carry) { const uint8_t *py = smem + (row_fast<YTH, false>(rowtab, 0).yoff + cur.cyo); t0 = T8(py[0]); t1 = T8(py[1]); }
                 auto row = [&](auto jc, auto carry_c) {
                     constexpr int j = decltype(jc)::value;
                     constexpr bool CARRY = decltype(carry_c)::value;
@@ -270,15 +251,15 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                     const uint8_t *py = smem + (rw.yoff + cur.cyo);
                     float luma;
                     if constexpr (CARRY) {
-                        const float b0 = T8(tab, py[p0pitch]), b1 = T8(tab, py[p0pitch + 1]);
+                        const float b0 = T8(py[p0pitch]), b1 = T8(py[p0pitch + 1]);
                         luma = mix4(ia * ib, a * ib, ia * b, a * b, t0, t1, b0, b1);
                         t0 = b0; t1 = b1;
                     } else {
-                        luma = mix4(ia * ib, a * ib, ia * b, a * b, T8(tab, py[0]), T8(tab, py[1]), T8(tab, py[p0pitch]), T8(tab, py[p0pitch + 1]));
+                        luma = mix4(ia * ib, a * ib, ia * b, a * b, T8(py[0]), T8(py[1]), T8(py[p0pitch]), T8(py[p0pitch + 1]));
                     }
                     uint32_t &lw = ly[j >> 2];
                     // opacity == 1: cur * 0 + luma * 1 = luma exactly
-                    const float v = OP ? luma : T8k<j & 3>(tab, lw) * ialpha + luma * alpha;
+                    const float v = OP ? luma : T8k<j & 3>(lw) * ialpha + luma * alpha;
                     const uint32_t nlw = put_code<j & 3>(lw, v);
                     lw = tk ? nlw : lw;
                     if constexpr ((j & 3) == 0) {
@@ -293,15 +274,15 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                         const float c00 = icaq * icb, c10 = cca_q * icb, c01 = icaq * cbw, c11 = cca_q * cbw;
                         float fu, fv;
                         if constexpr (PL) {
-                            fu = mix4(c00, c10, c01, c11, T8(tab, pc[0]), T8(tab, pc[1]), T8(tab, pc[p1pitch]), T8(tab, pc[p1pitch + 1]));
+                            fu = mix4(c00, c10, c01, c11, T8(pc[0]), T8(pc[1]), T8(pc[p1pitch]), T8(pc[p1pitch + 1]));
                             const uint8_t *pv = pc + voff;
-                            fv = mix4(c00, c10, c01, c11, T8(tab, pv[0]), T8(tab, pv[1]), T8(tab, pv[p1pitch]), T8(tab, pv[p1pitch + 1]));
+                            fv = mix4(c00, c10, c01, c11, T8(pv[0]), T8(pv[1]), T8(pv[p1pitch]), T8(pv[p1pitch + 1]));
                         } else {
-                            fu = mix4(c00, c10, c01, c11, T8(tab, pc[0]), T8(tab, pc[2]), T8(tab, pc[p1pitch]), T8(tab, pc[p1pitch + 2]));
-                            fv = mix4(c00, c10, c01, c11, T8(tab, pc[1]), T8(tab, pc[3]), T8(tab, pc[p1pitch + 1]), T8(tab, pc[p1pitch + 3]));
+                            fu = mix4(c00, c10, c01, c11, T8(pc[0]), T8(pc[2]), T8(pc[p1pitch]), T8(pc[p1pitch + 2]));
+                            fv = mix4(c00, c10, c01, c11, T8(pc[1]), T8(pc[3]), T8(pc[p1pitch + 1]), T8(pc[p1pitch + 3]));
                         }
-                        const uint32_t nnu = put_code<m>(nu, OP ? fu : T8k<m>(tab, nu) * ialpha + fu * alpha);
-                        const uint32_t nnv = put_code<m>(nv, OP ? fv : T8k<m>(tab, nv) * ialpha + fv * alpha);
+                        const uint32_t nnu = put_code<m>(nu, OP ? fu : T8k<m>(nu) * ialpha + fu * alpha);
+                        const uint32_t nnv = put_code<m>(nv, OP ? fv : T8k<m>(nv) * ialpha + fv * alpha);
                         nu = tkc ? nnu : nu; nv = tkc ? nnv : nv;
                     }
                 };
@@ -414,8 +395,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
             if (carry) {
                 const uint8_t *p0 = smem + (row_fast<YTH, false>(rowtab, 0).yoff + cur.cyo);
                 const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
-                t00 = T8k<0>(tab, u00); t01 = T8k<1>(tab, u00); t02 = T8k<2>(tab, u00); t03 = T8k<3>(tab, u00);
-                t10 = T8k<0>(tab, u10); t11 = T8k<1>(tab, u10); t12 = T8k<2>(tab, u10); t13 = T8k<3>(tab, u10);
+                t00 = T8k<0>(u00); t01 = T8k<1>(u00); t02 = T8k<2>(u00); t03 = T8k<3>(u00);
+                t10 = T8k<0>(u10); t11 = T8k<1>(u10); t12 = T8k<2>(u10); t13 = T8k<3>(u10);
             }
             auto row = [&](auto jc, auto carry_c) {
                 constexpr int j = decltype(jc)::value;
@@ -426,12 +407,12 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                 const uint8_t *p0 = smem + (rw.yoff + cur.cyo);
                 const uint32_t u01 = ((const uint32_t *)(p0 + p0pitch))[0], u11 = ((const uint32_t *)(p0 + p0pitch))[1];
                 const float w00 = ia * ib, w10 = a * ib, w01 = ia * b, w11 = a * b;
-                const float b00 = T8k<0>(tab, u01), b01 = T8k<1>(tab, u01), b02 = T8k<2>(tab, u01), b03 = T8k<3>(tab, u01);
-                const float b10 = T8k<0>(tab, u11), b11 = T8k<1>(tab, u11), b12 = T8k<2>(tab, u11), b13 = T8k<3>(tab, u11);
+                const float b00 = T8k<0>(u01), b01 = T8k<1>(u01), b02 = T8k<2>(u01), b03 = T8k<3>(u01);
+                const float b10 = T8k<0>(u11), b11 = T8k<1>(u11), b12 = T8k<2>(u11), b13 = T8k<3>(u11);
                 if constexpr (!CARRY) {
                     const uint32_t u00 = ((const uint32_t *)p0)[0], u10 = ((const uint32_t *)p0)[1];
-                    t00 = T8k<0>(tab, u00); t01 = T8k<1>(tab, u00); t02 = T8k<2>(tab, u00); t03 = T8k<3>(tab, u00);
-                    t10 = T8k<0>(tab, u10); t11 = T8k<1>(tab, u10); t12 = T8k<2>(tab, u10); t13 = T8k<3>(tab, u10);
+                    t00 = T8k<0>(u00); t01 = T8k<1>(u00); t02 = T8k<2>(u00); t03 = T8k<3>(u00);
+                    t10 = T8k<0>(u10); t11 = T8k<1>(u10); t12 = T8k<2>(u10); t13 = T8k<3>(u10);
                 }
                 const float r = mix4(w00, w10, w01, w11, t00, t10, b00, b10);
                 const float g = mix4(w00, w10, w01, w11, t01, t11, b01, b11);
@@ -442,7 +423,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                 float yy, uu, vv;
                 rgb2yuv(r * a2, g * a2, bl * a2, yy, uu, vv);
                 uint32_t &lw = ly[j >> 2];
-                const float rx = T8k<j & 3>(tab, lw) * iaf + fya;
+                const float rx = T8k<j & 3>(lw) * iaf + fya;
                 const uint32_t nlw = put_code<j & 3>(lw, rx * ia2 + yy * a2);
                 lw = tk ? nlw : lw;
                 if constexpr ((j & 1) == 0) {
@@ -459,8 +440,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                         stk = __builtin_amdgcn_update_dpp(stk, stk, 0xA0, 0xf, 0xf, false);
                     }
                     const bool mine = stk != 0 && par == (jj & 1);
-                    const float ry = clampf(T8k<m>(tab, nu) * iaf + fua, -1.f, 1.f);
-                    const float rz = clampf(T8k<m>(tab, nv) * iaf + fva, -1.f, 1.f);
+                    const float ry = clampf(T8k<m>(nu) * iaf + fua, -1.f, 1.f);
+                    const float rz = clampf(T8k<m>(nv) * iaf + fva, -1.f, 1.f);
                     const uint32_t nnu = put_code<m>(nu, ry * sia + su * sa);
                     const uint32_t nnv = put_code<m>(nv, rz * sia + sv * sa);
                     nu = mine ? nnu : nu; nv = mine ? nnv : nv;
@@ -615,8 +596,7 @@ static WaveDims wave_dims(const DTick &T, const DLayer &L, int WTH) {
     return d;
 }
 static size_t wave_lds(const WaveDims &d, bool planar, int target_format, int rows) {
-    return (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) +
-           (size_t)WAVES * ((size_t)rows * 48 + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
+    return            (size_t)WAVES * ((size_t)rows * 48 + (size_t)d.p0pitch * d.p0rows + (size_t)d.p1pitch * d.p1rows * (planar ? 2 : 1));
 }
 
 // tail: the launch continues on canvases another launch has composed (the second part of a split batch): strips no layer touches leave at once,
@@ -658,7 +638,7 @@ bool wave_layers_eligible(int target_format, const DTick *ticks, const DLayer *l
 
 #define CHV_STR2(x) #x
 #define CHV_STR(x) CHV_STR2(x)
-const char *yuv_wave_build_flags() { return "tick_yuv_wave:abl=" CHV_STR(CHV_ABL) ",unorm_table=" CHV_STR(CHV_UNORM_TABLE) ",strip_rows=8|16"; }
+const char *yuv_wave_build_flags() { return "tick_yuv_wave:abl=" CHV_STR(CHV_ABL) ",strip_rows=8|16"; }
 
 // kernels_wave.hip.cpp
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
@@ -736,7 +716,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     if (lds > (size_t)LDS_BUDGET) {
         // per-layer maxima combined exceed the budget: shrink the row counts; rectangles that do not fit fall back to
         // unstaged taps inside the kernel
-        const size_t fixed = (size_t)(target_format == TF_BGRA ? 0 : UNORM_TAB_BYTES) + (size_t)WAVES * WTH * 48;     // (row table: WaveCfg::ROWTAB_BYTES)
+        const size_t fixed = (size_t)WAVES * WTH * 48;     // (row table: WaveCfg::ROWTAB_BYTES)
         const size_t per_row = (size_t)WAVES * ((size_t)m.p0pitch + (size_t)m.p1pitch * (planar ? 2 : 1));
         int rows = std::max(1, (int)((LDS_BUDGET - fixed) / per_row));
         m.p0rows = std::min(m.p0rows, rows); m.p1rows = std::min(m.p1rows, rows);
@@ -748,6 +728,28 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     if (const char *pad = getenv("CHV_LDS_PAD")) { fprintf(stderr, "[chv] lds %zu + pad %d, rows %d\n", lds, atoi(pad), WTH); lds += (size_t)atoi(pad); }
 #endif
     int strips_x = (maxW + WTW - 1) / WTW, strips_y = (maxH + WTH - 1) / WTH;
+    const bool clear = ticks_host[0].clear_first != 0;
+    // A launch that continues on canvases something else composed (the second launch of a split batch: a logo or overlays over the videos the
+    // streaming kernel did; layers added to a canvas outside a clear) only has work where its layers are: the grid covers the strips the union of
+    // the layers' bounding boxes touches instead of the canvas (a 320 x 180 logo on 720p: ~40 of 1800 strips per tick; the other waves used to
+    // start, find no layer and leave — 115 us of a 730 us pipeline_logo batch).  The origin travels in the high halves of the two row counts.
+    int origin_x = 0, origin_y = 0;
+    if (!clear && CHV_WAVE_BBOX_GRID) {
+        int bx0 = maxW, by0 = maxH, bx1 = 0, by1 = 0;
+        for (int i = 0; i < n_ticks; i++)
+            for (int l = 0; l < ticks_host[i].n_layers; l++) {
+                const int32_t *bb = layers_host[ticks_host[i].first_layer + l].bbox;
+                bx0 = std::min(bx0, std::max(bb[0], 0)); by0 = std::min(by0, std::max(bb[1], 0));
+                bx1 = std::max(bx1, std::min(bb[2], maxW)); by1 = std::max(by1, std::min(bb[3], maxH));
+            }
+        if (bx1 > bx0 && by1 > by0) {
+            origin_x = bx0 / WTW; origin_y = by0 / WTH;
+            strips_x = (bx1 + WTW - 1) / WTW - origin_x; strips_y = (by1 + WTH - 1) / WTH - origin_y;
+        } else { strips_x = 1; strips_y = 1; }                     // (nothing visible: one strip per tick, which finds no layer and leaves)
+        if (origin_x > 0xFFFF || origin_y > 0xFFFF) { origin_x = origin_y = 0; strips_x = (maxW + WTW - 1) / WTW; strips_y = (maxH + WTH - 1) / WTH; }
+    }
+    m.p0rows = std::min(m.p0rows, 0xFFFF); m.p1rows = std::min(m.p1rows, 0xFFFF);      // (far beyond what LDS holds: such rectangles are not staged anyway)
+    const int p0rows_arg = m.p0rows | (origin_x << 16), p1rows_arg = m.p1rows | (origin_y << 16);
     // floor(2^32 / d) for the kernels' scalar divisions by the strips per tick and per row (WaveStrip::udivmod)
     auto magic = [](uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); };
     const uint32_t strips_magic = magic((uint32_t)(strips_x * strips_y)), strips_x_magic = magic((uint32_t)strips_x);
@@ -755,12 +757,11 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     long per_xcd = (total + 7) / 8;
     long blocks_per_xcd = (per_xcd + WAVES - 1) / WAVES;
     dim3 grid((unsigned)(blocks_per_xcd * 8));
-    const bool clear = ticks_host[0].clear_first != 0;
     if (target_format == TF_BGRA) {
-        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side, kinds);
+        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side, kinds);
     }
 #define CHV_LAUNCH_Y(TFV, C, R, K) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
-                                                      strips_magic, strips_x_magic, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side)
+                                                      strips_magic, strips_x_magic, m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side)
 #define CHV_LAUNCH_YK(TFV, C, R, OWN) do { if (kinds == OWN) CHV_LAUNCH_Y(TFV, C, R, OWN); else if (kinds == (OWN | 4)) CHV_LAUNCH_Y(TFV, C, R, (OWN | 4)); \
                                            else if (kinds & 8) CHV_LAUNCH_Y(TFV, C, R, 15); else CHV_LAUNCH_Y(TFV, C, R, 7); } while (0)
 #define CHV_LAUNCH_YR(TFV, C, OWN) do { if (WTH == 16) CHV_LAUNCH_YK(TFV, C, 16, OWN); else CHV_LAUNCH_YK(TFV, C, 8, OWN); } while (0)

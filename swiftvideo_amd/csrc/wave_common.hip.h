@@ -347,7 +347,10 @@ struct WaveStrip {
         const int tid = threadIdx.x;
         lane = tid & 63;
         const int wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);      // (one wave per block: no per-wave LDS offset arithmetic)
-        p0pitch = p0pitch_; p0rows = p0rows_; p1pitch = p1pitch_; p1rows = p1rows_;
+        // (bits 16-31 of the two row counts: the launch's ORIGIN in strips — a launch that continues on composed canvases covers only the strips
+        // its layers' bounding boxes touch, launch_wave_layers)
+        const int osx = (int)((uint32_t)p0rows_ >> 16), osy = (int)((uint32_t)p1rows_ >> 16);
+        p0pitch = p0pitch_; p0rows = p0rows_ & 0xFFFF; p1pitch = p1pitch_; p1rows = p1rows_ & 0xFFFF;
         // planar_any: bit 0 — the launch has planar pictures; bit 7: the SIDE-BY-SIDE layout (launch_wave_layers) — one region whose rows hold a YUV
         // layer's luma columns (bits 8-19, units of 16 bytes), then its chroma: the (u, v) rows of an NV12 picture, or the U and V rows of a planar
         // one, each bits 20-31 wide — instead of a plane-0 region followed by chroma regions; RGB rectangles use the whole rows
@@ -375,7 +378,7 @@ struct WaveStrip {
         udivmod((uint32_t)index, (uint32_t)strips, strips_magic, tick, strip);
         udivmod((uint32_t)strip, (uint32_t)strips_x, strips_x_magic, syi, sxi);
         T = ticks + tick;
-        x0 = sxi * WTW; y0 = syi * WTH;
+        x0 = (osx + sxi) * WTW; y0 = (osy + syi) * WTH;
         if (x0 >= T->W || y0 >= T->H) return false;
         L = layers + T->first_layer;
         nl = T->n_layers;

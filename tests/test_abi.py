@@ -121,7 +121,6 @@ def test_build_flags_report_a_product_build(built):
     abl = re.findall(r"abl=(\d+)", flags)
     assert len(abl) >= 5 and all(a == "0" for a in abl), flags          # tick_bgra_wave, tick_yuv_wave, tick_bgra_stream, tick_yuv_stream, lanczos3
     assert re.search(r";hipcc=\d+\.\d+\.", flags) and re.search(r";clang=\d+\.\d+;", flags), flags
-    assert "unorm_table=0" in flags
 
 
 def test_build_reports_whether_it_compiled(built, capsys):
