@@ -272,7 +272,8 @@ typedef struct chv_me_uniforms {      /* MotionEstimationUniforms, kernels.metal
  * batch, a custom or buffer kernel, an event, chv_context_stream, a kernel on another target, a clear after layers.  Buffers named by held
  * kernels may be passed to chv_buffer_free before the pass ends (a ComputeBuffer's deinit can run as soon as runComputeKernel returns,
  * compute.cl.swift:55-57): the free takes effect once they have been launched.  Work of OTHER contexts is ordered against a pass's kernels at the
- * pass's end, as against any kernel: events, or the per-buffer upload events.  CHV_PASS_FUSE=0 (environment / chv_debug_set_switch) launches
+ * pass's end, as against any kernel: events, or the per-buffer upload events.  Brackets nest (uploadComputePicture opens its own around its
+ * copies, compute.cl.swift:433,453): kernels are held while any bracket is open, and every chv_pass_end launches what is held.  CHV_PASS_FUSE=0 (environment / chv_debug_set_switch) launches
  * every kernel in its call, as rounds 1-5 did. */
 int chv_pass_begin(chv_context *ctx);
 /* runComputeKernel (both overloads), compute.cl.swift:250-344.  Launch domain

@@ -312,7 +312,7 @@ struct chv_context {
     int device = 0;
     hipStream_t stream = nullptr;
     std::shared_ptr<DeviceShared> shared;
-    bool in_pass = false;
+    int pass_depth = 0;                // open chv_pass_begin brackets (an upload helper that brackets its copies inside the mixer's pass nests)
     StagingSlot staging[kStagingSlots];
     int next_staging = 0;
     // descriptor ring in pinned, device-mapped host memory
@@ -1180,14 +1180,15 @@ static bool same_target(const chv_image &a, const chv_image &b) {
 
 extern "C" int chv_pass_begin(chv_context *c) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
-    FLUSH_PENDING(c);   // (a pass begun twice without its end: what the first one accepted goes out first)
-    c->in_pass = true;  // no device work: like OpenCL, a pass is just a bracket (compute.cl.swift:234-237)
+    // no device work: like OpenCL, a pass is just a bracket (compute.cl.swift:234-237).  Brackets nest (uploadComputePicture opens its own,
+    // compute.cl.swift:433,453, downloadComputePicture :470,492): kernels are held while any is open, every chv_pass_end launches what is held
+    if (c->pass_depth < (1 << 20)) c->pass_depth++;
     return CHV_OK;
 }
 
 extern "C" int chv_pass_end(chv_context *c, int wait) {
     if (!ctx_ok(c)) return fail(CHV_ERR_INVALID_CONTEXT, "bad context");
-    c->in_pass = false;
+    if (c->pass_depth > 0) c->pass_depth--;
     HIP_TRY(hipSetDevice(c->device));
     // the pass's picture kernels, held back since chv_run_kernel accepted them: one fused launch where they are `clear + layers on one target`
     FLUSH_PENDING(c);
@@ -1308,7 +1309,7 @@ extern "C" int chv_run_kernel(chv_context *c, int kernel, const chv_image *targe
     DepScope deps;
     rc = tick_to_device(t, c->device, s.is_clear ? s.target_format : -1, &dt, &dl, &tf);      // (every argument error surfaces here, in this call)
     if (rc) return rc;
-    if (c->in_pass && switches().pass_fuse.load(std::memory_order_relaxed)) {
+    if (c->pass_depth > 0 && switches().pass_fuse.load(std::memory_order_relaxed)) {
         // Inside a pass: accept the kernel, launch it with the rest of the pass (flush_pending).  A kernel on another target, or a clear
         // after something else, first sends out what is held — the stream sees the kernels in the order they were issued.
         chv_context::PendingPass &pp = c->pending;

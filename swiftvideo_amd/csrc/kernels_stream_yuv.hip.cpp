@@ -30,7 +30,7 @@
 // kind), so the bytes are those of oracle/ref_kernels.c::px_yuv_to_yuv / px_rgb_to_yuv / px_rgb_to_yuv_int, layer by layer.
 //
 // Eligibility (yuv_stream_eligible): cleared canvas with W % 8 == 0 and H % 4 == 0, 1..4 layers, every layer axis-aligned, bounded,
-// without fill paint and without flips, horizontal reduction <= 1.7 (YUV) / 1.17 (RGB), vertical <= 2.2, source rows a multiple of
+// without fill paint and without flips, horizontal reduction <= 1.7 (YUV) / 1.17 (RGB), vertical <= 2.1 (a step of 8 rows must span at most 15 source rows: yuv_stream_eligible), source rows a multiple of
 // 16 bytes, at most 16 KB of rings per wave.  Everything else keeps tick_yuv_wave.
 #include "wave_common.hip.h"
 #include "switches.h"

@@ -207,6 +207,23 @@ static void single_thread(chv_context *c) {
         EXPECT(chv_pass_end(c, 1) != CHV_OK);
         stubhip_fail_launch_after(0);
         CK(chv_pass_end(c, 1));
+        // brackets nest (uploadComputePicture brackets its copies, compute.cl.swift:433,453 — inside the mixer's pass in a host that uploads there): the
+        // inner end launches what is held so far, the outer pass goes on holding
+        l0 = stubhip_launches();
+        CK(chv_pass_begin(c));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        CK(chv_pass_begin(c));
+        CK(chv_upload(c, yp.buf, 0, W, host.data(), W, W, (size_t)H * 3 / 2, 0));
+        CK(chv_pass_end(c, 1));
+        EXPECT(stubhip_launches() == l0 + 1);
+        CK(chv_run_kernel(c, CHV_K_IMG_NV12_BGRA, &canvas.img, &nv.img, 1, &us[0], sizeof us[0], 1, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_Y420P_BGRA, &canvas.img, &yp.img, 1, &us[1], sizeof us[1], 1, nullptr));
+        EXPECT(stubhip_launches() == l0 + 1);                              // (still inside the outer bracket)
+        CK(chv_pass_end(c, 1));
+        EXPECT(stubhip_launches() == l0 + 2);
+        CK(chv_pass_end(c, 1));                                            // (an end without a begin: a plain wait, as before)
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        EXPECT(stubhip_launches() == l0 + 3);                              // outside every bracket: at once
         // the escape switch: every kernel of a pass launches at once again
         CK(chv_debug_set_switch("CHV_PASS_FUSE", "0"));
         l0 = stubhip_launches();

@@ -145,6 +145,17 @@ def test_fuzz_strip_routes(ctx, switch, rows, seed):
     YWV.test_random_yuv_ticks(ctx, rows, seed)
 
 
+@pytest.mark.parametrize("seed", range(24, 40))
+def test_fuzz_rgb_only_strips_without_dma_staging(ctx, switch, seed):
+    """the RGB-only instantiation of tick_bgra_wave with its LDS-DMA staging switched OFF (CHV_WAVE_DMA=0 through chv_debug_set_switch: the switch
+    used to be read from the environment once, so no in-process test could reach the register staging of that instantiation) — and ON, on the
+    same seeds"""
+    switch("CHV_WAVE_DMA", "0")
+    MIX.test_random_rgb_only_ticks(ctx, MIX.WAVE, seed)
+    switch("CHV_WAVE_DMA", None)
+    MIX.test_random_rgb_only_ticks(ctx, MIX.WAVE, seed)
+
+
 @pytest.mark.parametrize("seed", range(200, 252))
 def test_fuzz_yuv_stream_route(ctx, switch, seed):
     """tick_yuv_stream forced for every eligible launch: float and integer-matrix RGB layers, batched and lone"""

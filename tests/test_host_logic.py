@@ -91,3 +91,20 @@ def test_splitmix_is_the_documented_generator():
             out.append(z & 0xFF)
         return out
     assert util.splitmix_bytes(0x5EED0000, 64).tolist() == ref(0x5EED0000, 64)
+
+
+def test_uniform_blobs_of_picture_kernels_stay_float32_whatever_array_comes_in():
+    """ImageUniforms are 59 floats: a list or an integer array of matrix rows converts to float32 as it always did; raw bytes pass for the value
+    types that are not ImageUniforms — the buffer kernels' BufferUniforms / MotionEstimationUniforms and .custom kernels (`raw`), or explicit bytes"""
+    import numpy as np
+    from swiftvideo_amd import compute as sv
+    ints = np.arange(59, dtype=np.int64)
+    b = sv._uniform_blob(ints)
+    assert b.dtype == np.float32 and b.nbytes == 236 and b[7] == 7.0
+    assert sv._uniform_blob([0.5] * 59).dtype == np.float32
+    assert sv._uniform_blob(np.arange(59, dtype=np.int32)).dtype == np.float32            # int32 too, unless the kernel takes raw words
+    raw = sv._uniform_blob(np.arange(25, dtype=np.int32), raw=True)
+    assert raw.dtype == np.int32 and raw.nbytes == 100
+    assert sv._uniform_blob(np.zeros(4, dtype=np.float64), raw=True).dtype == np.float32    # floats are never "raw"
+    assert sv._uniform_blob(b"\x01\x02\x03").tolist() == [1, 2, 3]
+    assert sv._uniform_blob(None) is None

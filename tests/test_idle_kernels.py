@@ -218,6 +218,16 @@ def test_gpu_snd_argument_checks(ctx):
         sv.runComputeKernel(ctx, [sv.BufferImage(short, 32)], sv.BufferImage(buf, 64), K, uniforms=O.snd_uniforms([1.0], [0.5]))
     with pytest.raises(sv.ComputeError):          # the ImageUniforms blob is not BufferUniforms
         sv.runComputeKernel(ctx, [sv.BufferImage(buf, 64)], sv.BufferImage(buf, 64), K, uniforms=np.zeros(59, dtype=np.float32))
+    # an input that IS the output (or overlaps it): the source accumulates into out[gid] input after input (kernels.cl.swift:548-560), the kernel
+    # keeps the accumulator in a register — refused rather than mixed differently
+    other = sv.uploadComputeBuffer(ctx, np.ones(64, dtype=np.int16).tobytes())
+    with pytest.raises(sv.ComputeError):
+        sv.runComputeKernel(ctx, [sv.BufferImage(other, 64), sv.BufferImage(buf, 64)], sv.BufferImage(buf, 64), K, uniforms=O.snd_uniforms([1.0, 1.0], [0.5, 0.5]))
+    big = sv.uploadComputeBuffer(ctx, np.zeros(96, dtype=np.int16).tobytes())
+    with pytest.raises(sv.ComputeError):          # 64 samples at byte 0 and 64 samples at byte 64 of one buffer
+        sv.runComputeKernel(ctx, [sv.BufferImage(big, 64, offset=64)], sv.BufferImage(big, 64), K, uniforms=O.snd_uniforms([1.0], [0.5]))
+    sv.runComputeKernel(ctx, [sv.BufferImage(big, 32, offset=64)], sv.BufferImage(big, 32), K, uniforms=O.snd_uniforms([1.0], [0.5]))     # disjoint halves: fine
+    sv.endComputePass(ctx, True)
 
 
 GPU_ME_CASES = ME_CASES + [(11, 320, 180, (16, 16), (32, 32), True), (12, 1920, 1080, (16, 16), (64, 64), False), (13, 200, 120, (64, 64), (64, 64), False),
