@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 # 1. the default line, exactly as the driver runs it
-T0=$(date +%s.%N); python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default command: $(echo "$(date +%s.%N) - $T0" | bc) s wall" > $OUT/bench_default.time
+T0=$(date +%s.%N); python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; python -c "import time,sys; print('default command: %.1f s wall' % (time.time() - float(sys.argv[1])))" $T0 > $OUT/bench_default.time
 cp bench_detail.json $OUT/bench_default_detail.json
 # 1b. every leg (upload / end-to-end / one tick at a time / thread scaling / route regret / clock and power of every workload): --full
 python bench.py --gpus 1 --steps 20 --warmup 5 --full --detail-json $OUT/bench_full_detail.json > $OUT/bench_full.json 2> $OUT/bench_full.err

@@ -181,8 +181,14 @@ func beginComputePass(_ context: ComputeContext) -> ComputeContext {
     return context
 }
 
+// The library HOLDS the picture kernels issued since beginComputePass and launches them here as one fused tick (include/chipvideo.h,
+// "compute passes"): a launch error of those kernels surfaces in this call.  The reference's endComputePass cannot throw and drops the result
+// of clFinish / clFlush (compute.cl.swift:346-359), where OpenCL reports asynchronous launch errors too; the signature stays, the error is logged.
 func endComputePass(_ context: ComputeContext, _ waitForCompletion: Bool) -> ComputeContext {
-    _ = chv_pass_end(context.handle, waitForCompletion ? 1 : 0)
+    let status = chv_pass_end(context.handle, waitForCompletion ? 1 : 0)
+    if status != 0 {
+        context.logger.error("endComputePass: \(String(cString: chv_error_string(status))) (\(String(cString: chv_last_error_detail())))")
+    }
     return context
 }
 

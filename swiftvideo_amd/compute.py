@@ -165,8 +165,15 @@ def endComputePass(ctx, waitForCompletion):
 
 
 def usingContext(ctx, fun):
-    """compute.swift:131-134"""
-    return endComputePass(fun(beginComputePass(ctx)), True)
+    """compute.swift:131-134.  (When `fun` throws, the reference never reaches endComputePass; here the bracket is closed on the way out — the
+    library holds a pass's kernels until its end, and a bracket left open would keep holding whatever the caller issues next.)"""
+    ctx = beginComputePass(ctx)
+    try:
+        ctx = fun(ctx)
+    except BaseException:
+        cv.load().chv_pass_end(ctx.handle, 0)
+        raise
+    return endComputePass(ctx, True)
 
 
 # ---- buffers / samples ------------------------------------------------------------

@@ -196,9 +196,16 @@ inline ComputeContext endComputePass(ComputeContext ctx, bool waitForCompletion)
     check(chv_pass_end(ctx.get(), waitForCompletion ? 1 : 0));
     return ctx;
 }
-// compute.swift:131-134
+// compute.swift:131-134.  (When `fun` throws, the bracket is closed on the way out: the library holds a pass's kernels until its end.)
 inline ComputeContext usingContext(ComputeContext ctx, const std::function<ComputeContext(ComputeContext)> &fun) {
-    return endComputePass(fun(beginComputePass(ctx)), true);
+    ComputeContext c = beginComputePass(ctx);
+    try {
+        c = fun(c);
+    } catch (...) {
+        (void)chv_pass_end(ctx.get(), 0);
+        throw;
+    }
+    return endComputePass(c, true);
 }
 
 // ---- buffers and samples (compute.cl.swift:46-58, sample.pict.linux.swift:23-311) ---------------
