@@ -612,11 +612,13 @@ class HipDevice:
 
     def sync(self):
         self.cv.check(self.lib.chv_device_synchronize(self.ctx.handle))
+        # (torch is the N > 1 control plane only; it is synchronised too when something has ALREADY imported and initialised it — never imported
+        # here: the first `import torch` on a fresh box costs tens of seconds)
+        torch = sys.modules.get("torch")
         try:
-            import torch
-            if torch.cuda.is_available() and torch.cuda.is_initialized():
+            if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
                 torch.cuda.synchronize()
-        except Exception:
+        except Exception:       # noqa: BLE001
             pass
 
     def event(self):
