@@ -1313,7 +1313,15 @@ extern "C" int chv_run_kernel(chv_context *c, int kernel, const chv_image *targe
         // Inside a pass: accept the kernel, launch it with the rest of the pass (flush_pending).  A kernel on another target, or a clear
         // after something else, first sends out what is held — the stream sees the kernels in the order they were issued.
         chv_context::PendingPass &pp = c->pending;
-        if (pp.active && (s.is_clear || !same_target(pp.target, *target) || (pp.clear_tf >= 0 && pp.clear_tf != tf))) FLUSH_PENDING(c);
+        // ... and so does a layer that READS the canvas being held (issued kernel by kernel it would sample what the held layers wrote; inside one
+        // fused launch the canvas lives in registers and memory still has the old bytes), and a pass deeper than a batch's descriptor allows
+        bool reads_held_canvas = false;
+        if (pp.active && !s.is_clear)
+            for (int i = 0; i < inputs[0].n_planes && i < 3; i++)
+                for (int k = 0; k < pp.target.n_planes && k < 3; k++)
+                    reads_held_canvas = reads_held_canvas || inputs[0].planes[i].buffer == pp.target.planes[k].buffer;
+        if (pp.active && (s.is_clear || reads_held_canvas || pp.layers.size() >= 1024 || !same_target(pp.target, *target) || (pp.clear_tf >= 0 && pp.clear_tf != tf)))
+            FLUSH_PENDING(c);
         if (!pp.active) {
             pp.active = true;
             pp.target = *target;

@@ -199,6 +199,18 @@ static void single_thread(chv_context *c) {
         for (int l = 0; l < 40; l++) CK(chv_run_kernel(c, CHV_K_IMG_BGRA_BGRA_TX, &canvas.img, &rgb.img, 1, &us[l & 3], sizeof us[0], 1, nullptr));
         CK(chv_pass_end(c, 1));
         EXPECT(stubhip_launches() == l0 + 3);
+        // a layer that reads the held canvas sends it out first; a pass of thousands of layers goes out in instalments
+        l0 = stubhip_launches();
+        CK(chv_pass_begin(c));
+        CK(chv_run_kernel(c, CHV_K_IMG_CLEAR_BGRA, &canvas.img, nullptr, 0, nullptr, 0, 0, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_BGRA_BGRA_TX, &canvas.img, &rgb.img, 1, &us[0], sizeof us[0], 1, nullptr));
+        CK(chv_run_kernel(c, CHV_K_IMG_BGRA_BGRA_TX, &canvas.img, &canvas.img, 1, &us[1], sizeof us[1], 1, nullptr));       // reads what it writes
+        EXPECT(stubhip_launches() == l0 + 1);
+        CK(chv_pass_end(c, 1));
+        EXPECT(stubhip_launches() == l0 + 2);
+        CK(chv_pass_begin(c));
+        for (int l = 0; l < 2100; l++) CK(chv_run_kernel(c, CHV_K_IMG_BGRA_BGRA_TX, &canvas.img, &rgb.img, 1, &us[l & 3], sizeof us[0], 1, nullptr));
+        CK(chv_pass_end(c, 1));
         // the launch fails when the pass ends: the error comes back from chv_pass_end, nothing stays held, the context stays usable
         stubhip_fail_launch_after(1);
         CK(chv_pass_begin(c));

@@ -127,6 +127,34 @@ def test_two_canvases_a_clear_in_the_middle_and_a_deep_pass(ctx):
     G.assert_same(G.from_gpu(ctx, B, "nv12", cw, ch), exp_b, "canvas B")
 
 
+def test_a_layer_that_reads_the_canvas_held_before_it_sees_what_was_issued_before_it(ctx):
+    """pass: clear A, X -> A, then A -> B and B -> A (a picture-in-picture of the mix so far, and back): every kernel samples what the kernels issued
+    before it wrote — the held canvas goes out before anything reads it, whether as another target's source or as its own"""
+    cw, ch = 64, 36
+    x = util.alloc_image("nv12", 96, 54, seed=31)
+    ux = util.full_canvas_uniforms((cw, ch), (96, 54))
+    uab = util.make_uniforms((cw, ch), rect=(8, 4, 40, 24), opacity=0.7, in_size=(cw, ch))
+    uba = util.make_uniforms((cw, ch), rect=(20, 10, 30, 20), opacity=0.9, in_size=(cw, ch))
+    ea, eb = util.alloc_image("bgra", cw, ch, seed=32), util.alloc_image("bgra", cw, ch, seed=33)
+    A, B = G.to_gpu(ctx, "bgra", cw, ch, util.copy_image(ea)), G.to_gpu(ctx, "bgra", cw, ch, util.copy_image(eb))
+    gx = G.to_gpu(ctx, "nv12", 96, 54, x)
+    assert O.run_kernel("img_clear_bgra", ea) == 0 and O.run_kernel("img_nv12_bgra", ea, x, ux) == 0
+    assert O.run_kernel("img_bgra_bgra_tx", eb, ea, uab) == 0            # B <- A as composed so far
+    assert O.run_kernel("img_nv12_bgra", eb, x, util.full_canvas_uniforms((cw, ch), (96, 54), opacity=0.25)) == 0
+    assert O.run_kernel("img_bgra_bgra_tx", ea, eb, uba) == 0            # A <- B, after B's second layer
+    K = sv.ComputeKernel
+
+    def body(c):
+        c = sv.runComputeKernel(c, images=[], target=A, kernel=K.img_clear_bgra)
+        c = sv.runComputeKernel(c, images=[gx], target=A, kernel=K.img_nv12_bgra, uniforms=ux, blends=True)
+        c = sv.runComputeKernel(c, images=[A], target=B, kernel=K.img_bgra_bgra_tx, uniforms=uab, blends=True)
+        c = sv.runComputeKernel(c, images=[gx], target=B, kernel=K.img_nv12_bgra, uniforms=util.full_canvas_uniforms((cw, ch), (96, 54), opacity=0.25), blends=True)
+        return sv.runComputeKernel(c, images=[B], target=A, kernel=K.img_bgra_bgra_tx, uniforms=uba, blends=True)
+    sv.usingContext(ctx, body)
+    G.assert_same(G.from_gpu(ctx, A, "bgra", cw, ch), ea, "canvas A")
+    G.assert_same(G.from_gpu(ctx, B, "bgra", cw, ch), eb, "canvas B")
+
+
 def test_an_argument_error_comes_back_from_its_own_call_and_the_pass_goes_on(ctx):
     cw, ch = 64, 36
     src = util.alloc_image("nv12", 96, 54, seed=5)
