@@ -24,6 +24,7 @@
 
 #include "device_types.h"
 #include "switches.h"
+#include "geom_cache.h"
 
 namespace chv {
 const char *bgra_wave_build_flags();      // kernels_wave.hip.cpp
@@ -77,19 +78,20 @@ static int parse_switch(const char *name, const char *value, int *out) {
     if (n == "CHV_YUV_STREAM") { *out = v == "0" ? 0 : (v == "force" || v == "2") ? 2 : 1; return 7; }
     if (n == "CHV_WAVE_DMA") { *out = v == "0" ? 0 : 1; return 8; }
     if (n == "CHV_PASS_FUSE") { *out = v == "0" ? 0 : 1; return 9; }
+    if (n == "CHV_GEOM_CACHE") { *out = v == "0" ? 0 : 1; return 10; }
     return -1;
 }
 static void store_switch(Switches &s, int which, int val) {
-    std::atomic<int> *slots[10] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom, &s.desc_host, &s.stream, &s.yuv_stream, &s.wave_dma,
-                                    &s.pass_fuse };
+    std::atomic<int> *slots[11] = { &s.force_general, &s.bgra_path, &s.wave_rows, &s.tile_rows, &s.same_geom, &s.desc_host, &s.stream, &s.yuv_stream, &s.wave_dma,
+                                    &s.pass_fuse, &s.geom_cache };
     slots[which]->store(val, std::memory_order_relaxed);
 }
 Switches &chv::switches() {
     static Switches s;
     static std::once_flag once;
     std::call_once(once, [] {
-        static const char *const names[10] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC", "CHV_STREAM", "CHV_YUV_STREAM",
-                                               "CHV_WAVE_DMA", "CHV_PASS_FUSE" };
+        static const char *const names[11] = { "CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC", "CHV_STREAM", "CHV_YUV_STREAM",
+                                               "CHV_WAVE_DMA", "CHV_PASS_FUSE", "CHV_GEOM_CACHE" };
         for (const char *n : names) {
             const char *v = getenv(n);
             int val = 0, which = v ? parse_switch(n, v, &val) : -1;
@@ -103,7 +105,7 @@ extern "C" int chv_debug_set_switch(const char *name, const char *value) {
     Switches &s = switches();                     // (environment first, so that a later first use cannot overwrite this)
     const int which = parse_switch(name, value, &val);
     if (which < 0) { g_detail_set("unknown switch"); return CHV_ERR_INVALID_VALUE; }
-    if (!value || !*value) val = (which == 4 || which == 6 || which == 7 || which == 8 || which == 9) ? 1 : 0;      // empty / NULL: back to "the library decides"
+    if (!value || !*value) val = (which == 4 || which == 6 || which == 7 || which == 8 || which == 9 || which == 10) ? 1 : 0;      // empty / NULL: back to "the library decides"
     store_switch(s, which, val);
     return CHV_OK;
 }
@@ -394,6 +396,7 @@ struct chv_batch {
     std::vector<DTick> h_ticks;    // host copies: launch geometry of the fast paths
     std::vector<DLayer> h_layers;
     std::string kernel_name;
+    GeomCache geom;                // the strip kernels' per-layer geometry, computed once per launch configuration (geom_cache.h)
 };
 
 static bool ctx_ok(chv_context *c) { return c && c->magic == 0x43485643 && c->stream; }
@@ -1462,6 +1465,14 @@ extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
     int wrc = wait_for_uploads(c->stream, b->deps);
     if (wrc) return wrc;
     (void)hipGetLastError();   // see launch_transient
+    // (the strip kernels' launcher finds the batch's geometry tables through this: geom_cache.h)
+    struct CacheScope {
+        explicit CacheScope(chv_batch *bb) {
+            bb->geom.d_layers = bb->d_layers; bb->geom.h_layers = bb->h_layers.data(); bb->geom.n_layers = (int)bb->h_layers.size();
+            geom_cache_current() = &bb->geom;
+        }
+        ~CacheScope() { geom_cache_current() = nullptr; }
+    } scope(b);
     hipError_t e = b->fast_path >= 0
         ? launch_tick_fast(b->fast_path, b->h_ticks.data(), b->h_layers.data(), b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
         : launch_tick_general(b->target_format, b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
@@ -1481,6 +1492,7 @@ extern "C" int chv_batch_destroy(chv_batch *b) {
     (void)hipFree(b->d_ticks);
     (void)hipFree(b->d_layers);
     if (b->d_ticks2) (void)hipFree(b->d_ticks2);
+    geom_cache_release(b->geom);
     b->d_ticks = nullptr;
     delete b;
     return CHV_OK;

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
         if (CHV_WAVE_PRIO) asm("s_setprio 3" : "+s"(ptok));
         // Layers whose geometry inputs are bit-identical to their predecessor's (LF_SAME_GEOM, host-checked: equal bounding boxes, so
         // the predecessor was a hit for this strip as well) keep its column entry, row table and rectangles; only the planes change.
-        if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) S.setup(ptok, cur);      // (overwrites the row table: the previous layer's pixels are done)
+        // (overwrites the row table: the previous layer's pixels are done.  From the batch's geometry table where there is one — setup_cached)
+        if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) { if (!(CHV_GEOM_CACHE && S.setup_cached(l, cur))) S.setup(ptok, cur); }
         have_geom = true;
         // a rectangle LDS-DMA can fill: texels in canvas order, away from every picture edge, contiguous rows (not the pair form), at most eight
         // instructions' worth of them

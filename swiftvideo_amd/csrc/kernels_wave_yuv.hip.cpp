@@ -18,10 +18,19 @@
 #include "wave_common.hip.h"
 #include "yuv_pixel.hip.h"
 #include "switches.h"
+#include "geom_cache.h"
+#ifndef CHV_GEOM_HOST_ONLY
+#define CHV_GEOM_HOST_ONLY 0       // (debugging: tables are built and the layers patched, the kernels do not look)
+#endif
+
+#include <map>
+#include <string>
+#include <vector>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 // CHV_ABL: timing-only ablations (results are wrong): 1 = no staging, 2 = no pixel rows, 4 = no canvas stores
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
         int ptok = l;
         if (CHV_WAVE_PRIO) asm("s_setprio 3" : "+s"(ptok));
         // (LF_SAME_GEOM: geometry inputs bit-identical to the predecessor's — its column entry, row table and rectangles stand)
-        if (!general_layer) { if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) S.setup(ptok, cur); have_geom = true; }      // (setup overwrites the row table: the previous layer's pixels are done)
+        // (setup overwrites the row table: the previous layer's pixels are done.  From the batch's geometry table where there is one — setup_cached)
+        if (!general_layer) { if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) { if (!(CHV_GEOM_CACHE && !CHV_GEOM_HOST_ONLY && S.setup_cached(l, cur))) S.setup(ptok, cur); } have_geom = true; }
         else { have_geom = false; cur.staged = false; cur.all_inside = false; cur.unit_rows = false; cur.cfl = 0; cur.cyo = 0; cur.cco = 0; cur.cya = 0.f; cur.cca = 0.f; }
         // Strips entirely inside the picture, and — when the layer paints no fill (alpha of opacity x fill exactly 0: pixels of
         // the border quad outside the picture then keep their codes, to_code(c / 255) = c) — strips a picture edge crosses as
@@ -644,6 +654,167 @@ const char *yuv_wave_build_flags() { return "tick_yuv_wave:abl=" CHV_STR(CHV_ABL
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
                             int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds);
 
+// ---------------------------------------------------------------------------
+// geometry tables of a batch (geom_cache.h; device side: wave_common.hip.h)
+// ---------------------------------------------------------------------------
+// One wave per (class, strip): the strip kernels' own set-up on a representative layer of the class, stored where the tick kernels look it up.
+// KINDS = 7: the generic source-class tests (the single-class instantiations' shortcuts give the same answers for the kinds they see).
+template <int WTH>
+__global__ __launch_bounds__(64) void geom_precompute(const GeomJob *__restrict__ jobs, int n_jobs, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
+    const int b = (int)blockIdx.x;
+    int j = 0;
+    while (j + 1 < n_jobs && b >= jobs[j + 1].first_block) j++;
+    j = __builtin_amdgcn_readfirstlane(j);
+    const GeomJob &J = jobs[j];
+    const int strip = b - J.first_block;
+    const int sya = strip / J.strips_x, sxa = strip - sya * J.strips_x;
+    if (sya >= J.strips_y) return;
+    WaveStrip<WTH, 0, 7> S;
+    S.init_layout(smem_all, p0pitch, p0rows, p1pitch, p1rows, planar_any);
+    S.T = nullptr; S.L = &J.layer; S.nl = 1;
+    S.init_strip(J.W, J.H, sxa * WTW, sya * WTH);
+    WLayer w;
+    memset(&w, 0, sizeof w);
+    S.setup(0, w);
+    wave_lds_fence();
+    if (!w.staged) return;                      // (uniform) the strip's flag word stays 0: the tick kernels compute this strip's geometry themselves
+    S.geom_store(J.table, sxa, sya, w);
+}
+
+GeomCache *&geom_cache_current() {
+    static thread_local GeomCache *cur = nullptr;
+    return cur;
+}
+void geom_cache_release(GeomCache &c) {
+    if (c.tables) (void)hipFree(c.tables);
+    if (c.jobs) (void)hipFree(c.jobs);
+    c.tables = c.jobs = nullptr;
+    c.built = false; c.bytes = 0; c.classes = 0;
+}
+
+// (Re)build the tables of the batch being launched for this launch configuration and point its device layers at them; with the switch off,
+// take the pointers out again.  Everything is ordered on `stream` in front of the tick kernel.
+static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const DTick *ticks_host, int n_ticks, size_t rowtab_lds, hipStream_t stream) {
+    const bool on = CHV_GEOM_CACHE && switches().geom_cache.load(std::memory_order_relaxed) != 0;
+    DLayer *hl = gc.h_layers;
+    if (!hl || !gc.d_layers || gc.n_layers <= 0) return hipSuccess;
+    if (!on) {
+        if (gc.patched) {
+            // (rare: a switch flipped between two runs of a batch.  Nothing in flight may still read the layers: wait, then copy synchronously)
+            hipError_t e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            for (int i = 0; i < gc.n_layers; i++) hl[i].pad2[0] = hl[i].pad2[1] = 0;
+            e = hipMemcpy(gc.d_layers, hl, sizeof(DLayer) * (size_t)gc.n_layers, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return e;
+            gc.patched = false; gc.built = false;
+        }
+        return hipSuccess;
+    }
+    if (gc.built && gc.config == cfg) return hipSuccess;
+    // classes: layers whose set-up inputs are the same bytes — the three matrices, the source planes' sizes and layout class, the canvas size
+    struct Key { float u[48]; int32_t w0, h0, w1, h1, cls, W, H; };
+    std::map<std::string, int> index;
+    std::vector<GeomJob> jobs;
+    std::vector<int> cls_of((size_t)gc.n_layers, -1);
+    for (int i = 0; i < n_ticks; i++) {
+        const DTick &T = ticks_host[i];
+        for (int l = 0; l < T.n_layers; l++) {
+            const int li = T.first_layer + l;
+            if (li < 0 || li >= gc.n_layers) continue;
+            const DLayer &L = hl[li];
+            if (L.kind == LK_BGRA_METAL || (L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) continue;      // applied per pixel: no set-up
+            Key k;
+            memset(&k, 0, sizeof k);
+            memcpy(k.u, L.u, sizeof k.u);
+            const bool rgb = host_src_rgb(L.kind);
+            k.w0 = L.src.pl[0].w; k.h0 = L.src.pl[0].h; k.w1 = rgb ? 0 : L.src.pl[1].w; k.h1 = rgb ? 0 : L.src.pl[1].h;
+            k.cls = rgb ? 2 : host_src_planar(L.kind) ? 1 : 0; k.W = T.W; k.H = T.H;
+            const std::string ks((const char *)&k, sizeof k);
+            auto it = index.find(ks);
+            if (it == index.end()) {
+                GeomJob J;
+                memset(&J, 0, sizeof J);
+                J.layer = L;
+                J.layer.pad2[0] = J.layer.pad2[1] = 0;
+                J.W = T.W; J.H = T.H;
+                J.strips_x = (T.W + WTW - 1) / WTW; J.strips_y = (T.H + cfg.wth - 1) / cfg.wth;
+                it = index.emplace(ks, (int)jobs.size()).first;
+                jobs.push_back(J);
+            }
+            cls_of[(size_t)li] = it->second;
+        }
+    }
+    // A (re)build happens once per batch and launch configuration: an earlier run of the batch may still be reading the layers, and the host
+    // buffers below are pageable — the stream is drained first and every copy is a synchronous one (an asynchronous copy from pageable memory
+    // may read its source after this function has returned).
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    geom_cache_release(gc);
+    for (int i = 0; i < gc.n_layers; i++) hl[i].pad2[0] = hl[i].pad2[1] = 0;
+    // (a batch of a thousand distinct geometries gains nothing from tables that are each used once)
+    if (!jobs.empty() && jobs.size() <= 256) {
+        const size_t row_bytes = (size_t)3 * cfg.wth * 16 + 64;
+        std::vector<size_t> offs(jobs.size());
+        size_t total = 0;
+        int blocks = 0;
+        for (size_t c = 0; c < jobs.size(); c++) {
+            GeomJob &J = jobs[c];
+            offs[c] = total;
+            const size_t flags = ((size_t)J.strips_x * J.strips_y * 4 + 15) & ~(size_t)15;
+            total += sizeof(GeomHdr) + flags + (size_t)J.strips_x * sizeof(GeomCol) + (size_t)J.strips_y * row_bytes;
+            total = (total + 255) & ~(size_t)255;
+            J.first_block = blocks;
+            blocks += J.strips_x * J.strips_y;
+        }
+        e = hipMalloc(&gc.tables, total);
+        if (e == hipSuccess) e = hipMalloc(&gc.jobs, sizeof(GeomJob) * jobs.size());
+
+        if (e == hipSuccess) {
+            std::vector<uint8_t> image(total, 0);              // zeroed: a strip's flag word 0 = "not in the table"
+            for (size_t c = 0; c < jobs.size(); c++) {
+                GeomJob &J = jobs[c];
+                J.table = (uint8_t *)gc.tables + offs[c];
+                GeomHdr H;
+                memset(&H, 0, sizeof H);
+                H.strips_x = J.strips_x; H.strips_y = J.strips_y; H.wth = cfg.wth; H.row_bytes = (int32_t)row_bytes;
+                H.flags_off = (uint32_t)sizeof(GeomHdr);
+                H.cols_off = H.flags_off + (uint32_t)(((size_t)J.strips_x * J.strips_y * 4 + 15) & ~(size_t)15);
+                H.rows_off = H.cols_off + (uint32_t)((size_t)J.strips_x * sizeof(GeomCol));
+                memcpy(image.data() + offs[c], &H, sizeof H);
+            }
+            e = hipMemcpy(gc.tables, image.data(), total, hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess) e = hipMemcpy(gc.jobs, jobs.data(), sizeof(GeomJob) * jobs.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            (void)hipGetLastError();
+            if (cfg.wth == 16) hipLaunchKernelGGL(geom_precompute<16>, dim3((unsigned)blocks), dim3(64), rowtab_lds, stream, (const GeomJob *)gc.jobs, (int)jobs.size(),
+                                                  cfg.p0pitch, cfg.p0rows, cfg.p1pitch, cfg.p1rows, cfg.planar_any);
+            else hipLaunchKernelGGL(geom_precompute<8>, dim3((unsigned)blocks), dim3(64), rowtab_lds, stream, (const GeomJob *)gc.jobs, (int)jobs.size(),
+                                    cfg.p0pitch, cfg.p0rows, cfg.p1pitch, cfg.p1rows, cfg.planar_any);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) {
+            for (int i = 0; i < gc.n_layers; i++) {
+                if (cls_of[(size_t)i] < 0) continue;
+                const uint64_t tp = (uint64_t)(uintptr_t)jobs[(size_t)cls_of[(size_t)i]].table;
+                hl[i].pad2[0] = (int32_t)(uint32_t)(tp & 0xFFFFFFFFu); hl[i].pad2[1] = (int32_t)(uint32_t)(tp >> 32);
+            }
+            gc.bytes = total; gc.classes = (int)jobs.size();
+        } else {
+            (void)hipGetLastError();
+            geom_cache_release(gc);             // no tables: the kernels compute their geometry as before
+            e = hipSuccess;
+        }
+    }
+    hipError_t e2 = hipMemcpy(gc.d_layers, hl, sizeof(DLayer) * (size_t)gc.n_layers, hipMemcpyHostToDevice);
+    if (e2 != hipSuccess) return e2;
+    gc.patched = gc.tables != nullptr;
+    gc.built = true;
+    gc.config = cfg;
+    return e;
+}
+
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream) {
     // Strip height.  16 rows when the launch has enough strips to fill the chip's wave slots with them and the taller
@@ -750,6 +921,12 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     }
     m.p0rows = std::min(m.p0rows, 0xFFFF); m.p1rows = std::min(m.p1rows, 0xFFFF);      // (far beyond what LDS holds: such rectangles are not staged anyway)
     const int p0rows_arg = m.p0rows | (origin_x << 16), p1rows_arg = m.p1rows | (origin_y << 16);
+    // the batch's geometry tables for this configuration (a transient launch has none: its kernels compute their geometry in place)
+    if (GeomCache *gc = geom_cache_current()) {
+        GeomConfig cfg{ target_format, WTH, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side, (maxW + WTW - 1) / WTW, (maxH + WTH - 1) / WTH, gc->n_layers };
+        hipError_t ge = geom_cache_prepare(*gc, cfg, ticks_host, n_ticks, (size_t)WTH * 48, stream);
+        if (ge != hipSuccess) return ge;
+    }
     // floor(2^32 / d) for the kernels' scalar divisions by the strips per tick and per row (WaveStrip::udivmod)
     auto magic = [](uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); };
     const uint32_t strips_magic = magic((uint32_t)(strips_x * strips_y)), strips_x_magic = magic((uint32_t)strips_x);

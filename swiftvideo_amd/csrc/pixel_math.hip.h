@@ -37,6 +37,14 @@ template <typename T> CHV_DEV T gld(const void *p) { return *(const CHV_GLOBAL T
 template <> CHV_DEV uint2 gld<uint2>(const void *p) { chv_u32x2 v = *(const CHV_GLOBAL chv_u32x2 *)(uintptr_t)p; return make_uint2(v.x, v.y); }
 template <> CHV_DEV uint4 gld<uint4>(const void *p) { chv_u32x4 v = *(const CHV_GLOBAL chv_u32x4 *)(uintptr_t)p; return make_uint4(v.x, v.y, v.z, v.w); }
 template <typename T> CHV_DEV void gst(void *p, T v) { *(CHV_GLOBAL T *)(uintptr_t)p = v; }
+// Read-only data at a wave-uniform address that no launch in flight writes (the geometry tables of a batch, geom_cache.h): through the constant
+// address space these are scalar loads (s_load_dword*, several merged into one), whatever the compiler can prove about where the address came from.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CHV_CONSTANT __attribute__((address_space(4)))
+#else
+#define CHV_CONSTANT
+#endif
+template <typename T> CHV_DEV T cld(uint64_t addr) { return *(const CHV_CONSTANT T *)(uintptr_t)addr; }
 // wave-uniform base + 32-bit unsigned per-lane byte offset: selects the `global_* v_off, ..., s[base:base+1]` addressing form (the row
 // base stays on the scalar unit; the generic pointer + size_t form costs a v_mad_i64_i32 per access)
 template <typename T> CHV_DEV T gld_at(const uint8_t *base, uint32_t off) { return *(const CHV_GLOBAL T *)((const CHV_GLOBAL uint8_t *)(uintptr_t)base + off); }

@@ -2,7 +2,7 @@
 //
 // The environment is read ONCE, at the first use in the process (getenv on a hot path is undefined behaviour next to a
 // setenv in another thread, and the mixer and uploader threads run concurrently): CHV_FORCE_GENERAL, CHV_BGRA_PATH,
-// CHV_WAVE_ROWS, CHV_TILE_ROWS, CHV_SAME_GEOM, CHV_DESC, CHV_STREAM, CHV_YUV_STREAM, CHV_WAVE_DMA, CHV_PASS_FUSE.  Tests and A/B tools change them afterwards through chv_debug_set_switch (include/chipvideo.h),
+// CHV_WAVE_ROWS, CHV_TILE_ROWS, CHV_SAME_GEOM, CHV_DESC, CHV_STREAM, CHV_YUV_STREAM, CHV_WAVE_DMA, CHV_PASS_FUSE, CHV_GEOM_CACHE.  Tests and A/B tools change them afterwards through chv_debug_set_switch (include/chipvideo.h),
 // never through the environment.  Every value is an atomic int; 0 = "the library decides".
 #pragma once
 #include <atomic>
@@ -22,6 +22,8 @@ struct Switches {
                                          // (kernels_stream_yuv.hip.cpp::yuv_stream_eligible); force: every eligible launch (A/Bs and tests)
     std::atomic<int> wave_dma{1};        // CHV_WAVE_DMA: 0 the RGB-only strip kernel stages its rectangles through registers like the others (A/B, and the
                                          // fuzzers' way to the non-DMA staging of that instantiation); 1 (default) by LDS-DMA where the shape allows
+    std::atomic<int> geom_cache{1};      // CHV_GEOM_CACHE: 0 the strip kernels compute every layer's per-strip geometry in place also in batches (A/B, and the
+                                         // fuzzers' way to that path); 1 (default) batches keep it in tables built once per launch configuration (geom_cache.h)
     std::atomic<int> pass_fuse{1};       // CHV_PASS_FUSE: 1 (default) picture kernels issued inside chv_pass_begin ... chv_pass_end are held and leave as the one
                                          // fused launch chv_composite would make of them (chipvideo.cpp: PendingPass); 0 every chv_run_kernel launches at once
 };

@@ -10,6 +10,10 @@
 namespace chv {
 
 constexpr int WTW = 64;                 // strip width: one lane per column
+// 1: layers of a batch take their per-strip geometry from the batch's tables (geom_cache.h, WaveStrip::setup_cached); 0: always computed in place
+#ifndef CHV_GEOM_CACHE
+#define CHV_GEOM_CACHE 1
+#endif
 
 // Waves per block.  The waves of a block share nothing but the launch (every wave has its own LDS region and there is no block
 // barrier on the data path), so the block size only sets the granularity at which LDS is handed out: one wave per block
@@ -312,6 +316,25 @@ CHV_DEV bool src_is_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind
 // KINDS: the source classes the launch contains (bit 0 NV12, bit 1 y420p, bit 2 RGB; host-checked).  A launch of one class runs
 // an instantiation that holds no code for the others — the kernels are 70-100 KB of code, and the executed footprint counts
 // (the NV12-only instantiation: pipeline -3.4 %).
+// ---- geometry tables (geom_cache.h): what setup() derives for a layer, stored per strip column / per strip row / per strip -------------
+// One table per geometry class of a batch (same matrices, source plane sizes, canvas size), built by geom_precompute (kernels_wave_yuv.hip.cpp)
+// with setup() itself and read back by setup_cached().  A DLayer carries its class's table address in pad2 (0: none).
+struct GeomHdr { int32_t strips_x, strips_y, wth, row_bytes; uint32_t flags_off, cols_off, rows_off, pad; };     // 32 bytes, at the table's base
+struct GeomCol {                       // a strip column: the lanes' column entries (staged form) and the column halves of the rectangles
+    int32_t cyo[64], cco[64];
+    float cya[64], cca[64];
+    int32_t cfl[64];
+    int32_t s[16];                     // g0.b0, g0.nvec, inv20(nvec), inv20(nvec + 2), then the same four of g1
+};
+// a strip row (row_bytes each): uint4 rowtab[3 * WTH] as setup() leaves it in LDS, then int32 s[16]: g0.r_lo, g0.rows, g0.pair, g0.r_hi1, the same
+// four of g1, unit_rows
+enum : uint32_t { GF_STAGED = 1, GF_ALL_INSIDE = 2, GF_EDGE0 = 4, GF_EDGE1 = 8 };       // the flag word of a strip (row-major, strips_x per row)
+struct GeomJob {                       // one class for geom_precompute: a representative layer (its plane POINTERS are not used), the canvas, the table
+    DLayer layer;
+    int32_t W, H, strips_x, strips_y, first_block, pad;
+    uint8_t *table;
+};
+
 template <int WTH, int INTERIOR = 0, int KINDS = 7>
 struct WaveStrip {
     // (bit 3: the launch also has layers that are not staged at all — any transform, applied per pixel by the kernels)
@@ -342,14 +365,11 @@ struct WaveStrip {
         if (rr >= d) { qq++; rr -= d; }
         q = (int)qq; r = (int)rr;
     }
-    CHV_DEV bool init(const DTick *ticks, const DLayer *layers, int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
-                      uint8_t *smem_all, int p0pitch_, int p0rows_, int p1pitch_, int p1rows_, int planar_any) {
+    // the wave's LDS region and the launch's rectangle layout (everything that does not depend on which strip this is)
+    CHV_DEV void init_layout(uint8_t *smem_all, int p0pitch_, int p0rows_, int p1pitch_, int p1rows_, int planar_any) {
         const int tid = threadIdx.x;
         lane = tid & 63;
         const int wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);      // (one wave per block: no per-wave LDS offset arithmetic)
-        // (bits 16-31 of the two row counts: the launch's ORIGIN in strips — a launch that continues on composed canvases covers only the strips
-        // its layers' bounding boxes touch, launch_wave_layers)
-        const int osx = (int)((uint32_t)p0rows_ >> 16), osy = (int)((uint32_t)p1rows_ >> 16);
         p0pitch = p0pitch_; p0rows = p0rows_ & 0xFFFF; p1pitch = p1pitch_; p1rows = p1rows_ & 0xFFFF;
         // planar_any: bit 0 — the launch has planar pictures; bit 7: the SIDE-BY-SIDE layout (launch_wave_layers) — one region whose rows hold a YUV
         // layer's luma columns (bits 8-19, units of 16 bytes), then its chroma: the (u, v) rows of an NV12 picture, or the U and V rows of a planar
@@ -366,6 +386,25 @@ struct WaveStrip {
         }
         smem = smem_all + wave * wbytes;
         rowtab = (uint4 *)smem;
+    }
+    // this wave's strip: canvas of W x H pixels, strip origin (x0_, y0_)
+    CHV_DEV void init_strip(int W, int H, int x0_, int y0_) {
+        x0 = x0_; y0 = y0_;
+        sx = (float)W; sy = (float)H;
+        x = x0 + lane;
+        col_in = x < W;
+        row_in = lane < WTH && y0 + lane < H;
+        // NDC coordinates (layer-independent: gid / size * 2 - 1, kernels.cl.swift:70-72)
+        xe = min(x, W - 1); ye = min(y0 + min(lane, WTH - 1), H - 1);
+        nx = ((float)xe / sx) * 2.f - 1.f; ny = ((float)ye / sy) * 2.f - 1.f;
+    }
+    CHV_DEV bool init(const DTick *ticks, const DLayer *layers, int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
+                      uint8_t *smem_all, int p0pitch_, int p0rows_, int p1pitch_, int p1rows_, int planar_any) {
+        // (bits 16-31 of the two row counts: the launch's ORIGIN in strips — a launch that continues on composed canvases covers only the strips
+        // its layers' bounding boxes touch, launch_wave_layers)
+        const int osx = (int)((uint32_t)p0rows_ >> 16), osy = (int)((uint32_t)p1rows_ >> 16);
+        init_layout(smem_all, p0pitch_, p0rows_, p1pitch_, p1rows_, planar_any);
+        const int wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
         const int strips = strips_x * strips_y;
         const int total = strips * n_ticks;
         const int bid = blockIdx.x;
@@ -378,18 +417,89 @@ struct WaveStrip {
         udivmod((uint32_t)index, (uint32_t)strips, strips_magic, tick, strip);
         udivmod((uint32_t)strip, (uint32_t)strips_x, strips_x_magic, syi, sxi);
         T = ticks + tick;
-        x0 = (osx + sxi) * WTW; y0 = (osy + syi) * WTH;
-        if (x0 >= T->W || y0 >= T->H) return false;
+        const int x0_ = (osx + sxi) * WTW, y0_ = (osy + syi) * WTH;
+        if (x0_ >= T->W || y0_ >= T->H) return false;
         L = layers + T->first_layer;
         nl = T->n_layers;
-        sx = (float)T->W; sy = (float)T->H;
-        x = x0 + lane;
-        col_in = x < T->W;
-        row_in = lane < WTH && y0 + lane < T->H;
-        // NDC coordinates (layer-independent: gid / size * 2 - 1, kernels.cl.swift:70-72)
-        xe = min(x, T->W - 1); ye = min(y0 + min(lane, WTH - 1), T->H - 1);
-        nx = ((float)xe / sx) * 2.f - 1.f; ny = ((float)ye / sy) * 2.f - 1.f;
+        init_strip(T->W, T->H, x0_, y0_);
         return true;
+    }
+
+    // The geometry of layer l from its class's table instead of from its matrices (setup() below): false when the layer has no table, the strip
+    // lies outside it, or this strip's rectangles are not staged (then setup() computes what the per-pixel paths need).  Same values, bit for
+    // bit: the table was filled by setup() itself (geom_precompute).
+    CHV_DEV bool setup_cached(int l, WLayer &w) const {
+        const DLayer &Ly = L[l];
+        const uint64_t tp = ((uint64_t)(uint32_t)Ly.pad2[1] << 32) | (uint64_t)(uint32_t)Ly.pad2[0];          // (uniform: the descriptor's scalar loads)
+        if (tp == 0) return false;
+        // header, flag word and the scalar halves of both records: scalar loads through the constant address space (cld); the lanes' column
+        // entries and the row table: one coalesced vector load each, on a uniform base
+        const int hsx = cld<int32_t>(tp + 0), hsy = cld<int32_t>(tp + 4), row_bytes = cld<int32_t>(tp + 12);
+        const uint32_t flags_off = cld<uint32_t>(tp + 16), cols_off = cld<uint32_t>(tp + 20), rows_off = cld<uint32_t>(tp + 24);
+        const int sxa = x0 >> 6, sya = WTH == 16 ? y0 >> 4 : y0 >> 3;           // (WTW = 64)
+        if (sxa >= hsx || sya >= hsy) return false;
+        const uint32_t f = cld<uint32_t>(tp + flags_off + 4u * (uint32_t)(sya * hsx + sxa));
+        if (!(f & GF_STAGED)) return false;
+        const uint64_t C = tp + cols_off + (uint64_t)sxa * sizeof(GeomCol), R = tp + rows_off + (uint64_t)sya * (uint64_t)row_bytes;
+        const uint8_t *Cp = (const uint8_t *)C, *Rp = (const uint8_t *)R;
+        const uint32_t lo = (uint32_t)lane * 4u;
+        w.cyo = gld_at<int32_t>(Cp, lo); w.cco = gld_at<int32_t>(Cp, 256u + lo);
+        w.cya = gld_at<float>(Cp, 512u + lo); w.cca = gld_at<float>(Cp, 768u + lo); w.cfl = gld_at<int32_t>(Cp, 1024u + lo);
+        if (lane < 3 * WTH) rowtab[lane] = gld_at<uint4>(Rp, (uint32_t)lane * 16u);
+        const uint64_t rs = R + 3 * WTH * 16, cs = C + 1280;
+        const bool e0 = (f & GF_EDGE0) != 0, e1 = (f & GF_EDGE1) != 0;
+        w.g0.r_lo = cld<int32_t>(rs + 0); w.g0.rows = cld<int32_t>(rs + 4); w.g0.pair = cld<int32_t>(rs + 8); w.g0.r_hi1 = cld<int32_t>(rs + 12);
+        w.g1.r_lo = cld<int32_t>(rs + 16); w.g1.rows = cld<int32_t>(rs + 20); w.g1.pair = cld<int32_t>(rs + 24); w.g1.r_hi1 = cld<int32_t>(rs + 28);
+        const int nv0 = cld<int32_t>(cs + 4), nv1 = cld<int32_t>(cs + 20);
+        w.g0.b0 = cld<int32_t>(cs + 0); w.g0.nvec = nv0; w.g0.edge = e0 ? 1 : 0; w.g0.nslot = e0 ? nv0 + 2 : nv0; w.g0.inv20 = e0 ? cld<int32_t>(cs + 12) : cld<int32_t>(cs + 8);
+        w.g1.b0 = cld<int32_t>(cs + 16); w.g1.nvec = nv1; w.g1.edge = e1 ? 1 : 0; w.g1.nslot = e1 ? nv1 + 2 : nv1; w.g1.inv20 = e1 ? cld<int32_t>(cs + 28) : cld<int32_t>(cs + 24);
+        w.staged = true;
+        w.all_inside = (f & GF_ALL_INSIDE) != 0;
+        w.unit_rows = cld<int32_t>(rs + 32) != 0;
+#ifdef CHV_GEOM_VERIFY
+        {   // (debug builds: the table's values against setup()'s, field by field)
+            wave_lds_fence();
+            uint4 mine = lane < 3 * WTH ? rowtab[lane] : make_uint4(0, 0, 0, 0);
+            WLayer c;
+            setup(l, c);
+            wave_lds_fence();
+            uint4 ref = lane < 3 * WTH ? rowtab[lane] : make_uint4(0, 0, 0, 0);
+            const bool rt = mine.x != ref.x || mine.y != ref.y || mine.z != ref.z || mine.w != ref.w;
+            const bool pl = w.cyo != c.cyo || w.cco != c.cco || __float_as_int(w.cya) != __float_as_int(c.cya) || __float_as_int(w.cca) != __float_as_int(c.cca) || w.cfl != c.cfl;
+            const bool sc = w.g0.r_lo != c.g0.r_lo || w.g0.rows != c.g0.rows || w.g0.b0 != c.g0.b0 || w.g0.nvec != c.g0.nvec || w.g0.nslot != c.g0.nslot || w.g0.inv20 != c.g0.inv20 ||
+                            w.g0.edge != c.g0.edge || w.g0.pair != c.g0.pair || w.g0.r_hi1 != c.g0.r_hi1 || w.staged != c.staged || w.all_inside != c.all_inside || w.unit_rows != c.unit_rows;
+            const bool s1 = !is_rgb(Ly.kind) && (w.g1.r_lo != c.g1.r_lo || w.g1.rows != c.g1.rows || w.g1.b0 != c.g1.b0 || w.g1.nvec != c.g1.nvec || w.g1.nslot != c.g1.nslot ||
+                            w.g1.inv20 != c.g1.inv20 || w.g1.edge != c.g1.edge || w.g1.pair != c.g1.pair || w.g1.r_hi1 != c.g1.r_hi1);
+            if (rt) printf("GEOM rowtab strip (%d,%d) lane %d: %08x %08x %08x %08x vs %08x %08x %08x %08x\n", x0 >> 6, y0 / WTH, lane, mine.x, mine.y, mine.z, mine.w, ref.x, ref.y, ref.z, ref.w);
+            if (pl) printf("GEOM lane strip (%d,%d) lane %d: cyo %d/%d cco %d/%d cfl %d/%d\n", x0 >> 6, y0 / WTH, lane, w.cyo, c.cyo, w.cco, c.cco, w.cfl, c.cfl);
+            if ((sc || s1) && lane == 0) printf("GEOM scalars strip (%d,%d): g0 %d/%d %d/%d %d/%d %d/%d %d/%d %d/%d e %d/%d p %d/%d h %d/%d | st %d/%d ai %d/%d ur %d/%d | g1 %d/%d %d/%d %d/%d %d/%d e %d/%d p %d/%d h %d/%d\n",
+                x0 >> 6, y0 / WTH, w.g0.r_lo, c.g0.r_lo, w.g0.rows, c.g0.rows, w.g0.b0, c.g0.b0, w.g0.nvec, c.g0.nvec, w.g0.nslot, c.g0.nslot, w.g0.inv20, c.g0.inv20, w.g0.edge, c.g0.edge, w.g0.pair, c.g0.pair,
+                w.g0.r_hi1, c.g0.r_hi1, (int)w.staged, (int)c.staged, (int)w.all_inside, (int)c.all_inside, (int)w.unit_rows, (int)c.unit_rows,
+                w.g1.r_lo, c.g1.r_lo, w.g1.rows, c.g1.rows, w.g1.b0, c.g1.b0, w.g1.nvec, c.g1.nvec, w.g1.edge, c.g1.edge, w.g1.pair, c.g1.pair, w.g1.r_hi1, c.g1.r_hi1);
+        }
+#endif
+        return true;
+    }
+    // (geom_precompute) what setup() left in `w` and in the LDS row table, into the class's table — by every strip of the column / of the row
+    // with the same bytes
+    CHV_DEV void geom_store(uint8_t *tab, int sxa, int sya, const WLayer &w) const {
+        const uint64_t tp = (uint64_t)(uintptr_t)tab;
+        const int hsx = cld<int32_t>(tp + 0), row_bytes = cld<int32_t>(tp + 12);
+        const uint32_t flags_off = cld<uint32_t>(tp + 16), cols_off = cld<uint32_t>(tp + 20), rows_off = cld<uint32_t>(tp + 24);
+        uint8_t *Cp = tab + cols_off + (size_t)sxa * sizeof(GeomCol), *Rp = tab + rows_off + (size_t)sya * (size_t)row_bytes;
+        const uint32_t lo = (uint32_t)lane * 4u;
+        gst_at<int32_t>(Cp, lo, w.cyo); gst_at<int32_t>(Cp, 256u + lo, w.cco);
+        gst_at<float>(Cp, 512u + lo, w.cya); gst_at<float>(Cp, 768u + lo, w.cca); gst_at<int32_t>(Cp, 1024u + lo, w.cfl);
+        if (lane < 3 * WTH) gst_at<uint4>(Rp, (uint32_t)lane * 16u, rowtab[lane]);
+        if (lane == 0) {
+            auto inv = [](int nslot) { return nslot > 0 ? ((1 << 20) + nslot - 1) / nslot : 0; };      // stage_slots_init's
+            const int32_t rsv[9] = { w.g0.r_lo, w.g0.rows, w.g0.pair, w.g0.r_hi1, w.g1.r_lo, w.g1.rows, w.g1.pair, w.g1.r_hi1, w.unit_rows ? 1 : 0 };
+            const int32_t csv[8] = { w.g0.b0, w.g0.nvec, inv(w.g0.nvec), inv(w.g0.nvec + 2), w.g1.b0, w.g1.nvec, inv(w.g1.nvec), inv(w.g1.nvec + 2) };
+            for (int k = 0; k < 9; k++) gst_at<int32_t>(Rp, (uint32_t)(3 * WTH * 16 + 4 * k), rsv[k]);
+            for (int k = 0; k < 8; k++) gst_at<int32_t>(Cp, (uint32_t)(1280 + 4 * k), csv[k]);
+            gst_at<uint32_t>(tab + flags_off, 4u * (uint32_t)(sya * hsx + sxa),
+                             GF_STAGED | (w.all_inside ? GF_ALL_INSIDE : 0u) | (w.g0.edge ? GF_EDGE0 : 0u) | (w.g1.edge ? GF_EDGE1 : 0u));
+        }
     }
 
     // layers whose border quad cannot touch the strip are skipped (uniform test against the host-computed bounding box)

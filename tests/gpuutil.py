@@ -63,7 +63,9 @@ def run_both(ctx, kernel, cw, ch, iw, ih, uniforms, seed, csc=0, clear_first=Fal
 
 
 def make_batch(ctx, ticks):
-    """ticks: [(target PictureSample, clear_first, [(kernel, sample, uniforms, csc)])] -> (handle, kernel name, keepalive)"""
+    """ticks: [(target PictureSample, clear_first, [(kernel, sample, uniforms, csc)])] -> (handle, kernel name, keepalive).  The keepalive holds the
+    descriptor arrays AND the tick list itself: a batch borrows its pictures (device pointers), and a picture created inline in the argument
+    would otherwise be freed the moment this returns."""
     import ctypes as C
     from swiftvideo_amd import chipvideo as cv
     lib = cv.load()
@@ -80,7 +82,7 @@ def make_batch(ctx, ticks):
     cv.check(lib.chv_batch_create(ctx.handle, arr, len(ticks), C.byref(h)))
     name = C.create_string_buffer(128)
     cv.check(lib.chv_batch_describe(h, name, 128, None))
-    return h, name.value.decode(), (arr, keep)
+    return h, name.value.decode(), (arr, keep, ticks)
 
 
 def run_batch(ctx, h):

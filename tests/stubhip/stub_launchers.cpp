@@ -16,6 +16,7 @@
 
 #include "../../swiftvideo_amd/csrc/device_types.h"
 #include "../../swiftvideo_amd/csrc/switches.h"
+#include "../../swiftvideo_amd/csrc/geom_cache.h"
 
 namespace chv {
 enum { FP_NONE = -1, FP_WAVE = 2, FP_STREAM = 5, FP_CLEAR = 6 };
@@ -65,6 +66,8 @@ static hipError_t enqueue_ticks(const DTick *ticks_host, const DLayer *layers_ho
     return hipSuccess;
 }
 
+GeomCache *&geom_cache_current() { static thread_local GeomCache *cur = nullptr; return cur; }
+void geom_cache_release(GeomCache &) {}                    // (the stand-in launchers build no tables)
 const char *bgra_wave_build_flags() { return "stub:abl=0"; }
 const char *yuv_wave_build_flags() { return "stub:abl=0"; }
 const char *bgra_stream_build_flags() { return "stub:abl=0"; }

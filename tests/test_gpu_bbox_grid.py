@@ -45,11 +45,12 @@ def test_uncleared_launch_touches_only_its_layers_box(ctx, dst, rect):
     canvas0 = util.alloc_image(dst, CW, CH, seed=11 + rect)
     exp = util.copy_image(canvas0)
     assert O.run_kernel(name, exp, src, u) == 0
-    gd = G.to_gpu(ctx, dst, CW, CH, canvas0)
-    h_, kname, keep = G.make_batch(ctx, [(gd, False, [(sv.defaultComputeKernelFromString(name), G.to_gpu(ctx, s, iw, ih, src), u, 0)])])
+    gd, gs = G.to_gpu(ctx, dst, CW, CH, canvas0), G.to_gpu(ctx, s, iw, ih, src)      # (a batch borrows its pictures: both stay alive until it has run)
+    h_, kname, keep = G.make_batch(ctx, [(gd, False, [(sv.defaultComputeKernelFromString(name), gs, u, 0)])])
     G.run_batch(ctx, h_)
     G.destroy_batch(h_)
     G.assert_same(G.from_gpu(ctx, gd, dst, CW, CH), exp, f"{name} at {RECTS[rect]} through {kname}")
+    del gs
 
 
 @pytest.mark.parametrize("dst", ["bgra", "y420p"])

@@ -73,7 +73,8 @@ def test_yuv_bgra_32_row_tiles_match_oracle(ctx, switch, case, fmt):
     assert O.run_kernel("img_clear_bgra", exp) == 0
     assert O.run_kernel(kname, exp, src, u, threads=4) == 0
     gd = G.to_gpu(ctx, "bgra", cw, ch, util.alloc_image("bgra", cw, ch, seed=32))
-    h, name, keep = G.make_batch(ctx, [(gd, True, [(sv.defaultComputeKernelFromString(kname), G.to_gpu(ctx, fmt, sw, sh, src), u, 0)])])
+    gs = G.to_gpu(ctx, fmt, sw, sh, src)          # (a batch borrows its pictures: kept alive until it has run)
+    h, name, keep = G.make_batch(ctx, [(gd, True, [(sv.defaultComputeKernelFromString(kname), gs, u, 0)])])
     assert name == f"tick_{fmt}_bgra_tiled"
     G.run_batch(ctx, h)
     G.destroy_batch(h)

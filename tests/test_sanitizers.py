@@ -17,7 +17,7 @@ OUT = STUB / "_build"
 def _build(kind):
     OUT.mkdir(exist_ok=True)
     exe = OUT / f"abi_stress_{kind}"
-    srcs = [ROOT / "swiftvideo_amd" / "csrc" / "chipvideo.cpp", ROOT / "include" / "chipvideo.h", ROOT / "swiftvideo_amd" / "csrc" / "device_types.h",
+    srcs = [ROOT / "swiftvideo_amd" / "csrc" / "chipvideo.cpp", ROOT / "include" / "chipvideo.h", ROOT / "swiftvideo_amd" / "csrc" / "device_types.h", ROOT / "swiftvideo_amd" / "csrc" / "geom_cache.h",
             STUB / "stub_runtime.cpp", STUB / "stub_launchers.cpp", STUB / "abi_stress.cpp", STUB / "hip" / "hip_runtime.h", STUB / "build.sh"]
     if not exe.exists() or exe.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
         subprocess.check_call(["bash", str(STUB / "build.sh"), kind, str(exe)])
