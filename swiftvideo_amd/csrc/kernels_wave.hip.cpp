@@ -57,6 +57,11 @@
 #ifndef CHV_WAVE_DMA
 #define CHV_WAVE_DMA 1
 #endif
+// 0: this translation unit — the kernels that compute their geometry, the launcher, the build flags; 1: kernels_wave_cached.hip.cpp — the
+// instantiations that read it from a batch's tables (geom_cache.h), nothing else
+#ifndef CHV_WAVE_TU
+#define CHV_WAVE_TU 0
+#endif
 #pragma clang fp contract(off)
 
 namespace chv {
@@ -109,7 +114,9 @@ CHV_DEV void wave_dma_after(int &tok, const uint32_t (&cv)[N]) {
 #ifndef CHV_WAVE_PIXEL_UNROLL
 #define CHV_WAVE_PIXEL_UNROLL 4      // rows of a per-pixel layer in flight together (their gathers are dependent chains of L2 round trips)
 #endif
-template <int WTH, bool CLEAR, int KINDS>
+// CACHED: the per-layer geometry comes from the batch's tables (WaveStrip::setup_cached) — these instantiations contain no set-up code; they are
+// compiled in a translation unit of their own (kernels_wave_cached.hip.cpp) and launched for batches whose staged layers all have tables
+template <int WTH, bool CLEAR, int KINDS, bool CACHED>
 __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAVE_MINW16) : ((KINDS & 8) ? 5 : CHV_WAVE_MINW))) void tick_bgra_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
         // Layers whose geometry inputs are bit-identical to their predecessor's (LF_SAME_GEOM, host-checked: equal bounding boxes, so
         // the predecessor was a hit for this strip as well) keep its column entry, row table and rectangles; only the planes change.
         // (overwrites the row table: the previous layer's pixels are done.  From the batch's geometry table where there is one — setup_cached)
-        if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) { if (!(CHV_GEOM_CACHE && S.setup_cached(l, cur))) S.setup(ptok, cur); }
+        if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) { if constexpr (CACHED) S.setup_cached(l, cur); else S.setup(ptok, cur); }
         have_geom = true;
         // a rectangle LDS-DMA can fill: texels in canvas order, away from every picture edge, contiguous rows (not the pair form), at most eight
         // instructions' worth of them
@@ -454,16 +461,14 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
 #define CHV_STR2(x) #x
 #define CHV_STR(x) CHV_STR2(x)
 // what this translation unit was built with (chv_build_flags; a timing-only CHV_ABL build must never ship)
+#if CHV_WAVE_TU == 0
 const char *bgra_wave_build_flags() { return "tick_bgra_wave:abl=" CHV_STR(CHV_ABL) ",waves_per_block=" CHV_STR(CHV_WAVE_WAVES) ",strip_rows=8|16"; }
+#endif
 
-hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
-                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds) {
-    // bit 5 of `planar`: rectangles are staged by DMA where their shape allows (the RGB-only instantiation)
-    {
-        const int dma_on = switches().wave_dma.load(std::memory_order_relaxed);        // (CHV_WAVE_DMA=0 / chv_debug_set_switch: register staging)
-        if (CHV_WAVE_DMA && dma_on && (kinds == 4 || (CHV_WAVE_DMA > 1 && (kinds & 4)))) planar |= 32;
-    }
-#define CHV_LAUNCH_B(R, C, K) hipLaunchKernelGGL((tick_bgra_wave<R, C, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
+template <bool CACHED>
+hipError_t launch_bgra_wave_t(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
+                              int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds) {
+#define CHV_LAUNCH_B(R, C, K) hipLaunchKernelGGL((tick_bgra_wave<R, C, K, CACHED>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                  strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar)
 #define CHV_LAUNCH_BK(R, C) do { if (kinds == 1) CHV_LAUNCH_B(R, C, 1); else if (kinds == 2) CHV_LAUNCH_B(R, C, 2); \
                                  else if (kinds == 4) CHV_LAUNCH_B(R, C, 4); else if (kinds == 5) CHV_LAUNCH_B(R, C, 5); \
@@ -475,5 +480,25 @@ hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStre
 #undef CHV_LAUNCH_B
     return hipGetLastError();
 }
+
+#define CHV_BGRA_WAVE_ARGS int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks, \
+                           int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds
+#if CHV_WAVE_TU == 0
+template hipError_t launch_bgra_wave_t<false>(CHV_BGRA_WAVE_ARGS);
+extern template hipError_t launch_bgra_wave_t<true>(CHV_BGRA_WAVE_ARGS);            // kernels_wave_cached.hip.cpp
+
+hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
+                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds, bool cached) {
+    // bit 5 of `planar`: rectangles are staged by DMA where their shape allows (the RGB-only instantiation)
+    {
+        const int dma_on = switches().wave_dma.load(std::memory_order_relaxed);        // (CHV_WAVE_DMA=0 / chv_debug_set_switch: register staging)
+        if (CHV_WAVE_DMA && dma_on && (kinds == 4 || (CHV_WAVE_DMA > 1 && (kinds & 4)))) planar |= 32;
+    }
+    return cached ? launch_bgra_wave_t<true>(rows, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar, kinds)
+                  : launch_bgra_wave_t<false>(rows, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar, kinds);
+}
+#else
+template hipError_t launch_bgra_wave_t<true>(CHV_BGRA_WAVE_ARGS);
+#endif
 
 }  // namespace chv

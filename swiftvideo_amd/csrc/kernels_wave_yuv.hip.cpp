@@ -19,8 +19,10 @@
 #include "yuv_pixel.hip.h"
 #include "switches.h"
 #include "geom_cache.h"
-#ifndef CHV_GEOM_HOST_ONLY
-#define CHV_GEOM_HOST_ONLY 0       // (debugging: tables are built and the layers patched, the kernels do not look)
+// 0: this translation unit — the kernels that compute their geometry, eligibility, the launcher, the geometry tables' builder; 1:
+// kernels_wave_yuv_cached.hip.cpp — the instantiations that read their geometry from a batch's tables, nothing else
+#ifndef CHV_WAVE_TU
+#define CHV_WAVE_TU 0
 #endif
 
 #include <map>
@@ -124,7 +126,9 @@ CHV_DEV float mix4(float w00, float w10, float w01, float w11, float t00, float 
 // source rectangles whose 16-row version would not leave room for two strips per 64 KB of LDS.
 // KINDS: source classes in the launch (wave_common.hip.h): 1 / 2 = pictures of the canvas' own format only (NV12 / y420p), 5 / 6 = those
 // plus RGB overlays (the reference's usual mixer), 7 = any
-template <int TF, bool CLEAR, int YTH, int KINDS>
+// CACHED: the per-layer geometry comes from the batch's tables (WaveStrip::setup_cached) — no set-up code in these instantiations, which are
+// compiled in kernels_wave_yuv_cached.hip.cpp and launched for batches whose staged layers all have tables
+template <int TF, bool CLEAR, int YTH, int KINDS, bool CACHED>
 __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY_MINW : CHV_WAVEY_MINW_MIXED)) void tick_yuv_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
         if (CHV_WAVE_PRIO) asm("s_setprio 3" : "+s"(ptok));
         // (LF_SAME_GEOM: geometry inputs bit-identical to the predecessor's — its column entry, row table and rectangles stand)
         // (setup overwrites the row table: the previous layer's pixels are done.  From the batch's geometry table where there is one — setup_cached)
-        if (!general_layer) { if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) { if (!(CHV_GEOM_CACHE && !CHV_GEOM_HOST_ONLY && S.setup_cached(l, cur))) S.setup(ptok, cur); } have_geom = true; }
+        if (!general_layer) { if (!(have_geom && (Ly.flags & LF_SAME_GEOM))) { if constexpr (CACHED) S.setup_cached(l, cur); else S.setup(ptok, cur); } have_geom = true; }
         else { have_geom = false; cur.staged = false; cur.all_inside = false; cur.unit_rows = false; cur.cfl = 0; cur.cyo = 0; cur.cco = 0; cur.cya = 0.f; cur.cca = 0.f; }
         // Strips entirely inside the picture, and — when the layer paints no fill (alpha of opacity x fill exactly 0: pixels of
         // the border quad outside the picture then keep their codes, to_code(c / 255) = c) — strips a picture edge crosses as
@@ -565,6 +569,31 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
     }
 }
 
+// the launch of one instantiation (launch_wave_layers has sized everything)
+template <bool CACHED>
+hipError_t launch_yuv_wave_t(int target_format, bool clear, int WTH, int kinds, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
+                             int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows_arg, int p1pitch, int p1rows_arg, int planar_any) {
+#define CHV_LAUNCH_Y(TFV, C, R, K) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R, K, CACHED>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
+                                                      strips_magic, strips_x_magic, p0pitch, p0rows_arg, p1pitch, p1rows_arg, planar_any)
+#define CHV_LAUNCH_YK(TFV, C, R, OWN) do { if (kinds == OWN) CHV_LAUNCH_Y(TFV, C, R, OWN); else if (kinds == (OWN | 4)) CHV_LAUNCH_Y(TFV, C, R, (OWN | 4)); \
+                                           else if (kinds & 8) CHV_LAUNCH_Y(TFV, C, R, 15); else CHV_LAUNCH_Y(TFV, C, R, 7); } while (0)
+#define CHV_LAUNCH_YR(TFV, C, OWN) do { if (WTH == 16) CHV_LAUNCH_YK(TFV, C, 16, OWN); else CHV_LAUNCH_YK(TFV, C, 8, OWN); } while (0)
+    if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_YR(TF_NV12, true, 1); else CHV_LAUNCH_YR(TF_NV12, false, 1); }
+    else { if (clear) CHV_LAUNCH_YR(TF_Y420P, true, 2); else CHV_LAUNCH_YR(TF_Y420P, false, 2); }
+#undef CHV_LAUNCH_YK
+#undef CHV_LAUNCH_YR
+#undef CHV_LAUNCH_Y
+    return hipGetLastError();
+}
+#define CHV_YUV_WAVE_ARGS int target_format, bool clear, int WTH, int kinds, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks, \
+                          int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows_arg, int p1pitch, int p1rows_arg, int planar_any
+#if CHV_WAVE_TU != 0
+template hipError_t launch_yuv_wave_t<true>(CHV_YUV_WAVE_ARGS);
+#else
+template hipError_t launch_yuv_wave_t<false>(CHV_YUV_WAVE_ARGS);
+extern template hipError_t launch_yuv_wave_t<true>(CHV_YUV_WAVE_ARGS);              // kernels_wave_yuv_cached.hip.cpp
+
+
 // ---------------------------------------------------------------------------
 // host side: eligibility and launch of both wave kernels
 // ---------------------------------------------------------------------------
@@ -652,7 +681,7 @@ const char *yuv_wave_build_flags() { return "tick_yuv_wave:abl=" CHV_STR(CHV_ABL
 
 // kernels_wave.hip.cpp
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
-                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds);
+                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds, bool cached);
 
 // ---------------------------------------------------------------------------
 // geometry tables of a batch (geom_cache.h; device side: wave_common.hip.h)
@@ -675,11 +704,12 @@ __global__ __launch_bounds__(64) void geom_precompute(const GeomJob *__restrict_
     S.T = nullptr; S.L = &J.layer; S.nl = 1;
     S.init_strip(J.W, J.H, sxa * WTW, sya * WTH);
     WLayer w;
+    GeomRaw raw;
     memset(&w, 0, sizeof w);
-    S.setup(0, w);
+    memset(&raw, 0, sizeof raw);
+    S.template setup<true>(0, w, &raw);
     wave_lds_fence();
-    if (!w.staged) return;                      // (uniform) the strip's flag word stays 0: the tick kernels compute this strip's geometry themselves
-    S.geom_store(J.table, sxa, sya, w);
+    S.geom_store(J.table, sxa, sya, w, raw);
 }
 
 GeomCache *&geom_cache_current() {
@@ -695,7 +725,8 @@ void geom_cache_release(GeomCache &c) {
 
 // (Re)build the tables of the batch being launched for this launch configuration and point its device layers at them; with the switch off,
 // take the pointers out again.  Everything is ordered on `stream` in front of the tick kernel.
-static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const DTick *ticks_host, int n_ticks, size_t rowtab_lds, hipStream_t stream) {
+static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const DTick *ticks_host, int n_ticks, size_t rowtab_lds, hipStream_t stream, bool *covered) {
+    *covered = false;
     const bool on = CHV_GEOM_CACHE && switches().geom_cache.load(std::memory_order_relaxed) != 0;
     DLayer *hl = gc.h_layers;
     if (!hl || !gc.d_layers || gc.n_layers <= 0) return hipSuccess;
@@ -711,7 +742,7 @@ static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const
         }
         return hipSuccess;
     }
-    if (gc.built && gc.config == cfg) return hipSuccess;
+    if (gc.built && gc.config == cfg) { *covered = gc.patched; return hipSuccess; }
     // classes: layers whose set-up inputs are the same bytes — the three matrices, the source planes' sizes and layout class, the canvas size
     struct Key { float u[48]; int32_t w0, h0, w1, h1, cls, W, H; };
     std::map<std::string, int> index;
@@ -754,7 +785,7 @@ static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const
     for (int i = 0; i < gc.n_layers; i++) hl[i].pad2[0] = hl[i].pad2[1] = 0;
     // (a batch of a thousand distinct geometries gains nothing from tables that are each used once)
     if (!jobs.empty() && jobs.size() <= 256) {
-        const size_t row_bytes = (size_t)3 * cfg.wth * 16 + 64;
+        const size_t row_bytes = (size_t)2 * 3 * cfg.wth * 16 + 64;      // the staged and the unstaged row table, 16 scalars
         std::vector<size_t> offs(jobs.size());
         size_t total = 0;
         int blocks = 0;
@@ -809,9 +840,10 @@ static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const
     }
     hipError_t e2 = hipMemcpy(gc.d_layers, hl, sizeof(DLayer) * (size_t)gc.n_layers, hipMemcpyHostToDevice);
     if (e2 != hipSuccess) return e2;
-    gc.patched = gc.tables != nullptr;
+    gc.patched = gc.tables != nullptr;        // (every layer the kernels set up has a table, or none has: classes are all-or-nothing)
     gc.built = true;
     gc.config = cfg;
+    *covered = gc.patched;
     return e;
 }
 
@@ -922,9 +954,10 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     m.p0rows = std::min(m.p0rows, 0xFFFF); m.p1rows = std::min(m.p1rows, 0xFFFF);      // (far beyond what LDS holds: such rectangles are not staged anyway)
     const int p0rows_arg = m.p0rows | (origin_x << 16), p1rows_arg = m.p1rows | (origin_y << 16);
     // the batch's geometry tables for this configuration (a transient launch has none: its kernels compute their geometry in place)
+    bool cached = false;                       // -> the CACHED instantiations (no set-up code): every staged layer of the launch has its table
     if (GeomCache *gc = geom_cache_current()) {
         GeomConfig cfg{ target_format, WTH, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side, (maxW + WTW - 1) / WTW, (maxH + WTH - 1) / WTH, gc->n_layers };
-        hipError_t ge = geom_cache_prepare(*gc, cfg, ticks_host, n_ticks, (size_t)WTH * 48, stream);
+        hipError_t ge = geom_cache_prepare(*gc, cfg, ticks_host, n_ticks, (size_t)WTH * 48, stream, &cached);
         if (ge != hipSuccess) return ge;
     }
     // floor(2^32 / d) for the kernels' scalar divisions by the strips per tick and per row (WaveStrip::udivmod)
@@ -935,19 +968,14 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     long blocks_per_xcd = (per_xcd + WAVES - 1) / WAVES;
     dim3 grid((unsigned)(blocks_per_xcd * 8));
     if (target_format == TF_BGRA) {
-        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side, kinds);
+        return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg,
+                                (planar ? 1 : 0) | side, kinds, cached);
     }
-#define CHV_LAUNCH_Y(TFV, C, R, K) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R, K>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
-                                                      strips_magic, strips_x_magic, m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side)
-#define CHV_LAUNCH_YK(TFV, C, R, OWN) do { if (kinds == OWN) CHV_LAUNCH_Y(TFV, C, R, OWN); else if (kinds == (OWN | 4)) CHV_LAUNCH_Y(TFV, C, R, (OWN | 4)); \
-                                           else if (kinds & 8) CHV_LAUNCH_Y(TFV, C, R, 15); else CHV_LAUNCH_Y(TFV, C, R, 7); } while (0)
-#define CHV_LAUNCH_YR(TFV, C, OWN) do { if (WTH == 16) CHV_LAUNCH_YK(TFV, C, 16, OWN); else CHV_LAUNCH_YK(TFV, C, 8, OWN); } while (0)
-    if (target_format == TF_NV12) { if (clear) CHV_LAUNCH_YR(TF_NV12, true, 1); else CHV_LAUNCH_YR(TF_NV12, false, 1); }
-    else { if (clear) CHV_LAUNCH_YR(TF_Y420P, true, 2); else CHV_LAUNCH_YR(TF_Y420P, false, 2); }
-#undef CHV_LAUNCH_YK
-#undef CHV_LAUNCH_YR
-#undef CHV_LAUNCH_Y
-    return hipGetLastError();
+    return cached ? launch_yuv_wave_t<true>(target_format, clear, WTH, kinds, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic,
+                                            m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side)
+                  : launch_yuv_wave_t<false>(target_format, clear, WTH, kinds, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic,
+                                             m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side);
 }
+#endif      // CHV_WAVE_TU == 0
 
 }  // namespace chv

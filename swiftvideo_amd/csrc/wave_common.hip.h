@@ -318,17 +318,18 @@ CHV_DEV bool src_is_planar(int kind) { return kind == LK_BGRA_FROM_Y420P || kind
 // (the NV12-only instantiation: pipeline -3.4 %).
 // ---- geometry tables (geom_cache.h): what setup() derives for a layer, stored per strip column / per strip row / per strip -------------
 // One table per geometry class of a batch (same matrices, source plane sizes, canvas size), built by geom_precompute (kernels_wave_yuv.hip.cpp)
-// with setup() itself and read back by setup_cached().  A DLayer carries its class's table address in pad2 (0: none).
+// with setup() itself and read back by setup_cached() in the CACHED instantiations of the tick kernels — which contain no set-up code at all.
+// A table covers every strip of its canvas, staged or not.  A DLayer carries its class's table address in pad2 (0: none).
 struct GeomHdr { int32_t strips_x, strips_y, wth, row_bytes; uint32_t flags_off, cols_off, rows_off, pad; };     // 32 bytes, at the table's base
-struct GeomCol {                       // a strip column: the lanes' column entries (staged form) and the column halves of the rectangles
-    int32_t cyo[64], cco[64];
-    float cya[64], cca[64];
-    int32_t cfl[64];
+struct GeomCol {                       // a strip column: the lanes' column entries and the column halves of the rectangles
+    uint4 a[64];                       // staged form: { cyo, cco, bits(cya), bits(cca) }
+    uint4 b[64];                       // { tap-0 column of the unstaged form (luma / RGB), (chroma), cfl, - }
     int32_t s[16];                     // g0.b0, g0.nvec, inv20(nvec), inv20(nvec + 2), then the same four of g1
 };
-// a strip row (row_bytes each): uint4 rowtab[3 * WTH] as setup() leaves it in LDS, then int32 s[16]: g0.r_lo, g0.rows, g0.pair, g0.r_hi1, the same
-// four of g1, unit_rows
+// a strip row (row_bytes each): uint4 rowtab[3 * WTH] as setup() leaves it in LDS for a STAGED layer, the same for an unstaged one (row
+// positions instead of LDS offsets), then int32 s[16]: g0.r_lo, g0.rows, g0.pair, g0.r_hi1, the same four of g1, unit_rows
 enum : uint32_t { GF_STAGED = 1, GF_ALL_INSIDE = 2, GF_EDGE0 = 4, GF_EDGE1 = 8 };       // the flag word of a strip (row-major, strips_x per row)
+struct GeomRaw { int cy, cc, ry, rc, rfl; float rya, rca; };      // (setup<true>: what the unstaged form is made of)
 struct GeomJob {                       // one class for geom_precompute: a representative layer (its plane POINTERS are not used), the canvas, the table
     DLayer layer;
     int32_t W, H, strips_x, strips_y, first_block, pad;
@@ -425,80 +426,69 @@ struct WaveStrip {
         return true;
     }
 
-    // The geometry of layer l from its class's table instead of from its matrices (setup() below): false when the layer has no table, the strip
-    // lies outside it, or this strip's rectangles are not staged (then setup() computes what the per-pixel paths need).  Same values, bit for
-    // bit: the table was filled by setup() itself (geom_precompute).
-    CHV_DEV bool setup_cached(int l, WLayer &w) const {
+    // The geometry of layer l from its class's table instead of from its matrices (setup() below).  Same values, bit for bit: the table was
+    // filled by setup() itself (geom_precompute), for every strip of the canvas — staged rectangles or not.
+    CHV_DEV void setup_cached(int l, WLayer &w) const {
         const DLayer &Ly = L[l];
         const uint64_t tp = ((uint64_t)(uint32_t)Ly.pad2[1] << 32) | (uint64_t)(uint32_t)Ly.pad2[0];          // (uniform: the descriptor's scalar loads)
-        if (tp == 0) return false;
         // header, flag word and the scalar halves of both records: scalar loads through the constant address space (cld); the lanes' column
-        // entries and the row table: one coalesced vector load each, on a uniform base
-        const int hsx = cld<int32_t>(tp + 0), hsy = cld<int32_t>(tp + 4), row_bytes = cld<int32_t>(tp + 12);
+        // entries and the row table: coalesced vector loads on a uniform base
+        const int hsx = cld<int32_t>(tp + 0), row_bytes = cld<int32_t>(tp + 12);
         const uint32_t flags_off = cld<uint32_t>(tp + 16), cols_off = cld<uint32_t>(tp + 20), rows_off = cld<uint32_t>(tp + 24);
         const int sxa = x0 >> 6, sya = WTH == 16 ? y0 >> 4 : y0 >> 3;           // (WTW = 64)
-        if (sxa >= hsx || sya >= hsy) return false;
         const uint32_t f = cld<uint32_t>(tp + flags_off + 4u * (uint32_t)(sya * hsx + sxa));
-        if (!(f & GF_STAGED)) return false;
+        const bool st = (f & GF_STAGED) != 0;
         const uint64_t C = tp + cols_off + (uint64_t)sxa * sizeof(GeomCol), R = tp + rows_off + (uint64_t)sya * (uint64_t)row_bytes;
         const uint8_t *Cp = (const uint8_t *)C, *Rp = (const uint8_t *)R;
-        const uint32_t lo = (uint32_t)lane * 4u;
-        w.cyo = gld_at<int32_t>(Cp, lo); w.cco = gld_at<int32_t>(Cp, 256u + lo);
-        w.cya = gld_at<float>(Cp, 512u + lo); w.cca = gld_at<float>(Cp, 768u + lo); w.cfl = gld_at<int32_t>(Cp, 1024u + lo);
-        if (lane < 3 * WTH) rowtab[lane] = gld_at<uint4>(Rp, (uint32_t)lane * 16u);
-        const uint64_t rs = R + 3 * WTH * 16, cs = C + 1280;
+        const uint4 ca = gld_at<uint4>(Cp, (uint32_t)lane * 16u), cb = gld_at<uint4>(Cp, 1024u + (uint32_t)lane * 16u);
+        w.cyo = st ? (int)ca.x : (int)cb.x; w.cco = st ? (int)ca.y : (int)cb.y;
+        w.cya = __uint_as_float(ca.z); w.cca = __uint_as_float(ca.w); w.cfl = (int)cb.z;
+        if (lane < 3 * WTH) rowtab[lane] = gld_at<uint4>(Rp, (st ? 0u : (uint32_t)(3 * WTH * 16)) + (uint32_t)lane * 16u);
+        const uint64_t rs = R + 2 * 3 * WTH * 16, cs = C + 2048;
         const bool e0 = (f & GF_EDGE0) != 0, e1 = (f & GF_EDGE1) != 0;
         w.g0.r_lo = cld<int32_t>(rs + 0); w.g0.rows = cld<int32_t>(rs + 4); w.g0.pair = cld<int32_t>(rs + 8); w.g0.r_hi1 = cld<int32_t>(rs + 12);
         w.g1.r_lo = cld<int32_t>(rs + 16); w.g1.rows = cld<int32_t>(rs + 20); w.g1.pair = cld<int32_t>(rs + 24); w.g1.r_hi1 = cld<int32_t>(rs + 28);
         const int nv0 = cld<int32_t>(cs + 4), nv1 = cld<int32_t>(cs + 20);
         w.g0.b0 = cld<int32_t>(cs + 0); w.g0.nvec = nv0; w.g0.edge = e0 ? 1 : 0; w.g0.nslot = e0 ? nv0 + 2 : nv0; w.g0.inv20 = e0 ? cld<int32_t>(cs + 12) : cld<int32_t>(cs + 8);
         w.g1.b0 = cld<int32_t>(cs + 16); w.g1.nvec = nv1; w.g1.edge = e1 ? 1 : 0; w.g1.nslot = e1 ? nv1 + 2 : nv1; w.g1.inv20 = e1 ? cld<int32_t>(cs + 28) : cld<int32_t>(cs + 24);
-        w.staged = true;
+        w.staged = st;
         w.all_inside = (f & GF_ALL_INSIDE) != 0;
-        w.unit_rows = cld<int32_t>(rs + 32) != 0;
-#ifdef CHV_GEOM_VERIFY
-        {   // (debug builds: the table's values against setup()'s, field by field)
-            wave_lds_fence();
-            uint4 mine = lane < 3 * WTH ? rowtab[lane] : make_uint4(0, 0, 0, 0);
-            WLayer c;
-            setup(l, c);
-            wave_lds_fence();
-            uint4 ref = lane < 3 * WTH ? rowtab[lane] : make_uint4(0, 0, 0, 0);
-            const bool rt = mine.x != ref.x || mine.y != ref.y || mine.z != ref.z || mine.w != ref.w;
-            const bool pl = w.cyo != c.cyo || w.cco != c.cco || __float_as_int(w.cya) != __float_as_int(c.cya) || __float_as_int(w.cca) != __float_as_int(c.cca) || w.cfl != c.cfl;
-            const bool sc = w.g0.r_lo != c.g0.r_lo || w.g0.rows != c.g0.rows || w.g0.b0 != c.g0.b0 || w.g0.nvec != c.g0.nvec || w.g0.nslot != c.g0.nslot || w.g0.inv20 != c.g0.inv20 ||
-                            w.g0.edge != c.g0.edge || w.g0.pair != c.g0.pair || w.g0.r_hi1 != c.g0.r_hi1 || w.staged != c.staged || w.all_inside != c.all_inside || w.unit_rows != c.unit_rows;
-            const bool s1 = !is_rgb(Ly.kind) && (w.g1.r_lo != c.g1.r_lo || w.g1.rows != c.g1.rows || w.g1.b0 != c.g1.b0 || w.g1.nvec != c.g1.nvec || w.g1.nslot != c.g1.nslot ||
-                            w.g1.inv20 != c.g1.inv20 || w.g1.edge != c.g1.edge || w.g1.pair != c.g1.pair || w.g1.r_hi1 != c.g1.r_hi1);
-            if (rt) printf("GEOM rowtab strip (%d,%d) lane %d: %08x %08x %08x %08x vs %08x %08x %08x %08x\n", x0 >> 6, y0 / WTH, lane, mine.x, mine.y, mine.z, mine.w, ref.x, ref.y, ref.z, ref.w);
-            if (pl) printf("GEOM lane strip (%d,%d) lane %d: cyo %d/%d cco %d/%d cfl %d/%d\n", x0 >> 6, y0 / WTH, lane, w.cyo, c.cyo, w.cco, c.cco, w.cfl, c.cfl);
-            if ((sc || s1) && lane == 0) printf("GEOM scalars strip (%d,%d): g0 %d/%d %d/%d %d/%d %d/%d %d/%d %d/%d e %d/%d p %d/%d h %d/%d | st %d/%d ai %d/%d ur %d/%d | g1 %d/%d %d/%d %d/%d %d/%d e %d/%d p %d/%d h %d/%d\n",
-                x0 >> 6, y0 / WTH, w.g0.r_lo, c.g0.r_lo, w.g0.rows, c.g0.rows, w.g0.b0, c.g0.b0, w.g0.nvec, c.g0.nvec, w.g0.nslot, c.g0.nslot, w.g0.inv20, c.g0.inv20, w.g0.edge, c.g0.edge, w.g0.pair, c.g0.pair,
-                w.g0.r_hi1, c.g0.r_hi1, (int)w.staged, (int)c.staged, (int)w.all_inside, (int)c.all_inside, (int)w.unit_rows, (int)c.unit_rows,
-                w.g1.r_lo, c.g1.r_lo, w.g1.rows, c.g1.rows, w.g1.b0, c.g1.b0, w.g1.nvec, c.g1.nvec, w.g1.edge, c.g1.edge, w.g1.pair, c.g1.pair, w.g1.r_hi1, c.g1.r_hi1);
-        }
-#endif
-        return true;
+        w.unit_rows = st && cld<int32_t>(rs + 32) != 0;
     }
-    // (geom_precompute) what setup() left in `w` and in the LDS row table, into the class's table — by every strip of the column / of the row
-    // with the same bytes
-    CHV_DEV void geom_store(uint8_t *tab, int sxa, int sya, const WLayer &w) const {
+    // (geom_precompute) what setup<true>() left in `w`, `raw` and the LDS row table, into the class's table.  Every strip writes the unstaged form
+    // of its column and of its row and its flag word; a strip whose rectangles are staged the staged form as well — by every strip of the
+    // column / of the row with the same bytes.
+    CHV_DEV void geom_store(uint8_t *tab, int sxa, int sya, const WLayer &w, const GeomRaw &raw) const {
         const uint64_t tp = (uint64_t)(uintptr_t)tab;
         const int hsx = cld<int32_t>(tp + 0), row_bytes = cld<int32_t>(tp + 12);
         const uint32_t flags_off = cld<uint32_t>(tp + 16), cols_off = cld<uint32_t>(tp + 20), rows_off = cld<uint32_t>(tp + 24);
         uint8_t *Cp = tab + cols_off + (size_t)sxa * sizeof(GeomCol), *Rp = tab + rows_off + (size_t)sya * (size_t)row_bytes;
-        const uint32_t lo = (uint32_t)lane * 4u;
-        gst_at<int32_t>(Cp, lo, w.cyo); gst_at<int32_t>(Cp, 256u + lo, w.cco);
-        gst_at<float>(Cp, 512u + lo, w.cya); gst_at<float>(Cp, 768u + lo, w.cca); gst_at<int32_t>(Cp, 1024u + lo, w.cfl);
-        if (lane < 3 * WTH) gst_at<uint4>(Rp, (uint32_t)lane * 16u, rowtab[lane]);
+        gst_at<uint4>(Cp, 1024u + (uint32_t)lane * 16u, make_uint4((uint32_t)raw.cy, (uint32_t)raw.cc, (uint32_t)w.cfl, 0u));
+        if (lane < WTH) {
+            // the unstaged row entries (setup(): yoff = ry, coff = rc)
+            uint8_t *Rr = Rp + 3 * WTH * 16;
+            gst_at<uint4>(Rr, (uint32_t)(2 * lane) * 16u, make_uint4((uint32_t)raw.ry, (uint32_t)raw.rc, (uint32_t)raw.rfl, 0u));
+            gst_at<uint4>(Rr, (uint32_t)(2 * lane + 1) * 16u, make_uint4(__float_as_uint(raw.rya), __float_as_uint(1.0f - raw.rya), __float_as_uint(raw.rca), __float_as_uint(1.0f - raw.rca)));
+            gst_at<uint4>(Rr, (uint32_t)(2 * WTH + lane) * 16u,
+                          make_uint4(__float_as_uint(raw.rya), __float_as_uint(raw.rca), ((uint32_t)raw.ry & 0xFFFFu) | ((uint32_t)raw.rc << 16), (uint32_t)raw.rfl));
+        }
+        if (w.staged) {
+            gst_at<uint4>(Cp, (uint32_t)lane * 16u, make_uint4((uint32_t)w.cyo, (uint32_t)w.cco, __float_as_uint(w.cya), __float_as_uint(w.cca)));
+            if (lane < 3 * WTH) gst_at<uint4>(Rp, (uint32_t)lane * 16u, rowtab[lane]);
+        } else {
+            // (a column no strip of which is staged still needs its weights: they are the same in both forms)
+            gst_at<uint2>(Cp, (uint32_t)lane * 16u + 8u, make_uint2(__float_as_uint(w.cya), __float_as_uint(w.cca)));
+        }
         if (lane == 0) {
-            auto inv = [](int nslot) { return nslot > 0 ? ((1 << 20) + nslot - 1) / nslot : 0; };      // stage_slots_init's
-            const int32_t rsv[9] = { w.g0.r_lo, w.g0.rows, w.g0.pair, w.g0.r_hi1, w.g1.r_lo, w.g1.rows, w.g1.pair, w.g1.r_hi1, w.unit_rows ? 1 : 0 };
-            const int32_t csv[8] = { w.g0.b0, w.g0.nvec, inv(w.g0.nvec), inv(w.g0.nvec + 2), w.g1.b0, w.g1.nvec, inv(w.g1.nvec), inv(w.g1.nvec + 2) };
-            for (int k = 0; k < 9; k++) gst_at<int32_t>(Rp, (uint32_t)(3 * WTH * 16 + 4 * k), rsv[k]);
-            for (int k = 0; k < 8; k++) gst_at<int32_t>(Cp, (uint32_t)(1280 + 4 * k), csv[k]);
+            if (w.staged) {
+                auto inv = [](int nslot) { return nslot > 0 ? ((1 << 20) + nslot - 1) / nslot : 0; };      // stage_slots_init's
+                const int32_t rsv[9] = { w.g0.r_lo, w.g0.rows, w.g0.pair, w.g0.r_hi1, w.g1.r_lo, w.g1.rows, w.g1.pair, w.g1.r_hi1, w.unit_rows ? 1 : 0 };
+                const int32_t csv[8] = { w.g0.b0, w.g0.nvec, inv(w.g0.nvec), inv(w.g0.nvec + 2), w.g1.b0, w.g1.nvec, inv(w.g1.nvec), inv(w.g1.nvec + 2) };
+                for (int k = 0; k < 9; k++) gst_at<int32_t>(Rp, (uint32_t)(2 * 3 * WTH * 16 + 4 * k), rsv[k]);
+                for (int k = 0; k < 8; k++) gst_at<int32_t>(Cp, (uint32_t)(2048 + 4 * k), csv[k]);
+            }
             gst_at<uint32_t>(tab + flags_off, 4u * (uint32_t)(sya * hsx + sxa),
-                             GF_STAGED | (w.all_inside ? GF_ALL_INSIDE : 0u) | (w.g0.edge ? GF_EDGE0 : 0u) | (w.g1.edge ? GF_EDGE1 : 0u));
+                             (w.staged ? GF_STAGED : 0u) | (w.all_inside ? GF_ALL_INSIDE : 0u) | ((w.staged && w.g0.edge) ? GF_EDGE0 : 0u) | ((w.staged && w.g1.edge) ? GF_EDGE1 : 0u));
         }
     }
 
@@ -512,7 +502,8 @@ struct WaveStrip {
     }
 
     // per-layer geometry: column entry, row entries (into the LDS table), summaries, staging rectangles
-    CHV_DEV void setup(int l, WLayer &w) const {
+    template <bool RAW = false>
+    CHV_DEV void setup(int l, WLayer &w, GeomRaw *raw = nullptr) const {
         constexpr unsigned long long ROWMASK = WTH >= 64 ? ~0ull : ((1ull << WTH) - 1ull);
         const DLayer &Ly = L[l];
         const bool rgb = is_rgb(Ly.kind);
@@ -538,6 +529,7 @@ struct WaveStrip {
         w.cfl = col_in ? fl : AX_ALL;                               // past the canvas edge: never stored; copy of the last column
         const AxisSum rs = axis_summary(ROWMASK, row_in, rfl, ry, rc);
         if (!row_in) rfl = AX_ALL;
+        if constexpr (RAW) { raw->cy = cy; raw->cc = cc; raw->ry = ry; raw->rc = rc; raw->rfl = rfl; raw->rya = rya; raw->rca = rca; }
         w.all_inside = cs.any && cs.all && rs.any && rs.all;
         w.staged = false;
         int cyo = cy, cco = cc, yoff = ry, coff = rc;              // unstaged: the positions themselves

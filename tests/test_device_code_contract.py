@@ -12,7 +12,7 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "swiftvideo_amd" / "csrc"
 LLVM = Path("/opt/rocm/lib/llvm/bin")
-OBJECTS = ["kernels_general", "kernels_fast", "kernels_wave", "kernels_wave_yuv", "kernels_lanczos", "kernels_stream", "kernels_stream_yuv"]
+OBJECTS = ["kernels_general", "kernels_fast", "kernels_wave", "kernels_wave_cached", "kernels_wave_yuv", "kernels_wave_yuv_cached", "kernels_lanczos", "kernels_stream", "kernels_stream_yuv"]
 VALIDATED_HIPCC_MAJOR_MINOR = "7.2"       # the hipcc the hand-scheduled kernels were validated with (GPU suite + tools/check_inflight.py)
 
 
@@ -186,7 +186,7 @@ def test_hand_awaited_loads_are_not_touched_while_in_flight(tmp_path):
     assert not bad, bad[:5]
 
 
-@pytest.mark.parametrize("stem", ["kernels_wave", "kernels_wave_yuv"])
+@pytest.mark.parametrize("stem", ["kernels_wave", "kernels_wave_yuv", "kernels_wave_cached", "kernels_wave_yuv_cached"])
 def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem):
     """One wave per strip (profiles/HISTORY.md 5.1): <= 80 VGPRs = 6 waves per SIMD (5 measured 8 % slower on the 4 x NV12
     pipeline), at most the two spills of the per-pixel fallback; and the tick / layer descriptors — uniform, read-only — come
@@ -198,12 +198,12 @@ def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem)
         tall = "tick_bgra_waveILi16E" in name             # BGRA canvas, 16-row strips: 96 VGPRs = 5 waves, no spills
         # (the instantiation that also carries the per-pixel code for rotated layers — KINDS bit 3 — gets one wave less instead of
         # scratch traffic: the kernels are VALU-bound, profiles/r03_notes.md, and a fifth / sixth wave buys ~3 %)
-        with_general = "tick_bgra_wave" in name and re.search(r"ELi15EEEv", name) is not None
+        with_general = "tick_bgra_wave" in name and re.search(r"ELi15ELb[01]EEEv", name) is not None
         if "tick_yuv_wave" in name:
             # 4:2:0 canvases: the own-format instantiations (KINDS 1 / 2) at 6 waves, a register or two in scratch at most
             # (16-row strips: 0.41 vs 0.43 ms on y420p_main at 5); the ones that also carry the RGB-overlay rows at 5 waves with
             # NOTHING in scratch (at 6 they spilled five or six registers: 1.5x write traffic and no faster)
-            own = re.search(r"ELi(8|16)ELi[12]EEEv", name) is not None
+            own = re.search(r"ELi(8|16)ELi[12]ELb[01]EEEv", name) is not None
             assert m["vgpr_count"] <= (80 if own else 96), (name, m)
             assert m["private_segment_fixed_size"] <= (64 if own else 0), (name, m)
         else:
@@ -220,18 +220,21 @@ def test_wave_kernel_dma_staging_owns_m0_and_leaves_descriptor_reads_scalar(tmp_
     contract of the streaming kernels — from asm statements that are NOT volatile and clobber no memory: a first version that was volatile made
     every descriptor read after it a per-lane load (75 instead of 16 global_load_dword in this instantiation, cfg3 1.35 -> 2.41 ms on the GPU,
     profiles/r05_notes.md section 9).  Per instantiation, not over the object: the aggregate test above did not notice."""
-    co = _code_object(tmp_path, "kernels_wave")
-    _lds_dma_contract(co, 4)
-    asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
-    bodies = re.split(r"\n[0-9a-f]+ <(_ZN3chv14tick_bgra_wave[^>]*)>:\n", asm)
     seen = 0
+    bodies = []
+    for stem in ("kernels_wave", "kernels_wave_cached"):          # (the instantiations that compute their geometry, and the ones that read it from tables)
+        co = _code_object(tmp_path, stem)
+        _lds_dma_contract(co, 4)
+        asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+        bodies += re.split(r"\n[0-9a-f]+ <(_ZN3chv14tick_bgra_wave[^>]*)>:\n", asm)[1:]
+    bodies = [None] + bodies
     for name, body in zip(bodies[1::2], bodies[2::2]):
         body = re.split(r"\n[0-9a-f]+ <_Z", body)[0]
-        rgb_only = re.search(r"ELi4EEEv", name) is not None
+        rgb_only = re.search(r"ELi4ELb[01]EEEv", name) is not None
         assert ("global_load_lds_dwordx4" in body) == rgb_only, name
         if rgb_only:
             seen += 1
             scalar, vector1 = len(re.findall(r"\bs_load_dword", body)), len(re.findall(r"\bglobal_load_dword\s", body))
             assert scalar >= 80 and vector1 <= 40, (name, scalar, vector1)       # (CLEAR = false: one canvas load per row on top of the 16 of the per-pixel path)
             assert "s_waitcnt vmcnt(0)" in body
-    assert seen == 4
+    assert seen == 8
