@@ -78,7 +78,7 @@ static int parse_switch(const char *name, const char *value, int *out) {
     if (n == "CHV_YUV_STREAM") { *out = v == "0" ? 0 : (v == "force" || v == "2") ? 2 : 1; return 7; }
     if (n == "CHV_WAVE_DMA") { *out = v == "0" ? 0 : 1; return 8; }
     if (n == "CHV_PASS_FUSE") { *out = v == "0" ? 0 : 1; return 9; }
-    if (n == "CHV_GEOM_CACHE") { *out = v == "0" ? 0 : 1; return 10; }
+    if (n == "CHV_GEOM_CACHE") { *out = v == "0" ? 0 : v == "eager" ? 2 : 1; return 10; }
     return -1;
 }
 static void store_switch(Switches &s, int which, int val) {

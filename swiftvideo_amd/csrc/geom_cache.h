@@ -28,6 +28,8 @@ struct GeomCache {
     bool built = false;          // tables hold `config`'s geometry and the batch's device layers point at them
     bool patched = false;        // the device layers carry table pointers (cleared again when the switch goes off)
     GeomConfig config{};
+    bool seen = false;           // a launch with `seen_config` has been issued (tables are built at the second one: a batch run once never pays)
+    GeomConfig seen_config{};
     void *tables = nullptr;      // device: every class's tables, back to back
     void *jobs = nullptr;        // device: the precompute kernel's job list (kept: freed with the cache)
     size_t bytes = 0;

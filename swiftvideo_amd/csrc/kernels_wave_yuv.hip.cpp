@@ -743,6 +743,20 @@ static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const
         return hipSuccess;
     }
     if (gc.built && gc.config == cfg) { *covered = gc.patched; return hipSuccess; }
+    // A batch that is run once (a host that builds one per tick) never pays for tables: they are built at the SECOND launch with a configuration
+    // (draining the stream, three small copies and a kernel: tens of microseconds), the first one computes its geometry in place.
+    if (!(gc.seen && gc.seen_config == cfg) && switches().geom_cache.load(std::memory_order_relaxed) != 2) {
+        gc.seen = true; gc.seen_config = cfg;
+        if (gc.patched) {          // (tables of another configuration: the kernels about to run compute in place and never look, but the pointers go)
+            hipError_t e0 = hipStreamSynchronize(stream);
+            if (e0 != hipSuccess) return e0;
+            for (int i = 0; i < gc.n_layers; i++) hl[i].pad2[0] = hl[i].pad2[1] = 0;
+            e0 = hipMemcpy(gc.d_layers, hl, sizeof(DLayer) * (size_t)gc.n_layers, hipMemcpyHostToDevice);
+            if (e0 != hipSuccess) return e0;
+            gc.patched = false; gc.built = false;
+        }
+        return hipSuccess;
+    }
     // classes: layers whose set-up inputs are the same bytes — the three matrices, the source planes' sizes and layout class, the canvas size
     struct Key { float u[48]; int32_t w0, h0, w1, h1, cls, W, H; };
     std::map<std::string, int> index;

@@ -23,7 +23,9 @@ struct Switches {
     std::atomic<int> wave_dma{1};        // CHV_WAVE_DMA: 0 the RGB-only strip kernel stages its rectangles through registers like the others (A/B, and the
                                          // fuzzers' way to the non-DMA staging of that instantiation); 1 (default) by LDS-DMA where the shape allows
     std::atomic<int> geom_cache{1};      // CHV_GEOM_CACHE: 0 the strip kernels compute every layer's per-strip geometry in place also in batches (A/B, and the
-                                         // fuzzers' way to that path); 1 (default) batches keep it in tables built once per launch configuration (geom_cache.h)
+                                         // fuzzers' way to that path); 1 (default) batches keep it in tables built at their SECOND launch with a
+                                         // configuration (geom_cache.h: a batch run once never pays); eager: at the first one (the test suite, whose
+                                         // batches mostly run once, so that its fuzzers reach the table-reading kernels)
     std::atomic<int> pass_fuse{1};       // CHV_PASS_FUSE: 1 (default) picture kernels issued inside chv_pass_begin ... chv_pass_end are held and leave as the one
                                          // fused launch chv_composite would make of them (chipvideo.cpp: PendingPass); 0 every chv_run_kernel launches at once
 };

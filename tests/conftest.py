@@ -34,6 +34,19 @@ def ctx(built):
     sv.destroyComputeContext(c)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def eager_geometry_tables(request):
+    """-m gpu sessions: batches build their geometry tables at their FIRST launch (CHV_GEOM_CACHE=eager; the product builds them at the second, so
+    that a batch run once never pays) — most batches of this suite run once, and every fuzzer that runs one is meant to reach the table-reading
+    instantiations of the strip kernels.  The kernels that compute their geometry in place are every transient launch's, and
+    tests/test_gpu_geom_cache.py forces them onto batches."""
+    lib = ROOT / "swiftvideo_amd" / "libchipvideo.so"
+    if lib.exists() and os.environ.get("CHV_GEOM_CACHE") is None and "gpu" in (request.config.getoption("-m") or "") and "not gpu" not in (request.config.getoption("-m") or ""):
+        from swiftvideo_amd import chipvideo
+        chipvideo.set_switch("CHV_GEOM_CACHE", "eager")
+    yield
+
+
 @pytest.fixture
 def switch(built):
     """Path-selection switches through the library's own hook (chv_debug_set_switch) instead of the environment: the library
@@ -47,4 +60,5 @@ def switch(built):
 
     yield _set
     for name in touched:
-        chipvideo.set_switch(name, None)
+        # (CHV_GEOM_CACHE goes back to what the session runs with: eager_geometry_tables)
+        chipvideo.set_switch(name, "eager" if name == "CHV_GEOM_CACHE" and os.environ.get("CHV_GEOM_CACHE") is None else None)
