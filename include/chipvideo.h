@@ -63,7 +63,7 @@ int chv_version(void);
 const char *chv_build_flags(void);
 /* Measurement / test hook: path-selection switches.  Names and values are those of the environment variables read once at
  * first use (CHV_FORCE_GENERAL=1, CHV_BGRA_PATH=wave|tiled|stream, CHV_WAVE_ROWS=8|16, CHV_TILE_ROWS=16|32, CHV_SAME_GEOM=0,
- * CHV_DESC=host|device, CHV_STREAM=0, CHV_YUV_STREAM=0|force, CHV_WAVE_DMA=0, CHV_PASS_FUSE=0);
+ * CHV_DESC=host|device, CHV_STREAM=0, CHV_YUV_STREAM=0|force, CHV_WAVE_DMA=0, CHV_PASS_FUSE=0, CHV_GEOM_CACHE=0|eager);
  * NULL or "" restores the default.  Process-wide, atomic; not part of the Swift-facing contract. */
 int chv_debug_set_switch(const char *name, const char *value);
 

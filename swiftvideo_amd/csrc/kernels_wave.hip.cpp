@@ -470,8 +470,10 @@ hipError_t launch_bgra_wave_t(int rows, bool clear, dim3 grid, size_t lds, hipSt
                               int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds) {
 #define CHV_LAUNCH_B(R, C, K) hipLaunchKernelGGL((tick_bgra_wave<R, C, K, CACHED>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
                                                  strips_magic, strips_x_magic, p0pitch, p0rows, p1pitch, p1rows, planar)
+    /* (launches of RGB layers only — cfg3, cfg5: stacks of ONE geometry, set up once per strip for all layers, power-bound — gain nothing from
+       tables and would pay for them in counted traffic: launch_wave_layers never asks for the CACHED form of KINDS = 4, and it is not built) */
 #define CHV_LAUNCH_BK(R, C) do { if (kinds == 1) CHV_LAUNCH_B(R, C, 1); else if (kinds == 2) CHV_LAUNCH_B(R, C, 2); \
-                                 else if (kinds == 4) CHV_LAUNCH_B(R, C, 4); else if (kinds == 5) CHV_LAUNCH_B(R, C, 5); \
+                                 else if (kinds == 4) { if constexpr (!CACHED) CHV_LAUNCH_B(R, C, 4); } else if (kinds == 5) CHV_LAUNCH_B(R, C, 5); \
                                  else if (kinds & 8) CHV_LAUNCH_B(R, C, 15); \
                                  else CHV_LAUNCH_B(R, C, 7); } while (0)      /* (y420p + RGB alone: its instantiation spills, 7 does not) */
     if (rows == 16) { if (clear) CHV_LAUNCH_BK(16, true); else CHV_LAUNCH_BK(16, false); }

@@ -969,7 +969,10 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     const int p0rows_arg = m.p0rows | (origin_x << 16), p1rows_arg = m.p1rows | (origin_y << 16);
     // the batch's geometry tables for this configuration (a transient launch has none: its kernels compute their geometry in place)
     bool cached = false;                       // -> the CACHED instantiations (no set-up code): every staged layer of the launch has its table
-    if (GeomCache *gc = geom_cache_current()) {
+    // (not for launches of RGB layers only: stacks of one geometry are set up once per strip for all their layers — cfg3 -1 %, cfg5 +-0 with
+    // tables, for 5 % more counted traffic: profiles/r06_notes.md section 9)
+    GeomCache *gc = kinds != 4 ? geom_cache_current() : nullptr;
+    if (gc) {
         GeomConfig cfg{ target_format, WTH, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side, (maxW + WTW - 1) / WTW, (maxH + WTH - 1) / WTH, gc->n_layers };
         hipError_t ge = geom_cache_prepare(*gc, cfg, ticks_host, n_ticks, (size_t)WTH * 48, stream, &cached);
         if (ge != hipSuccess) return ge;

@@ -224,7 +224,8 @@ def test_wave_kernel_dma_staging_owns_m0_and_leaves_descriptor_reads_scalar(tmp_
     bodies = []
     for stem in ("kernels_wave", "kernels_wave_cached"):          # (the instantiations that compute their geometry, and the ones that read it from tables)
         co = _code_object(tmp_path, stem)
-        _lds_dma_contract(co, 4)
+        if stem == "kernels_wave":
+            _lds_dma_contract(co, 4)                                # (RGB-only launches never take tables: KINDS = 4 exists in the first object only)
         asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
         bodies += re.split(r"\n[0-9a-f]+ <(_ZN3chv14tick_bgra_wave[^>]*)>:\n", asm)[1:]
     bodies = [None] + bodies
@@ -237,4 +238,4 @@ def test_wave_kernel_dma_staging_owns_m0_and_leaves_descriptor_reads_scalar(tmp_
             scalar, vector1 = len(re.findall(r"\bs_load_dword", body)), len(re.findall(r"\bglobal_load_dword\s", body))
             assert scalar >= 80 and vector1 <= 40, (name, scalar, vector1)       # (CLEAR = false: one canvas load per row on top of the 16 of the per-pixel path)
             assert "s_waitcnt vmcnt(0)" in body
-    assert seen == 8
+    assert seen == 4
