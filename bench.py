@@ -12,21 +12,22 @@ One step = `launches_per_step` passes of the path over the batch.  The count is 
 timed region lasts >= --min-seconds whatever --steps is (a 256-tick launch is ~1 ms); the K steps are timed exactly as
 the contract says (barrier + device sync on both sides, max over ranks).
 
-The other BASELINE configs (cfg2 convert+scale, cfg3 4 x BGRA composite, cfg5 4K 8-layer + Lanczos, the reference's
-own 4:2:0 mixer canvas, and cfg2 end-to-end with H2D uploads on a side stream) are timed the same way right after
-and reported under "workloads" in the same JSON line.
+The other BASELINE configs (cfg2 convert+scale, cfg3 4 x BGRA composite, cfg5 4K 8-layer + Lanczos, the reference's own 4:2:0 mixer canvas, the
+encoder-side frame, the planar / grid / logo variants of the pipeline) are timed the same way right after; `--full` adds the legs that are not
+kernel throughput (cfg2 and the whole chain end to end over PCIe, one tick at a time, thread scaling, route regret, clock and power of every
+workload).
 
-Multi-GPU: weak scaling, one process per GPU, no collective on the data path (stream s -> device s mod N).  When
-started without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the script spawns its N
-ranks itself; under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.  The control plane (barrier,
-max over ranks) is gloo on the host.
+Multi-GPU: weak scaling, one process per GPU, no collective on the data path (stream s -> device s mod N).  When started without a launcher
+(`python bench.py --gpus N`, no WORLD_SIZE in the environment) the script spawns its N ranks itself; under torch.distributed.run it reads
+RANK / LOCAL_RANK / WORLD_SIZE.  The control plane (barrier, max over ranks) is gloo on the host.
 
-Prints ONE JSON line on rank 0:
+Output (rank 0): the LAST stdout line is ONE compact JSON object (< 4 KB, compact_line()):
   value        = target pixels written per second, whole job, inputs resident in HBM
-  roofline     = algorithmic bytes per launch / mean launch duration (HIP events on the context's stream) against the
-                 8 TB/s HBM peak (frac) and the 6.29 TB/s measured copy ceiling (frac_of_copy_ceiling)
-  cpu_baseline = the oracle (CPU restatement of the same kernels, "port") timed on the host cores of this box on a
-                 bounded sample of the same workload (N=1 only)
+  config       = the workload, launches and frames per step, kernel, oracle verdict, per-GPU rates, every workload's [fraction of 8 TB/s, ms per launch]
+  roofline     = algorithmic bytes per launch / mean launch duration (HIP events on the context's stream) against the 8 TB/s HBM peak, the counted
+                 HBM traffic of the same kernel (two rocprofv3 --pmc child passes), the limiter the round's probes name, clock and power
+  cpu_baseline = the oracle (CPU restatement of the same kernels, "port") timed on the host cores of this box on a bounded sample (N=1 only)
+and everything else — every workload's full record, the legs, build flags, prose — is written to bench_detail.json (--detail-json).
 """
 import argparse
 import ctypes as C
