@@ -166,7 +166,8 @@ __global__ void selftest_pack_codes_kernel(const float *in, uint32_t *out, int n
 //   dir 0: i = Y << 16 | U << 8 | V  ->  out[i] = B | G << 8 | R << 16 | 255 << 24 through the plain form (yuv_to_bgra_word(Csc)); every OTHER
 //          form the kernels use — offsets folded into one constant per channel, operands carrying the float adder's bias 0x4B400000 + code
 //          (what code_biased hands the tiled / wave / stream kernels) packed by v_ashr_pk_u8_i32, and the float-code form of the blending
-//          kernels packed by v_cvt_pk_u8_f32 — is compared with it on the device: *mism counts the triples on which any of them differs
+//          kernels packed by v_cvt_pk_u8_f32, the same with the offsets absorbed into the conversion biases
+//          (yuv_to_bgr_floats_absorbed, where the matrix has such biases) — is compared with it on the device: *mism counts the triples on which any of them differs
 //   dir 1: i = R << 16 | G << 8 | B  ->  out[i] = Y | U << 8 | V << 16 through rgb_to_yuv_int
 __global__ void selftest_matrices_kernel(int dir, int csc, uint32_t *out, uint32_t *mism) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,8 +182,25 @@ __global__ void selftest_matrices_kernel(int dir, int csc, uint32_t *out, uint32
         float pb, pg, pr;
         yuv_to_bgr_floats(fb, ya, ua, va, pb, pg, pr);
         const uint32_t w3 = pack_codes(pb, pg, pr, 0xFF000000u);
+        // the absorbed form (csc_fold_absorbed: conversion biases that finish the red and blue channels in their multiply-adds), fed floats
+        uint32_t w4 = w0;
+        if (csc_absorbable(csc)) {
+            float qb, qg, qr;
+            yuv_to_bgr_floats_absorbed(csc_fold_absorbed(csc), (float)a, (float)b, (float)c, qb, qg, qr);
+            w4 = pack_codes(qb, qg, qr, 0xFF000000u);
+            // ... and its three conversions on samples BETWEEN codes (a + b / 256: the ties at b = 128 must go to the even code, as code_biased's)
+            const CscAbsorbed q = csc_fold_absorbed(csc);
+            const float f = (float)min(a, 254) + (float)b * (1.0f / 256.0f);
+            const uint32_t want = code_biased(f) & 255u;
+            const float mags[3] = { q.my, q.mu, q.mv };
+            for (int m = 0; m < 3; m++) {
+                const int32_t low = (int32_t)(__float_as_uint(f + mags[m]) & 0xFFFFFFu), bias = (int32_t)fabsf(mags[m]) - (1 << 23);
+                const int32_t code = mags[m] > 0.f ? low - bias : bias - low;
+                if (code != (int32_t)want) w4 = ~w0;
+            }
+        }
         out[i] = w0;
-        if (w1 != w0 || w2 != w0 || w3 != w0) atomicAdd(mism, 1u);
+        if (w1 != w0 || w2 != w0 || w3 != w0 || w4 != w0) atomicAdd(mism, 1u);
     } else {
         uint32_t y, u, v;
         rgb_to_yuv_int(kR2Y[csc & 3], a, b, c, y, u, v);

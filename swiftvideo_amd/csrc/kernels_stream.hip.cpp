@@ -31,6 +31,12 @@ namespace chv {
 #ifndef CHV_ST_ABL
 #define CHV_ST_ABL 0        // timing-only (wrong pixels): 1 no ring fills, 2 no canvas stores, 4 no layer arithmetic (rings and stores only)
 #endif
+#ifndef CHV_STREAM_ABSORB
+#define CHV_STREAM_ABSORB 1       // 0: the plain form of the colour matrix for every launch (A/B builds)
+#endif
+#ifndef CHV_STREAM_PMIX
+#define CHV_STREAM_PMIX 1
+#endif
 #ifndef CHV_STREAM_ROWS_FIXED
 #define CHV_STREAM_ROWS_FIXED 0
 #endif
@@ -53,6 +59,7 @@ namespace chv {
 #define CHV_STREAM_WAVES 6
 #endif
 
+constexpr float kRintBias = 8388608.0f;       // 2^23 (stream_body: the rounding between two layers)
 constexpr int ST_PITCH = 128;                 // bytes per ring row (8 vectors)
 constexpr int ST_YROWS = 8, ST_CROWS = 4;     // ring rows: luma (batches of 4), chroma (batches of 2)
 // LDS layout (NL layers): luma [2 batch slots][NL layers][4 rows][128], then chroma [2 batch slots][NL layers][2 rows][128] — the layers of one
@@ -85,7 +92,8 @@ CHV_DEV void st_dma(const uint8_t *p, bool active, uint32_t m0) {
 // ONE: a launch of one tick whose descriptors are kernel ARGUMENTS (tick_bgra_stream_one below) — `ticks` / `layers` point into the kernarg
 // segment, every field is a scalar load at a constant offset from one base, issued together: no tick -> first_layer -> layer chain of
 // dependent loads in front of a lone tick's waves, and no descriptor copy in front of the launch.
-template <int NL, bool ONE, bool PL>
+// ABS: every layer's colour matrix has absorbing biases (csc_fold_absorbed, pixel_math.hip.h; launch_bgra_stream decides)
+template <int NL, bool ONE, bool PL, bool ABS>
 CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restrict__ layers, int n_ticks, int strips_x, int chunks_y, int rows_per_chunk) {
     // ST_WAVES independent waves per block, on neighbouring strips (no barrier anywhere): their source windows overlap by a vector or two,
     // and waves of one block start together on one CU — the shared lines are fetched once (HBM traffic 1.47x -> see profiles/r03_notes.md)
@@ -150,13 +158,22 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
 
     // per-layer constants (wave-uniform), read once: the asm statements below clobber "memory", and every descriptor read after one of
     // them would be a fresh scalar load with its latency in the middle of the ring logic
-    CscFolded csc[NL];
-    float al[NL], ial[NL];
+    std::conditional_t<ABS, CscAbsorbed, CscFolded> csc[NL];
+    float al[NL], ial[NL], nrb[NL], al24[NL];
     const uint8_t *planeY[NL], *planeC[NL], *planeV[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) {
-        csc[l] = csc_fold_biased(kCsc[L[l].csc & 3]);
+        if constexpr (ABS) csc[l] = csc_fold_absorbed(L[l].csc);
+        else csc[l] = csc_fold_biased(kCsc[L[l].csc & 3]);
         al[l] = 1.0f * L[l].u[U_OPACITY]; ial[l] = 1.f - al[l];
+        // Between two layers the canvas pixel is rounded to codes (what the first layer's store would have kept) and multiplied by the next
+        // layer's 1 - opacity.  The rounding is one add of 2^23 (x + 2^23 = 2^23 + rint(x) exactly, ties to even, for 0 <= x < 2^22); taking the
+        // 2^23 out again and the multiply are ONE fused multiply-add: fma(x + 2^23, ia, -2^23 ia) rounds the exact (rint(x) + 2^23) ia - 2^23 ia
+        // = rint(x) ia — the product the separate multiply rounds — because 2^23 ia is exact (a power of two times a float).  The constant
+        // lives in a vector register: a VOP3 instruction reads one scalar operand, and that is the layer's 1 - opacity.
+        al24[l] = al[l] * kTapScale;                     // (exact: a power of two; the layer's pixel arrives scaled by 2^-24, see the blend)
+        nrb[l] = -kRintBias * ial[l];
+        asm volatile("" : "+v"(nrb[l]));
         planeY[l] = L[l].src.pl[0].ptr; planeC[l] = L[l].src.pl[1].ptr; planeV[l] = L[l].src.pl[PL ? 2 : 1].ptr;
     }
     // this lane's place in a batch: (row, vector) and its byte column, luma and chroma
@@ -179,6 +196,8 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
         lastY = __builtin_amdgcn_readfirstlane(ry) + 1; lastC = __builtin_amdgcn_readfirstlane(rc) + 1;
     }
     uint32_t pending = 0u;                                        // the previous row's pixel, stored after this row's wait
+    uint32_t alpha_word = 0xFF000000u;                            // img_clear_bgra's pixel; the word the colour bytes are packed into
+    asm volatile("" : "+v"(alpha_word));
     int issued = 0, seqY = 0, seqC = 0;                           // load instructions issued so far; the count right after the newest luma / chroma batch
     int nextY = 0, nextC = 0, landY = 0, landC = 0, baseY = 0, baseC = 0;      // ring state: rows below next* are requested, below land* have arrived
     for (int j = 0; j < nrows; j++) {
@@ -288,29 +307,50 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
             const float fy = cs_mix_h(w00, w10, w01, w11, tap_h(pY00 + lo), tap_h(pY10 + lo), tap_h(pY01 + lo), tap_h(pY11 + lo));
             const float fu = cs_mix_h(c00, c10, c01, c11, tap_h(pC00 + lc), tap_h(pC10 + lc), tap_h(pC01 + lc), tap_h(pC11 + lc));
             const float fv = cs_mix_h(c00, c10, c01, c11, tap_h(pC00 + lc + VOFF), tap_h(pC10 + lc + VOFF), tap_h(pC01 + lc + VOFF), tap_h(pC11 + lc + VOFF));
+            if constexpr (ABS && CHV_STREAM_PMIX) {
+                // the layer's pixel enters the blend as a binary16 read from the high half of its clamped 16.16 sum (code x 2^-24, exact;
+                // the opacity carries the 2^24): p * a + inner in one v_fma_mix_f32, the same real numbers into the same single rounding
+                int32_t cb, cg, cr;
+                yuv_to_bgr_fixed_absorbed(csc[l], fy, fu, fv, cb, cg, cr);
+                const float a24 = al24[l];
+                if (l == 0) {
+                    r0 = __builtin_fmaf(a24, (float)code_h(cb), 0.0f); r1 = __builtin_fmaf(a24, (float)code_h(cg), 0.0f); r2 = __builtin_fmaf(a24, (float)code_h(cr), 0.0f);
+                } else {
+                    r0 = __builtin_fmaf(a24, (float)code_h(cb), __builtin_fmaf(r0, ial[l], nrb[l]));
+                    r1 = __builtin_fmaf(a24, (float)code_h(cg), __builtin_fmaf(r1, ial[l], nrb[l]));
+                    r2 = __builtin_fmaf(a24, (float)code_h(cr), __builtin_fmaf(r2, ial[l], nrb[l]));
+                }
+                if (l + 1 < NL) { r0 += kRintBias; r1 += kRintBias; r2 += kRintBias; }
+                continue;
+            }
             float pb, pg, pr;
-            yuv_to_bgr_floats(csc[l], (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv), pb, pg, pr);
+            if constexpr (ABS) yuv_to_bgr_floats_absorbed(csc[l], fy, fu, fv, pb, pg, pr);
+            else yuv_to_bgr_floats(csc[l], (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv), pb, pg, pr);
             if (l == 0) {                // the cleared canvas: fma(p, a, 0 * (1 - a)) = RN(p * a) for a in [0, 1]
                 r0 = pb * al[0]; r1 = pg * al[0]; r2 = pr * al[0];
-            } else {
-                r0 = __builtin_fmaf(pb, al[l], r0 * ial[l]);
-                r1 = __builtin_fmaf(pg, al[l], r1 * ial[l]);
-                r2 = __builtin_fmaf(pr, al[l], r2 * ial[l]);
+            } else {                     // (r holds 2^23 + the codes the previous layer's store would have kept: see nrb above)
+                r0 = __builtin_fmaf(pb, al[l], __builtin_fmaf(r0, ial[l], nrb[l]));
+                r1 = __builtin_fmaf(pg, al[l], __builtin_fmaf(r1, ial[l], nrb[l]));
+                r2 = __builtin_fmaf(pr, al[l], __builtin_fmaf(r2, ial[l], nrb[l]));
             }
-            if (l + 1 < NL) { r0 = code_rintf(r0); r1 = code_rintf(r1); r2 = code_rintf(r2); }      // what the layer's store would have kept
+            if (l + 1 < NL) { r0 += kRintBias; r1 += kRintBias; r2 += kRintBias; }
         }
-        const uint32_t out = pack_codes(r0, r1, r2, 0xFF000000u);
+        // (pack_codes with the alpha word as a separate source: tied to the destination it is re-materialised every row)
+        uint32_t out;
+        asm("v_cvt_pk_u8_f32 %0, %1, 0, %2" : "=v"(out) : "v"(r0), "v"(alpha_word));
+        asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(out) : "v"(r1));
+        asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(out) : "v"(r2));
         // a pixel outside the picture keeps the cleared canvas (inside the border quad its alpha is forced: the same word)
-        const uint32_t res = (lane_pic && rfl == AX_ALL) ? out : 0xFF000000u;
+        const uint32_t res = (lane_pic && rfl == AX_ALL) ? out : alpha_word;
         pending = res;
     }
     if (nrows > 0 && x < T.W && !(CHV_ST_ABL & 2)) gst_at<uint32_t>(D.ptr + (size_t)(y0 + nrows - 1) * D.pitch, (uint32_t)x * 4u, pending);
 }
 
-template <int NL, bool PL>
+template <int NL, bool PL, bool ABS>
 __global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_stream(const DTick *__restrict__ ticks, const DLayer *__restrict__ layers, int n_ticks,
                                                                           int strips_x, int chunks_y, int rows_per_chunk) {
-    stream_body<NL, false, PL>(ticks, layers, n_ticks, strips_x, chunks_y, rows_per_chunk);
+    stream_body<NL, false, PL, ABS>(ticks, layers, n_ticks, strips_x, chunks_y, rows_per_chunk);
 }
 
 // one tick, descriptors by value (96 + NL x 368 bytes of kernel arguments)
@@ -319,9 +359,9 @@ struct StreamOne {
     DTick t;
     DLayer l[NL];
 };
-template <int NL, bool PL>
+template <int NL, bool PL, bool ABS>
 __global__ __launch_bounds__(64 * ST_WAVES, CHV_STREAM_WAVES) void tick_bgra_stream_one(const StreamOne<NL> a, int strips_x, int chunks_y, int rows_per_chunk) {
-    stream_body<NL, true, PL>(&a.t, a.l, 1, strips_x, chunks_y, rows_per_chunk);
+    stream_body<NL, true, PL, ABS>(&a.t, a.l, 1, strips_x, chunks_y, rows_per_chunk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -403,6 +443,10 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
     const bool planar = layers_host[ticks_host[0].first_layer].kind == LK_BGRA_FROM_Y420P;
     const size_t layer_bytes = planar ? (size_t)st_layer_bytes<1, true>() : (size_t)st_layer_bytes<1, false>();
     const size_t lds = (size_t)ST_WAVES * ((size_t)nl * layer_bytes + ST_TAB * (sizeof(uint4) + sizeof(uint32_t)));
+    // the absorbed form of the colour matrix (pixel_math.hip.h) when every layer's matrix has one — all but BT.601 full range
+    bool absorb = CHV_STREAM_ABSORB != 0;
+    for (int i = 0; i < n_ticks && absorb; i++)
+        for (int l = 0; l < nl; l++) absorb = absorb && csc_absorbable(layers_host[ticks_host[i].first_layer + l].csc);
     if (!ticks) {
         // one tick, descriptors as kernel arguments (launch_transient)
         if (n_ticks != 1 || !layers_host) return hipErrorInvalidValue;
@@ -412,8 +456,11 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
             a.t = ticks_host[0];
             a.t.first_layer = 0;
             for (int l = 0; l < NL; l++) a.l[l] = layers_host[ticks_host[0].first_layer + l];
-            if (planar) hipLaunchKernelGGL((tick_bgra_stream_one<NL, true>), grid, dim3(64 * ST_WAVES), lds, stream, a, strips_x, chunks_y, rows);
-            else hipLaunchKernelGGL((tick_bgra_stream_one<NL, false>), grid, dim3(64 * ST_WAVES), lds, stream, a, strips_x, chunks_y, rows);
+            auto fire = [&](auto pl, auto ab) {
+                hipLaunchKernelGGL((tick_bgra_stream_one<NL, decltype(pl)::value, decltype(ab)::value>), grid, dim3(64 * ST_WAVES), lds, stream, a, strips_x, chunks_y, rows);
+            };
+            if (planar) { if (absorb) fire(std::true_type{}, std::true_type{}); else fire(std::true_type{}, std::false_type{}); }
+            else { if (absorb) fire(std::false_type{}, std::true_type{}); else fire(std::false_type{}, std::false_type{}); }
         };
         switch (nl) {
         case 1: go(std::integral_constant<int, 1>{}); break;
@@ -423,8 +470,9 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
         }
         return hipGetLastError();
     }
-#define CHV_ST_GO(N) do { if (planar) hipLaunchKernelGGL((tick_bgra_stream<N, true>), grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); \
-                          else hipLaunchKernelGGL((tick_bgra_stream<N, false>), grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows); } while (0)
+#define CHV_ST_GO2(N, P, A) hipLaunchKernelGGL((tick_bgra_stream<N, P, A>), grid, dim3(64 * ST_WAVES), lds, stream, ticks, layers, n_ticks, strips_x, chunks_y, rows)
+#define CHV_ST_GO(N) do { if (planar) { if (absorb) CHV_ST_GO2(N, true, true); else CHV_ST_GO2(N, true, false); } \
+                          else { if (absorb) CHV_ST_GO2(N, false, true); else CHV_ST_GO2(N, false, false); } } while (0)
     switch (nl) {
     case 1: CHV_ST_GO(1); break;
     case 2: CHV_ST_GO(2); break;
@@ -432,6 +480,7 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
     default: CHV_ST_GO(4); break;
     }
 #undef CHV_ST_GO
+#undef CHV_ST_GO2
     return hipGetLastError();
 }
 

@@ -402,4 +402,50 @@ CHV_DEV void yuv_to_bgr_floats(const CscFolded &k, int y, int u, int v, float &f
     asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fr) : "v"(cr));
 }
 
+// ---- the same matrix with the red and blue channel offsets ABSORBED into the float -> code conversion -------------------------------
+// code_biased adds 1.5 x 2^23 to a sample and hands the raw bits to the 24-bit multiplier, which sees 2^22 + code; csc_fold_biased folds
+// 2^22 x coefficient into the three channel offsets.  Any other even bias B works the same way (M = 2^23 + B: bits 0x4B000000 + B + rint(f),
+// ties still to the even code; B + 255 < 2^23), and so does M = -(2^23 + B): the operand is B - rint(f) and the layer's coefficients for that
+// operand change sign.  A bias adds coefficient x bias to every channel its operand feeds, so biases (by, bu, bv) with
+//     crv bv + cy by = KR   and   cbu bu + cy by = KB   (mod 2^32)
+// leave the red and the blue channel FINISHED after their last multiply-add: two vector adds fewer per pixel and layer, the third offset
+// becomes kg' = KG - (cy by - cgu bu - cgv bv).  tools/csc_absorb_search.py finds them (126 / 127 / 0 / 256 solutions for the four matrices:
+// BT.601 full range has none — its luma coefficient 2^16 leaves the luma bias sixteen useful bits) and tests/test_host_logic.py re-derives
+// the table.  Same integers into the same clamp: the same bytes (tests/test_gpu_matrices.py runs every code triple through both forms).
+// The table holds the folded form: coefficients with their operand's sign, kg', and the three conversion constants +-(2^23 + |bias|)
+// (printed by the tool; scalar loads from constant memory in the kernels).
+struct CscAbsorbed { int32_t cy, crv, ncgu, ncgv, cbu, kg; float my, mu, mv; };
+__device__ __constant__ const CscAbsorbed kCscAbsorbed[4] = {
+    { 76309, 104597, -25675, -53279, 132201, 1649788258, 10041594.0f, 13672062.0f, 9933686.0f },      // BT.601 limited: biases 1652986, 5283454, 1545078
+    { 76309, 117489, -13975, -34925, 138438, -1793622274, 8659076.0f, 15468090.0f, 11137308.0f },     // BT.709 limited: biases 270468, 7079482, 2748700
+    { 0, 0, 0, 0, 0, 0, 0.f, 0.f, 0.f },                                                              // BT.601 full: no such biases
+    { 65536, -103206, 12276, 30679, -121609, -223690752, 8400986.0f, -15564928.0f, -9977984.0f },     // BT.709 full: biases 12378, -7176320, -1589376
+};
+constexpr bool csc_absorbable(int csc) { return (csc & 3) != 2; }
+CHV_DEV CscAbsorbed csc_fold_absorbed(int csc) { return kCscAbsorbed[csc & 3]; }
+// The channels as 16.16 sums clamped to [0, 2^24): the code is byte 2 — as a binary16 read from the register's HIGH half, code x 2^-24
+// (code_h below: the denormal trick of tap_h), which is how tick_bgra_stream's blend consumes it: one v_fma_mix_f32 per channel where
+// v_cvt_f32_ubyte2 + v_fmac_f32 were two.
+CHV_DEV void yuv_to_bgr_fixed_absorbed(const CscAbsorbed &k, float fy, float fu, float fv, int32_t &cb, int32_t &cg, int32_t &cr) {
+    const int y = (int)__float_as_uint(fy + k.my), u = (int)__float_as_uint(fu + k.mu), v = (int)__float_as_uint(fv + k.mv);
+    const int32_t t = __mul24(y, k.cy);
+    const int32_t r = mad24_uniform(v, k.crv, t);
+    const int32_t g = mad24_uniform(v, k.ncgv, mad24_uniform(u, k.ncgu, t)) + k.kg;
+    const int32_t b = mad24_uniform(u, k.cbu, t);
+    cb = min(max(b, 0), 0xFFFFFF); cg = min(max(g, 0), 0xFFFFFF); cr = min(max(r, 0), 0xFFFFFF);
+}
+CHV_DEV chv_half code_h(int32_t fixed24) { return __builtin_bit_cast(chv_half, (unsigned short)((uint32_t)fixed24 >> 16)); }
+// yuv_to_bgr_floats on FLOAT samples in code scale (the conversion is part of the form)
+CHV_DEV void yuv_to_bgr_floats_absorbed(const CscAbsorbed &k, float fy, float fu, float fv, float &fb, float &fg, float &fr) {
+    const int y = (int)__float_as_uint(fy + k.my), u = (int)__float_as_uint(fu + k.mu), v = (int)__float_as_uint(fv + k.mv);
+    const int32_t t = __mul24(y, k.cy);
+    const int32_t r = mad24_uniform(v, k.crv, t);
+    const int32_t g = mad24_uniform(v, k.ncgv, mad24_uniform(u, k.ncgu, t)) + k.kg;
+    const int32_t b = mad24_uniform(u, k.cbu, t);
+    const int32_t cb = min(max(b, 0), 0xFFFFFF), cg = min(max(g, 0), 0xFFFFFF), cr = min(max(r, 0), 0xFFFFFF);
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fb) : "v"(cb));
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fg) : "v"(cg));
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(fr) : "v"(cr));
+}
+
 }  // namespace chv
