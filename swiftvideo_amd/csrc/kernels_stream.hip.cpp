@@ -89,6 +89,12 @@ CHV_DEV void st_dma(const uint8_t *p, bool active, uint32_t m0) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0), "v"(p) : "memory");
 }
 
+// A row's store: the row's address stays on the scalar unit (gst_at asks for the same, and here hipcc adds the lane's offset to it with a
+// 64-bit vector add per row instead).  The stores share the counter the ring's loads are awaited by; they only ever make a wait longer.
+CHV_DEV void st_store(uint8_t *row, uint32_t off, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, %2" :: "v"(off), "v"(v), "s"(row) : "memory");
+}
+
 // ONE: a launch of one tick whose descriptors are kernel ARGUMENTS (tick_bgra_stream_one below) — `ticks` / `layers` point into the kernarg
 // segment, every field is a scalar load at a constant offset from one base, issued together: no tick -> first_layer -> layer chain of
 // dependent loads in front of a lone tick's waves, and no descriptor copy in front of the launch.
@@ -101,11 +107,11 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
     constexpr int LBYTES = st_layer_bytes<NL, PL>();
     constexpr int CPITCH = PL ? ST_CPP : ST_PITCH, CLB = PL ? ST_CLP : ST_CL;             // chroma ring row, one layer inside a chroma batch slot
     constexpr int VOFF = PL ? 2 * NL * ST_CLP : 1;                                       // from a U sample to its V sample
-    constexpr int WBYTES = NL * LBYTES + ST_TAB * (int)(sizeof(uint4) + sizeof(uint32_t));
+    constexpr int WBYTES = NL * LBYTES + ST_TAB * (int)(sizeof(uint4) + sizeof(uint2));
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     uint8_t *lds = lds_all + wave * WBYTES;
-    uint4 *rowtab = (uint4 *)(lds + NL * LBYTES);                 // [ST_TAB]
-    uint32_t *rowfl = (uint32_t *)(rowtab + ST_TAB);              // [ST_TAB] row flags
+    uint4 *rowtab = (uint4 *)(lds + NL * LBYTES);                 // [ST_TAB] what vector instructions use: {luma row weight, chroma row weight, 1 - luma, 1 - chroma}
+    uint2 *rowpos = (uint2 *)(rowtab + ST_TAB);                   // [ST_TAB] what the scalar unit uses: {luma tap row, chroma tap row (30 bits) | row inside the picture << 30}
     const uint32_t lds0 = (uint32_t)(size_t)lds;                  // LDS byte address of the rings (the DMA's M0)
     const int lane = threadIdx.x & 63;
     // XCD-aware numbering: block b runs on XCD b % 8; an XCD owns a contiguous range of (tick, chunk, group of ST_WAVES strips)
@@ -214,17 +220,21 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
             float rya, rca;
             lin_axis_raw(v, SY.h, ry, rya); lin_axis_raw(v, SC.h, rc, rca);
             if (lane < ST_TAB) {
-                rowtab[lane] = make_uint4((uint32_t)ry, (uint32_t)rc, __float_as_uint(rya), __float_as_uint(rca));
-                rowfl[lane] = (uint32_t)rfl;
+                rowtab[lane] = make_uint4(__float_as_uint(rya), __float_as_uint(rca), __float_as_uint(1.0f - rya), __float_as_uint(1.0f - rca));
+                // (tap rows stay within a few picture heights of the picture — the host admits vertical reductions up to 4 —: 30 bits hold them)
+                rowpos[lane] = make_uint2((uint32_t)ry, ((uint32_t)rc & 0x3FFFFFFFu) | (rfl == AX_ALL ? 0x40000000u : 0u));
             }
             wave_lds_fence();
         }
         const uint4 re = rowtab[j & (ST_TAB - 1)];
-        const int ry = __builtin_amdgcn_readfirstlane((int)re.x);
-        const int rc = __builtin_amdgcn_readfirstlane((int)re.y);
-        const int rfl = __builtin_amdgcn_readfirstlane((int)rowfl[j & (ST_TAB - 1)]);
-        const float yb = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)re.z));
-        const float cbw = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)re.w));
+        const uint2 rp = rowpos[j & (ST_TAB - 1)];
+        const int ry = __builtin_amdgcn_readfirstlane((int)rp.x);
+        const int rcw = __builtin_amdgcn_readfirstlane((int)rp.y);
+        const int rc = (int)((uint32_t)rcw << 2) >> 2;
+        const bool row_pic = (rcw & 0x40000000) != 0;
+        // (the row weights and their complements are used by vector instructions only: they stay the broadcast registers the LDS read
+        // returned — no v_readfirstlane, and the two subtractions were done once per row by the table's lane)
+        const float yb = __uint_as_float(re.x), cbw = __uint_as_float(re.y);
         // ---- residency: source rows ry, ry + 1 (luma) and rc, rc + 1 (chroma) of every layer ------------------------------
         // A ring holds two batches.  The next batch is REQUESTED as soon as the taps have left the older of the two (ry has entered the
         // newer one) and AWAITED only when a tap row reaches it — about two canvas rows later at a 1.5 : 1 reduction, time the other waves
@@ -289,14 +299,14 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
         // The previous row's pixels are stored HERE, right after this row's wait: gfx950 has one counter for loads and stores, the wait above
         // drains it, and a store issued just before it would be waited for every time (a write latency per wait); issued now it has
         // until the next wait, a row or two away.
-        if (j > 0 && x < T.W && !(CHV_ST_ABL & 2)) gst_at<uint32_t>(D.ptr + (size_t)(y0 + j - 1) * D.pitch, (uint32_t)x * 4u, pending);
+        if (j > 0 && x < T.W && !(CHV_ST_ABL & 2)) st_store(D.ptr + (size_t)(y0 + j - 1) * D.pitch, (uint32_t)x * 4u, pending);
         // ---- tap addresses and weights, once for all layers -----------------------------------------------------------------
         auto yoff = [&](int q) { return ((q >> 2) & 1) * (NL * ST_YL) + (q & 3) * ST_PITCH; };                       // layer 0's copy of luma row baseY + q
         auto coff = [&](int q) { return 2 * NL * ST_YL + ((q >> 1) & 1) * (NL * CLB) + (q & 1) * CPITCH; };
         const int sY0 = yoff(ry - baseY), sY1 = yoff(ry + 1 - baseY), sC0 = coff(rc - baseC), sC1 = coff(rc + 1 - baseC);
         const uint8_t *pY00 = lds + (oy0 + sY0), *pY10 = lds + (oy1 + sY0), *pY01 = lds + (oy0 + sY1), *pY11 = lds + (oy1 + sY1);
         const uint8_t *pC00 = lds + (oc0v + sC0), *pC10 = lds + (oc1v + sC0), *pC01 = lds + (oc0v + sC1), *pC11 = lds + (oc1v + sC1);
-        const float iyb = 1.0f - yb, icb = 1.0f - cbw;
+        const float iyb = __uint_as_float(re.z), icb = __uint_as_float(re.w);
         const float w00 = iya * iyb, w10 = ya * iyb, w01 = iya * yb, w11 = ya * yb;
         const float c00 = ica * icb, c10 = ca * icb, c01 = ica * cbw, c11 = ca * cbw;
         float r0 = 0.f, r1 = 0.f, r2 = 0.f;                          // img_clear_bgra: (0, 0, 0, 1) — the canvas pixel as float codes
@@ -341,10 +351,10 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
         asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(out) : "v"(r1));
         asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(out) : "v"(r2));
         // a pixel outside the picture keeps the cleared canvas (inside the border quad its alpha is forced: the same word)
-        const uint32_t res = (lane_pic && rfl == AX_ALL) ? out : alpha_word;
+        const uint32_t res = (lane_pic && row_pic) ? out : alpha_word;
         pending = res;
     }
-    if (nrows > 0 && x < T.W && !(CHV_ST_ABL & 2)) gst_at<uint32_t>(D.ptr + (size_t)(y0 + nrows - 1) * D.pitch, (uint32_t)x * 4u, pending);
+    if (nrows > 0 && x < T.W && !(CHV_ST_ABL & 2)) st_store(D.ptr + (size_t)(y0 + nrows - 1) * D.pitch, (uint32_t)x * 4u, pending);
 }
 
 template <int NL, bool PL, bool ABS>
@@ -442,7 +452,7 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     const bool planar = layers_host[ticks_host[0].first_layer].kind == LK_BGRA_FROM_Y420P;
     const size_t layer_bytes = planar ? (size_t)st_layer_bytes<1, true>() : (size_t)st_layer_bytes<1, false>();
-    const size_t lds = (size_t)ST_WAVES * ((size_t)nl * layer_bytes + ST_TAB * (sizeof(uint4) + sizeof(uint32_t)));
+    const size_t lds = (size_t)ST_WAVES * ((size_t)nl * layer_bytes + ST_TAB * (sizeof(uint4) + sizeof(uint2)));
     // the absorbed form of the colour matrix (pixel_math.hip.h) when every layer's matrix has one — all but BT.601 full range
     bool absorb = CHV_STREAM_ABSORB != 0;
     for (int i = 0; i < n_ticks && absorb; i++)
