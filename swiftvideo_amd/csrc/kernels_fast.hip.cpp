@@ -221,7 +221,10 @@ CHV_DEV void tiled_body(const DTick *__restrict__ ticks, const DLayer *__restric
         cyo[k] = tb.cy[c] - ycol0 + 16; cco[k] = (tb.cc[c] - ccol0 + CVEC) * CTB;
     }
     const CscFolded csc = csc_fold(kCsc[L.csc & 3]);
-    const CscFolded cscb = csc_fold_biased(kCsc[L.csc & 3]);
+    // the fast rows use the matrix with its red and blue offsets absorbed into the conversion biases (pixel_math.hip.h); a layer whose matrix
+    // has no such biases (BT.601 full range: the host sends it to the strip kernel, select_single_purpose) takes the per-pixel rows here
+    const bool absorbable = csc_absorbable(L.csc);
+    const CscAbsorbed csca = csc_fold_absorbed(L.csc);
     const bool opaque = (L.flags & LF_OPAQUE) != 0;
 
     for (int j = 0; j < ntiles; j++) {
@@ -278,7 +281,7 @@ CHV_DEV void tiled_body(const DTick *__restrict__ ticks, const DLayer *__restric
                     sample_nv12_lds_mix(smem, yrow + cyo[k], ypitch, crow + cco[k], cpitch,
                                         icya[k] * iyb, cya[k] * iyb, icya[k] * yb, cya[k] * yb,
                                         icca[k] * icb, cca[k] * icb, icca[k] * cb, cca[k] * cb, fy, fu, fv);
-                outw[k] = yuv_to_bgra_word(cscb, (int)code_biased(fy), (int)code_biased(fu), (int)code_biased(fv));
+                outw[k] = yuv_to_bgra_word_absorbed(csca, fy, fu, fv);
             }
         };
         auto store_row = [&](uint8_t *drow, const uint32_t (&outw)[PXT]) {
@@ -296,7 +299,7 @@ CHV_DEV void tiled_body(const DTick *__restrict__ ticks, const DLayer *__restric
                 if (STREAM) gst_stream(drow + (uint32_t)(xq * 4), outw[0]); else gst<uint32_t>(drow + (uint32_t)(xq * 4), outw[0]);
             }
         };
-        const bool fast_tile = uniform_inside && opaque;
+        const bool fast_tile = uniform_inside && opaque && absorbable;
         const bool whole_tile = fast_tile && full4 && ys0 + (j + 1) * TH <= T.H;
         uint32_t outw[RPT][PXT];
         if (whole_tile) {
@@ -455,6 +458,7 @@ static int select_single_purpose(const DTick *ticks, const DLayer *layers, int n
         const DLayer &L = layers[T.first_layer];
         if ((L.kind != LK_BGRA_FROM_NV12 && L.kind != LK_BGRA_FROM_Y420P) || !(L.flags & LF_AXIS_ALIGNED)) return FP_NONE;
         if (L.kind != layers[ticks[0].first_layer].kind) return FP_NONE;
+        if (!csc_absorbable(L.csc) && switches().bgra_path.load(std::memory_order_relaxed) != 2) return FP_NONE;      // (its fast rows need the absorbed matrix: the strip kernel is the faster one there)
         if (L.kind == LK_BGRA_FROM_Y420P && !aligned16(L.src.pl[2])) return FP_NONE;
         if (!finite16(L.u + U_TRANSFORM) || !finite16(L.u + U_TEXTURE) || !finite16(L.u + U_BORDER)) return FP_NONE;
         if (!aligned16(T.dst.pl[0]) || !aligned16(L.src.pl[0]) || !aligned16(L.src.pl[1])) return FP_NONE;

@@ -434,6 +434,15 @@ CHV_DEV void yuv_to_bgr_fixed_absorbed(const CscAbsorbed &k, float fy, float fu,
     const int32_t b = mad24_uniform(u, k.cbu, t);
     cb = min(max(b, 0), 0xFFFFFF); cg = min(max(g, 0), 0xFFFFFF); cr = min(max(r, 0), 0xFFFFFF);
 }
+// ... and packed into a memory-order BGRA word (yuv_to_bgra_word on biased operands, two adds shorter): the tiled kernel's opaque pixel
+CHV_DEV uint32_t yuv_to_bgra_word_absorbed(const CscAbsorbed &k, float fy, float fu, float fv) {
+    const int y = (int)__float_as_uint(fy + k.my), u = (int)__float_as_uint(fu + k.mu), v = (int)__float_as_uint(fv + k.mv);
+    const int32_t t = __mul24(y, k.cy);
+    const int32_t r = mad24_uniform(v, k.crv, t);
+    const int32_t g = mad24_uniform(v, k.ncgv, mad24_uniform(u, k.ncgu, t)) + k.kg;
+    const int32_t b = mad24_uniform(u, k.cbu, t);
+    return pack_bgra_fixed_pk(b, g, r);
+}
 CHV_DEV chv_half code_h(int32_t fixed24) { return __builtin_bit_cast(chv_half, (unsigned short)((uint32_t)fixed24 >> 16)); }
 // yuv_to_bgr_floats on FLOAT samples in code scale (the conversion is part of the form)
 CHV_DEV void yuv_to_bgr_floats_absorbed(const CscAbsorbed &k, float fy, float fu, float fv, float &fb, float &fg, float &fr) {
