@@ -168,7 +168,8 @@ __global__ void selftest_pack_codes_kernel(const float *in, uint32_t *out, int n
 //          (what code_biased hands the tiled / wave / stream kernels) packed by v_ashr_pk_u8_i32, and the float-code form of the blending
 //          kernels packed by v_cvt_pk_u8_f32, the same with the offsets absorbed into the conversion biases
 //          (yuv_to_bgr_floats_absorbed, where the matrix has such biases) — is compared with it on the device: *mism counts the triples on which any of them differs
-//   dir 1: i = R << 16 | G << 8 | B  ->  out[i] = Y | U << 8 | V << 16 through rgb_to_yuv_int
+//   dir 1: i = R << 16 | G << 8 | B  ->  out[i] = Y | U << 8 | V << 16 through rgb_to_yuv_int; *mism counts the triples on which the tick kernels'
+//          form of the rows (biased operands, folded offsets, float codes) differs from it
 __global__ void selftest_matrices_kernel(int dir, int csc, uint32_t *out, uint32_t *mism) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int a = (int)(i >> 16), b = (int)((i >> 8) & 255u), c = (int)(i & 255u);
@@ -209,6 +210,14 @@ __global__ void selftest_matrices_kernel(int dir, int csc, uint32_t *out, uint32
         // half that instruction does not leave zero — the defect pixel_math.hip.h::pack_bgra_fixed documents; it showed here as 15.5 M wrong
         // V codes in the first version of this very test)
         out[i] = pack_codes((float)y, (float)u, (float)v, 0u);
+        // the form the tick kernels use: operands that keep code_biased's 2^22, row offsets that take it out again (r2y_base_biased), the
+        // code as a float through clamp + v_cvt_f32_ubyte2 (fixed_to_codef)
+        const R2Y &k = kR2Y[csc & 3];
+        const int ra = (int)code_biased((float)a), ga = (int)code_biased((float)b), ba = (int)code_biased((float)c);
+        const float fy = fixed_to_codef(r2y_row(k.y[0], k.y[1], k.y[2], r2y_base_biased(k.y[0], k.y[1], k.y[2], (k.yoff << 16) + 32768), ra, ga, ba));
+        const float fu = fixed_to_codef(r2y_row(k.u[0], k.u[1], k.u[2], r2y_base_biased(k.u[0], k.u[1], k.u[2], (128 << 16) + 32768), ra, ga, ba));
+        const float fv = fixed_to_codef(r2y_row(k.v[0], k.v[1], k.v[2], r2y_base_biased(k.v[0], k.v[1], k.v[2], (128 << 16) + 32768), ra, ga, ba));
+        if (fy != (float)y || fu != (float)u || fv != (float)v) atomicAdd(mism, 1u);
     }
 }
 hipError_t launch_selftest_matrices(int dir, int csc, uint32_t *out, uint32_t *mism, hipStream_t stream) {

@@ -778,22 +778,23 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
                                 const float q2f = cs_mix(w00, w10, w01, w11, t02, t12, b02, b12);
                                 const float q3f = cs_mix(w00, w10, w01, w11, t03, t13, b03, b13);
                                 // to_code_raw of a convex combination of codes: no clamp can trigger; rint through the float adder
-                                const int cr = (int)(code_biased(q0f) & 255u), cg = (int)(code_biased(q1f) & 255u), cb = (int)(code_biased(q2f) & 255u);
+                                // (the multiplier's operands keep the adder's bias: r2y_base_biased, pixel_math.hip.h)
+                                const int cr = (int)code_biased(q0f), cg = (int)code_biased(q1f), cb = (int)code_biased(q2f);
                                 const float a2 = q3f * ka, ia2 = 1.f - a2;
-                                const int py = clip8(r2y_row(kk.y[0], kk.y[1], kk.y[2], (kk.yoff << 16) + 32768, cr, cg, cb) >> 16);
-                                const uint32_t nlw = ys_put_raw_k(lw, __builtin_fmaf((float)py, a2, curf * ia2), k);
+                                const float py = fixed_to_codef(r2y_row(kk.y[0], kk.y[1], kk.y[2], r2y_base_biased(kk.y[0], kk.y[1], kk.y[2], (kk.yoff << 16) + 32768), cr, cg, cb));
+                                const uint32_t nlw = ys_put_raw_k(lw, __builtin_fmaf(py, a2, curf * ia2), k);
                                 lw = tk ? nlw : lw;
                                 if (even_row) {
                                     // chroma of the quad: the even lane's pixel of this (even) row; the trip's second chroma row lives in the odd
                                     // lane (the values travel one lane up, quad_perm [0, 0, 2, 2])
-                                    int pu = clip8(r2y_row(kk.u[0], kk.u[1], kk.u[2], (128 << 16) + 32768, cr, cg, cb) >> 16);
-                                    int pv = clip8(r2y_row(kk.v[0], kk.v[1], kk.v[2], (128 << 16) + 32768, cr, cg, cb) >> 16);
+                                    float pu = fixed_to_codef(r2y_row(kk.u[0], kk.u[1], kk.u[2], r2y_base_biased(kk.u[0], kk.u[1], kk.u[2], (128 << 16) + 32768), cr, cg, cb));
+                                    float pv = fixed_to_codef(r2y_row(kk.v[0], kk.v[1], kk.v[2], r2y_base_biased(kk.v[0], kk.v[1], kk.v[2], (128 << 16) + 32768), cr, cg, cb));
                                     float sa = a2, sia = ia2;
                                     int stk = (tk && owner_lane) ? 1 : 0;
                                     if (k == 2) { pu = ys_dpp_even(pu); pv = ys_dpp_even(pv); sa = ys_dpp_even(a2); sia = ys_dpp_even(ia2); stk = ys_dpp_even(stk); }
                                     const bool mine = stk != 0 && par == (k >> 1);
-                                    const uint32_t nnu = ys_put_raw<0>(cu, __builtin_fmaf((float)pu, sa, ub0(cu) * sia));
-                                    const uint32_t nnv = ys_put_raw<0>(cv, __builtin_fmaf((float)pv, sa, ub0(cv) * sia));
+                                    const uint32_t nnu = ys_put_raw<0>(cu, __builtin_fmaf(pu, sa, ub0(cu) * sia));
+                                    const uint32_t nnv = ys_put_raw<0>(cv, __builtin_fmaf(pv, sa, ub0(cv) * sia));
                                     cu = mine ? nnu : cu; cv = mine ? nnv : cv;
                                 }
                             } else {
@@ -855,7 +856,9 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
         const int o0 = ys_o0(col[0].off);
         const R2Y &kk = kR2Y[(lf[0] >> 8) & 3];
         const int ky0 = kk.y[0], ky1 = kk.y[1], ky2 = kk.y[2], ku0 = kk.u[0], ku1 = kk.u[1], ku2 = kk.u[2], kv0 = kk.v[0], kv1 = kk.v[1], kv2 = kk.v[2];
-        const int cy_ = (kk.yoff << 16) + 32768, cc_ = (128 << 16) + 32768;
+        // (row offsets for operands that keep the float adder's bias: r2y_base_biased, pixel_math.hip.h)
+        const int cy_ = r2y_base_biased(ky0, ky1, ky2, (kk.yoff << 16) + 32768), ccu_ = r2y_base_biased(ku0, ku1, ku2, (128 << 16) + 32768),
+                  ccv_ = r2y_base_biased(kv0, kv1, kv2, (128 << 16) + 32768);
         const float ka = opac[0] * kInv255;
         auto fix = [&](uint32_t w) { return SWZ ? __builtin_amdgcn_perm(w, w, 0x03000102u) : w; };
         int q = ring_row<RingR>(rY[0], ry0);
@@ -881,20 +884,20 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
             const float q3f = cs_mix(wt, wt, wb, wb, rt03, rt13, b03, b13);
             rt00 = b00; rt01 = b01; rt02 = b02; rt03 = b03; rt10 = b10; rt11 = b11; rt12 = b12; rt13 = b13;
             // to_code_raw of a convex combination of codes: no clamp can trigger; rint through the float adder
-            const int cr = (int)(code_biased(q0f) & 255u), cg = (int)(code_biased(q1f) & 255u), cb = (int)(code_biased(q2f) & 255u);
+            const int cr = (int)code_biased(q0f), cg = (int)code_biased(q1f), cb = (int)code_biased(q2f);
             const float a2 = q3f * ka, ia2 = 1.f - a2;
-            const int py = (int)clip8(mad24_uniform(cr, ky0, mad24_uniform(cg, ky1, mad24_uniform(cb, ky2, cy_))) >> 16);
-            lw = ys_put_raw<k>(lw, (float)py * a2);
+            const float py = fixed_to_codef(mad24_uniform(cr, ky0, mad24_uniform(cg, ky1, mad24_uniform(cb, ky2, cy_))));
+            lw = ys_put_raw<k>(lw, py * a2);
             if constexpr ((k & 1) == 0) {
                 // chroma of the quad: the even lane's pixel of this (even) row; the trip's second chroma row lives in the odd lane (the values
                 // travel one lane up, quad_perm [0, 0, 2, 2])
-                int pu = (int)clip8(mad24_uniform(cr, ku0, mad24_uniform(cg, ku1, mad24_uniform(cb, ku2, cc_))) >> 16);
-                int pv = (int)clip8(mad24_uniform(cr, kv0, mad24_uniform(cg, kv1, mad24_uniform(cb, kv2, cc_))) >> 16);
+                float pu = fixed_to_codef(mad24_uniform(cr, ku0, mad24_uniform(cg, ku1, mad24_uniform(cb, ku2, ccu_))));
+                float pv = fixed_to_codef(mad24_uniform(cr, kv0, mad24_uniform(cg, kv1, mad24_uniform(cb, kv2, ccv_))));
                 float sa = a2, sia = ia2;
                 if constexpr (k == 2) { pu = ys_dpp_even(pu); pv = ys_dpp_even(pv); sa = ys_dpp_even(a2); sia = ys_dpp_even(ia2); }
                 const bool mine = par == (k >> 1);            // (every column of the strip is inside the picture and the canvas)
-                const uint32_t nnu = ys_put_raw<0>(cu, __builtin_fmaf((float)pu, sa, ub0(cu) * sia));
-                const uint32_t nnv = ys_put_raw<0>(cv, __builtin_fmaf((float)pv, sa, ub0(cv) * sia));
+                const uint32_t nnu = ys_put_raw<0>(cu, __builtin_fmaf(pu, sa, ub0(cu) * sia));
+                const uint32_t nnv = ys_put_raw<0>(cv, __builtin_fmaf(pv, sa, ub0(cv) * sia));
                 cu = mine ? nnu : cu; cv = mine ? nnv : cv;
             }
         };

@@ -359,25 +359,26 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                     const float q3 = cs_mix(w00, w10, w01, w11, t03, t13, b03, b13);
                     if constexpr (CARRY) { t00 = b00; t01 = b01; t02 = b02; t03 = b03; t10 = b10; t11 = b11; t12 = b12; t13 = b13; }
                     // to_code_raw of a convex combination of codes: no clamp can trigger; rint through the float adder
-                    const int cr = (int)(code_biased(q0) & 255u), cg = (int)(code_biased(q1) & 255u), cb = (int)(code_biased(q2) & 255u);
+                    // (the multiplier's operands keep the adder's bias: r2y_base_biased, pixel_math.hip.h)
+                    const int cr = (int)code_biased(q0), cg = (int)code_biased(q1), cb = (int)code_biased(q2);
                     const float a2 = q3 * ka, ia2 = 1.f - a2;
-                    const int py = clip8(r2y_row(k.y[0], k.y[1], k.y[2], (k.yoff << 16) + 32768, cr, cg, cb) >> 16);
+                    const float py = fixed_to_codef(r2y_row(k.y[0], k.y[1], k.y[2], r2y_base_biased(k.y[0], k.y[1], k.y[2], (k.yoff << 16) + 32768), cr, cg, cb));
                     uint32_t &lw = ly[j >> 2];
                     const float cyf = ubk<j & 3>(lw);
                     const float r0 = FILL ? clampf(__builtin_fmaf(fyf, af, cyf * iaf), 0.f, 255.f) : cyf;
-                    const uint32_t nlw = put_code_raw<j & 3>(lw, __builtin_fmaf((float)py, a2, r0 * ia2));
+                    const uint32_t nlw = put_code_raw<j & 3>(lw, __builtin_fmaf(py, a2, r0 * ia2));
                     lw = tk ? nlw : lw;
                     if constexpr ((j & 1) == 0) {
                         // chroma of the quad: the even lane's pixel of this (even) row; chroma row jj = j / 2 lives in the even lane
                         // (jj even) or in its odd neighbour (jj odd: the values travel one lane up, quad_perm [0, 0, 2, 2])
                         constexpr int jj = j >> 1, m = jj >> 1;
-                        int pu = clip8(r2y_row(k.u[0], k.u[1], k.u[2], (128 << 16) + 32768, cr, cg, cb) >> 16);
-                        int pv = clip8(r2y_row(k.v[0], k.v[1], k.v[2], (128 << 16) + 32768, cr, cg, cb) >> 16);
+                        float pu = fixed_to_codef(r2y_row(k.u[0], k.u[1], k.u[2], r2y_base_biased(k.u[0], k.u[1], k.u[2], (128 << 16) + 32768), cr, cg, cb));
+                        float pv = fixed_to_codef(r2y_row(k.v[0], k.v[1], k.v[2], r2y_base_biased(k.v[0], k.v[1], k.v[2], (128 << 16) + 32768), cr, cg, cb));
                         float sa = a2, sia = ia2;
                         int stk = (tk && owner_lane) ? 1 : 0;
                         if constexpr ((jj & 1) != 0) {
-                            pu = __builtin_amdgcn_update_dpp(pu, pu, 0xA0, 0xf, 0xf, false);
-                            pv = __builtin_amdgcn_update_dpp(pv, pv, 0xA0, 0xf, 0xf, false);
+                            pu = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pu), __float_as_int(pu), 0xA0, 0xf, 0xf, false));
+                            pv = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pv), __float_as_int(pv), 0xA0, 0xf, 0xf, false));
                             sa = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a2), __float_as_int(a2), 0xA0, 0xf, 0xf, false));
                             sia = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ia2), __float_as_int(ia2), 0xA0, 0xf, 0xf, false));
                             stk = __builtin_amdgcn_update_dpp(stk, stk, 0xA0, 0xf, 0xf, false);
@@ -386,8 +387,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
                         const float cuf = ubk<m>(nu), cvf = ubk<m>(nv);
                         const float r1 = FILL ? clampf(__builtin_fmaf(fuf, af, cuf * iaf), 0.f, 255.f) : cuf;
                         const float r2 = FILL ? clampf(__builtin_fmaf(fvf, af, cvf * iaf), 0.f, 255.f) : cvf;
-                        const uint32_t nnu = put_code_raw<m>(nu, __builtin_fmaf((float)pu, sa, r1 * sia));
-                        const uint32_t nnv = put_code_raw<m>(nv, __builtin_fmaf((float)pv, sa, r2 * sia));
+                        const uint32_t nnu = put_code_raw<m>(nu, __builtin_fmaf(pu, sa, r1 * sia));
+                        const uint32_t nnv = put_code_raw<m>(nv, __builtin_fmaf(pv, sa, r2 * sia));
                         nu = mine ? nnu : nu; nv = mine ? nnv : nv;
                     }
                 };

@@ -304,6 +304,16 @@ __device__ __constant__ const R2Y kR2Y[4] = {
 CHV_DEV int32_t r2y_row(int32_t c0, int32_t c1, int32_t c2, int32_t base, int r, int g, int b) {
     return __mul24(c0, r) + (__mul24(c1, g) + (__mul24(c2, b) + base));
 }
+// The kernels' form of a row.  The operands are code_biased's raw bits — the 24-bit multiplier sees 2^22 + code, no mask in front of it — and the
+// row's offset takes 2^22 x (c0 + c1 + c2) out again, in wrap-around arithmetic (r2y_base_biased); the row's code leaves as a float through
+// clamp-to-24-bits + v_cvt_f32_ubyte2, which is clip8(sum >> 16) (pack_bgra_fixed) without the shift.
+CHV_DEV int32_t r2y_base_biased(int32_t c0, int32_t c1, int32_t c2, int32_t base) { return (int32_t)((uint32_t)base - ((uint32_t)(c0 + c1 + c2) << 22)); }
+CHV_DEV float fixed_to_codef(int32_t sum16) {
+    const int32_t c = min(max(sum16, 0), 0xFFFFFF);
+    float f;
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(c));
+    return f;
+}
 CHV_DEV void rgb_to_yuv_int(const R2Y &k, int r, int g, int b, uint32_t &y, uint32_t &u, uint32_t &v) {
     y = clip8(r2y_row(k.y[0], k.y[1], k.y[2], (k.yoff << 16) + 32768, r, g, b) >> 16);
     u = clip8(r2y_row(k.u[0], k.u[1], k.u[2], (128 << 16) + 32768, r, g, b) >> 16);

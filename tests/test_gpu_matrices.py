@@ -50,7 +50,7 @@ def test_yuv_to_rgb_every_triple(ctx, csc):
 
 @pytest.mark.parametrize("csc", [0, 1, 2, 3])
 def test_rgb_to_yuv_every_triple(ctx, csc):
-    got, _ = _device(ctx, 1, csc)
+    got, mism = _device(ctx, 1, csc)
     r, g, b = _triples()
     yoff, ky, ku, kv = tables(csc)
     clip = lambda t: np.clip(t >> 16, 0, 255)      # noqa: E731
@@ -61,3 +61,4 @@ def test_rgb_to_yuv_every_triple(ctx, csc):
     bad = np.flatnonzero(got != exp)
     assert bad.size == 0, f"csc {csc}: {bad.size} of 2^24 triples differ, first (R, G, B) = {(int(bad[0]) >> 16, (int(bad[0]) >> 8) & 255, int(bad[0]) & 255)}: " \
                           f"device {int(got[bad[0]]):06x}, formula {int(exp[bad[0]]):06x}"
+    assert mism == 0, f"csc {csc}: the tick kernels' form of the rows (biased operands, folded offsets, float codes) differs from rgb_to_yuv_int on {mism} triples"
