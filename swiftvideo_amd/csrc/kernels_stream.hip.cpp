@@ -107,11 +107,11 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
     constexpr int LBYTES = st_layer_bytes<NL, PL>();
     constexpr int CPITCH = PL ? ST_CPP : ST_PITCH, CLB = PL ? ST_CLP : ST_CL;             // chroma ring row, one layer inside a chroma batch slot
     constexpr int VOFF = PL ? 2 * NL * ST_CLP : 1;                                       // from a U sample to its V sample
-    constexpr int WBYTES = NL * LBYTES + ST_TAB * (int)(sizeof(uint4) + sizeof(uint2));
+    constexpr int WBYTES = NL * LBYTES + ST_TAB * (int)(sizeof(uint4) + sizeof(uint32_t));       // (NV12, four layers: 6784 — six blocks of four waves per CU)
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     uint8_t *lds = lds_all + wave * WBYTES;
     uint4 *rowtab = (uint4 *)(lds + NL * LBYTES);                 // [ST_TAB] what vector instructions use: {luma row weight, chroma row weight, 1 - luma, 1 - chroma}
-    uint2 *rowpos = (uint2 *)(rowtab + ST_TAB);                   // [ST_TAB] what the scalar unit uses: {luma tap row, chroma tap row (30 bits) | row inside the picture << 30}
+    uint32_t *rowpos = (uint32_t *)(rowtab + ST_TAB);             // [ST_TAB] what the scalar unit uses: luma tap row (16 bits) | chroma tap row (15 bits) << 16 | row inside the picture << 31
     const uint32_t lds0 = (uint32_t)(size_t)lds;                  // LDS byte address of the rings (the DMA's M0)
     const int lane = threadIdx.x & 63;
     // XCD-aware numbering: block b runs on XCD b % 8; an XCD owns a contiguous range of (tick, chunk, group of ST_WAVES strips)
@@ -221,17 +221,16 @@ CHV_DEV void stream_body(const DTick *__restrict__ ticks, const DLayer *__restri
             lin_axis_raw(v, SY.h, ry, rya); lin_axis_raw(v, SC.h, rc, rca);
             if (lane < ST_TAB) {
                 rowtab[lane] = make_uint4(__float_as_uint(rya), __float_as_uint(rca), __float_as_uint(1.0f - rya), __float_as_uint(1.0f - rca));
-                // (tap rows stay within a few picture heights of the picture — the host admits vertical reductions up to 4 —: 30 bits hold them)
-                rowpos[lane] = make_uint2((uint32_t)ry, ((uint32_t)rc & 0x3FFFFFFFu) | (rfl == AX_ALL ? 0x40000000u : 0u));
+                // (rows of the picture: -1 .. plane rows - 1, which the host holds to 16 / 15 signed bits; rows outside it are not stored, and
+                // clamped — still rising with the canvas row — they steer the rings as their unclamped values would)
+                rowpos[lane] = ((uint32_t)min(max(ry, -32768), 32767) & 0xFFFFu) | (((uint32_t)min(max(rc, -16384), 16383) & 0x7FFFu) << 16) | (rfl == AX_ALL ? 0x80000000u : 0u);
             }
             wave_lds_fence();
         }
         const uint4 re = rowtab[j & (ST_TAB - 1)];
-        const uint2 rp = rowpos[j & (ST_TAB - 1)];
-        const int ry = __builtin_amdgcn_readfirstlane((int)rp.x);
-        const int rcw = __builtin_amdgcn_readfirstlane((int)rp.y);
-        const int rc = (int)((uint32_t)rcw << 2) >> 2;
-        const bool row_pic = (rcw & 0x40000000) != 0;
+        const int rp = __builtin_amdgcn_readfirstlane((int)rowpos[j & (ST_TAB - 1)]);
+        const int ry = (int)((uint32_t)rp << 16) >> 16, rc = (int)((uint32_t)rp << 1) >> 17;
+        const bool row_pic = rp < 0;
         // (the row weights and their complements are used by vector instructions only: they stay the broadcast registers the LDS read
         // returned — no v_readfirstlane, and the two subtractions were done once per row by the table's lane)
         const float yb = __uint_as_float(re.x), cbw = __uint_as_float(re.y);
@@ -407,6 +406,7 @@ bool bgra_stream_eligible(const DTick *ticks, const DLayer *layers, int n_ticks)
             const float op = Y.u[U_OPACITY];
             if (!(op >= 0.f && op <= 1.f)) return false;
             if (!stream_plane_ok(Y.src.pl[0]) || !stream_plane_ok(Y.src.pl[1])) return false;
+            if (Y.src.pl[0].h > 32767 || Y.src.pl[1].h > 16383) return false;          // (the row table packs tap rows into 16 / 15 signed bits)
             if (Y.src.pl[1].comps != (planar ? 1 : 2) || Y.src.pl[0].comps != 1) return false;
             if (planar) {
                 const DPlane &cu = Y.src.pl[1], &cv = Y.src.pl[2];
@@ -452,7 +452,7 @@ hipError_t launch_bgra_stream(const DTick *ticks_host, const DLayer *layers_host
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     const bool planar = layers_host[ticks_host[0].first_layer].kind == LK_BGRA_FROM_Y420P;
     const size_t layer_bytes = planar ? (size_t)st_layer_bytes<1, true>() : (size_t)st_layer_bytes<1, false>();
-    const size_t lds = (size_t)ST_WAVES * ((size_t)nl * layer_bytes + ST_TAB * (sizeof(uint4) + sizeof(uint2)));
+    const size_t lds = (size_t)ST_WAVES * ((size_t)nl * layer_bytes + ST_TAB * (sizeof(uint4) + sizeof(uint32_t)));
     // the absorbed form of the colour matrix (pixel_math.hip.h) when every layer's matrix has one — all but BT.601 full range
     bool absorb = CHV_STREAM_ABSORB != 0;
     for (int i = 0; i < n_ticks && absorb; i++)
