@@ -1617,9 +1617,10 @@ LIMITER_TABLE = {"pipeline": "valu_issue", "pipeline_y420p": "valu_issue", "pipe
                  "cfg3": "power_cap", "cfg5": "power_cap", "mixer_y420p": "valu_issue", "mixer_nv12": "valu_issue", "y420p_main": "valu_issue",
                  "encode_nv12": "valu_issue", "pipeline_grid": "latency", "mixed": "latency"}
 SCLK_MAX_MHZ = 2400.0
-# the headline kernel's additive issue model (profiles/r03_notes.md section 1, r05_notes.md 10.4): per 64-pixel row of a 4-layer tick one wave issues
-# 83 full-rate + 95 half-rate vector instructions + 48 LDS instructions at 1.1 / 1.8 / 1.05 ns; 256 CUs x 4 SIMDs issue in parallel
-ISSUE_MODEL = {"tick_bgra_stream": {"layers": 4, "fast": 83, "slow": 95, "lds": 48, "ns": (1.1, 1.8, 1.05), "simds": 1024}}
+# the headline kernel's additive issue model (profiles/r03_notes.md section 1, r05_notes.md 10.4, r06_notes.md section 11): per 64-pixel row of a
+# 4-layer tick one wave issues 54 full-rate + 95 half-rate vector instructions + 50 LDS instructions (83 + 95 + 48 until round 6 took 29
+# full-rate ones out) at 1.1 / 1.8 / 1.05 ns; 256 CUs x 4 SIMDs issue in parallel
+ISSUE_MODEL = {"tick_bgra_stream": {"layers": 4, "fast": 54, "slow": 95, "lds": 50, "ns": (1.1, 1.8, 1.05), "simds": 1024}}
 
 
 def limiter_of(name, probe):

@@ -125,6 +125,30 @@ def test_stream_kernel_owns_m0_and_keeps_six_waves(tmp_path):
     assert not others, others[:3]
 
 
+def test_stream_kernel_keeps_its_shortened_row(tmp_path):
+    """The headline instantiation (four NV12 layers, absorbed colour matrix): what round 6 took OUT of a row must stay out.  Per layer and row:
+    12 taps + 3 blend inputs through v_fma_mix_f32 (no v_cvt_f32_ubyte2 in front of the blend), one integer add (the green offset: red and blue
+    are absorbed into the conversion biases), no mask and no subtraction of the rounding constant, the row's store addressed from a scalar base.
+    Counted on the whole kernel (its row loop is not unrolled): the plain-matrix twin carries the three adds per layer."""
+    co = _code_object(tmp_path, "kernels_stream")
+    asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    bodies = re.split(r"\n[0-9a-f]+ <(_ZN3chv16tick_bgra_streamILi4ELb0ELb[01]E[^>]*)>:\n", asm)
+    found = {}
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        body = re.split(r"\n[0-9a-f]+ <_Z", body)[0]
+        ops = [l.split("//")[0].split()[0] for l in body.splitlines() if l.strip() and not l.strip().endswith(":")]
+        found["ELb1EEE" in name[:40] or name.startswith("_ZN3chv16tick_bgra_streamILi4ELb0ELb1E")] = ops
+    assert set(found) == {True, False}
+    ab, plain = found[True], found[False]
+    assert ab.count("v_fma_mix_f32") == 60 and plain.count("v_fma_mix_f32") == 48
+    assert ab.count("v_cvt_f32_ubyte2_e32") == 0 and plain.count("v_cvt_f32_ubyte2_e32") == 12
+    assert ab.count("v_mad_i32_i24") == plain.count("v_mad_i32_i24") == 16
+    assert plain.count("v_add_u32_e32") - ab.count("v_add_u32_e32") == 8          # two channel offsets x four layers
+    assert ab.count("v_readfirstlane_b32") <= 12                                     # (one per row: the packed row entry; the rest is set-up)
+    for ops in (ab, plain):
+        assert ops.count("v_lshl_add_u64") <= 5 and ops.count("global_store_dword") == 2       # (no 64-bit vector add per row in front of the store)
+
+
 def _lds_dma_contract(co, min_loads):
     asm = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
     lines = [l.split("//")[0].strip() for l in asm.splitlines()]

@@ -55,6 +55,20 @@
 #define I_XOR(d)      "v_xor_b32 " #d ", " #d ", %10"
 #define I_LSHLOR(d)   "v_lshl_or_b32 " #d ", " #d ", 8, %10"
 #define I_PKMULF32(d) "v_mul_f32 " #d ", " #d ", %8"
+#define I_SATPK(d)    "v_sat_pk_u8_i16 " #d ", " #d
+#define I_MED3I(d)    "v_med3_i32 " #d ", " #d ", 0, %10"
+#define I_CVTFI(d)    "v_cvt_f32_i32 " #d ", " #d
+#define I_ALIGNBIT(d) "v_alignbit_b32 " #d ", " #d ", %10, 16"
+// whole packs of three 16.16 sums (registers r0..r2 / r4..r6) into a BGRA word, two pixels per group of (5 | 5 | 3) x 2 instructions
+#define PACK_MED3 asm volatile("v_med3_i32 %0, %0, 0, %10\n v_med3_i32 %1, %1, 0, %10\n v_med3_i32 %2, %2, 0, %10\n v_perm_b32 %3, %1, %0, %10\n v_perm_b32 %3, %2, %3, %10\n" \
+    "v_med3_i32 %4, %4, 0, %10\n v_med3_i32 %5, %5, 0, %10\n v_med3_i32 %6, %6, 0, %10\n v_perm_b32 %7, %5, %4, %10\n v_perm_b32 %7, %6, %7, %10" \
+    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(b0), "v"(b1), "v"(i2));
+#define PACK_SATPK asm volatile("v_perm_b32 %3, %1, %0, %10\n v_sat_pk_u8_i16 %3, %3\n v_perm_b32 %0, %10, %2, %10\n v_sat_pk_u8_i16 %0, %0\n v_lshl_or_b32 %3, %0, 16, %3\n" \
+    "v_perm_b32 %7, %5, %4, %10\n v_sat_pk_u8_i16 %7, %7\n v_perm_b32 %4, %10, %6, %10\n v_sat_pk_u8_i16 %4, %4\n v_lshl_or_b32 %7, %4, 16, %7" \
+    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(b0), "v"(b1), "v"(i2));
+#define PACK_ASHR asm volatile("v_ashr_pk_u8_i32 %3, %0, %1, 16\n v_ashr_pk_u8_i32 %0, %2, %10, 16\n v_perm_b32 %3, %0, %3, %10\n" \
+    "v_ashr_pk_u8_i32 %7, %4, %5, 16\n v_ashr_pk_u8_i32 %4, %6, %10, 16\n v_perm_b32 %7, %4, %7, %10" \
+    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(b0), "v"(b1), "v"(i2));
 // mixes: 4 fast + 4 slow alternating on different registers
 #define MIX_FMA_CVT asm volatile("v_fma_f32 %0, %0, %8, %9\n v_cvt_f32_ubyte1 %1, %10\n v_fma_f32 %2, %2, %8, %9\n v_cvt_f32_ubyte2 %3, %10\n" \
     "v_fma_f32 %4, %4, %8, %9\n v_cvt_f32_ubyte3 %5, %10\n v_fma_f32 %6, %6, %8, %9\n v_cvt_f32_ubyte0 %7, %10" \
@@ -111,6 +125,13 @@ __global__ __launch_bounds__(256) void bench(uint32_t *out, int iters, float see
         if (OP == 35) { REP16(G8(I_XOR)) }
         if (OP == 36) { REP16(G8(I_LSHLOR)) }
         if (OP == 37) { REP16(G8(I_CVTUBS)) }
+        if (OP == 50) { REP16(G8(I_SATPK)) }
+        if (OP == 51) { REP16(G8(I_MED3I)) }
+        if (OP == 52) { REP16(G8(I_CVTFI)) }
+        if (OP == 53) { REP16(G8(I_ALIGNBIT)) }
+        if (OP == 54) { REP16(PACK_MED3) }
+        if (OP == 55) { REP16(PACK_SATPK) }
+        if (OP == 56) { REP16(PACK_ASHR) }
         if (OP == 40) { REP16(MIX_FMA_CVT) }
         if (OP == 41) { REP16(MIX_FMA_MAD) }
         if (OP == 42) { REP16(MIX_FMA_SALU) }
@@ -143,6 +164,13 @@ void run(const char *name, uint32_t *d_out, int waves_per_simd, int per_group = 
 #define RUN(OP, NAME) for (int w : {1, 2, 4, 8}) run<OP>(NAME, d_out, w);
 int main(int argc, char **argv) {
     uint32_t *d_out; hipMalloc(&d_out, 1024);
+    if (argc > 1 && argv[1][0] == 'p') {      // packing three 16.16 sums into a BGRA word: single instructions, then whole packs (ns per PIXEL = ns x instructions per pack)
+        RUN(50, "v_sat_pk_u8_i16") RUN(51, "v_med3_i32") RUN(52, "v_cvt_f32_i32") RUN(53, "v_alignbit_b32") RUN(11, "v_perm_b32") RUN(12, "v_ashr_pk_u8_i32")
+        for (int w : {1, 2, 4, 8}) run<54>("pack: 3 med3 + 2 perm (5 per pixel)", d_out, w, 10);
+        for (int w : {1, 2, 4, 8}) run<55>("pack: 2 perm + 2 sat_pk + lshl_or (5)", d_out, w, 10);
+        for (int w : {1, 2, 4, 8}) run<56>("pack: 2 ashr_pk + perm (3)", d_out, w, 6);
+        return 0;
+    }
     if (argc > 1) {      // second part only (the first call of the round ran out of its time limit behind v_lshl_add_u32)
         RUN(20, "v_lshrrev_b32") RUN(21, "v_mov_b32") RUN(26, "v_med3_f32") RUN(27, "v_max_f32") RUN(28, "v_rndne_f32")
         RUN(40, "mix fma+cvt_ubyte") RUN(41, "mix fma+mad24")
