@@ -538,9 +538,9 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
         // ---- the trip's luma: a 4 x 4 byte transpose inside every quad of lanes turns "4 rows of one column" into "4 columns of one row" ----
         {
             const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
-            const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lw, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+            const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)lw, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
             const uint32_t aa = __builtin_amdgcn_perm(p1, lw, sel1);
-            const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)aa, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
+            const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)aa, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
             pend_lw = __builtin_amdgcn_perm(p2, aa, sel2);
             // (lane 4 c + r holds row r, columns 4 c .. 4 c + 3; lane 16 r + c takes it: a quarter wave then holds 64 contiguous bytes of one row)
             if (CHV_YS_STORE & 1) pend_lw = (uint32_t)__builtin_amdgcn_ds_bpermute((4 * (lane & 15) + (lane >> 4)) * 4, (int)pend_lw);
@@ -559,12 +559,12 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
                 const int srcl = ((lane & ~7) + 2 * (lane & 3) + ((lane >> 2) & 1)) * 4;
                 const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
                 auto regroup = [&](uint32_t v) {
-                    const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+                    const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)v, 0xB1, 0xf, 0xf, false);
                     uint32_t q = __builtin_amdgcn_perm(p, v, selp);
                     q = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)q);
-                    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q, 0xB1, 0xf, 0xf, false);
+                    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)q, 0xB1, 0xf, 0xf, false);
                     const uint32_t bq = __builtin_amdgcn_perm(p1, q, sel1);
-                    const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bq, 0x4E, 0xf, 0xf, false);
+                    const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)bq, 0x4E, 0xf, 0xf, false);
                     return __builtin_amdgcn_perm(p2, bq, sel2);
                 };
                 const uint32_t tu = regroup(nu), tv = regroup(nv);
@@ -860,13 +860,16 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
         const int cy_ = r2y_base_biased(ky0, ky1, ky2, (kk.yoff << 16) + 32768), ccu_ = r2y_base_biased(ku0, ku1, ku2, (128 << 16) + 32768),
                   ccv_ = r2y_base_biased(kv0, kv1, kv2, (128 << 16) + 32768);
         const float ka = opac[0] * kInv255;
-        auto fix = [&](uint32_t w) { return SWZ ? __builtin_amdgcn_perm(w, w, 0x03000102u) : w; };
+        // (texels are taken as R, G, B, A whatever the source order: a swizzled source has R in byte 2 and B in byte 0 — which byte a
+        // conversion reads is free, a v_perm_b32 per texel in front of the conversions was not)
+        auto red = [](uint32_t w) { return SWZ ? ub2(w) : ub0(w); };
+        auto blue = [](uint32_t w) { return SWZ ? ub0(w) : ub2(w); };
         int q = ring_row<RingR>(rY[0], ry0);
         if (rt_row != ry0) {
             const uint8_t *p0 = ldsY + (q + o0);
-            const uint32_t u00 = fix(*(const uint32_t *)p0), u10 = fix(*(const uint32_t *)(p0 + 4));
-            rt00 = ub0(u00); rt01 = ub1(u00); rt02 = ub2(u00); rt03 = ub3(u00);
-            rt10 = ub0(u10); rt11 = ub1(u10); rt12 = ub2(u10); rt13 = ub3(u10);
+            const uint32_t u00 = *(const uint32_t *)p0, u10 = *(const uint32_t *)(p0 + 4);
+            rt00 = red(u00); rt01 = ub1(u00); rt02 = blue(u00); rt03 = ub3(u00);
+            rt10 = red(u10); rt11 = ub1(u10); rt12 = blue(u10); rt13 = ub3(u10);
         }
         uint32_t lw = 0, cu = 128u, cv = 128u;
         auto row = [&](auto kc) {
@@ -874,9 +877,9 @@ CHV_DEV void ys_body(const DTick *__restrict__ ticks, const DLayer *__restrict__
             const float bw = rya[k], ib = 1.0f - bw;
             q = ring_next<RingR>(q);
             const uint8_t *p1 = ldsY + (q + o0);
-            const uint32_t u01 = fix(*(const uint32_t *)p1), u11 = fix(*(const uint32_t *)(p1 + 4));
-            const float b00 = ub0(u01), b01 = ub1(u01), b02 = ub2(u01), b03 = ub3(u01);
-            const float b10 = ub0(u11), b11 = ub1(u11), b12 = ub2(u11), b13 = ub3(u11);
+            const uint32_t u01 = *(const uint32_t *)p1, u11 = *(const uint32_t *)(p1 + 4);
+            const float b00 = red(u01), b01 = ub1(u01), b02 = blue(u01), b03 = ub3(u01);
+            const float b10 = red(u11), b11 = ub1(u11), b12 = blue(u11), b13 = ub3(u11);
             const float wt = 0.5f * ib, wb = 0.5f * bw;
             const float q0f = cs_mix(wt, wt, wb, wb, rt00, rt10, b00, b10);
             const float q1f = cs_mix(wt, wt, wb, wb, rt01, rt11, b01, b11);

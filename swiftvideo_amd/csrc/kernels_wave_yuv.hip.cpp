@@ -518,9 +518,9 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
         if (wide) {
             const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
             auto quad_transpose = [&](uint32_t v) {
-                const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+                const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
                 const uint32_t a = __builtin_amdgcn_perm(p1, v, sel1);
-                const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
+                const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)a, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
                 return __builtin_amdgcn_perm(p2, a, sel2);
             };
             const uint32_t loff = (uint32_t)(lane & 3) * (uint32_t)PY.pitch + (uint32_t)(x0 + (lane & ~3));
@@ -537,12 +537,12 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
             const int src = ((lane & ~7) + 2 * (lane & 3) + ((lane >> 2) & 1)) * 4;         // ds_bpermute: lane 8c + i <- column 4c + i (rows 0-3), lane 8c + 4 + i <- the same column (rows 4-7)
             const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
             auto regroup = [&](uint32_t v) {
-                const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+                const uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)v, 0xB1, 0xf, 0xf, false);
                 uint32_t a = __builtin_amdgcn_perm(p, v, selp);
                 a = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)a);
-                const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1, 0xf, 0xf, false);
+                const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)a, 0xB1, 0xf, 0xf, false);
                 const uint32_t b = __builtin_amdgcn_perm(p1, a, sel1);
-                const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xf, 0xf, false);
+                const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp(dpp_old(), (int)b, 0x4E, 0xf, 0xf, false);
                 return __builtin_amdgcn_perm(p2, b, sel2);                                   // lane 8c + i: row i (+ 4 for lanes 8c + 4 ..), columns 4c .. 4c + 3
             };
             const uint32_t tu = regroup(nu), tv = regroup(nv);

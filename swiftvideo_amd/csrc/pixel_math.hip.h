@@ -53,6 +53,9 @@ template <typename T> CHV_DEV void gst_at(uint8_t *base, uint32_t off, T v) { *(
 CHV_DEV void gst_stream(void *p, uint2 v) { chv_u32x2 t = { v.x, v.y }; __builtin_nontemporal_store(t, (CHV_GLOBAL chv_u32x2 *)(uintptr_t)p); }
 CHV_DEV void gst_stream(void *p, uint4 v) { chv_u32x4 t = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(t, (CHV_GLOBAL chv_u32x4 *)(uintptr_t)p); }
 CHV_DEV void gst_stream(void *p, uint32_t v) { __builtin_nontemporal_store(v, (CHV_GLOBAL uint32_t *)(uintptr_t)p); }
+// The `old` operand of a DPP move whose every lane reads a valid lane (quad_perm, all rows and banks): never used, and a register that no
+// instruction had to initialise (an empty asm "defines" it) — update_dpp(0, ...) costs a v_mov_b32 per move.
+CHV_DEV int dpp_old() { int v; asm("" : "=v"(v)); return v; }
 // An unconditional (empty) use of prefetched registers.  hipcc places its s_waitcnt for a load in front of the
 // first use it sees on a path and merges paths pessimistically: with the prefetch consumed only under conditions
 // (staged? lane owns a slot?) the registers stay "maybe pending" on the paths that skip the use, and every load
