@@ -79,3 +79,25 @@ def test_batches_of_many_ticks_choose_per_launch(ctx, cscs):
     G.destroy_batch(h)
     for i, (gd, exp) in enumerate(zip(gds, exps)):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", CW, CH), exp, f"tick {i}")
+
+
+@pytest.mark.parametrize("rows, streamed", [(32766, True), (32770, False)])
+def test_stream_row_table_holds_the_tallest_planes_it_admits(ctx, rows, streamed):
+    """The streaming kernel's row table packs a row's two tap rows into 16 / 15 signed bits (kernels_stream.hip.cpp): planes of up to 32767 luma /
+    16383 chroma rows are admitted — the last rows of such a picture are the largest values the fields ever hold — taller ones go to the strip
+    kernel.  Two same-geometry NV12 layers, 4 : 1 down onto an 8200-row canvas."""
+    cw, ch, sw = 64, (rows + 3) // 4 + 8, 64
+    exp = util.alloc_image("bgra", cw, ch)
+    assert O.run_kernel("img_clear_bgra", exp) == 0
+    layers = []
+    for i, o in enumerate((1.0, 0.5)):
+        u = util.make_uniforms((cw, ch), in_size=(sw, rows), opacity=o)
+        src = util.alloc_image("nv12", sw, rows, seed=810 + i)
+        assert O.run_kernel("img_nv12_bgra", exp, src, u, threads=8) == 0
+        layers.append((sv.ComputeKernel.img_nv12_bgra, G.to_gpu(ctx, "nv12", sw, rows, src), u, 0))
+    gd = G.to_gpu(ctx, "bgra", cw, ch, util.alloc_image("bgra", cw, ch, seed=820))
+    h, name, keep = G.make_batch(ctx, [(gd, True, layers)])
+    assert (name == "tick_bgra_stream") == streamed, name
+    G.run_batch(ctx, h)
+    G.destroy_batch(h)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"{rows} source rows via {name}")
