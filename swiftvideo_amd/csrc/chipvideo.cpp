@@ -32,7 +32,7 @@ const char *yuv_wave_build_flags();       // kernels_wave_yuv.hip.cpp
 const char *bgra_stream_build_flags();   // kernels_stream.hip.cpp
 const char *yuv_stream_build_flags();    // kernels_stream_yuv.hip.cpp
 const char *lanczos_build_flags();       // kernels_lanczos.hip.cpp
-hipError_t launch_tick_general(int target_format, const DTick *ticks, const DLayer *layers,
+hipError_t launch_tick_general(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                                int n_ticks, int maxW, int maxH, hipStream_t stream);
 hipError_t launch_selftest(float *out_f, const float *in_f, uint8_t *out_c, const float *num,
                            const float *den, float *out_q, int n, hipStream_t stream);
@@ -1135,7 +1135,7 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     }
     DLayer *dl = (DLayer *)((uint8_t *)dt + sizeof(DTick));
     hipError_t e = path >= 0 ? launch_tick_fast(path, st, sl, dt, dl, 1, st->W, st->H, c->stream)
-                             : launch_tick_general(tf, dt, dl, 1, st->W, st->H, c->stream);
+                             : launch_tick_general(tf, st, sl, dt, dl, 1, st->W, st->H, c->stream);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CHV_OK;
 }
@@ -1475,12 +1475,12 @@ extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
     } scope(b);
     hipError_t e = b->fast_path >= 0
         ? launch_tick_fast(b->fast_path, b->h_ticks.data(), b->h_layers.data(), b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
-        : launch_tick_general(b->target_format, b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
+        : launch_tick_general(b->target_format, b->h_ticks.data(), b->h_layers.data(), b->d_ticks, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     if (b->fast_path2 != -2) {
         e = b->fast_path2 >= 0
             ? launch_tick_fast(b->fast_path2, b->h_ticks2.data(), b->h_layers.data(), b->d_ticks2, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream)
-            : launch_tick_general(b->target_format, b->d_ticks2, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
+            : launch_tick_general(b->target_format, b->h_ticks2.data(), b->h_layers.data(), b->d_ticks2, b->d_layers, b->n_ticks, b->maxW, b->maxH, c->stream);
         if (e != hipSuccess) return hip_fail(e, "kernel launch (second part of the batch)");
     }
     return CHV_OK;

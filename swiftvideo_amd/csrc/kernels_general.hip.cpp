@@ -16,17 +16,21 @@
 #include "bgra_pixel.hip.h"
 #include "yuv_pixel.hip.h"
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace chv {
 
 // apply_layer_bgra: bgra_pixel.hip.h (shared with kernels_wave.hip.cpp)
 
+// (ox, oy): the grid's first pixel — launches on canvases that are not cleared cover the union of their layers' bounding boxes only
+// (launch_tick_general: a pixel outside every layer's box keeps its bytes)
 __global__ __launch_bounds__(256) void tick_general_bgra(const DTick *__restrict__ ticks,
-                                                         const DLayer *__restrict__ layers) {
+                                                         const DLayer *__restrict__ layers, int ox, int oy) {
     const DTick &T = ticks[blockIdx.z];
-    int x = blockIdx.x * 64 + threadIdx.x;
-    int y = blockIdx.y * 4 + threadIdx.y;
+    int x = ox + blockIdx.x * 64 + threadIdx.x;
+    int y = oy + blockIdx.y * 4 + threadIdx.y;
     if (x >= T.W || y >= T.H) return;
     const DPlane &D = T.dst.pl[0];
     if (x >= D.w || y >= D.h) return;
@@ -116,12 +120,33 @@ __global__ __launch_bounds__(256) void tick_general_yuv(const DTick *__restrict_
 // ---------------------------------------------------------------------------
 // launchers (called from chipvideo.cpp)
 // ---------------------------------------------------------------------------
-hipError_t launch_tick_general(int target_format, const DTick *ticks, const DLayer *layers,
+// ticks_host / layers_host (may be null): the same descriptors on the host, for the grid of launches that do not clear
+hipError_t launch_tick_general(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                                int n_ticks, int maxW, int maxH, hipStream_t stream) {
     if (n_ticks <= 0) return hipSuccess;
     if (target_format == TF_BGRA) {
-        dim3 block(64, 4), grid((maxW + 63) / 64, (maxH + 3) / 4, n_ticks);
-        hipLaunchKernelGGL(tick_general_bgra, grid, block, 0, stream, ticks, layers);
+        int x0 = 0, y0 = 0, x1 = maxW, y1 = maxH;
+        if (ticks_host && layers_host) {
+            // no tick clears: the union of every layer's bounding box (what the second launch of a split batch — a rotated logo over videos the
+            // streaming kernel composed — has to touch: a few thousand pixels of a 720p canvas)
+            bool clears = false;
+            int bx0 = maxW, by0 = maxH, bx1 = 0, by1 = 0;
+            for (int i = 0; i < n_ticks && !clears; i++) {
+                const DTick &T = ticks_host[i];
+                clears = T.clear_first != 0;
+                for (int l = 0; l < T.n_layers; l++) {
+                    const DLayer &L = layers_host[T.first_layer + l];
+                    bx0 = std::min(bx0, std::max(L.bbox[0], 0)); by0 = std::min(by0, std::max(L.bbox[1], 0));
+                    bx1 = std::max(bx1, std::min(L.bbox[2], T.W)); by1 = std::max(by1, std::min(L.bbox[3], T.H));
+                }
+            }
+            if (!clears) {
+                if (bx1 <= bx0 || by1 <= by0) return hipSuccess;          // nothing any layer could touch
+                x0 = bx0 & ~15; y0 = by0 & ~3; x1 = bx1; y1 = by1;        // (64-byte aligned rows of four)
+            }
+        }
+        dim3 block(64, 4), grid((x1 - x0 + 63) / 64, (y1 - y0 + 3) / 4, n_ticks);
+        hipLaunchKernelGGL(tick_general_bgra, grid, block, 0, stream, ticks, layers, x0, y0);
     } else {
         int qw = (maxW + 1) / 2, qh = (maxH + 1) / 2;
         dim3 block(32, 8), grid((qw + 31) / 32, (qh + 7) / 8, n_ticks);

@@ -73,7 +73,7 @@ const char *yuv_wave_build_flags() { return "stub:abl=0"; }
 const char *bgra_stream_build_flags() { return "stub:abl=0"; }
 const char *yuv_stream_build_flags() { return "stub:abl=0"; }
 const char *lanczos_build_flags() { return "stub:abl=0"; }
-hipError_t launch_tick_general(int, const DTick *ticks, const DLayer *layers, int n_ticks, int, int, hipStream_t stream) {
+hipError_t launch_tick_general(int, const DTick *, const DLayer *, const DTick *ticks, const DLayer *layers, int n_ticks, int, int, hipStream_t stream) {
     return enqueue_ticks(nullptr, nullptr, ticks, layers, n_ticks, stream);
 }
 hipError_t launch_selftest(float *, const float *, uint8_t *, const float *, const float *, float *, int, hipStream_t) { return hipErrorNotSupported; }

@@ -107,3 +107,27 @@ def test_split_batch_second_launch_covers_the_logo_only(ctx):
     G.destroy_batch(h_)
     for i, (gd, exp) in enumerate(zip(gds, exps)):
         G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"tick {i}")
+
+
+@pytest.mark.parametrize("rect", range(len(RECTS)))
+def test_general_kernel_on_an_uncleared_canvas_covers_its_layers_boxes(ctx, rect, switch):
+    """tick_general_bgra too (launch_tick_general: the grid of a launch that clears nothing is the union of its layers' bounding boxes)"""
+    switch("CHV_FORCE_GENERAL", "1")
+    x, y, w, h, rot = RECTS[rect]
+    rng = np.random.default_rng(500 + rect)
+    (name, s, iw, ih), = _layers_for("bgra", rng, 1)
+    u = util.make_uniforms((CW, CH), rect=(x, y, w, h), rotation=rot, opacity=0.7, in_size=(iw, ih))
+    u2 = util.make_uniforms((CW, CH), rect=(CW - x - w, CH - y - h, w, h), rotation=-rot, opacity=0.5, in_size=(iw, ih))
+    src = util.alloc_image(s, iw, ih, seed=17 + rect)
+    canvas0 = util.alloc_image("bgra", CW, CH, seed=19 + rect)
+    exp = util.copy_image(canvas0)
+    assert O.run_kernel(name, exp, src, u) == 0
+    assert O.run_kernel(name, exp, src, u2) == 0
+    gd, gs = G.to_gpu(ctx, "bgra", CW, CH, canvas0), G.to_gpu(ctx, s, iw, ih, src)
+    k = sv.defaultComputeKernelFromString(name)
+    h_, kname, keep = G.make_batch(ctx, [(gd, False, [(k, gs, u, 0), (k, gs, u2, 0)])])
+    assert kname == "tick_general_bgra", kname
+    G.run_batch(ctx, h_)
+    G.destroy_batch(h_)
+    G.assert_same(G.from_gpu(ctx, gd, "bgra", CW, CH), exp, f"{name} at {RECTS[rect]} and mirrored through {kname}")
+    del gs
