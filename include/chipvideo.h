@@ -66,6 +66,10 @@ const char *chv_build_flags(void);
  * CHV_DESC=host|device, CHV_STREAM=0, CHV_YUV_STREAM=0|force, CHV_WAVE_DMA=0, CHV_PASS_FUSE=0, CHV_GEOM_CACHE=0|eager);
  * NULL or "" restores the default.  Process-wide, atomic; not part of the Swift-facing contract. */
 int chv_debug_set_switch(const char *name, const char *value);
+/* Measurement / test hook: counters of the current device's store of strip-kernel geometry tables (csrc/geom_cache.h): "geom_store_patched"
+ * (launches whose layers were pointed at stored tables before their descriptors travelled: batches at creation, lone ticks),
+ * "geom_store_batch_hits", "geom_store_builds", "geom_store_bytes", "geom_store_tables".  Unknown name -> CHV_ERR_INVALID_VALUE. */
+int chv_debug_get_counter(const char *name, unsigned long long *value);
 
 /* ---- kernels: `enum ComputeKernel`, compute.swift:49-74 ------------------ */
 typedef enum chv_kernel {

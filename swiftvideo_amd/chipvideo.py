@@ -96,6 +96,7 @@ _SIGNATURES = {
     "chv_version": (C.c_int, []),
     "chv_build_flags": (C.c_char_p, []),
     "chv_debug_set_switch": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "chv_debug_get_counter": (C.c_int, [C.c_char_p, C.POINTER(C.c_ulonglong)]),
     "chv_kernel_from_string": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "chv_kernel_name": (C.c_char_p, [C.c_int]),
     "chv_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -173,6 +174,13 @@ def check(status):
 def build_flags():
     """chv_build_flags(): what the loaded library was built with (arch, ablation switches)."""
     return load().chv_build_flags().decode()
+
+
+def get_counter(name):
+    """chv_debug_get_counter: the device's geometry-table store in numbers (tests / probes)."""
+    v = C.c_ulonglong(0)
+    check(load().chv_debug_get_counter(name.encode(), C.byref(v)))
+    return v.value
 
 
 def set_switch(name, value):

@@ -41,6 +41,7 @@ hipError_t launch_selftest_pack_codes(const float *in, uint32_t *out, int n, hip
 hipError_t launch_selftest_matrices(int dir, int csc, uint32_t *out, uint32_t *mism, hipStream_t stream);
 // kernels_fast.hip.cpp
 const char *fast_path_name(int path);
+bool fast_path_is_wave(int path);                // the strip kernels (they take per-layer geometry tables: geom_cache.h)
 bool fast_path_by_value(int path);
 int split_stream_prefix(const DTick *ticks, const DLayer *layers, int n_ticks);      // kernels_fast.hip.cpp
 int fast_path_stream_bgra();
@@ -108,6 +109,14 @@ extern "C" int chv_debug_set_switch(const char *name, const char *value) {
     if (!value || !*value) val = (which == 4 || which == 6 || which == 7 || which == 8 || which == 9 || which == 10) ? 1 : 0;      // empty / NULL: back to "the library decides"
     store_switch(s, which, val);
     return CHV_OK;
+}
+extern "C" int chv_debug_get_counter(const char *name, unsigned long long *value) {
+    static const char *const names[] = { "geom_store_patched", "geom_store_batch_hits", "geom_store_builds", "geom_store_bytes", "geom_store_tables" };
+    if (!name || !value) { g_detail_set("null argument"); return CHV_ERR_INVALID_VALUE; }
+    for (int i = 0; i < 5; i++)
+        if (!strcmp(name, names[i])) { *value = (unsigned long long)geom_store_counter(i); return CHV_OK; }
+    g_detail_set("unknown counter");
+    return CHV_ERR_INVALID_VALUE;
 }
 extern "C" const char *chv_build_flags(void) {
     // what the library was built with: the architecture the Makefile compiled for, the compiler (the hand-scheduled kernels — LDS-DMA through
@@ -1126,6 +1135,12 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     DLayer *sl = (DLayer *)(base + sizeof(DTick));
     *st = tick;
     if (!layers.empty()) memcpy(sl, layers.data(), layers.size() * sizeof(DLayer));
+    // the strip kernels' geometry tables, where the device's store has them for this scene: the layers are pointed at them before they travel
+    bool build_tables = false;
+    GeomTransient &gt = geom_transient_current();
+    gt.covered = false;
+    if (fast_path_is_wave(path) && !layers.empty())
+        gt.covered = geom_store_patch(tf, st, sl, 1, st->W, st->H, (int)layers.size(), &gt.cfg, &build_tables);
     DTick *dt = nullptr;
     if (desc_mode == 1) {
         HIP_TRY(hipHostGetDevicePointer((void **)&dt, st, 0));
@@ -1134,8 +1149,22 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
         HIP_TRY(hipMemcpyAsync(dt, st, used, hipMemcpyHostToDevice, c->stream));
     }
     DLayer *dl = (DLayer *)((uint8_t *)dt + sizeof(DTick));
-    hipError_t e = path >= 0 ? launch_tick_fast(path, st, sl, dt, dl, 1, st->W, st->H, c->stream)
-                             : launch_tick_general(tf, st, sl, dt, dl, 1, st->W, st->H, c->stream);
+    hipError_t e;
+    if (build_tables) {
+        // a geometry the device's store has been asked for before and does not have yet: this launch builds its tables (as a batch's second launch
+        // does) and gives them to the store — the next tick of the scene finds them before its descriptors are copied
+        GeomCache tmp;
+        tmp.d_layers = dl; tmp.h_layers = sl; tmp.n_layers = (int)layers.size(); tmp.force_build = true;
+        geom_cache_current() = &tmp;
+        e = launch_tick_fast(path, st, sl, dt, dl, 1, st->W, st->H, c->stream);
+        geom_cache_current() = nullptr;
+        if (tmp.owns && tmp.tables) (void)hipStreamSynchronize(c->stream);          // (the store was full: the tables die with this launch)
+        geom_cache_release(tmp);
+    } else {
+        e = path >= 0 ? launch_tick_fast(path, st, sl, dt, dl, 1, st->W, st->H, c->stream)
+                      : launch_tick_general(tf, st, sl, dt, dl, 1, st->W, st->H, c->stream);
+    }
+    geom_transient_current().covered = false;
     if (e != hipSuccess) return hip_fail(e, "kernel launch");
     return CHV_OK;
 }
@@ -1446,6 +1475,21 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
                 b->h_ticks2 = tail;
                 dts = head;
                 b->kernel_name = path_name(p1) + " + " + path_name(p2);
+            }
+        }
+    }
+    // The strip kernels' geometry tables, where the device's store has them for this scene (a batch is bound to its pictures: a host builds one per
+    // group of frames, and the second one of a scene onwards starts with tables): the layers are pointed at them and sent again, once, here.
+    {
+        const bool w1 = fast_path_is_wave(b->fast_path), w2 = b->fast_path2 != -2 && fast_path_is_wave(b->fast_path2);
+        if ((w1 || w2) && !dls.empty()) {
+            GeomConfig cfg{};
+            bool want_build = false;
+            const std::vector<DTick> &tk = w1 ? dts : b->h_ticks2;
+            if (geom_store_patch(tf0, tk.data(), dls.data(), n_ticks, b->maxW, b->maxH, (int)dls.size(), &cfg, &want_build)) {
+                e = hipMemcpy(b->d_layers, dls.data(), sizeof(DLayer) * dls.size(), hipMemcpyHostToDevice);
+                if (e != hipSuccess) { (void)hipFree(b->d_ticks); (void)hipFree(b->d_layers); if (b->d_ticks2) (void)hipFree(b->d_ticks2); return hip_fail(e, "hipMemcpy(layers with tables)"); }
+                b->geom.built = true; b->geom.patched = true; b->geom.config = cfg; b->geom.owns = false; b->geom.tables = nullptr;
             }
         }
     }

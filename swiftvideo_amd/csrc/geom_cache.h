@@ -30,6 +30,8 @@ struct GeomCache {
     GeomConfig config{};
     bool seen = false;           // a launch with `seen_config` has been issued (tables are built at the second one: a batch run once never pays)
     GeomConfig seen_config{};
+    bool owns = true;            // `tables` / `jobs` are this cache's to free (false: given to the device's store, or taken from it)
+    bool force_build = false;    // build at the next launch whatever has been seen (a lone tick whose geometry the store has seen before)
     void *tables = nullptr;      // device: every class's tables, back to back
     void *jobs = nullptr;        // device: the precompute kernel's job list (kept: freed with the cache)
     size_t bytes = 0;
@@ -39,6 +41,30 @@ struct GeomCache {
     DLayer *h_layers = nullptr;
     int n_layers = 0;
 };
+
+// ---- the device's STORE of tables ----------------------------------------------------------------------------------------------------
+// A batch is bound to its pictures' addresses, so a host that batches builds a new batch for every group of frames and runs it once: tables owned
+// by the batch would serve benchmarks only.  What recurs in a real pipeline is the GEOMETRY (a scene's layers keep their matrices and sizes for
+// seconds), so a table, once built, is given to a per-device store keyed by (the class's set-up inputs, the launch configuration) and lives
+// there (bounded: kGeomStoreBytes; beyond it batches keep their tables to themselves, as before).  Anything about to be launched through the
+// strip kernels asks the store BEFORE its descriptors go to the device — a batch at creation, a lone tick before its descriptor slot is copied —
+// and, where every staged layer has a table, gets its layers pointed at them for nothing.  A geometry seen for the second time (by any batch or
+// tick of the device) is built at that launch, as a batch's second launch always did.
+constexpr size_t kGeomStoreBytes = (size_t)256 << 20;
+constexpr size_t kGeomStoreSightings = 8192;      // geometries asked for and not found that the store remembers (animated layers: one per tick)
+// Point `layers_host` (the launch's layers, about to be copied to the device) at the store's tables: true when EVERY layer the kernels set up
+// has one (the layers are patched), false otherwise (their table pointers are zeroed).  `cfg`: the launch configuration the strip kernels'
+// launcher will use (n_layers = n_layers_total).  `want_build`: not covered, but every missing geometry has been seen before (or tables are
+// built eagerly): worth building at this launch.  Counts the sighting.
+bool geom_store_patch(int target_format, const DTick *ticks_host, DLayer *layers_host, int n_ticks, int maxW, int maxH, int n_layers_total,
+                      GeomConfig *cfg, bool *want_build);
+// the outcome of geom_store_patch for the TRANSIENT launch this thread is about to issue (no batch: launch_wave_layers looks here)
+struct GeomTransient { bool covered = false; GeomConfig cfg{}; };
+GeomTransient &geom_transient_current();
+// the store of the current device in numbers (chv_debug_get_counter; tests and probes): 0 launches whose layers were all pointed at the store's
+// tables before their descriptors travelled (batches at creation, lone ticks), 1 batches pointed at them at a launch, 2 builds given to the
+// store, 3 bytes it holds, 4 tables (geometry classes x launch configurations) it holds
+uint64_t geom_store_counter(int which);
 
 // the cache of the batch whose launch is being issued by this thread (nullptr: a transient launch — geometry is computed in the kernel)
 GeomCache *&geom_cache_current();

@@ -537,6 +537,7 @@ int select_tail_path(int target_format, const DTick *ticks, const DLayer *layers
     return p;
 }
 
+bool fast_path_is_wave(int path) { return path == FP_WAVE_LAYERS || path == FP_WAVE_NV12 || path == FP_WAVE_Y420P; }
 bool fast_path_by_value(int path) { return path == FP_STREAM || path == FP_STREAM_NV12 || path == FP_STREAM_Y420P || path == FP_NV12_BGRA_TILED || path == FP_Y420P_BGRA_TILED || path == FP_CLEAR_BGRA; }
 
 hipError_t launch_tick_fast(int path, const DTick *ticks_host, const DLayer *layers_host,

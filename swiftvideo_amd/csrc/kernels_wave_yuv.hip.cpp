@@ -26,6 +26,8 @@
 #endif
 
 #include <map>
+#include <unordered_map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -718,10 +720,64 @@ GeomCache *&geom_cache_current() {
     return cur;
 }
 void geom_cache_release(GeomCache &c) {
-    if (c.tables) (void)hipFree(c.tables);
-    if (c.jobs) (void)hipFree(c.jobs);
+    if (c.owns) {
+        if (c.tables) (void)hipFree(c.tables);
+        if (c.jobs) (void)hipFree(c.jobs);
+    }
     c.tables = c.jobs = nullptr;
+    c.owns = true;
     c.built = false; c.bytes = 0; c.classes = 0;
+}
+
+// ---- the device's store (geom_cache.h) ----
+struct GeomStore {
+    std::mutex mu;
+    std::unordered_map<std::string, void *> tables;          // (class key + configuration key) -> the class's table
+    std::unordered_map<std::string, int> sightings;          // launches that asked for it and did not find it
+    std::vector<void *> owned;                               // allocations given to the store (never freed: the store lives as long as the process)
+    size_t bytes = 0;
+    bool full = false;                                       // a build did not fit any more: nothing asks for builds on the store's behalf from here on
+    uint64_t patched = 0, batch_hits = 0, builds = 0;       // (geom_store_counter)
+};
+static GeomStore &geom_store() {
+    static GeomStore stores[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return stores[dev & 15];
+}
+GeomTransient &geom_transient_current() {
+    static thread_local GeomTransient t;
+    return t;
+}
+uint64_t geom_store_counter(int which) {
+    GeomStore &st = geom_store();
+    std::lock_guard<std::mutex> lk(st.mu);
+    switch (which) {
+    case 0: return st.patched;
+    case 1: return st.batch_hits;
+    case 2: return st.builds;
+    case 3: return (uint64_t)st.bytes;
+    case 4: return (uint64_t)st.tables.size();
+    }
+    return 0;
+}
+// the inputs of a layer's set-up as bytes: the three matrices, the source planes' sizes and layout class, the canvas size (false: the layer is
+// applied per pixel — no set-up, no table)
+static bool geom_class_key(const DTick &T, const DLayer &L, std::string &out) {
+    if (L.kind == LK_BGRA_METAL || (L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) return false;
+    struct Key { float u[48]; int32_t w0, h0, w1, h1, cls, W, H; } k;
+    memset(&k, 0, sizeof k);
+    memcpy(k.u, L.u, sizeof k.u);
+    const bool rgb = host_src_rgb(L.kind);
+    k.w0 = L.src.pl[0].w; k.h0 = L.src.pl[0].h; k.w1 = rgb ? 0 : L.src.pl[1].w; k.h1 = rgb ? 0 : L.src.pl[1].h;
+    k.cls = rgb ? 2 : host_src_planar(L.kind) ? 1 : 0; k.W = T.W; k.H = T.H;
+    out.assign((const char *)&k, sizeof k);
+    return true;
+}
+// what of a launch configuration a class's table depends on (everything but the size of the batch's layer array)
+static std::string geom_config_key(const GeomConfig &c) {
+    const int32_t v[9] = { c.target_format, c.wth, c.p0pitch, c.p0rows, c.p1pitch, c.p1rows, c.planar_any, c.strips_x, c.strips_y };
+    return std::string((const char *)v, sizeof v);
 }
 
 // (Re)build the tables of the batch being launched for this launch configuration and point its device layers at them; with the switch off,
@@ -744,24 +800,10 @@ static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const
         return hipSuccess;
     }
     if (gc.built && gc.config == cfg) { *covered = gc.patched; return hipSuccess; }
-    // A batch that is run once (a host that builds one per tick) never pays for tables: they are built at the SECOND launch with a configuration
-    // (draining the stream, three small copies and a kernel: tens of microseconds), the first one computes its geometry in place.
-    if (!(gc.seen && gc.seen_config == cfg) && switches().geom_cache.load(std::memory_order_relaxed) != 2) {
-        gc.seen = true; gc.seen_config = cfg;
-        if (gc.patched) {          // (tables of another configuration: the kernels about to run compute in place and never look, but the pointers go)
-            hipError_t e0 = hipStreamSynchronize(stream);
-            if (e0 != hipSuccess) return e0;
-            for (int i = 0; i < gc.n_layers; i++) hl[i].pad2[0] = hl[i].pad2[1] = 0;
-            e0 = hipMemcpy(gc.d_layers, hl, sizeof(DLayer) * (size_t)gc.n_layers, hipMemcpyHostToDevice);
-            if (e0 != hipSuccess) return e0;
-            gc.patched = false; gc.built = false;
-        }
-        return hipSuccess;
-    }
     // classes: layers whose set-up inputs are the same bytes — the three matrices, the source planes' sizes and layout class, the canvas size
-    struct Key { float u[48]; int32_t w0, h0, w1, h1, cls, W, H; };
     std::map<std::string, int> index;
     std::vector<GeomJob> jobs;
+    std::vector<std::string> keys;
     std::vector<int> cls_of((size_t)gc.n_layers, -1);
     for (int i = 0; i < n_ticks; i++) {
         const DTick &T = ticks_host[i];
@@ -769,14 +811,8 @@ static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const
             const int li = T.first_layer + l;
             if (li < 0 || li >= gc.n_layers) continue;
             const DLayer &L = hl[li];
-            if (L.kind == LK_BGRA_METAL || (L.flags & (LF_AXIS_ALIGNED | LF_BOUNDED)) != (LF_AXIS_ALIGNED | LF_BOUNDED)) continue;      // applied per pixel: no set-up
-            Key k;
-            memset(&k, 0, sizeof k);
-            memcpy(k.u, L.u, sizeof k.u);
-            const bool rgb = host_src_rgb(L.kind);
-            k.w0 = L.src.pl[0].w; k.h0 = L.src.pl[0].h; k.w1 = rgb ? 0 : L.src.pl[1].w; k.h1 = rgb ? 0 : L.src.pl[1].h;
-            k.cls = rgb ? 2 : host_src_planar(L.kind) ? 1 : 0; k.W = T.W; k.H = T.H;
-            const std::string ks((const char *)&k, sizeof k);
+            std::string ks;
+            if (!geom_class_key(T, L, ks)) continue;             // applied per pixel: no set-up
             auto it = index.find(ks);
             if (it == index.end()) {
                 GeomJob J;
@@ -787,9 +823,61 @@ static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const
                 J.strips_x = (T.W + WTW - 1) / WTW; J.strips_y = (T.H + cfg.wth - 1) / cfg.wth;
                 it = index.emplace(ks, (int)jobs.size()).first;
                 jobs.push_back(J);
+                keys.push_back(ks);
             }
             cls_of[(size_t)li] = it->second;
         }
+    }
+    // The device's store first: tables another batch (or lone tick) of this geometry and configuration left there.  All found: the layers are
+    // pointed at them (one drain + one copy of the layer array, no allocation, no kernel) whatever this batch has seen.
+    const std::string ck = geom_config_key(cfg);
+    bool known = !jobs.empty();                 // every class has been asked for before (by anything on this device)
+    {
+        GeomStore &st = geom_store();
+        std::vector<void *> found(jobs.size(), nullptr);
+        bool all = !jobs.empty() && jobs.size() <= 256;
+        {
+            std::lock_guard<std::mutex> lk(st.mu);
+            for (size_t c = 0; c < jobs.size(); c++) {
+                const std::string full = keys[c] + ck;
+                auto it = st.tables.find(full);
+                if (it != st.tables.end()) found[c] = it->second; else all = false;
+                auto sg = st.sightings.find(full);
+                if (sg == st.sightings.end() || sg->second < 2 || st.full) known = false;
+            }
+        }
+        if (all) {
+            hipError_t es = hipStreamSynchronize(stream);
+            if (es != hipSuccess) return es;
+            geom_cache_release(gc);
+            for (int i = 0; i < gc.n_layers; i++) {
+                hl[i].pad2[0] = hl[i].pad2[1] = 0;
+                if (cls_of[(size_t)i] < 0) continue;
+                const uint64_t tp = (uint64_t)(uintptr_t)found[(size_t)cls_of[(size_t)i]];
+                hl[i].pad2[0] = (int32_t)(uint32_t)(tp & 0xFFFFFFFFu); hl[i].pad2[1] = (int32_t)(uint32_t)(tp >> 32);
+            }
+            es = hipMemcpy(gc.d_layers, hl, sizeof(DLayer) * (size_t)gc.n_layers, hipMemcpyHostToDevice);
+            if (es != hipSuccess) return es;
+            gc.owns = false; gc.tables = found[0]; gc.patched = true; gc.built = true; gc.config = cfg; gc.classes = (int)jobs.size();
+            { std::lock_guard<std::mutex> lk(st.mu); st.batch_hits++; }
+            *covered = true;
+            return hipSuccess;
+        }
+    }
+    // A batch that is run once (a host that builds one per tick) never pays for tables: they are built at the SECOND launch with a configuration
+    // (draining the stream, three small copies and a kernel: tens of microseconds) — the second launch of this batch, or a launch of geometry the
+    // store has been asked for before —, the first one computes its geometry in place.
+    if (!(gc.seen && gc.seen_config == cfg) && !gc.force_build && !known && switches().geom_cache.load(std::memory_order_relaxed) != 2) {
+        gc.seen = true; gc.seen_config = cfg;
+        if (gc.patched) {          // (tables of another configuration: the kernels about to run compute in place and never look, but the pointers go)
+            hipError_t e0 = hipStreamSynchronize(stream);
+            if (e0 != hipSuccess) return e0;
+            for (int i = 0; i < gc.n_layers; i++) hl[i].pad2[0] = hl[i].pad2[1] = 0;
+            e0 = hipMemcpy(gc.d_layers, hl, sizeof(DLayer) * (size_t)gc.n_layers, hipMemcpyHostToDevice);
+            if (e0 != hipSuccess) return e0;
+            gc.patched = false; gc.built = false;
+        }
+        return hipSuccess;
     }
     // A (re)build happens once per batch and launch configuration: an earlier run of the batch may still be reading the layers, and the host
     // buffers below are pageable — the stream is drained first and every copy is a synchronous one (an asynchronous copy from pageable memory
@@ -847,6 +935,20 @@ static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const
                 hl[i].pad2[0] = (int32_t)(uint32_t)(tp & 0xFFFFFFFFu); hl[i].pad2[1] = (int32_t)(uint32_t)(tp >> 32);
             }
             gc.bytes = total; gc.classes = (int)jobs.size();
+            gc.owns = true;
+            // The tables go to the device's store (another stream may read them: the precompute kernel has to be done first).
+            if (hipStreamSynchronize(stream) == hipSuccess) {
+                GeomStore &st = geom_store();
+                std::lock_guard<std::mutex> lk(st.mu);
+                const size_t give = total + sizeof(GeomJob) * jobs.size();
+                if (st.bytes + give <= kGeomStoreBytes) {
+                    for (size_t c = 0; c < jobs.size(); c++) st.tables.emplace(keys[c] + ck, (void *)jobs[c].table);      // (a class another thread gave meanwhile keeps its first table)
+                    st.owned.push_back(gc.tables); st.owned.push_back(gc.jobs);
+                    st.bytes += give;
+                    st.builds++;
+                    gc.owns = false;
+                } else st.full = true;
+            } else (void)hipGetLastError();
         } else {
             (void)hipGetLastError();
             geom_cache_release(gc);             // no tables: the kernels compute their geometry as before
@@ -857,13 +959,16 @@ static hipError_t geom_cache_prepare(GeomCache &gc, const GeomConfig &cfg, const
     if (e2 != hipSuccess) return e2;
     gc.patched = gc.tables != nullptr;        // (every layer the kernels set up has a table, or none has: classes are all-or-nothing)
     gc.built = true;
+    gc.force_build = false;
     gc.config = cfg;
     *covered = gc.patched;
     return e;
 }
 
-hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
-                              int n_ticks, int maxW, int maxH, hipStream_t stream) {
+// What a launch of the strip kernels is shaped like — strip height, LDS layout, source classes — from its descriptors alone (launch_wave_layers
+// launches with it; geom_store_patch asks for it before the descriptors go to the device: the tables it looks up were built for one shape).
+struct WavePlan { int WTH; WaveDims m; bool planar; int kinds, side; size_t lds; };
+static WavePlan plan_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, int n_ticks, int maxW, int maxH) {
     // Strip height.  16 rows when the launch has enough strips to fill the chip's wave slots with them and the taller
     // rectangles leave room for two strips per 64 KB of LDS; on BGRA canvases (whose 16-row instantiation has no masked rows:
     // registers) only when every layer covers (almost) the whole canvas, so that hardly any strip is crossed by a layer's
@@ -945,6 +1050,84 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     // occupancy the strip kernels need (profiles/r03_notes.md section 7)
     if (const char *pad = getenv("CHV_LDS_PAD")) { fprintf(stderr, "[chv] lds %zu + pad %d, rows %d\n", lds, atoi(pad), WTH); lds += (size_t)atoi(pad); }
 #endif
+    m.p0rows = std::min(m.p0rows, 0xFFFF); m.p1rows = std::min(m.p1rows, 0xFFFF);      // (far beyond what LDS holds: such rectangles are not staged anyway)
+    return WavePlan{ WTH, m, planar, kinds, side, lds };
+}
+static GeomConfig plan_config(const WavePlan &P, int target_format, int maxW, int maxH, int n_layers_total) {
+    return GeomConfig{ target_format, P.WTH, P.m.p0pitch, P.m.p0rows, P.m.p1pitch, P.m.p1rows, (P.planar ? 1 : 0) | P.side, (maxW + WTW - 1) / WTW, (maxH + P.WTH - 1) / P.WTH, n_layers_total };
+}
+
+bool geom_store_patch(int target_format, const DTick *ticks_host, DLayer *layers_host, int n_ticks, int maxW, int maxH, int n_layers_total,
+                      GeomConfig *cfg_out, bool *want_build) {
+    *want_build = false;
+    const int mode = CHV_GEOM_CACHE ? switches().geom_cache.load(std::memory_order_relaxed) : 0;
+    if (n_ticks < 1 || !layers_host) return false;
+    const WavePlan P = plan_wave_layers(target_format, ticks_host, layers_host, n_ticks, maxW, maxH);
+    *cfg_out = plan_config(P, target_format, maxW, maxH, n_layers_total);
+    auto zero = [&]() {
+        for (int i = 0; i < n_ticks; i++)
+            for (int l = 0; l < ticks_host[i].n_layers; l++) { DLayer &L = layers_host[ticks_host[i].first_layer + l]; L.pad2[0] = L.pad2[1] = 0; }
+    };
+    if (!mode || P.kinds == 4 || (P.kinds & 7) == 0) { zero(); return false; }        // (off; launches of RGB layers only keep computing in place; nothing staged)
+    const std::string ck = geom_config_key(*cfg_out);
+    GeomStore &st = geom_store();
+    std::vector<std::pair<int, void *>> hits;
+    bool all = true, known = true;
+    int classes = 0;
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        std::string ks, last;
+        void *last_tab = nullptr;
+        std::unordered_map<std::string, void *> asked;      // this call's classes (a sighting is a LAUNCH that asked, whatever its number of ticks)
+        for (int i = 0; i < n_ticks; i++) {
+            const DTick &T = ticks_host[i];
+            for (int l = 0; l < T.n_layers; l++) {
+                const int li = T.first_layer + l;
+                if (!geom_class_key(T, layers_host[li], ks)) continue;
+                if (ks != last) {                          // (a tick's layers, and a batch's ticks, mostly repeat their predecessor's geometry)
+                    last = ks;
+                    auto seen = asked.find(ks);
+                    if (seen != asked.end()) last_tab = seen->second;
+                    else {
+                        const std::string full = ks + ck;
+                        auto it = st.tables.find(full);
+                        last_tab = it != st.tables.end() ? it->second : nullptr;
+                        if (!last_tab) {
+                            // (an animated layer is a new geometry every tick, seen once: the count of sightings is bounded by starting over)
+                            if (st.sightings.size() >= kGeomStoreSightings) st.sightings.clear();
+                            int &n = st.sightings[full];
+                            if (n < (1 << 20)) n++;
+                            if (n < 2 || st.full) known = false;
+                        }
+                        asked.emplace(ks, last_tab);
+                        classes++;
+                    }
+                }
+                if (last_tab) hits.emplace_back(li, last_tab); else all = false;
+            }
+        }
+    }
+    if (!all || hits.empty()) {
+        zero();
+        *want_build = !hits.empty() || classes > 0 ? (known || mode == 2) && !all : false;
+        return false;
+    }
+    zero();
+    { std::lock_guard<std::mutex> lk(st.mu); st.patched++; }
+    for (auto &h : hits) {
+        const uint64_t tp = (uint64_t)(uintptr_t)h.second;
+        layers_host[h.first].pad2[0] = (int32_t)(uint32_t)(tp & 0xFFFFFFFFu); layers_host[h.first].pad2[1] = (int32_t)(uint32_t)(tp >> 32);
+    }
+    return true;
+}
+
+hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
+                              int n_ticks, int maxW, int maxH, hipStream_t stream) {
+    const WavePlan P = plan_wave_layers(target_format, ticks_host, layers_host, n_ticks, maxW, maxH);
+    const int WTH = P.WTH, kinds = P.kinds, side = P.side;
+    WaveDims m = P.m;
+    const bool planar = P.planar;
+    size_t lds = P.lds;
     int strips_x = (maxW + WTW - 1) / WTW, strips_y = (maxH + WTH - 1) / WTH;
     const bool clear = ticks_host[0].clear_first != 0;
     // A launch that continues on canvases something else composed (the second launch of a split batch: a logo or overlays over the videos the
@@ -966,7 +1149,6 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
         } else { strips_x = 1; strips_y = 1; }                     // (nothing visible: one strip per tick, which finds no layer and leaves)
         if (origin_x > 0xFFFF || origin_y > 0xFFFF) { origin_x = origin_y = 0; strips_x = (maxW + WTW - 1) / WTW; strips_y = (maxH + WTH - 1) / WTH; }
     }
-    m.p0rows = std::min(m.p0rows, 0xFFFF); m.p1rows = std::min(m.p1rows, 0xFFFF);      // (far beyond what LDS holds: such rectangles are not staged anyway)
     const int p0rows_arg = m.p0rows | (origin_x << 16), p1rows_arg = m.p1rows | (origin_y << 16);
     // the batch's geometry tables for this configuration (a transient launch has none: its kernels compute their geometry in place)
     bool cached = false;                       // -> the CACHED instantiations (no set-up code): every staged layer of the launch has its table
@@ -974,9 +1156,13 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     // tables, for 5 % more counted traffic: profiles/r06_notes.md section 9)
     GeomCache *gc = kinds != 4 ? geom_cache_current() : nullptr;
     if (gc) {
-        GeomConfig cfg{ target_format, WTH, m.p0pitch, m.p0rows, m.p1pitch, m.p1rows, (planar ? 1 : 0) | side, (maxW + WTW - 1) / WTW, (maxH + WTH - 1) / WTH, gc->n_layers };
+        const GeomConfig cfg = plan_config(P, target_format, maxW, maxH, gc->n_layers);
         hipError_t ge = geom_cache_prepare(*gc, cfg, ticks_host, n_ticks, (size_t)WTH * 48, stream, &cached);
         if (ge != hipSuccess) return ge;
+    } else if (kinds != 4) {
+        // a lone tick: geom_store_patch pointed its layers at the store's tables before they went to the device, for exactly this shape
+        GeomTransient &gt = geom_transient_current();
+        cached = gt.covered && gt.cfg == plan_config(P, target_format, maxW, maxH, gt.cfg.n_layers);
     }
     // floor(2^32 / d) for the kernels' scalar divisions by the strips per tick and per row (WaveStrip::udivmod)
     auto magic = [](uint32_t d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / d); };

@@ -1,6 +1,8 @@
 """tools/lone_tick_tables.py — would a LONE tick gain from geometry tables?  The reference-default mixer tick (1080p y420p canvas <- y420p video + two
 BGRA overlays) and the mixed BGRA tick as ONE-tick batches run + waited for one at a time, with the batch's tables (CHV_GEOM_CACHE default) and
-with the geometry computed in place (=0): wall us per tick and device us between two events.  GPU box."""
+with the geometry computed in place (=0): wall us per tick and device us between two events; then the same tick through chv_composite (a transient
+launch: what an unmodified VideoMixer issues), which since the device's table store (csrc/geom_cache.h) finds the scene's tables from its third
+sighting on — CHV_GEOM_CACHE default against =0 in turn.  GPU box."""
 import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -45,4 +47,18 @@ for fmt in ("y420p", "bgra"):
         h, name, keep = G.make_batch(ctx, [(dst, True, layers)])
         probe(f"{fmt} canvas, video + 2 overlays, {name}, CHV_GEOM_CACHE={sw}", h)
         G.destroy_batch(h)
+    tdesc, arr = sv._image_desc(dst), sv._layer_array(layers)
+
+    class Lone:            # (probe() runs a "batch" through G.run_batch: the same bracket around chv_composite)
+        pass
+    run_batch = G.run_batch
+    G.run_batch = lambda c, h: (lib.chv_pass_begin(c.handle), lib.chv_composite(c.handle, C.byref(tdesc), 1, arr, len(layers)), lib.chv_pass_end(c.handle, 1))
+    try:
+        for sw in (None, "0", None, "0"):
+            cv.set_switch("CHV_GEOM_CACHE", sw)
+            p0 = cv.get_counter("geom_store_patched")
+            probe(f"{fmt} canvas, video + 2 overlays, chv_composite, CHV_GEOM_CACHE={sw}", None)
+            print(f"    (launches pointed at the store's tables: {cv.get_counter('geom_store_patched') - p0})")
+    finally:
+        G.run_batch = run_batch
     cv.set_switch("CHV_GEOM_CACHE", None)
