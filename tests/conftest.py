@@ -38,7 +38,8 @@ def ctx(built):
 def eager_geometry_tables(request):
     """-m gpu sessions: batches build their geometry tables at their FIRST launch (CHV_GEOM_CACHE=eager; the product builds them at the second, so
     that a batch run once never pays) — most batches of this suite run once, and every fuzzer that runs one is meant to reach the table-reading
-    instantiations of the strip kernels.  The kernels that compute their geometry in place are every transient launch's, and
+    instantiations of the strip kernels (eager also lets a transient launch build at a scene's first sighting: the device's store,
+    tests/test_gpu_geom_store.py).  The kernels that compute their geometry in place are what every first sighting takes in the product, and
     tests/test_gpu_geom_cache.py forces them onto batches."""
     lib = ROOT / "swiftvideo_amd" / "libchipvideo.so"
     if lib.exists() and os.environ.get("CHV_GEOM_CACHE") is None and "gpu" in (request.config.getoption("-m") or "") and "not gpu" not in (request.config.getoption("-m") or ""):
