@@ -1127,6 +1127,25 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
         hipError_t e = launch_tick_fast(path, ht, hl, nullptr, nullptr, 1, ht->W, ht->H, c->stream);
         return e == hipSuccess ? CHV_OK : hip_fail(e, "kernel launch");
     }
+    // The strip kernels of 4:2:0 canvases take a lone tick of up to WAVE_ONE_LAYERS layers as their last ARGUMENT (wave_common.hip.h: wave_one_descriptors): no ring
+    // slot, no copy in front of the launch.  The layers are pointed at the device's geometry tables first, where its store has them for this
+    // scene; a launch that is to BUILD tables (a scene's second sighting) needs its layers in device memory and goes through the slot below.
+    const bool wave = fast_path_is_wave(path);
+    GeomTransient &gt = geom_transient_current();
+    gt.covered = false;
+    if (wave && tf != TF_BGRA && desc_mode == 0 && !layers.empty() && (int)layers.size() <= WAVE_ONE_LAYERS) {
+        WaveOne one;
+        one.t = tick;
+        memcpy(one.l, layers.data(), layers.size() * sizeof(DLayer));
+        bool build = false;
+        gt.covered = geom_store_patch(tf, &one.t, one.l, 1, one.t.W, one.t.H, (int)layers.size(), &gt.cfg, &build);
+        if (!build) {
+            hipError_t e = launch_tick_fast(path, &one.t, one.l, nullptr, nullptr, 1, one.t.W, one.t.H, c->stream);
+            gt.covered = false;
+            return e == hipSuccess ? CHV_OK : hip_fail(e, "kernel launch");
+        }
+        gt.covered = false;
+    }
     DescSlot ds(c);
     if (ds.rc) return ds.rc;
     const int slot = ds.slot;
@@ -1136,10 +1155,9 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
     *st = tick;
     if (!layers.empty()) memcpy(sl, layers.data(), layers.size() * sizeof(DLayer));
     // the strip kernels' geometry tables, where the device's store has them for this scene: the layers are pointed at them before they travel
+    // (not with CHV_DESC=host: a build would copy the slot onto itself)
     bool build_tables = false;
-    GeomTransient &gt = geom_transient_current();
-    gt.covered = false;
-    if (fast_path_is_wave(path) && !layers.empty())
+    if (wave && !layers.empty() && desc_mode != 1)
         gt.covered = geom_store_patch(tf, st, sl, 1, st->W, st->H, (int)layers.size(), &gt.cfg, &build_tables);
     DTick *dt = nullptr;
     if (desc_mode == 1) {

@@ -78,6 +78,15 @@ struct DTick {
     int32_t cover_mask;    // bit l: layer l of the tick is flagged LF_COVERS (most ticks: 0 — the strip kernels look no further)
 };
 
+// A lone tick and its layers as ONE kernel argument of the strip kernels (wave_common.hip.h: wave_one_descriptors): a transient launch of up to
+// WAVE_ONE_LAYERS layers carries its descriptors in the kernarg segment instead of copying them to device memory in front of the kernel.
+constexpr int WAVE_ONE_LAYERS = 6;
+struct WaveOne {
+    DTick t;
+    DLayer l[WAVE_ONE_LAYERS];
+};
+static_assert(sizeof(WaveOne) <= 3072, "kernel arguments: 4 KB in all");
+
 // uniforms blob offsets (floats)
 enum { U_TRANSFORM = 0, U_TEXTURE = 16, U_BORDER = 32, U_FILL = 48, U_INSIZE = 52,
        U_OUTSIZE = 54, U_OPACITY = 56, U_IMAGETIME = 57, U_TARGETTIME = 58 };

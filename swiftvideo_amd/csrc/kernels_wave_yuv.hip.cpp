@@ -134,7 +134,8 @@ template <int TF, bool CLEAR, int YTH, int KINDS, bool CACHED>
 __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY_MINW : CHV_WAVEY_MINW_MIXED)) void tick_yuv_wave(const DTick *__restrict__ ticks,
                                                                          const DLayer *__restrict__ layers,
                                                                          int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
-                                                                         int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
+                                                                         int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any, const WaveOne one) {
+    wave_one_descriptors(ticks, layers);
     constexpr int YLW = YTH / 4;                     // registers holding the lane's luma codes (4 rows per register)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     // (compact staging of interior rectangles: measured better for the mixed-class instantiations, worse for the own-format one)
@@ -575,9 +576,11 @@ __global__ __launch_bounds__(WAVE_BLOCK, ((KINDS == 1 || KINDS == 2) ? CHV_WAVEY
 // the launch of one instantiation (launch_wave_layers has sized everything)
 template <bool CACHED>
 hipError_t launch_yuv_wave_t(int target_format, bool clear, int WTH, int kinds, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
-                             int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows_arg, int p1pitch, int p1rows_arg, int planar_any) {
+                             int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows_arg, int p1pitch, int p1rows_arg, int planar_any, const WaveOne *one_arg) {
+    static const WaveOne none{};
+    const WaveOne &one = one_arg ? *one_arg : none;            // (with `ticks` == nullptr the kernel reads its descriptors from this argument: wave_one_descriptors)
 #define CHV_LAUNCH_Y(TFV, C, R, K) hipLaunchKernelGGL((tick_yuv_wave<TFV, C, R, K, CACHED>), grid, dim3(WAVE_BLOCK), lds, stream, ticks, layers, n_ticks, strips_x, strips_y, \
-                                                      strips_magic, strips_x_magic, p0pitch, p0rows_arg, p1pitch, p1rows_arg, planar_any)
+                                                      strips_magic, strips_x_magic, p0pitch, p0rows_arg, p1pitch, p1rows_arg, planar_any, one)
 #define CHV_LAUNCH_YK(TFV, C, R, OWN) do { if (kinds == OWN) CHV_LAUNCH_Y(TFV, C, R, OWN); else if (kinds == (OWN | 4)) CHV_LAUNCH_Y(TFV, C, R, (OWN | 4)); \
                                            else if (kinds & 8) CHV_LAUNCH_Y(TFV, C, R, 15); else CHV_LAUNCH_Y(TFV, C, R, 7); } while (0)
 #define CHV_LAUNCH_YR(TFV, C, OWN) do { if (WTH == 16) CHV_LAUNCH_YK(TFV, C, 16, OWN); else CHV_LAUNCH_YK(TFV, C, 8, OWN); } while (0)
@@ -589,7 +592,8 @@ hipError_t launch_yuv_wave_t(int target_format, bool clear, int WTH, int kinds, 
     return hipGetLastError();
 }
 #define CHV_YUV_WAVE_ARGS int target_format, bool clear, int WTH, int kinds, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks, \
-                          int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows_arg, int p1pitch, int p1rows_arg, int planar_any
+                          int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows_arg, int p1pitch, int p1rows_arg, int planar_any, \
+                          const WaveOne *one_arg
 #if CHV_WAVE_TU != 0
 template hipError_t launch_yuv_wave_t<true>(CHV_YUV_WAVE_ARGS);
 #else
@@ -1171,14 +1175,26 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     long per_xcd = (total + 7) / 8;
     long blocks_per_xcd = (per_xcd + WAVES - 1) / WAVES;
     dim3 grid((unsigned)(blocks_per_xcd * 8));
+    // a lone tick without descriptors in device memory (launch_transient): they travel as the 4:2:0 kernels' last argument.  (tick_bgra_wave
+    // has none: the two more scalar registers its 8-row instantiations need for the chosen pointers cost them 2 - 14 vector registers in scratch)
+    WaveOne one_store;
+    const WaveOne *one = nullptr;
+    if (!ticks) {
+        if (n_ticks != 1 || ticks_host[0].n_layers > WAVE_ONE_LAYERS || target_format == TF_BGRA) return hipErrorInvalidValue;
+        one_store.t = ticks_host[0];
+        one_store.t.first_layer = 0;
+        if (one_store.t.n_layers > 0) memcpy(one_store.l, layers_host + ticks_host[0].first_layer, sizeof(DLayer) * (size_t)one_store.t.n_layers);
+        one = &one_store;
+        layers = nullptr;
+    }
     if (target_format == TF_BGRA) {
         return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg,
                                 (planar ? 1 : 0) | side, kinds, cached);
     }
     return cached ? launch_yuv_wave_t<true>(target_format, clear, WTH, kinds, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic,
-                                            m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side)
+                                            m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side, one)
                   : launch_yuv_wave_t<false>(target_format, clear, WTH, kinds, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic,
-                                             m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side);
+                                             m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side, one);
 }
 #endif      // CHV_WAVE_TU == 0
 

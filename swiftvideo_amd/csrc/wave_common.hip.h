@@ -38,6 +38,23 @@ struct WaveCfg {
 };
 
 // ---- wave-level helpers ---------------------------------------------------------------------------------------
+// ---- a lone tick's descriptors as kernel ARGUMENTS ------------------------------------------------------------------------------------------------
+// A transient launch (chv_composite, a held pass: what an unmodified VideoMixer issues) used to copy its descriptor slot to device memory in
+// front of the kernel: a second command on the stream, 5 us of a 30 us tick.  The strip kernels are the library's largest instantiations, so
+// instead of by-value twins (tick_bgra_stream_one) every instantiation of tick_yuv_wave carries a trailing argument `WaveOne one` that no code names: launched
+// with `ticks == nullptr` the kernel reads its tick and layers from where that argument lies in the kernarg segment (constant-address-space
+// memory the runtime wrote with the launch), through the same pointers and the same scalar loads as a batch's descriptors.
+// (WaveOne: device_types.h)
+// the kernels' explicit arguments as the kernarg segment lays them out (declaration order, natural alignment): where `one` starts
+struct WaveKernArgs { const DTick *ticks; const DLayer *layers; int32_t n_ticks, strips_x, strips_y; uint32_t strips_magic, strips_x_magic; int32_t p0pitch, p0rows, p1pitch, p1rows, planar_any; WaveOne one; };
+CHV_DEV void wave_one_descriptors(const DTick *__restrict__ &ticks, const DLayer *__restrict__ &layers) {
+    if (ticks == nullptr) {
+        const uint64_t ka = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WaveKernArgs, one);
+        ticks = (const DTick *)(const __attribute__((address_space(1))) DTick *)(uintptr_t)ka;
+        layers = (const DLayer *)(const __attribute__((address_space(1))) DLayer *)(uintptr_t)(ka + sizeof(DTick));
+    }
+}
+
 CHV_DEV void wave_lds_fence() {
     // The wave's own LDS writes are visible to its later reads (LDS operations of a wave execute in order); this only keeps
     // the compiler from moving LDS accesses across the point.  The fence names the LDS address space: a fence over all

@@ -196,3 +196,23 @@ def test_held_pass_of_a_scene(ctx, switch):
         sv.usingContext(ctx, seq)
         G.assert_same(G.from_gpu(ctx, gd, "y420p", cw, ch), exp, f"held pass {t}")
     assert cv.get_counter("geom_store_patched") == p0 + 3
+
+
+@pytest.mark.parametrize("dst", ["nv12", "y420p"])
+@pytest.mark.parametrize("n_layers", [1, 5, 6, 7, 9])
+def test_lone_ticks_carry_their_descriptors_as_kernel_arguments(ctx, switch, dst, n_layers):
+    """a lone tick on a 4:2:0 canvas reaches tick_yuv_wave with ticks == nullptr and its descriptors in the kernels' last argument (WaveOne: up to
+    six layers; wave_common.hip.h); seven layers and more — and CHV_DESC=device, the A/B — go through the descriptor ring and the device copy.
+    Same bytes either way, on first sightings (in place), on the building launch (always through the ring) and on served ones (tables)."""
+    _force_strips(switch, dst)
+    switch("CHV_GEOM_CACHE", None)
+    cw, ch = 208 + 16 * n_layers, 120 + 8 * (dst == "nv12")
+    ovk = f"img_bgra_{dst}"
+    scene = [(f"img_{dst}_{dst}", dst, (240, 136), util.full_canvas_uniforms((cw, ch), (240, 136)))] + \
+            [(ovk, "bgra", (64, 36), util.make_uniforms((cw, ch), rect=(8 + 14 * l, 6 + 9 * l, 64, 36), opacity=0.9 - 0.07 * l, in_size=(64, 36))) for l in range(n_layers - 1)]
+    for desc in (None, "device"):
+        switch("CHV_DESC", desc)
+        for t in range(4):
+            gd, layers, exp, keep = _tick(ctx, dst, cw, ch, scene, 1500 + 10 * n_layers + t)
+            sv.usingContext(ctx, lambda c: sv.compositeTick(c, gd, layers, True))
+            G.assert_same(G.from_gpu(ctx, gd, dst, cw, ch), exp, f"{dst}, {n_layers} layers, CHV_DESC={desc}, tick {t}")
