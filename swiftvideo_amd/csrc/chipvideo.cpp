@@ -41,6 +41,7 @@ hipError_t launch_selftest_pack_codes(const float *in, uint32_t *out, int n, hip
 hipError_t launch_selftest_matrices(int dir, int csc, uint32_t *out, uint32_t *mism, hipStream_t stream);
 // kernels_fast.hip.cpp
 const char *fast_path_name(int path);
+bool wave_layers_by_value(int target_format, const DTick *tick_host, const DLayer *layers_host);      // kernels_wave_yuv.hip.cpp
 bool fast_path_is_wave(int path);                // the strip kernels (they take per-layer geometry tables: geom_cache.h)
 bool fast_path_by_value(int path);
 int split_stream_prefix(const DTick *ticks, const DLayer *layers, int n_ticks);      // kernels_fast.hip.cpp
@@ -1127,13 +1128,13 @@ static int launch_transient(chv_context *c, const DTick &tick_in, const std::vec
         hipError_t e = launch_tick_fast(path, ht, hl, nullptr, nullptr, 1, ht->W, ht->H, c->stream);
         return e == hipSuccess ? CHV_OK : hip_fail(e, "kernel launch");
     }
-    // The strip kernels of 4:2:0 canvases take a lone tick of up to WAVE_ONE_LAYERS layers as their last ARGUMENT (wave_common.hip.h: wave_one_descriptors): no ring
+    // The strip kernels take a lone tick of up to WAVE_ONE_LAYERS layers as an ARGUMENT (wave_common.hip.h: wave_one_descriptors; tick_bgra_wave_one): no ring
     // slot, no copy in front of the launch.  The layers are pointed at the device's geometry tables first, where its store has them for this
     // scene; a launch that is to BUILD tables (a scene's second sighting) needs its layers in device memory and goes through the slot below.
     const bool wave = fast_path_is_wave(path);
     GeomTransient &gt = geom_transient_current();
     gt.covered = false;
-    if (wave && tf != TF_BGRA && desc_mode == 0 && !layers.empty() && (int)layers.size() <= WAVE_ONE_LAYERS) {
+    if (wave && desc_mode == 0 && wave_layers_by_value(tf, &tick, layers.data())) {
         WaveOne one;
         one.t = tick;
         memcpy(one.l, layers.data(), layers.size() * sizeof(DLayer));

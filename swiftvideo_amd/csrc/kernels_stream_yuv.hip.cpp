@@ -1099,7 +1099,7 @@ struct YsOne {
     DLayer l[NL];
 };
 template <int TF, int NL, int KINDS>
-__global__ __launch_bounds__(64 * YS_WAVES, ys_min_waves(KINDS, NL))
+__global__ __launch_bounds__(64 * YS_WAVES, ys_min_waves(KINDS, NL) > 5 ? 5 : ys_min_waves(KINDS, NL))
 void tick_yuv_stream_one(const YsOne<NL> a, int strips_x, int chunks_y, int rows_per_chunk, int wave_bytes) {
     ys_body<TF, NL, KINDS, true>(&a.t, a.l, 1, strips_x, chunks_y, rows_per_chunk, wave_bytes);
 }

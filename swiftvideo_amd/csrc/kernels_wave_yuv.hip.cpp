@@ -688,7 +688,8 @@ const char *yuv_wave_build_flags() { return "tick_yuv_wave:abl=" CHV_STR(CHV_ABL
 
 // kernels_wave.hip.cpp
 hipError_t launch_bgra_wave(int rows, bool clear, dim3 grid, size_t lds, hipStream_t stream, const DTick *ticks, const DLayer *layers, int n_ticks,
-                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds, bool cached);
+                            int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic, int p0pitch, int p0rows, int p1pitch, int p1rows, int planar, int kinds, bool cached,
+                            const WaveOne *one_arg);
 
 // ---------------------------------------------------------------------------
 // geometry tables of a batch (geom_cache.h; device side: wave_common.hip.h)
@@ -1125,6 +1126,16 @@ bool geom_store_patch(int target_format, const DTick *ticks_host, DLayer *layers
     return true;
 }
 
+// May this lone tick travel as a kernel argument (launch_transient: no descriptor slot, no copy)?  4:2:0 canvases: every instantiation of
+// tick_yuv_wave takes one; BGRA canvases: tick_bgra_wave_one exists for cleared canvases, 8-row strips and launches without per-pixel layers.
+bool wave_layers_by_value(int target_format, const DTick *tick_host, const DLayer *layers_host) {
+    if (tick_host->n_layers < 1 || tick_host->n_layers > WAVE_ONE_LAYERS) return false;
+    if (target_format != TF_BGRA) return true;
+    if (!tick_host->clear_first) return false;
+    const WavePlan P = plan_wave_layers(target_format, tick_host, layers_host, 1, tick_host->W, tick_host->H);
+    return P.WTH == 8 && !(P.kinds & 8) && P.kinds != 2 && P.kinds != 4;
+}
+
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,
                               int n_ticks, int maxW, int maxH, hipStream_t stream) {
     const WavePlan P = plan_wave_layers(target_format, ticks_host, layers_host, n_ticks, maxW, maxH);
@@ -1175,12 +1186,12 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     long per_xcd = (total + 7) / 8;
     long blocks_per_xcd = (per_xcd + WAVES - 1) / WAVES;
     dim3 grid((unsigned)(blocks_per_xcd * 8));
-    // a lone tick without descriptors in device memory (launch_transient): they travel as the 4:2:0 kernels' last argument.  (tick_bgra_wave
-    // has none: the two more scalar registers its 8-row instantiations need for the chosen pointers cost them 2 - 14 vector registers in scratch)
+    // a lone tick without descriptors in device memory (launch_transient, which asked wave_layers_by_value first): they travel as the 4:2:0
+    // kernels' last argument / as the first argument of tick_bgra_wave_one
     WaveOne one_store;
     const WaveOne *one = nullptr;
     if (!ticks) {
-        if (n_ticks != 1 || ticks_host[0].n_layers > WAVE_ONE_LAYERS || target_format == TF_BGRA) return hipErrorInvalidValue;
+        if (n_ticks != 1 || ticks_host[0].n_layers > WAVE_ONE_LAYERS) return hipErrorInvalidValue;
         one_store.t = ticks_host[0];
         one_store.t.first_layer = 0;
         if (one_store.t.n_layers > 0) memcpy(one_store.l, layers_host + ticks_host[0].first_layer, sizeof(DLayer) * (size_t)one_store.t.n_layers);
@@ -1189,7 +1200,7 @@ hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const 
     }
     if (target_format == TF_BGRA) {
         return launch_bgra_wave(WTH, clear, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic, m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg,
-                                (planar ? 1 : 0) | side, kinds, cached);
+                                (planar ? 1 : 0) | side, kinds, cached, one);
     }
     return cached ? launch_yuv_wave_t<true>(target_format, clear, WTH, kinds, grid, lds, stream, ticks, layers, n_ticks, strips_x, strips_y, strips_magic, strips_x_magic,
                                             m.p0pitch, p0rows_arg, m.p1pitch, p1rows_arg, (planar ? 1 : 0) | side, one)

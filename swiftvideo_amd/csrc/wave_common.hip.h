@@ -416,6 +416,9 @@ struct WaveStrip {
         xe = min(x, W - 1); ye = min(y0 + min(lane, WTH - 1), H - 1);
         nx = ((float)xe / sx) * 2.f - 1.f; ny = ((float)ye / sy) * 2.f - 1.f;
     }
+    // ONE (tick_bgra_wave_one): the launch is one tick whose layers follow it in the kernarg segment — tick 0, first_layer 0: `T` and `L` are the
+    // kernarg base plus constants (no scalar registers of their own)
+    template <bool ONE = false>
     CHV_DEV bool init(const DTick *ticks, const DLayer *layers, int n_ticks, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
                       uint8_t *smem_all, int p0pitch_, int p0rows_, int p1pitch_, int p1rows_, int planar_any) {
         // (bits 16-31 of the two row counts: the launch's ORIGIN in strips — a launch that continues on composed canvases covers only the strips
@@ -432,12 +435,13 @@ struct WaveStrip {
         const int index = xcd * per_xcd + widx;
         if (widx >= per_xcd || index >= total) return false;
         int tick, strip, sxi, syi;
-        udivmod((uint32_t)index, (uint32_t)strips, strips_magic, tick, strip);
+        if constexpr (ONE) { tick = 0; strip = index; }
+        else udivmod((uint32_t)index, (uint32_t)strips, strips_magic, tick, strip);
         udivmod((uint32_t)strip, (uint32_t)strips_x, strips_x_magic, syi, sxi);
         T = ticks + tick;
         const int x0_ = (osx + sxi) * WTW, y0_ = (osy + syi) * WTH;
         if (x0_ >= T->W || y0_ >= T->H) return false;
-        L = layers + T->first_layer;
+        L = ONE ? layers : layers + T->first_layer;
         nl = T->n_layers;
         init_strip(T->W, T->H, x0_, y0_);
         return true;

@@ -91,6 +91,7 @@ bool geom_store_patch(int, const DTick *ticks_host, DLayer *layers_host, int n_t
 }
 uint64_t geom_store_counter(int) { return 0; }
 bool fast_path_is_wave(int path) { return path == FP_WAVE; }
+bool wave_layers_by_value(int, const DTick *t, const DLayer *) { return t->n_layers >= 1 && t->n_layers <= WAVE_ONE_LAYERS; }
 const char *bgra_wave_build_flags() { return "stub:abl=0"; }
 const char *yuv_wave_build_flags() { return "stub:abl=0"; }
 const char *bgra_stream_build_flags() { return "stub:abl=0"; }

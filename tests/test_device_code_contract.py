@@ -174,7 +174,12 @@ def test_yuv_stream_kernel_owns_m0_and_keeps_its_waves(tmp_path):
         nl, kinds = [int(x) for x in re.search(r"ILi\d+ELi(\d+)ELi(\d+)E", name).groups()]
         scratch = m.get("private_segment_fixed_size", 0)
         if kinds in (1, 2, 8) and nl == 1:
-            assert m["vgpr_count"] <= 80 and scratch <= 48, (name, m)
+            if "tick_yuv_stream_one" in name:
+                # a lone tick's twin: never more than five waves, and with that NOTHING in scratch (the encoder-side frame's twin kept seven
+                # registers there at six: a kernel with a scratch segment is dispatched ~1 us later — profiles/r06_notes.md section 15)
+                assert m["vgpr_count"] <= 96 and scratch == 0, (name, m)
+            else:
+                assert m["vgpr_count"] <= 80 and scratch <= 48, (name, m)
         elif kinds in (1, 2):
             assert m["vgpr_count"] <= 96, (name, m)
         else:
@@ -235,6 +240,10 @@ def test_wave_kernels_keep_six_waves_and_scalar_descriptor_reads(tmp_path, stem)
             assert m["vgpr_count"] <= (80 if own else 96), (name, m)
             assert m["private_segment_fixed_size"] <= (64 if own else 8 if per_pixel_uncleared else 0), (name, m)
             assert name.endswith("NS_7WaveOneE"), name              # every instantiation takes a lone tick's descriptors by value
+        elif "tick_bgra_wave_one" in name:
+            # the lone tick's twins (descriptors as the first kernel argument): five waves, and NOTHING in scratch — a kernel with a scratch segment
+            # is dispatched 2 us later, which is what the twins exist to avoid (at six waves they kept 2 - 14 registers there)
+            assert m["vgpr_count"] <= 96 and m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
         else:
             assert m["vgpr_count"] <= ((128 if with_general else 96) if tall else (96 if with_general else 80)), (name, m)
             assert m["vgpr_spill_count"] <= (0 if tall else 2), (name, m)

@@ -33,16 +33,20 @@ def probe(label, tdesc, layers, n=300):
     print(f"{label:52s} wall {wall:6.1f} us/tick   device (events) median {dev[len(dev)//2]:6.1f} us  min {dev[0]:6.1f}", flush=True)
 
 
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)          # canvas (and video) size; the overlays are a third of it
+
+
 def ticks(fmt):
-    dst = G.to_gpu(ctx, fmt, 1920, 1080, util.alloc_image(fmt, 1920, 1080))
-    src = G.to_gpu(ctx, fmt, 1920, 1080, util.alloc_image(fmt, 1920, 1080, seed=9))
-    ov = [G.to_gpu(ctx, "bgra", 640, 360, util.alloc_image("bgra", 640, 360, seed=10 + i)) for i in range(2)]
-    rgb = G.to_gpu(ctx, "bgra", 1920, 1080, util.alloc_image("bgra", 1920, 1080, seed=12))
-    full = util.full_canvas_uniforms((1920, 1080), (1920, 1080))
+    dst = G.to_gpu(ctx, fmt, W, H, util.alloc_image(fmt, W, H))
+    src = G.to_gpu(ctx, fmt, W, H, util.alloc_image(fmt, W, H, seed=9))
+    ow, oh = W // 3 // 2 * 2, H // 3 // 2 * 2
+    ov = [G.to_gpu(ctx, "bgra", ow, oh, util.alloc_image("bgra", ow, oh, seed=10 + i)) for i in range(2)]
+    rgb = G.to_gpu(ctx, "bgra", W, H, util.alloc_image("bgra", W, H, seed=12))
+    full = util.full_canvas_uniforms((W, H), (W, H))
     K = sv.defaultComputeKernelFromString
     main = [(K(f"img_{fmt}_{fmt}"), src, full, 0)]
-    mixer = main + [(K(f"img_bgra_{fmt}"), o, util.make_uniforms((1920, 1080), rect=(px, py, 640, 360), opacity=op, in_size=(640, 360)), 0)
-                    for o, (px, py), op in zip(ov, ((64, 64), (1200, 640)), (0.8, 0.6))]
+    mixer = main + [(K(f"img_bgra_{fmt}"), o, util.make_uniforms((W, H), rect=(px, py, ow, oh), opacity=op, in_size=(ow, oh)), 0)
+                    for o, (px, py), op in zip(ov, ((W // 30, H // 17), (W * 5 // 8, H * 16 // 27)), (0.8, 0.6))]
     enc = [(K(f"img_bgra_{fmt}_int"), rgb, full, 0)]
     return sv._image_desc(dst), main, mixer, enc, (dst, src, ov, rgb)
 
@@ -52,7 +56,7 @@ for fmt in ("y420p", "nv12"):
     for sw in ("1", "0"):
         cv.set_switch("CHV_YUV_STREAM", sw)
         tag = "tick_yuv_stream" if sw == "1" else "tick_yuv_wave"
-        probe(f"{fmt} {tag}: one video layer", tdesc, main)
+        probe(f"{W}x{H} {fmt} {tag}: one video layer", tdesc, main)
         probe(f"{fmt} {tag}: mixer tick (video + 2 overlays)", tdesc, mixer)
         probe(f"{fmt} {tag}: encoder frame (BGRA -> {fmt}, int)", tdesc, enc)
     cv.set_switch("CHV_YUV_STREAM", None)
