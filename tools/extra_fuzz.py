@@ -2,7 +2,8 @@
 suite runs, every kernel family forced in turn; HIP == oracle byte for byte or the case is listed.  A one-off sweep after a kernel change
 (GPU box; a few thousand cases take well under a minute).  Round 5, final library: seeds 1000..1399 — 4497 cases, 0 failures, 39 s.
 Round 6, final library (geometry tables, the shortened headline row, absorbed matrices): seeds 2000..3199 — 13 487 cases, 0 failures, 121 s;
-seeds 4000..4399 with CHV_GEOM_CACHE=eager (tables at every batch's first launch) — 4497 cases, 0 failures."""
+seeds 4000..4399 with CHV_GEOM_CACHE=eager (tables at every batch's first launch) — 4497 cases, 0 failures.  With the device's table store and lone ticks'
+descriptors as kernel arguments: seeds 5000..5799 — 8 991 cases, 0 failures; 6000..6399 eager — 4 500 cases, 0 failures."""
 import sys
 import time
 
