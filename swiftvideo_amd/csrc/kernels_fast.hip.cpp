@@ -478,12 +478,13 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     // 4:2:0 canvases (the reference's own kernels): one wave per strip, or the general quad kernel
     // 4:2:0 canvases: cleared ticks of 1..4 axis-aligned layers without fill paint can stream their source rows (kernels_stream_yuv.hip.cpp: rows
     // outermost, a ring per layer, launches of every size); by default where that measured faster, everything else keeps the strip kernel
-    if (target_format != TF_BGRA && yuv_stream_eligible(target_format, ticks, layers, n_ticks, transient)) {
+    if (target_format != TF_BGRA) {
         // Lone ticks of video layers from 720p up go to the strip kernel since ITS descriptors travel as a kernel argument too (WaveOne): 19.3 /
         // 20.3 / 30.6 us per 720p / 1080p / 2160p tick with the host wait against 20.5 / 22.5 / 35.7 through the rings; at 360p the streaming
         // kernel's short chunks keep it ahead (17.8 against 19.0), and the encoder side's integer frames are level (profiles/r06_notes.md section 15).
+        // (Asked before the streaming kernel's own, longer list of conditions: where the strips can take such a tick they do either way.)
         if (transient && n_ticks == 1 && switches().yuv_stream.load(std::memory_order_relaxed) == 1 && (long)ticks[0].W * ticks[0].H >= 500000 &&
-            ticks[0].n_layers <= WAVE_ONE_LAYERS) {
+            ticks[0].n_layers >= 1 && ticks[0].n_layers <= WAVE_ONE_LAYERS && ticks[0].clear_first) {
             bool video_only = true;
             for (int l = 0; l < ticks[0].n_layers; l++) {
                 const int k = layers[ticks[0].first_layer + l].kind;
@@ -491,7 +492,7 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
             }
             if (video_only && wave_layers_eligible(target_format, ticks, layers, n_ticks)) return target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P;
         }
-        return target_format == TF_NV12 ? FP_STREAM_NV12 : FP_STREAM_Y420P;
+        if (yuv_stream_eligible(target_format, ticks, layers, n_ticks, transient)) return target_format == TF_NV12 ? FP_STREAM_NV12 : FP_STREAM_Y420P;
     }
     if (target_format != TF_BGRA)
         return wave_layers_eligible(target_format, ticks, layers, n_ticks) ? (target_format == TF_NV12 ? FP_WAVE_NV12 : FP_WAVE_Y420P) : FP_NONE;
