@@ -360,7 +360,7 @@ struct chv_buffer {
     // pipeline — a Bus runner and the mixer's queue)
     std::mutex mu;
     hipEvent_t ready = nullptr;
-    hipStream_t ready_stream = nullptr;
+    std::atomic<hipStream_t> ready_stream{nullptr};      // (atomic: launches look without the lock first — most buffers have nothing pending)
     uint64_t ready_seq = 0;
     // Deferred passes (chv_context::PendingPass): kernels that were accepted but not launched yet hold their buffers.  chv_buffer_free on a held
     // buffer marks it `doomed` and returns; the release that drops the last hold frees it (OpenCL keeps a cl_mem alive the same way from
@@ -837,6 +837,7 @@ struct DepScope {
 static int wait_for_uploads(hipStream_t stream, std::vector<BatchDep> &deps) {
     for (BatchDep &d : deps) {
         chv_buffer *b = d.buf;
+        if (!b->ready_stream.load(std::memory_order_acquire)) continue;          // nothing pending (a batch of 256 mixers names a thousand buffers)
         std::lock_guard<std::mutex> lock(b->mu);
         if (!b->ready_stream || b->ready_stream == stream) continue;
         if (d.stream == stream && d.seq == b->ready_seq) continue;
