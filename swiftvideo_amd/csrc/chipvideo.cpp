@@ -390,7 +390,70 @@ struct BatchDep {
     uint64_t seq;         // ... and the upload it saw
 };
 
+// ---- descriptor blocks of batches -----------------------------------------------------------------------------------------------------------
+// A host that groups its mixers builds a batch for every group tick, runs it once and frees it (tools/batch_create_probe.cpp): two hipMalloc, two
+// synchronous copies and two hipFree (which wait for the device) per tick were 45 of the 105 us a group of eight ticks took.  A batch's
+// descriptors — ticks | layers | the second launch's ticks — now live in ONE block of a per-device pool: device memory with a pinned host twin
+// and an event.  Creation fills the twin and sends it with one asynchronous copy on the creating context's stream; every run records the
+// block's event behind its launches (a run on another stream first makes that stream wait for it); a block taken from the pool again waits
+// for its event on the host before the twin is overwritten (a host that waited for its tick never blocks there).  Blocks are never returned
+// to the system below kDescPoolBytes per device; beyond it, and when pinned memory runs out, a batch allocates and frees as before.
+struct DescBlock {
+    uint8_t *dev = nullptr, *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool recorded = false;         // `ev` has been recorded at least once since the block was (re)taken
+    hipStream_t last = nullptr;    // the stream it was recorded on last
+};
+constexpr size_t kDescPoolBytes = (size_t)64 << 20;
+struct DescPool { std::mutex mu; std::vector<DescBlock> free_blocks; size_t bytes = 0; };
+// (never destroyed: freeing device memory from a static destructor would call into a runtime that may be gone already)
+static DescPool &desc_pool(int device) { static DescPool *pools = new DescPool[16]; return pools[device & 15]; }
+// (the device is current)
+static bool desc_block_acquire(int device, size_t need, DescBlock *out) {
+    DescPool &P = desc_pool(device);
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        size_t best = P.free_blocks.size();
+        for (size_t i = 0; i < P.free_blocks.size(); i++)
+            if (P.free_blocks[i].cap >= need && (best == P.free_blocks.size() || P.free_blocks[i].cap < P.free_blocks[best].cap)) best = i;
+        if (best != P.free_blocks.size()) {
+            *out = P.free_blocks[best];
+            P.free_blocks.erase(P.free_blocks.begin() + (long)best);
+            return true;
+        }
+        size_t cap = (size_t)64 << 10;
+        while (cap < need) cap <<= 1;
+        if (P.bytes + cap > kDescPoolBytes) return false;
+        P.bytes += cap;
+        need = cap;
+    }
+    DescBlock b;
+    b.cap = need;
+    hipError_t e = hipMalloc((void **)&b.dev, b.cap);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&b.host, b.cap, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (b.dev) (void)hipFree(b.dev);
+        if (b.host) (void)hipHostFree(b.host);
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.bytes -= b.cap;
+        return false;
+    }
+    *out = b;
+    return true;
+}
+static void desc_block_release(int device, DescBlock &b) {
+    if (!b.dev) return;
+    DescPool &P = desc_pool(device);
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.free_blocks.push_back(b);
+    b = DescBlock{};
+}
+
 struct chv_batch {
+    DescBlock blk;                 // pooled descriptors (d_ticks / d_layers / d_ticks2 point into blk.dev); blk.dev == nullptr: allocations of its own
     int device = 0;
     int n_ticks = 0, n_layers = 0;
     int target_format = 0;
@@ -1472,13 +1535,8 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
     std::unique_ptr<chv_batch> b(new chv_batch);
     b->device = c->device; b->n_ticks = n_ticks; b->n_layers = (int)dls.size();
     b->target_format = tf0; b->maxW = maxW; b->maxH = maxH;
-    HIP_TRY(hipMalloc((void **)&b->d_ticks, sizeof(DTick) * dts.size()));
-    hipError_t e = hipMalloc((void **)&b->d_layers, sizeof(DLayer) * (dls.size() ? dls.size() : 1));
-    if (e != hipSuccess) { (void)hipFree(b->d_ticks); return hip_fail(e, "hipMalloc(layers)"); }
-    e = hipMemcpy(b->d_ticks, dts.data(), sizeof(DTick) * dts.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !dls.empty())
-        e = hipMemcpy(b->d_layers, dls.data(), sizeof(DLayer) * dls.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(b->d_ticks); (void)hipFree(b->d_layers); return hip_fail(e, "hipMemcpy(descriptors)"); }
+    // Everything that decides what the descriptors look like happens on the host first — the route, a split into two launches, the geometry
+    // tables the device's store has for the scene — so that they travel once.
     b->fast_path = select_fast_path(tf0, dts.data(), dls.data(), n_ticks);
     auto path_name = [&](int path) { return path >= 0 ? std::string(fast_path_name(path))
                                                        : std::string(tf0 == TF_BGRA ? "tick_general_bgra" : (tf0 == TF_NV12 ? "tick_general_yuv<nv12>" : "tick_general_yuv<y420p>")); };
@@ -1495,19 +1553,15 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
             }
             const int p1 = select_fast_path(tf0, head.data(), dls.data(), n_ticks), p2 = select_tail_path(tf0, tail.data(), dls.data(), n_ticks);
             if (p1 == fast_path_stream_bgra()) {
-                e = hipMalloc((void **)&b->d_ticks2, sizeof(DTick) * tail.size());
-                if (e == hipSuccess) e = hipMemcpy(b->d_ticks2, tail.data(), sizeof(DTick) * tail.size(), hipMemcpyHostToDevice);
-                if (e == hipSuccess) e = hipMemcpy(b->d_ticks, head.data(), sizeof(DTick) * head.size(), hipMemcpyHostToDevice);
-                if (e != hipSuccess) { (void)hipFree(b->d_ticks); (void)hipFree(b->d_layers); (void)hipFree(b->d_ticks2); return hip_fail(e, "descriptors of the second launch"); }
                 b->fast_path = p1; b->fast_path2 = p2;
-                b->h_ticks2 = tail;
-                dts = head;
+                b->h_ticks2 = std::move(tail);
+                dts = std::move(head);
                 b->kernel_name = path_name(p1) + " + " + path_name(p2);
             }
         }
     }
     // The strip kernels' geometry tables, where the device's store has them for this scene (a batch is bound to its pictures: a host builds one per
-    // group of frames, and the second one of a scene onwards starts with tables): the layers are pointed at them and sent again, once, here.
+    // group of frames, and the second one of a scene onwards starts with tables): the layers are pointed at them before they are sent.
     {
         const bool w1 = fast_path_is_wave(b->fast_path), w2 = b->fast_path2 != -2 && fast_path_is_wave(b->fast_path2);
         if ((w1 || w2) && !dls.empty()) {
@@ -1515,10 +1569,39 @@ extern "C" int chv_batch_create(chv_context *c, const chv_tick *ticks, int n_tic
             bool want_build = false;
             const std::vector<DTick> &tk = w1 ? dts : b->h_ticks2;
             if (geom_store_patch(tf0, tk.data(), dls.data(), n_ticks, b->maxW, b->maxH, (int)dls.size(), &cfg, &want_build)) {
-                e = hipMemcpy(b->d_layers, dls.data(), sizeof(DLayer) * dls.size(), hipMemcpyHostToDevice);
-                if (e != hipSuccess) { (void)hipFree(b->d_ticks); (void)hipFree(b->d_layers); if (b->d_ticks2) (void)hipFree(b->d_ticks2); return hip_fail(e, "hipMemcpy(layers with tables)"); }
                 b->geom.built = true; b->geom.patched = true; b->geom.config = cfg; b->geom.owns = false; b->geom.tables = nullptr;
             }
+        }
+    }
+    // ticks | layers | the second launch's ticks: one block of the device's pool (DescBlock), one asynchronous copy on this context's stream
+    const size_t tb = sizeof(DTick) * dts.size(), lb = sizeof(DLayer) * (dls.size() ? dls.size() : 1), t2b = sizeof(DTick) * b->h_ticks2.size();
+    const size_t lo = (tb + 255) & ~(size_t)255, t2o = (lo + lb + 255) & ~(size_t)255, total = t2o + t2b;
+    hipError_t e = hipSuccess;
+    if (desc_block_acquire(c->device, total, &b->blk)) {
+        DescBlock &K = b->blk;
+        if (K.recorded) e = hipEventSynchronize(K.ev);                 // (its last user's copy and launches: long done for a host that waited for its tick)
+        if (e == hipSuccess) {
+            memcpy(K.host, dts.data(), tb);
+            if (!dls.empty()) memcpy(K.host + lo, dls.data(), sizeof(DLayer) * dls.size());
+            if (t2b) memcpy(K.host + t2o, b->h_ticks2.data(), t2b);
+            e = hipMemcpyAsync(K.dev, K.host, total, hipMemcpyHostToDevice, c->stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(K.ev, c->stream);
+        if (e != hipSuccess) { desc_block_release(c->device, K); return hip_fail(e, "descriptors of a batch"); }
+        K.recorded = true; K.last = c->stream;
+        b->d_ticks = (DTick *)K.dev; b->d_layers = (DLayer *)(K.dev + lo); b->d_ticks2 = t2b ? (DTick *)(K.dev + t2o) : nullptr;
+    } else {
+        e = hipMalloc((void **)&b->d_ticks, tb);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->d_layers, lb);
+        if (e == hipSuccess && t2b) e = hipMalloc((void **)&b->d_ticks2, t2b);
+        if (e == hipSuccess) e = hipMemcpy(b->d_ticks, dts.data(), tb, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !dls.empty()) e = hipMemcpy(b->d_layers, dls.data(), sizeof(DLayer) * dls.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess && t2b) e = hipMemcpy(b->d_ticks2, b->h_ticks2.data(), t2b, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (b->d_ticks) (void)hipFree(b->d_ticks);
+            if (b->d_layers) (void)hipFree(b->d_layers);
+            if (b->d_ticks2) (void)hipFree(b->d_ticks2);
+            return hip_fail(e, "descriptors of a batch");
         }
     }
     b->h_ticks = std::move(dts);
@@ -1537,6 +1620,14 @@ extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
     int wrc = wait_for_uploads(c->stream, b->deps);
     if (wrc) return wrc;
     (void)hipGetLastError();   // see launch_transient
+    // (pooled descriptors: their copy went out on the creating context's stream, and the block's event marks the last thing that used it)
+    if (b->blk.dev && b->blk.last != c->stream) HIP_TRY(hipStreamWaitEvent(c->stream, b->blk.ev, 0));
+    // ... and on every way out from here the block's event goes behind whatever this call queued (the launchers may queue more than the tick
+    // kernels — a table build —, and a failing second launch leaves the first one in flight): what the next user of the block waits for
+    struct BlockMark {
+        chv_batch *bb; hipStream_t st;
+        ~BlockMark() { if (bb->blk.dev) { if (hipEventRecord(bb->blk.ev, st) == hipSuccess) bb->blk.last = st; else (void)hipGetLastError(); } }
+    } mark{ b, c->stream };
     // (the strip kernels' launcher finds the batch's geometry tables through this: geom_cache.h)
     struct CacheScope {
         explicit CacheScope(chv_batch *bb) {
@@ -1561,9 +1652,12 @@ extern "C" int chv_batch_run(chv_context *c, chv_batch *b) {
 extern "C" int chv_batch_destroy(chv_batch *b) {
     if (!b) return fail(CHV_ERR_INVALID_VALUE, "null batch");
     (void)hipSetDevice(b->device);
-    (void)hipFree(b->d_ticks);
-    (void)hipFree(b->d_layers);
-    if (b->d_ticks2) (void)hipFree(b->d_ticks2);
+    if (b->blk.dev) desc_block_release(b->device, b->blk);           // (back to the pool: whoever takes it next waits for its event)
+    else {
+        (void)hipFree(b->d_ticks);
+        (void)hipFree(b->d_layers);
+        if (b->d_ticks2) (void)hipFree(b->d_ticks2);
+    }
     geom_cache_release(b->geom);
     b->d_ticks = nullptr;
     delete b;
