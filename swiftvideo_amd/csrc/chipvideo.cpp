@@ -1089,6 +1089,7 @@ static int tick_to_device(const chv_tick &t, int device, int forced_target_forma
     if (t.n_layers > 0 && !t.layers) return fail(CHV_ERR_BAD_INPUT, "null layers");
     int tf = forced_target_format;
     int first = (int)layers->size();
+    if (layers->capacity() < layers->size() + (size_t)t.n_layers) layers->reserve(std::max(layers->capacity() * 2, layers->size() + (size_t)t.n_layers));
     for (int i = 0; i < t.n_layers; i++) {
         DLayer dl;
         int rc = layer_to_device(t.layers[i], device, &tf, &dl);
