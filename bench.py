@@ -1170,6 +1170,31 @@ def run_per_tick(args, sv, cv, lib, ctx, seconds=0.35, ring=10, distinct=4, mixe
     }
 
 
+def run_group_tick_fresh(cv, lib, ctx):
+    """What a host that GROUPS its mixers pays per group tick when it builds the batch of every tick afresh (new pictures every tick), runs it once
+    and frees it — against running one prebuilt batch again, which is what the headline times: native host over the C ABI
+    (tools/batch_create_probe.cpp), groups of 8 / 64 / 256 headline ticks, microseconds."""
+    out = {"workload": "group_tick_built_fresh: chv_batch_create + chv_batch_run + chv_pass_end(wait) + chv_batch_destroy per GROUP tick of 8 / 64 / 256 "
+                       "headline ticks (what a VideoMixerGroup does every tick) against the same batch run again; native host, us"}
+    exe = ROOT / "tools" / "batch_create_probe.bin"
+    if not exe.exists():
+        out["error"] = "tools/batch_create_probe.bin not built (__graft_entry__.build())"
+        return {"group_tick_built_fresh": out}
+    dev = C.c_int(0)
+    cv.check(lib.chv_context_device(ctx.handle, C.byref(dev)))
+    try:
+        p = subprocess.run([str(exe), "--json", str(dev.value)], capture_output=True, text=True, timeout=120)
+        if p.returncode == 0:
+            out["groups"] = json.loads(p.stdout)
+            for g, r in out["groups"].items():
+                r["fresh_over_prebuilt"] = round(r["built_fresh_us"] / r["run_again_us"], 3) if r.get("run_again_us") else None
+        else:
+            out["error"] = p.stderr[-300:]
+    except Exception as e:    # noqa: BLE001
+        out["error"] = repr(e)
+    return {"group_tick_built_fresh": out}
+
+
 def run_thread_scaling(args, sv, cv, lib, ctx, seconds=0.25):
     """How the one-tick-at-a-time path scales with host threads (one mixer = one thread + context, all on this device), from BOTH hosts: Python
     threads over ctypes (this process) and native threads over the C ABI (tools/tick_threads.cpp, what a Swift composer's mixer queues would
@@ -1579,6 +1604,7 @@ def run_rank(args, rank, local, world, dist):
         reports.update(run_per_tick(args, sv, cv, lib, ctx))
         reports.update(run_per_tick_mixer420(args, sv, cv, lib, ctx, fmt="y420p"))
         reports.update(run_thread_scaling(args, sv, cv, lib, ctx))
+        reports.update(run_group_tick_fresh(cv, lib, ctx))
     regret = None
     if ((args.full and others) or args.route_regret) and real and not args.no_route_regret and n_gpus == 1:
         regret = run_route_regret(args, sv, cv, lib, ctx, [n for n in ([args.workload] + others) if n in WORKLOADS])

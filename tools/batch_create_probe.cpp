@@ -12,9 +12,13 @@
 #define CK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s: %s (%s)\n", #x, chv_error_string(rc_), chv_last_error_detail()); exit(2); } } while (0)
 static const int SW = 1920, SH = 1080, DW = 1280, DH = 720, LAYERS = 4, NSRC = 8, NCAN = 256;
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-int main() {
+int main(int argc, char **argv) {
+    const bool json = argc > 1 && !strcmp(argv[1], "--json");          // (bench.py --full: the leg group_tick_built_fresh)
+    const int device = argc > 2 ? atoi(argv[2]) : 0;
     chv_context *ctx = nullptr;
-    CK(chv_context_create(0, &ctx));
+    CK(chv_context_create(device, &ctx));
+    if (json) printf("{");
+    bool first_group = true;
     chv_uniforms u;
     memset(&u, 0, sizeof u);
     const float rows[16] = { .5f, 0, 0, .5f, 0, .5f, 0, .5f, 0, 0, 1, -1, 0, 0, 0, 1 };
@@ -72,9 +76,14 @@ int main() {
                 double g = now();
                 t_create += c - a; t_run += d - c; t_wait += e - d; t_rerun += f - e; t_destroy += g - f;
             }
-            if (rep) printf("group of %3d ticks: create %7.1f us, run (enqueue) %6.1f, wait %7.1f, destroy %6.1f  => %7.1f us per group tick built fresh; the same batch run again + wait: %7.1f us\n",
+            if (rep && json) {
+                printf("%s\"%d\": {\"create_us\": %.1f, \"run_us\": %.1f, \"wait_us\": %.1f, \"destroy_us\": %.1f, \"built_fresh_us\": %.1f, \"run_again_us\": %.1f}", first_group ? "" : ", ", G,
+                       t_create / N, t_run / N, t_wait / N, t_destroy / N, (t_create + t_run + t_wait + t_destroy) / N, t_rerun / N);
+                first_group = false;
+            } else if (rep) printf("group of %3d ticks: create %7.1f us, run (enqueue) %6.1f, wait %7.1f, destroy %6.1f  => %7.1f us per group tick built fresh; the same batch run again + wait: %7.1f us\n",
                             G, t_create / N, t_run / N, t_wait / N, t_destroy / N, (t_create + t_run + t_wait + t_destroy) / N, t_rerun / N);
         }
     }
+    if (json) printf("}\n");
     return 0;
 }
