@@ -1108,11 +1108,26 @@ static int tick_to_device(const chv_tick &t, int device, int forced_target_forma
     if (rc) return rc;
     dt->W = dt->dst.pl[0].w;
     dt->H = dt->dst.pl[0].h;
+    // (the boxes are functions of the matrices, the kind, the flags and the canvas: a group of mixers repeats a handful of geometries a thousand
+    // times per batch, a lone mixer the same ones every tick — the last few answers are kept per thread; a dozen double divisions per miss)
+    struct BoxMemo { float m[48]; int32_t kind, flags, W, H, tf, bbox[4], ibox[4], flags_out; bool used; };
+    static thread_local BoxMemo memo[8];
+    static thread_local unsigned memo_next = 0;
     for (int i = first; i < (int)layers->size(); i++) {
         DLayer &L = (*layers)[i];
-        if (L.kind == LK_BGRA_METAL) { L.bbox[0] = 0; L.bbox[1] = 0; L.bbox[2] = dt->W; L.bbox[3] = dt->H; }
-        else layer_bbox(&L, dt->W, dt->H);
-        layer_inner_box(&L, dt->W, dt->H, tf);
+        BoxMemo *hit = nullptr;
+        for (BoxMemo &M : memo)
+            if (M.used && M.kind == L.kind && M.flags == L.flags && M.W == dt->W && M.H == dt->H && M.tf == tf && memcmp(M.m, L.u, sizeof M.m) == 0) { hit = &M; break; }
+        if (hit) {
+            memcpy(L.bbox, hit->bbox, sizeof L.bbox); memcpy(L.ibox, hit->ibox, sizeof L.ibox); L.flags = hit->flags_out;
+        } else {
+            BoxMemo &M = memo[memo_next++ & 7];
+            memcpy(M.m, L.u, sizeof M.m); M.kind = L.kind; M.flags = L.flags; M.W = dt->W; M.H = dt->H; M.tf = tf;
+            if (L.kind == LK_BGRA_METAL) { L.bbox[0] = 0; L.bbox[1] = 0; L.bbox[2] = dt->W; L.bbox[3] = dt->H; }
+            else layer_bbox(&L, dt->W, dt->H);
+            layer_inner_box(&L, dt->W, dt->H, tf);
+            memcpy(M.bbox, L.bbox, sizeof L.bbox); memcpy(M.ibox, L.ibox, sizeof L.ibox); M.flags_out = L.flags; M.used = true;
+        }
         if ((L.flags & LF_COVERS) && i - first < 31) dt->cover_mask |= 1 << (i - first);
     }
     // LF_SAME_GEOM (device_types.h): a layer whose geometry inputs equal its predecessor's
