@@ -882,14 +882,30 @@ struct DepScope {
     ~DepScope() { g_deps = nullptr; }
     // distinct buffers (a picture's planes usually share one allocation)
     std::vector<BatchDep> deps() const {
-        // (sorted: a 256-tick batch names 2 300 planes of some hundreds of buffers, and is built afresh for every group tick of a host that
-        // batches — the quadratic walk this replaces was 130 of the 300 us chv_batch_create took for it, tools/batch_create_probe.cpp)
-        std::vector<chv_buffer *> u(bufs);
-        std::sort(u.begin(), u.end());
-        u.erase(std::unique(u.begin(), u.end()), u.end());
+        // (a 256-tick batch names 2 300 planes of some hundreds of buffers, and is built afresh for every group tick of a host that batches: the
+        // quadratic walk this replaces was 130 of the 300 us chv_batch_create took for it, tools/batch_create_probe.cpp.  A picture's planes
+        // share an allocation — consecutive repeats go first —, the rest through a small open-addressing set.)
         std::vector<BatchDep> out;
-        out.reserve(u.size());
-        for (chv_buffer *b : u) out.push_back(BatchDep{ b, nullptr, 0 });
+        const size_t n = bufs.size();
+        if (n <= 24) {
+            for (chv_buffer *b : bufs) {
+                bool seen = false;
+                for (const BatchDep &d : out) seen = seen || d.buf == b;
+                if (!seen) out.push_back(BatchDep{ b, nullptr, 0 });
+            }
+            return out;
+        }
+        size_t cap = 64;
+        while (cap < 2 * n) cap <<= 1;
+        std::vector<chv_buffer *> tab(cap, nullptr);
+        chv_buffer *last = nullptr;
+        for (chv_buffer *b : bufs) {
+            if (b == last) continue;
+            last = b;
+            size_t h = (size_t)(((uintptr_t)b >> 6) * 0x9E3779B97F4A7C15ull >> 32) & (cap - 1);
+            while (tab[h] && tab[h] != b) h = (h + 1) & (cap - 1);
+            if (!tab[h]) { tab[h] = b; out.push_back(BatchDep{ b, nullptr, 0 }); }
+        }
         return out;
     }
 };
