@@ -506,9 +506,17 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     if (transient && n_ticks == 1 && ticks[0].n_layers == 0 && ticks[0].clear_first && (((uintptr_t)ticks[0].dst.pl[0].ptr) & 3) == 0 &&
         (ticks[0].dst.pl[0].pitch & 3) == 0)
         return FP_CLEAR_BGRA;
+    // A lone tick of ONE NV12 layer on a cleared canvas, now that the strip kernel has a twin that takes such a tick as a kernel argument
+    // (tick_bgra_wave_one): the strips are ahead of the streaming kernel's twin on canvases from ~1.4 Mpixel up (a 1080p canvas: 20.8 against
+    // 23.2 us with the host wait; at 720p the streaming kernel keeps it, 19.4 against 21.3) and of the tiled kernel's twin wherever the
+    // streaming kernel does not apply (a picture-in-picture inset: 22.5 against 24.1 us at 720p, 21.2 against 23.4 at 1080p) —
+    // tools/lone_bgra_routes.py.  Planar sources stay (their strip instantiation has no twin).
+    const bool lone_nv12 = transient && bp == 0 && n_ticks == 1 && ticks[0].n_layers == 1 && ticks[0].clear_first &&
+                           layers[ticks[0].first_layer].kind == LK_BGRA_FROM_NV12;
     if ((bp == 0 || bp == 3) && bgra_stream_eligible(ticks, layers, n_ticks)) {
+        if (lone_nv12 && (long)ticks[0].W * ticks[0].H >= 1400000 && wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks)) return FP_WAVE_LAYERS;
         if (bp == 3 || ticks[0].n_layers >= 2 || transient) return FP_STREAM;
-    }
+    } else if (lone_nv12 && wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks)) return FP_WAVE_LAYERS;
     if (bp != 1) {
         int p = select_single_purpose(ticks, layers, n_ticks);
         // planar sources in launches that fill the chip: the y420p-only instantiation of the wave kernel is the faster one
