@@ -512,7 +512,7 @@ int select_fast_path(int target_format, const DTick *ticks, const DLayer *layers
     // streaming kernel does not apply (a picture-in-picture inset: 22.5 against 24.1 us at 720p, 21.2 against 23.4 at 1080p) —
     // tools/lone_bgra_routes.py.  Planar sources stay (their strip instantiation has no twin).
     const bool lone_nv12 = transient && bp == 0 && n_ticks == 1 && ticks[0].n_layers == 1 && ticks[0].clear_first &&
-                           layers[ticks[0].first_layer].kind == LK_BGRA_FROM_NV12;
+                           (layers[ticks[0].first_layer].kind == LK_BGRA_FROM_NV12 || layers[ticks[0].first_layer].kind == LK_BGRA_FROM_Y420P);
     if ((bp == 0 || bp == 3) && bgra_stream_eligible(ticks, layers, n_ticks)) {
         if (lone_nv12 && (long)ticks[0].W * ticks[0].H >= 1400000 && wave_layers_eligible(TF_BGRA, ticks, layers, n_ticks)) return FP_WAVE_LAYERS;
         if (bp == 3 || ticks[0].n_layers >= 2 || transient) return FP_STREAM;

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(WAVE_BLOCK, (WTH == 16 ? ((KINDS & 8) ? 4 : CHV_WAV
 // reloaded from the kernarg segment at will, and the two scalar registers that cost put 2 - 14 vector registers of the 8-row instantiations
 // (80 VGPRs: six waves) into scratch — and a kernel with a scratch segment is dispatched 2 us later than one without (measured on the twin at six
 // waves: 28.5 against 26.4 us between events).  The twins are built for FIVE waves (96 VGPRs, nothing in scratch): a lone tick up to 1080p is
-// at most 4 080 strips on 5 120 wave slots, all resident at once either way.  KINDS 1 / 5 / 7: what launch_bgra_wave_t picks for video,
-// video + RGB overlays and everything else without per-pixel layers.
+// at most 4 080 strips on 5 120 wave slots, all resident at once either way.  KINDS 1 / 2 / 5 / 7: what launch_bgra_wave_t picks for NV12
+// video, planar video, NV12 video + RGB overlays and everything else without per-pixel layers.
 template <int KINDS, bool CACHED>
 __global__ __launch_bounds__(WAVE_BLOCK, CHV_WAVE_MINW - 1) void tick_bgra_wave_one(const WaveOne, int strips_x, int strips_y, uint32_t strips_magic, uint32_t strips_x_magic,
                                                                                   int p0pitch, int p0rows, int p1pitch, int p1rows, int planar_any) {
@@ -161,10 +161,10 @@ hipError_t launch_bgra_wave_t(int rows, bool clear, dim3 grid, size_t lds, hipSt
                               const WaveOne *one_arg) {
     if (one_arg) {
         // a lone tick whose descriptors are the kernel's first argument (launch_wave_layers asked wave_layers_by_value first)
-        if (rows != 8 || !clear || (kinds & 8) || kinds == 2 || kinds == 4) return hipErrorNotSupported;
+        if (rows != 8 || !clear || (kinds & 8) || kinds == 4) return hipErrorNotSupported;
 #define CHV_LAUNCH_ONE(K) hipLaunchKernelGGL((tick_bgra_wave_one<K, CACHED>), grid, dim3(WAVE_BLOCK), lds, stream, *one_arg, strips_x, strips_y, strips_magic, strips_x_magic, \
                                              p0pitch, p0rows, p1pitch, p1rows, planar)
-        if (kinds == 1) CHV_LAUNCH_ONE(1); else if (kinds == 5) CHV_LAUNCH_ONE(5); else CHV_LAUNCH_ONE(7);
+        if (kinds == 1) CHV_LAUNCH_ONE(1); else if (kinds == 2) CHV_LAUNCH_ONE(2); else if (kinds == 5) CHV_LAUNCH_ONE(5); else CHV_LAUNCH_ONE(7);
 #undef CHV_LAUNCH_ONE
         return hipGetLastError();
     }

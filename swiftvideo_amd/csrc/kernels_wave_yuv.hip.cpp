@@ -1182,7 +1182,7 @@ bool wave_layers_by_value(int target_format, const DTick *tick_host, const DLaye
     if (target_format != TF_BGRA) return true;
     if (!tick_host->clear_first) return false;
     const WavePlan P = plan_wave_layers(target_format, tick_host, layers_host, 1, tick_host->W, tick_host->H);
-    return P.WTH == 8 && !(P.kinds & 8) && P.kinds != 2 && P.kinds != 4;
+    return P.WTH == 8 && !(P.kinds & 8) && P.kinds != 4;
 }
 
 hipError_t launch_wave_layers(int target_format, const DTick *ticks_host, const DLayer *layers_host, const DTick *ticks, const DLayer *layers,

@@ -216,3 +216,27 @@ def test_lone_ticks_carry_their_descriptors_as_kernel_arguments(ctx, switch, dst
             gd, layers, exp, keep = _tick(ctx, dst, cw, ch, scene, 1500 + 10 * n_layers + t)
             sv.usingContext(ctx, lambda c: sv.compositeTick(c, gd, layers, True))
             G.assert_same(G.from_gpu(ctx, gd, dst, cw, ch), exp, f"{dst}, {n_layers} layers, CHV_DESC={desc}, tick {t}")
+
+
+@pytest.mark.parametrize("vf", ["nv12", "y420p"])
+@pytest.mark.parametrize("canvas", [(1280, 720), (1472, 960)])
+@pytest.mark.parametrize("inset", [False, True])
+def test_lone_one_layer_ticks_on_bgra_canvases_by_route(ctx, switch, vf, canvas, inset):
+    """a lone tick of ONE video layer on a cleared BGRA canvas: streaming twin below 1.4 Mpixel, strip twin (tick_bgra_wave_one, KINDS 1 / 2) from
+    there up and for insets the streaming kernel cannot take (kernels_fast.hip.cpp::select_fast_path) — and the tiled twin and the descriptor ring
+    when asked for: the oracle's canvas every way, four ticks each (in place, building, served from the store)"""
+    cw, ch = canvas
+    sw, sh = 960, 544
+    u = util.make_uniforms((cw, ch), rect=(cw // 8, ch // 8, cw // 2, ch // 2), in_size=(sw, sh)) if inset else util.full_canvas_uniforms((cw, ch), (sw, sh))
+    name = f"img_{vf}_bgra"
+    for route, desc in ((None, None), ("tiled", None), ("wave", None), ("wave", "device")):
+        switch("CHV_BGRA_PATH", route)
+        switch("CHV_DESC", desc)
+        for t in range(4):
+            src = util.alloc_image(vf, sw, sh, seed=2000 + t)
+            exp = util.alloc_image("bgra", cw, ch, seed=7)
+            assert O.run_kernel("img_clear_bgra", exp, threads=8) == 0 and O.run_kernel(name, exp, src, u, threads=8) == 0
+            gs = G.to_gpu(ctx, vf, sw, sh, src)
+            gd = G.to_gpu(ctx, "bgra", cw, ch, util.alloc_image("bgra", cw, ch, seed=7))
+            sv.usingContext(ctx, lambda c: sv.compositeTick(c, gd, [(K(name), gs, u, 0)], True))
+            G.assert_same(G.from_gpu(ctx, gd, "bgra", cw, ch), exp, f"{vf} -> {cw}x{ch}, inset {inset}, CHV_BGRA_PATH={route}, CHV_DESC={desc}, tick {t}")
