@@ -1,6 +1,9 @@
+"""tools/lone_bgra_routes.py — a lone tick of ONE video layer on a cleared BGRA canvas through each of its three routes (streaming twin — the
+default below 1.4 Mpixel —, tiled twin, strip twin): 720p and 1080p canvases, NV12 and y420p sources, full canvas and a picture-in-picture inset;
+wall us per tick with the host wait and us between two stream events.  GPU box.  (profiles/r06_notes.md section 18.)"""
 import sys, time
 from pathlib import Path
-ROOT = Path("/root/repo") if Path("/root/repo/tests").exists() else Path(".").resolve()
+ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import ctypes as C
 import util, gpuutil as G
