@@ -141,3 +141,18 @@ def test_switch_hook_validates_names(built):
     for name in ("CHV_FORCE_GENERAL", "CHV_BGRA_PATH", "CHV_WAVE_ROWS", "CHV_TILE_ROWS", "CHV_SAME_GEOM", "CHV_DESC", "CHV_STREAM"):
         assert lib.chv_debug_set_switch(name.encode(), b"") == 0
         assert lib.chv_debug_set_switch(name.encode(), None) == 0
+
+
+def test_counter_hook_validates_names(built):
+    """chv_debug_get_counter (the geometry-table store in numbers): unknown names and null arguments are refused; the known ones read 0 in a
+    process that has launched nothing (no device needed)"""
+    import ctypes as C
+    lib = cv.load()
+    v = C.c_ulonglong(7)
+    assert lib.chv_debug_get_counter(b"no_such_counter", C.byref(v)) == 1
+    assert lib.chv_debug_get_counter(None, C.byref(v)) == 1
+    assert lib.chv_debug_get_counter(b"geom_store_patched", None) == 1
+    for name in ("geom_store_patched", "geom_store_batch_hits", "geom_store_builds", "geom_store_bytes", "geom_store_tables"):
+        v.value = 7
+        assert lib.chv_debug_get_counter(name.encode(), C.byref(v)) == 0 and v.value == 0, name
+        assert cv.get_counter(name) == 0
