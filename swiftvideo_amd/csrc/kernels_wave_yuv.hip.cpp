@@ -1119,34 +1119,53 @@ bool geom_store_patch(int target_format, const DTick *ticks_host, DLayer *layers
     int classes = 0;
     {
         std::lock_guard<std::mutex> lk(st.mu);
-        std::string ks, last;
-        void *last_tab = nullptr;
-        std::unordered_map<std::string, void *> asked;      // this call's classes (a sighting is a LAUNCH that asked, whatever its number of ticks)
+        // this call's classes (a sighting is a LAUNCH that asked, whatever its number of ticks): the first sixteen as raw keys compared by bytes,
+        // starting from where the same layer of the previous tick was found (a group's ticks repeat their predecessor's geometry: one memcmp
+        // per layer — a batch of 128 mixer ticks used to pay 27 us of strings and hashing here); further ones through a map
+        struct Seen { GeomRawKey k; void *tab; };
+        Seen seen[16];
+        int n_seen = 0;
+        std::string ks;
+        std::unordered_map<std::string, void *> asked;
+        auto lookup = [&](const std::string &key) -> void * {
+            const std::string full = key + ck;
+            auto it = st.tables.find(full);
+            void *tab = it != st.tables.end() ? it->second : nullptr;
+            if (!tab) {
+                // (an animated layer is a new geometry every tick, seen once: the count of sightings is bounded by starting over)
+                if (st.sightings.size() >= kGeomStoreSightings) st.sightings.clear();
+                int &n = st.sightings[full];
+                if (n < (1 << 20)) n++;
+                if (n < 2 || st.full) known = false;
+            }
+            classes++;
+            return tab;
+        };
         for (int i = 0; i < n_ticks; i++) {
             const DTick &T = ticks_host[i];
             for (int l = 0; l < T.n_layers; l++) {
                 const int li = T.first_layer + l;
-                if (!geom_class_key(T, layers_host[li], ks)) continue;
-                if (ks != last) {                          // (a tick's layers, and a batch's ticks, mostly repeat their predecessor's geometry)
-                    last = ks;
-                    auto seen = asked.find(ks);
-                    if (seen != asked.end()) last_tab = seen->second;
-                    else {
-                        const std::string full = ks + ck;
-                        auto it = st.tables.find(full);
-                        last_tab = it != st.tables.end() ? it->second : nullptr;
-                        if (!last_tab) {
-                            // (an animated layer is a new geometry every tick, seen once: the count of sightings is bounded by starting over)
-                            if (st.sightings.size() >= kGeomStoreSightings) st.sightings.clear();
-                            int &n = st.sightings[full];
-                            if (n < (1 << 20)) n++;
-                            if (n < 2 || st.full) known = false;
-                        }
-                        asked.emplace(ks, last_tab);
-                        classes++;
+                GeomRawKey rk;
+                if (!geom_class_raw(T, layers_host[li], rk)) continue;
+                void *tab = nullptr;
+                int at = -1;
+                for (int q = 0; q < n_seen && at < 0; q++) {
+                    const int j = (l + q) % n_seen;                  // (layer l of a tick is usually class l of the group)
+                    if (memcmp(&seen[j].k, &rk, sizeof rk) == 0) at = j;
+                }
+                if (at >= 0) tab = seen[at].tab;
+                else {
+                    ks.assign((const char *)&rk, sizeof rk);
+                    if (n_seen < 16) {
+                        tab = lookup(ks);
+                        seen[n_seen].k = rk; seen[n_seen].tab = tab; n_seen++;
+                    } else {
+                        auto f = asked.find(ks);
+                        if (f != asked.end()) tab = f->second;
+                        else { tab = lookup(ks); asked.emplace(ks, tab); }
                     }
                 }
-                if (last_tab) hits.emplace_back(li, last_tab); else all = false;
+                if (tab) hits.emplace_back(li, tab); else all = false;
             }
         }
     }

@@ -14,6 +14,7 @@ static const int SW = 1920, SH = 1080, DW = 1280, DH = 720, LAYERS = 4, NSRC = 8
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char **argv) {
     const bool json = argc > 1 && !strcmp(argv[1], "--json");          // (bench.py --full: the leg group_tick_built_fresh)
+    const bool mixer = argc > 1 && !strcmp(argv[1], "--mixer");        // the reference-default mixer tick instead (1080p y420p canvas <- video + 2 BGRA overlays: strip kernel)
     const int device = argc > 2 ? atoi(argv[2]) : 0;
     chv_context *ctx = nullptr;
     CK(chv_context_create(device, &ctx));
@@ -46,7 +47,39 @@ int main(int argc, char **argv) {
         cimg[r].planes[0] = chv_plane{ b, 0, DW, DH, (int32_t)pitch, 4 };
     }
     const float op[4] = { 1.f, .75f, .5f, .25f };
-    for (int G : { 8, 64, 256 }) {
+    // --mixer: y420p canvases and sources, two 640x360 BGRA overlays
+    std::vector<chv_image> ysrc(NSRC), ycan(mixer ? 128 : 0), ov(2);
+    chv_uniforms uy = u, uo[2];
+    if (mixer) {
+        uy.input_size[0] = 1920; uy.input_size[1] = 1080; uy.output_size[0] = 1920; uy.output_size[1] = 1080;
+        auto y420 = [&](chv_image &im) {
+            chv_buffer *b = nullptr;
+            CK(chv_buffer_alloc(ctx, (size_t)1920 * 1080 * 3 / 2, &b));
+            memset(&im, 0, sizeof im);
+            im.format = CHV_FMT_Y420P; im.width = 1920; im.height = 1080; im.n_planes = 3;
+            im.planes[0] = chv_plane{ b, 0, 1920, 1080, 1920, 1 };
+            im.planes[1] = chv_plane{ b, (size_t)1920 * 1080, 960, 540, 960, 1 };
+            im.planes[2] = chv_plane{ b, (size_t)1920 * 1080 * 5 / 4, 960, 540, 960, 1 };
+        };
+        for (auto &im : ysrc) y420(im);
+        for (auto &im : ycan) y420(im);
+        for (int k = 0; k < 2; k++) {
+            chv_buffer *b = nullptr; size_t pitch = 0;
+            CK(chv_plane_alloc(ctx, 640, 360, 4, &b, &pitch));
+            memset(&ov[k], 0, sizeof(chv_image));
+            ov[k].format = CHV_FMT_BGRA; ov[k].width = 640; ov[k].height = 360; ov[k].n_planes = 1;
+            ov[k].planes[0] = chv_plane{ b, 0, 640, 360, (int32_t)pitch, 4 };
+            // a 640 x 360 rectangle at (px, py) of the 1920 x 1080 canvas: border / transform rows map its pixels to [0, 1]
+            const float px = k ? 1200.f : 64.f, py = k ? 640.f : 64.f, sx = 1920.f / 640.f, sy = 1080.f / 360.f;
+            memset(&uo[k], 0, sizeof(chv_uniforms));
+            const float r[16] = { .5f * sx, 0, 0, .5f * sx - px / 640.f, 0, .5f * sy, 0, .5f * sy - py / 360.f, 0, 0, 1, -1, 0, 0, 0, 1 };
+            memcpy(uo[k].transform, r, sizeof r); memcpy(uo[k].border_matrix, r, sizeof r);
+            for (int i = 0; i < 4; i++) uo[k].texture_transform[5 * i] = 1.f;
+            uo[k].input_size[0] = 640; uo[k].input_size[1] = 360; uo[k].output_size[0] = 1920; uo[k].output_size[1] = 1080; uo[k].opacity = k ? .6f : .8f;
+        }
+    }
+    const int NL = mixer ? 3 : LAYERS;
+    for (int G : { 8, 64, mixer ? 128 : 256 }) {
         std::vector<chv_layer> layers((size_t)G * LAYERS);
         std::vector<chv_tick> ticks(G);
         for (int rep = 0; rep < 2; rep++) {            // rep 0: warm-up
@@ -54,13 +87,16 @@ int main(int argc, char **argv) {
             const int N = 30;
             for (int it = 0; it < N; it++) {
                 for (int t = 0; t < G; t++) {
-                    for (int l = 0; l < LAYERS; l++) {
+                    for (int l = 0; l < NL; l++) {
                         chv_layer &L = layers[(size_t)t * LAYERS + l];
                         memset(&L, 0, sizeof L);
-                        L.kernel = CHV_K_IMG_NV12_BGRA; L.image = simg[(t + l + it) % NSRC]; L.uniforms = u; L.uniforms.opacity = op[l]; L.opts = opts;
+                        if (!mixer) { L.kernel = CHV_K_IMG_NV12_BGRA; L.image = simg[(t + l + it) % NSRC]; L.uniforms = u; L.uniforms.opacity = op[l]; }
+                        else if (l == 0) { L.kernel = CHV_K_IMG_Y420P_Y420P; L.image = ysrc[(t + it) % NSRC]; L.uniforms = uy; L.uniforms.opacity = 1.f; }
+                        else { L.kernel = CHV_K_IMG_BGRA_Y420P; L.image = ov[l - 1]; L.uniforms = uo[l - 1]; }
+                        L.opts = opts;
                     }
                     memset(&ticks[t], 0, sizeof(chv_tick));
-                    ticks[t].target = cimg[(t + it) % NCAN]; ticks[t].clear_first = 1; ticks[t].n_layers = LAYERS; ticks[t].layers = &layers[(size_t)t * LAYERS];
+                    ticks[t].target = mixer ? ycan[(t + it) % 128] : cimg[(t + it) % NCAN]; ticks[t].clear_first = 1; ticks[t].n_layers = NL; ticks[t].layers = &layers[(size_t)t * LAYERS];
                 }
                 chv_batch *b = nullptr;
                 double a = now();
